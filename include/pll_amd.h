@@ -1,0 +1,325 @@
+/*
+ * pll_amd.h -- public C interface of libpll_amd, the MI355X-native
+ * Felsenstein-pruning library.
+ *
+ * The library is a drop-in for ONE path of libpll 0.3.2: partition container
+ * -> P-matrices -> conditional-likelihood-vector (CLV) updates -> edge/root
+ * log-likelihood -> sumtable / branch-length derivatives.  Every function
+ * below keeps the name, argument order, argument meaning and error behaviour
+ * of the reference declaration it replaces (cited as pll.h:<line>, relative to
+ * the reference's src/ directory), so a client written against the
+ * reference's header links against libpll_amd.so unchanged.
+ *
+ * What is different underneath:
+ *   - all likelihood arithmetic runs in hand-written HIP kernels on gfx950;
+ *     CLVs, scale buffers, tip characters and P-matrices live in HBM;
+ *   - there is NO CPU compute path.  If no HIP device can be opened,
+ *     pll_partition_create fails with PLL_ERROR_HIP_* (it never falls back);
+ *   - partition->clv[i], ->scale_buffer[i] and ->pmatrix[i] are host MIRRORS,
+ *     refreshed only on demand: pll_show_clv / pll_show_pmatrix refresh what
+ *     they print; other readers call pll_amd_sync_* first (bottom of file).
+ *   - the ISA bits of `attributes` (PLL_ATTRIB_ARCH_*) are accepted and
+ *     ignored: states_padded == states and alignment == 16 always.
+ */
+#ifndef PLL_AMD_H_
+#define PLL_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLL_EXPORT __attribute__((visibility("default")))
+
+/* ---- constants: values fixed by the reference ABI (pll.h:75-167) ---- */
+
+#define PLL_FAILURE 0
+#define PLL_SUCCESS 1
+#define PLL_FALSE 0
+#define PLL_TRUE 1
+
+#define PLL_ASCII_SIZE 256
+
+/* 2^256 and 2^-256: numerical scaling of CLVs (pll.h:89-93) */
+#define PLL_SCALE_FACTOR 0x1p+256
+#define PLL_SCALE_THRESHOLD 0x1p-256
+#define PLL_SCALE_BUFFER_NONE (-1)
+/* per-rate scaling: cap on the scaler difference undone in lnL (pll.h:97) */
+#define PLL_SCALE_RATE_MAXDIFF 4
+
+#define PLL_MISC_EPSILON 1e-8
+
+#define PLL_ALIGNMENT_CPU 8
+#define PLL_ALIGNMENT_SSE 16
+#define PLL_ALIGNMENT_AVX 32
+#define PLL_ALIGNMENT_HIP 16
+
+/* attribute word (pll.h:106-122); bits 0-3 are accepted but select nothing */
+#define PLL_ATTRIB_ARCH_CPU 0
+#define PLL_ATTRIB_ARCH_SSE (1 << 0)
+#define PLL_ATTRIB_ARCH_AVX (1 << 1)
+#define PLL_ATTRIB_ARCH_AVX2 (1 << 2)
+#define PLL_ATTRIB_ARCH_AVX512 (1 << 3)
+#define PLL_ATTRIB_ARCH_MASK 0xF
+#define PLL_ATTRIB_PATTERN_TIP (1 << 4)
+#define PLL_ATTRIB_AB_LEWIS (1 << 5)
+#define PLL_ATTRIB_AB_FELSENSTEIN (2 << 5)
+#define PLL_ATTRIB_AB_STAMATAKIS (3 << 5)
+#define PLL_ATTRIB_AB_MASK (7 << 5)
+#define PLL_ATTRIB_AB_FLAG (1 << 8)
+#define PLL_ATTRIB_RATE_SCALERS (1 << 9)
+
+/* error codes shared with the reference (pll.h:137-167) */
+#define PLL_ERROR_MEM_ALLOC 112
+#define PLL_ERROR_PARAM_INVALID 113
+#define PLL_ERROR_TIPDATA_ILLEGALSTATE 114
+#define PLL_ERROR_TIPDATA_ILLEGALFUNCTION 115
+#define PLL_ERROR_INVAR_INCOMPAT 117
+#define PLL_ERROR_INVAR_PROPORTION 118
+#define PLL_ERROR_INVAR_PARAMINDEX 119
+#define PLL_ERROR_INVAR_NONEFOUND 120
+#define PLL_ERROR_AB_INVALIDMETHOD 121
+#define PLL_ERROR_AB_NOSUPPORT 122
+#define PLL_ERROR_EINVAL 130
+/* new codes of this library, outside the reference's range */
+#define PLL_ERROR_HIP_NODEVICE 200
+#define PLL_ERROR_HIP_RUNTIME 201
+#define PLL_ERROR_HIP_UNSUPPORTED 202
+
+#define PLL_GAMMA_RATES_MEAN 0
+#define PLL_GAMMA_RATES_MEDIAN 1
+
+/* ---- data types: field order and types are the reference ABI ---- */
+
+/* pll.h:202-244.  Clients read these fields directly, so the layout is frozen.
+ * The device state hangs off a private tail allocated behind this struct. */
+typedef struct pll_partition
+{
+  unsigned int tips;
+  unsigned int clv_buffers;
+  unsigned int states;
+  unsigned int sites;
+  unsigned int pattern_weight_sum;
+  unsigned int rate_matrices;
+  unsigned int prob_matrices;
+  unsigned int rate_cats;
+  unsigned int scale_buffers;
+  unsigned int attributes;
+
+  size_t alignment;
+  unsigned int states_padded;
+
+  double ** clv;                /* host mirrors, NULL until synced        */
+  double ** pmatrix;            /* host mirrors of the device P-matrices  */
+  double * rates;
+  double * rate_weights;
+  double ** subst_params;
+  unsigned int ** scale_buffer; /* host mirrors, NULL until synced        */
+  double ** frequencies;
+  double * prop_invar;
+  int * invariant;
+  unsigned int * pattern_weights;
+
+  int * eigen_decomp_valid;
+  double ** eigenvecs;
+  double ** inv_eigenvecs;
+  double ** eigenvals;
+
+  unsigned int maxstates;
+  unsigned char ** tipchars;    /* host copies of the encoded tip sequences */
+  unsigned char * charmap;
+  double * ttlookup;            /* unused: tip-tip products are formed on the fly */
+  unsigned int * tipmap;
+
+  int asc_bias_alloc;
+} pll_partition_t;
+
+/* pll.h:249-259: one pruning step parent <- (child1, child2) */
+typedef struct pll_operation
+{
+  unsigned int parent_clv_index;
+  int parent_scaler_index;
+  unsigned int child1_clv_index;
+  unsigned int child1_matrix_index;
+  int child1_scaler_index;
+  unsigned int child2_clv_index;
+  unsigned int child2_matrix_index;
+  int child2_scaler_index;
+} pll_operation_t;
+
+/* ---- global data (pll.h:470-522) ---- */
+
+PLL_EXPORT extern __thread int pll_errno;
+PLL_EXPORT extern __thread char pll_errmsg[200];
+
+PLL_EXPORT extern const unsigned int pll_map_bin[256];
+PLL_EXPORT extern const unsigned int pll_map_nt[256];
+PLL_EXPORT extern const unsigned int pll_map_aa[256];
+
+PLL_EXPORT extern const double pll_aa_rates_lg[190];
+PLL_EXPORT extern const double pll_aa_freqs_lg[20];
+PLL_EXPORT extern const double pll_aa_rates_wag[190];
+PLL_EXPORT extern const double pll_aa_freqs_wag[20];
+PLL_EXPORT extern const double pll_aa_rates_jtt[190];
+PLL_EXPORT extern const double pll_aa_freqs_jtt[20];
+PLL_EXPORT extern const double pll_aa_rates_dayhoff[190];
+PLL_EXPORT extern const double pll_aa_freqs_dayhoff[20];
+
+/* ---- partition container (replaces pll.h:530-555) ---- */
+
+PLL_EXPORT pll_partition_t * pll_partition_create(unsigned int tips,
+                                                  unsigned int clv_buffers,
+                                                  unsigned int states,
+                                                  unsigned int sites,
+                                                  unsigned int rate_matrices,
+                                                  unsigned int prob_matrices,
+                                                  unsigned int rate_cats,
+                                                  unsigned int scale_buffers,
+                                                  unsigned int attributes);
+PLL_EXPORT void pll_partition_destroy(pll_partition_t * partition);
+
+PLL_EXPORT int pll_set_tip_states(pll_partition_t * partition,
+                                  unsigned int tip_index,
+                                  const unsigned int * map,
+                                  const char * sequence);
+PLL_EXPORT int pll_set_tip_clv(pll_partition_t * partition,
+                               unsigned int tip_index,
+                               const double * clv,
+                               int padding);
+PLL_EXPORT void pll_set_pattern_weights(pll_partition_t * partition,
+                                        const unsigned int * pattern_weights);
+
+/* ---- model parameters (replaces pll.h:569-597) ---- */
+
+PLL_EXPORT void pll_set_subst_params(pll_partition_t * partition,
+                                     unsigned int params_index,
+                                     const double * params);
+PLL_EXPORT void pll_set_frequencies(pll_partition_t * partition,
+                                    unsigned int params_index,
+                                    const double * frequencies);
+PLL_EXPORT void pll_set_category_rates(pll_partition_t * partition,
+                                       const double * rates);
+PLL_EXPORT void pll_set_category_weights(pll_partition_t * partition,
+                                         const double * rate_weights);
+PLL_EXPORT int pll_update_eigen(pll_partition_t * partition,
+                                unsigned int params_index);
+PLL_EXPORT int pll_update_prob_matrices(pll_partition_t * partition,
+                                        const unsigned int * params_index,
+                                        const unsigned int * matrix_indices,
+                                        const double * branch_lengths,
+                                        unsigned int count);
+PLL_EXPORT unsigned int pll_count_invariant_sites(pll_partition_t * partition,
+                                                  unsigned int * state_inv_count);
+PLL_EXPORT int pll_update_invariant_sites(pll_partition_t * partition);
+PLL_EXPORT int pll_update_invariant_sites_proportion(pll_partition_t * partition,
+                                                     unsigned int params_index,
+                                                     double prop_invar);
+
+PLL_EXPORT void * pll_aligned_alloc(size_t size, size_t alignment);
+PLL_EXPORT void pll_aligned_free(void * ptr);
+
+/* ---- the hot path (replaces pll.h:607-646) ---- */
+
+PLL_EXPORT void pll_update_partials(pll_partition_t * partition,
+                                    const pll_operation_t * operations,
+                                    unsigned int count);
+
+PLL_EXPORT double pll_compute_root_loglikelihood(pll_partition_t * partition,
+                                                 unsigned int clv_index,
+                                                 int scaler_index,
+                                                 const unsigned int * freqs_indices,
+                                                 double * persite_lnl);
+
+PLL_EXPORT double pll_compute_edge_loglikelihood(pll_partition_t * partition,
+                                                 unsigned int parent_clv_index,
+                                                 int parent_scaler_index,
+                                                 unsigned int child_clv_index,
+                                                 int child_scaler_index,
+                                                 unsigned int matrix_index,
+                                                 const unsigned int * freqs_indices,
+                                                 double * persite_lnl);
+
+/* `sumtable` is a caller-owned host buffer as in the reference.  The library
+ * keeps the authoritative copy on the device, keyed by this pointer, and
+ * writes the host buffer only when pll_amd_set_mirror_mode(1) is active or
+ * pll_amd_sync_sumtable is called. */
+PLL_EXPORT int pll_update_sumtable(pll_partition_t * partition,
+                                   unsigned int parent_clv_index,
+                                   unsigned int child_clv_index,
+                                   int parent_scaler_index,
+                                   int child_scaler_index,
+                                   const unsigned int * params_indices,
+                                   double * sumtable);
+
+PLL_EXPORT int pll_compute_likelihood_derivatives(pll_partition_t * partition,
+                                                  int parent_scaler_index,
+                                                  int child_scaler_index,
+                                                  double branch_length,
+                                                  const unsigned int * params_indices,
+                                                  const double * sumtable,
+                                                  double * d_f,
+                                                  double * dd_f);
+
+/* ---- support (replaces pll.h:650-664) ---- */
+
+PLL_EXPORT int pll_compute_gamma_cats(double alpha,
+                                      unsigned int categories,
+                                      double * output_rates,
+                                      int rates_mode);
+PLL_EXPORT void pll_show_pmatrix(const pll_partition_t * partition,
+                                 unsigned int index,
+                                 unsigned int float_precision);
+PLL_EXPORT void pll_show_clv(const pll_partition_t * partition,
+                             unsigned int clv_index,
+                             int scaler_index,
+                             unsigned int float_precision);
+
+/* ---- additions of this library (no reference counterpart) ---- */
+
+/* Device the NEXT pll_partition_create binds to (default: env
+ * PLL_AMD_DEVICE, else LOCAL_RANK, else 0). */
+PLL_EXPORT int pll_amd_set_device(int device);
+PLL_EXPORT int pll_amd_device_count(void);
+
+/* Mirror mode: 1 = after every mutating call copy the touched CLVs, scale
+ * buffers, P-matrices and sumtables back to the host mirrors (lets unmodified
+ * reference programs that peek at partition->clv[] work); 0 (default) = the
+ * host mirrors are refreshed only by the pll_amd_sync_* calls. */
+PLL_EXPORT void pll_amd_set_mirror_mode(int on);
+
+PLL_EXPORT int pll_amd_sync_clv(pll_partition_t * partition, unsigned int clv_index);
+PLL_EXPORT int pll_amd_sync_scaler(pll_partition_t * partition, unsigned int scaler_index);
+PLL_EXPORT int pll_amd_sync_pmatrix(pll_partition_t * partition, unsigned int matrix_index);
+PLL_EXPORT int pll_amd_sync_sumtable(pll_partition_t * partition, double * sumtable);
+/* block until all work enqueued for this partition has finished */
+PLL_EXPORT int pll_amd_wait(pll_partition_t * partition);
+
+/* Site sharding across GPUs (one process per GPU).  After this call every
+ * log-likelihood / derivative result of the partition is summed over the
+ * `nranks` shards with one RCCL all-reduce on the partition's stream.
+ * unique_id: the 128-byte ncclUniqueId obtained from pll_amd_comm_unique_id on
+ * rank 0 and distributed by the caller (e.g. torch.distributed broadcast). */
+PLL_EXPORT int pll_amd_comm_unique_id(void * unique_id_128bytes);
+PLL_EXPORT int pll_amd_comm_init(pll_partition_t * partition, int rank, int nranks,
+                                 const void * unique_id_128bytes);
+
+/* The host eigen solver behind pll_update_eigen, callable without a partition
+ * (and without a GPU): eigen system of the reversible rate matrix given by the
+ * n(n-1)/2 exchangeabilities and n frequencies.  evecs / inv_evecs are n x n
+ * row-major. */
+PLL_EXPORT int pll_amd_eigen_decompose(unsigned int n, const double * subst_params,
+                                       const double * freqs, double * eigenvals,
+                                       double * evecs, double * inv_evecs);
+
+/* HIP-event stopwatch on the partition's stream (bench.py needs the kernel
+ * time of THIS stream; torch.cuda.Event only sees torch's own stream). */
+PLL_EXPORT int pll_amd_timer_start(pll_partition_t * partition);
+PLL_EXPORT int pll_amd_timer_stop_ms(pll_partition_t * partition, float * ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLL_AMD_H_ */

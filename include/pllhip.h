@@ -1,0 +1,186 @@
+/*
+ * pllhip.h -- the thin C-ABI shim between the C host library (pll_* API,
+ * include/pll_amd.h) and the hand-written HIP kernels for gfx950.
+ *
+ * Everything here is `extern "C"`, plain pointers, integers and sizes: no C++
+ * and no torch types cross this boundary.  The host library is the only
+ * intended caller, but the symbols are exported so that a binding from another
+ * language can drive the device directly.
+ *
+ * Each compute entry point replaces one reference "core" routine; the
+ * reference function it stands in for is cited as <file>:<line> relative to
+ * the reference's src/ directory.  All pointers named `h_*` are HOST memory,
+ * read or written synchronously during the call; device memory is never
+ * exposed except through pllhip_dev_* accessors.
+ *
+ * Return value of every int function: 0 on success, otherwise a hipError_t /
+ * ncclResult_t value (>0) or -1 for argument errors; pllhip_last_error()
+ * returns a thread-local description.
+ */
+#ifndef PLLHIP_H_
+#define PLLHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLLHIP_EXPORT __attribute__((visibility("default")))
+
+typedef struct pllhip_ctx pllhip_ctx_t;
+
+/* Geometry of one partition on one device (reference: the scalar fields of
+ * pll_partition_t, pll.h:202-215, after pll_partition_create, pll.c:399). */
+typedef struct pllhip_shape
+{
+  int device;                 /* HIP device ordinal                        */
+  unsigned int states;        /* 4 = DNA, 20 = AA, anything >= 2 accepted  */
+  unsigned int rate_cats;
+  unsigned int sites;         /* sites held by THIS device (incl. asc-bias extra sites) */
+  unsigned int tips;
+  unsigned int clv_buffers;
+  unsigned int rate_matrices;
+  unsigned int prob_matrices;
+  unsigned int scale_buffers;
+  int pattern_tip;            /* tips are 1-byte codes, not CLVs           */
+  int rate_scalers;           /* per-(site,rate) scalers instead of per-site */
+} pllhip_shape_t;
+
+/* same layout as pll_operation_t (pll.h:249-259) */
+typedef struct pllhip_op
+{
+  unsigned int parent_clv;
+  int parent_scaler;
+  unsigned int child1_clv;
+  unsigned int child1_matrix;
+  int child1_scaler;
+  unsigned int child2_clv;
+  unsigned int child2_matrix;
+  int child2_scaler;
+} pllhip_op_t;
+
+PLLHIP_EXPORT const char * pllhip_last_error(void);
+PLLHIP_EXPORT int pllhip_device_count(int * count);
+
+/* ---- context: owns every device buffer of one partition ---- */
+PLLHIP_EXPORT int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** out);
+PLLHIP_EXPORT void pllhip_ctx_destroy(pllhip_ctx_t * ctx);
+PLLHIP_EXPORT int pllhip_wait(pllhip_ctx_t * ctx);
+
+/* ---- host -> device ---- */
+/* encoded tip sequence, `sites` bytes (pll.c:825-883) */
+PLLHIP_EXPORT int pllhip_put_tipchars(pllhip_ctx_t * ctx, unsigned int tip,
+                                      const unsigned char * h_chars);
+/* tipmap[code] = state bitmask, `maxstates` entries (pll.c:305-325) */
+PLLHIP_EXPORT int pllhip_put_tipmap(pllhip_ctx_t * ctx, const unsigned int * h_tipmap,
+                                    unsigned int maxstates);
+/* a full CLV, sites*rate_cats*states doubles (pll.c:905-1045) */
+PLLHIP_EXPORT int pllhip_put_clv(pllhip_ctx_t * ctx, unsigned int clv_index,
+                                 const double * h_clv);
+/* a tip CLV given as ONE states-vector per site (stride doubles apart),
+ * replicated over the rate categories on the device (pll.c:1001-1020) */
+PLLHIP_EXPORT int pllhip_put_tip_clv_persite(pllhip_ctx_t * ctx, unsigned int clv_index,
+                                             const double * h_site_vectors,
+                                             unsigned int stride);
+PLLHIP_EXPORT int pllhip_put_pattern_weights(pllhip_ctx_t * ctx, const unsigned int * h_w);
+/* NULL clears the invariant-site index array (models.c:558-647) */
+PLLHIP_EXPORT int pllhip_put_invariant(pllhip_ctx_t * ctx, const int * h_invariant);
+PLLHIP_EXPORT int pllhip_put_rates(pllhip_ctx_t * ctx, const double * h_rates,
+                                   const double * h_rate_weights);
+/* eigen system + frequencies + proportion of invariant sites of one rate
+ * matrix; eigenvecs/inv_eigenvecs are states x states row-major
+ * (models.c:251-331) */
+PLLHIP_EXPORT int pllhip_put_model(pllhip_ctx_t * ctx, unsigned int params_index,
+                                   const double * h_eigenvals,
+                                   const double * h_eigenvecs,
+                                   const double * h_inv_eigenvecs,
+                                   const double * h_freqs,
+                                   double prop_invar);
+
+/* ---- device -> host ---- */
+PLLHIP_EXPORT int pllhip_get_clv(pllhip_ctx_t * ctx, unsigned int clv_index, double * h_clv);
+PLLHIP_EXPORT int pllhip_get_scaler(pllhip_ctx_t * ctx, unsigned int scaler_index,
+                                    unsigned int * h_scaler);
+PLLHIP_EXPORT int pllhip_get_pmatrix(pllhip_ctx_t * ctx, unsigned int matrix_index,
+                                     double * h_pmatrix);
+
+/* ---- compute ---- */
+
+/* replaces pll_core_update_pmatrix (core_pmatrix.c:24; AVX2-flag kernels
+ * core_pmatrix_avx.c:42 for 4 states, core_pmatrix_avx2.c:37 for 20).
+ * params_indices has rate_cats entries; the other arrays `count`. */
+PLLHIP_EXPORT int pllhip_update_pmatrices(pllhip_ctx_t * ctx,
+                                          const unsigned int * h_params_indices,
+                                          const unsigned int * h_matrix_indices,
+                                          const double * h_branch_lengths,
+                                          unsigned int count);
+
+/* replaces the op loop of pll_update_partials (partials.c:177) and the three
+ * kernels pll_core_update_partial_{tt,ti,ii} (core_partials.c:82,354,510;
+ * AVX2-flag kernels core_partials_avx.c:366,581,899,1097 and
+ * core_partials_avx2.c:568) including pll_core_create_lookup
+ * (core_partials.c:725).  Ops are executed in list order. */
+PLLHIP_EXPORT int pllhip_update_partials(pllhip_ctx_t * ctx, const pllhip_op_t * h_ops,
+                                         unsigned int count);
+
+/* replaces pll_core_edge_loglikelihood_ii / _ti / _ti_4x4
+ * (core_likelihood.c:726,412,211).  A clv index < tips in pattern-tip mode
+ * selects the tip-inner kernel.  h_persite_lnl may be NULL.  The returned
+ * value is the sum over this device's sites (and, once pllhip_comm_init has
+ * been called, over all ranks). */
+PLLHIP_EXPORT int pllhip_edge_loglikelihood(pllhip_ctx_t * ctx,
+                                            unsigned int parent_clv, int parent_scaler,
+                                            unsigned int child_clv, int child_scaler,
+                                            unsigned int matrix_index,
+                                            const unsigned int * h_freqs_indices,
+                                            double * h_persite_lnl,
+                                            double * h_lnl);
+
+/* replaces pll_core_root_loglikelihood (core_likelihood.c:25) */
+PLLHIP_EXPORT int pllhip_root_loglikelihood(pllhip_ctx_t * ctx,
+                                            unsigned int clv_index, int scaler_index,
+                                            const unsigned int * h_freqs_indices,
+                                            double * h_persite_lnl,
+                                            double * h_lnl);
+
+/* replaces pll_core_update_sumtable_ii / _ti (core_derivatives.c:125,277).
+ * The table stays on the device in slot `slot` (0..PLLHIP_SUMTABLE_SLOTS-1). */
+#define PLLHIP_SUMTABLE_SLOTS 4
+PLLHIP_EXPORT int pllhip_update_sumtable(pllhip_ctx_t * ctx,
+                                         unsigned int parent_clv, int parent_scaler,
+                                         unsigned int child_clv, int child_scaler,
+                                         const unsigned int * h_params_indices,
+                                         unsigned int slot);
+PLLHIP_EXPORT int pllhip_put_sumtable(pllhip_ctx_t * ctx, unsigned int slot,
+                                      const double * h_sumtable);
+PLLHIP_EXPORT int pllhip_get_sumtable(pllhip_ctx_t * ctx, unsigned int slot,
+                                      double * h_sumtable);
+
+/* replaces the site loop of pll_core_likelihood_derivatives
+ * (core_derivatives.c:501; AVX2 kernel core_derivatives_avx2.c:523).
+ * h_diagptable: rate_cats*states*4 doubles built by the host exactly as
+ * core_derivatives.c:560-575 does.  Outputs are derivatives of -lnL. */
+PLLHIP_EXPORT int pllhip_likelihood_derivatives(pllhip_ctx_t * ctx, unsigned int slot,
+                                                const unsigned int * h_params_indices,
+                                                const double * h_diagptable,
+                                                double * h_d_f, double * h_dd_f);
+
+/* ---- multi-GPU: one process per GPU, RCCL sum of the scalar results ---- */
+PLLHIP_EXPORT int pllhip_comm_unique_id(void * id128);
+PLLHIP_EXPORT int pllhip_comm_init(pllhip_ctx_t * ctx, int rank, int nranks,
+                                   const void * id128);
+
+/* ---- HIP-event stopwatch on the context's stream ---- */
+PLLHIP_EXPORT int pllhip_timer_start(pllhip_ctx_t * ctx);
+PLLHIP_EXPORT int pllhip_timer_stop_ms(pllhip_ctx_t * ctx, float * ms);
+
+/* raw device pointer of a CLV (for tools that share HBM buffers, e.g. a
+ * torch tensor wrapped around it); NULL if out of range */
+PLLHIP_EXPORT void * pllhip_dev_clv(pllhip_ctx_t * ctx, unsigned int clv_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLLHIP_H_ */

@@ -1,0 +1,456 @@
+// ctx.hip -- device context of one partition: HBM allocation, host<->device
+// transfers, the HIP-event stopwatch and the RCCL communicator.
+//
+// HBM layout (one allocation per kind, sized for 288 GB parts):
+//   clv_arena     [n_clv][sites][rate_cats][states] f64   site-major, state fastest --
+//                 the reference layout (pll.c:527-541), which is also the coalesced
+//                 one for "one lane per (site,rate)" kernels: a wave touches
+//                 64 * states * 8 contiguous bytes.
+//   scaler_arena  [scale_buffers][sites (* rate_cats)] u32
+//   tipchars      [tips][sites rounded up to 256 B] u8
+//   pmatrix       [prob_matrices][rate_cats][states][states] f64  (KBs; L2-resident)
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <rccl/rccl.h>
+
+#include "ctx.hpp"
+
+static thread_local char g_err[512] = "";
+
+void pllhip_set_error(const char * fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char * pllhip_last_error(void) { return g_err; }
+
+extern "C" int pllhip_device_count(int * count)
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess)
+  {
+    *count = 0;
+    pllhip_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  *count = n;
+  return 0;
+}
+
+template <typename T>
+static int dev_alloc(T ** p, size_t count, bool zero, hipStream_t s)
+{
+  *p = nullptr;
+  if (!count) return 0;
+  HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+  if (zero) HIP_TRY(hipMemsetAsync(*p, 0, count * sizeof(T), s));
+  return 0;
+}
+
+extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** out)
+{
+  *out = nullptr;
+  if (!shape || shape->states < 2 || !shape->rate_cats || !shape->sites)
+  {
+    pllhip_set_error("pllhip_ctx_create: bad shape");
+    return -1;
+  }
+  if (shape->rate_cats > PLLHIP_MAX_RATE_CATS)
+  {
+    pllhip_set_error("pllhip_ctx_create: rate_cats %u > %d unsupported",
+                     shape->rate_cats, PLLHIP_MAX_RATE_CATS);
+    return -1;
+  }
+  if (shape->states > 64)
+  {
+    pllhip_set_error("pllhip_ctx_create: states %u > 64 unsupported", shape->states);
+    return -1;
+  }
+  int ndev = 0;
+  int rc = pllhip_device_count(&ndev);
+  if (rc) return rc;
+  if (shape->device < 0 || shape->device >= ndev)
+  {
+    pllhip_set_error("pllhip_ctx_create: device %d not present (%d visible)",
+                     shape->device, ndev);
+    return (int)hipErrorInvalidDevice;
+  }
+  HIP_TRY(hipSetDevice(shape->device));
+
+  pllhip_ctx * c = new pllhip_ctx();
+  c->sh = *shape;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, shape->device));
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+
+  const size_t S = shape->states, R = shape->rate_cats, N = shape->sites;
+  c->span = S * R;
+  c->clv_elems = N * c->span;
+  c->scaler_elems = shape->rate_scalers ? N * R : N;
+  c->tip_stride = (N + 255) & ~(size_t)255;
+  c->pmat_elems = R * S * S;
+
+  const unsigned int nodes = shape->tips + shape->clv_buffers;
+  const unsigned int first = shape->pattern_tip ? shape->tips : 0;
+  const size_t n_clv = nodes - first;
+
+  // CLVs are zeroed like the reference's (pll.c:525-542); scalers calloc'd (pll.c:800-815)
+  if ((rc = dev_alloc(&c->clv_arena, n_clv * c->clv_elems, true, c->stream))) goto fail;
+  c->clv.assign(nodes, nullptr);
+  for (unsigned int i = first; i < nodes; ++i)
+    c->clv[i] = c->clv_arena + (size_t)(i - first) * c->clv_elems;
+  if (shape->pattern_tip)
+    if ((rc = dev_alloc(&c->tipchars, shape->tips * c->tip_stride, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->scaler_arena, (size_t)shape->scale_buffers * c->scaler_elems,
+                      true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->pmatrix, (size_t)shape->prob_matrices * c->pmat_elems, true,
+                      c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->eigenvals, (size_t)shape->rate_matrices * S, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->eigenvecs, (size_t)shape->rate_matrices * S * S, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->inv_eigenvecs, (size_t)shape->rate_matrices * S * S, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->freqs, (size_t)shape->rate_matrices * S, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->prop_invar, (size_t)shape->rate_matrices, true, c->stream))) goto fail;
+  c->h_prop_invar.assign(shape->rate_matrices, 0.0);
+  if ((rc = dev_alloc(&c->rates, R, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->rate_weights, R, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->pattern_weights, N, false, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->tipmap, (size_t)256, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->block_partials, (size_t)PLLHIP_REDUCE_BLOCKS * 2, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->d_result, (size_t)4, true, c->stream))) goto fail;
+  HIP_TRY(hipHostMalloc((void **)&c->h_result, 4 * sizeof(double), hipHostMallocDefault));
+
+  c->stage_bytes = 64 * 1024 + (size_t)shape->prob_matrices * 16 +
+                   (size_t)(shape->tips + shape->clv_buffers) * sizeof(pllhip_op_t);
+  HIP_TRY(hipHostMalloc(&c->h_stage, c->stage_bytes, hipHostMallocDefault));
+  HIP_TRY(hipMalloc(&c->d_stage, c->stage_bytes));
+
+  {
+    // pattern weights default to 1 (pll.c:773-786)
+    std::vector<unsigned int> ones(N, 1u);
+    HIP_TRY(hipMemcpyAsync(c->pattern_weights, ones.data(), N * sizeof(unsigned int),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  *out = c;
+  return 0;
+
+fail:
+  pllhip_ctx_destroy(c);
+  return rc;
+}
+
+// ---- RCCL, bound lazily so single-GPU users never load the library ----
+struct rccl_api
+{
+  void * handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
+                            ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char * (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static rccl_api g_rccl;
+
+static int rccl_load()
+{
+  if (g_rccl.handle) return 0;
+  void * h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h)
+  {
+    pllhip_set_error("cannot load librccl: %s", dlerror());
+    return -1;
+  }
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+  {
+    pllhip_set_error("librccl lacks an expected symbol");
+    dlclose(h);
+    return -1;
+  }
+  g_rccl.handle = h;
+  return 0;
+}
+
+#define NCCL_TRY(expr)                                                       \
+  do {                                                                       \
+    ncclResult_t r_ = (expr);                                                \
+    if (r_ != ncclSuccess) {                                                 \
+      pllhip_set_error("%s failed: %s", #expr,                               \
+                       g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+      return 1000 + (int)r_;                                                 \
+    }                                                                        \
+  } while (0)
+
+extern "C" int pllhip_comm_unique_id(void * id128)
+{
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (rccl_load()) return -1;
+  ncclUniqueId id;
+  NCCL_TRY(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int pllhip_comm_init(pllhip_ctx_t * c, int rank, int nranks, const void * id128)
+{
+  if (nranks <= 1) { c->nranks = 1; return 0; }
+  if (rccl_load()) return -1;
+  HIP_TRY(hipSetDevice(c->sh.device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm;
+  NCCL_TRY(g_rccl.CommInitRank(&comm, nranks, id, rank));
+  c->comm = (ncclComm *)comm;
+  c->nranks = nranks;
+  return 0;
+}
+
+// sum d_result[0..count) over all ranks, in place, on the context's stream
+int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count)
+{
+  if (c->nranks <= 1 || !c->comm) return 0;
+  NCCL_TRY(g_rccl.AllReduce(c->d_result, c->d_result, count, ncclDouble, ncclSum,
+                            (ncclComm_t)c->comm, c->stream));
+  return 0;
+}
+
+extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->sh.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
+  void * bufs[] = {c->clv_arena, c->tipchars, c->scaler_arena, c->pmatrix, c->eigenvals,
+                   c->eigenvecs, c->inv_eigenvecs, c->freqs, c->prop_invar, c->rates,
+                   c->rate_weights, c->pattern_weights, c->invariant, c->tipmap,
+                   c->block_partials, c->d_result, c->d_persite, c->d_stage,
+                   c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3]};
+  for (void * p : bufs)
+    if (p) (void)hipFree(p);
+  if (c->h_result) (void)hipHostFree(c->h_result);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int pllhip_wait(pllhip_ctx_t * c)
+{
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- transfers.  Host buffers are pageable caller memory, so every copy is
+// followed by a stream sync: the caller may reuse the buffer on return. ----
+static int h2d(pllhip_ctx * c, void * dst, const void * src, size_t bytes)
+{
+  HIP_TRY(hipSetDevice(c->sh.device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int d2h(pllhip_ctx * c, void * dst, const void * src, size_t bytes)
+{
+  HIP_TRY(hipSetDevice(c->sh.device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pllhip_put_tipchars(pllhip_ctx_t * c, unsigned int tip, const unsigned char * h)
+{
+  if (!c->sh.pattern_tip || tip >= c->sh.tips)
+  {
+    pllhip_set_error("pllhip_put_tipchars: tip %u invalid", tip);
+    return -1;
+  }
+  return h2d(c, c->tipchars + (size_t)tip * c->tip_stride, h, c->sh.sites);
+}
+
+extern "C" int pllhip_put_tipmap(pllhip_ctx_t * c, const unsigned int * h, unsigned int maxstates)
+{
+  if (maxstates > 256) { pllhip_set_error("tipmap too large"); return -1; }
+  c->maxstates = maxstates;
+  return h2d(c, c->tipmap, h, maxstates * sizeof(unsigned int));
+}
+
+extern "C" int pllhip_put_clv(pllhip_ctx_t * c, unsigned int idx, const double * h)
+{
+  if (idx >= c->clv.size() || !c->clv[idx])
+  {
+    pllhip_set_error("pllhip_put_clv: index %u has no CLV", idx);
+    return -1;
+  }
+  return h2d(c, c->clv[idx], h, c->clv_elems * sizeof(double));
+}
+
+__global__ void k_replicate_tip_clv(double * __restrict__ clv, const double * __restrict__ v,
+                                    unsigned int sites, unsigned int rate_cats,
+                                    unsigned int states)
+{
+  const size_t total = (size_t)sites * rate_cats * states;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total;
+       t += (size_t)gridDim.x * blockDim.x)
+  {
+    const size_t n = t / ((size_t)rate_cats * states);
+    const unsigned int i = (unsigned int)(t % states);
+    clv[t] = v[n * states + i];
+  }
+}
+
+extern "C" int pllhip_put_tip_clv_persite(pllhip_ctx_t * c, unsigned int idx,
+                                          const double * h, unsigned int stride)
+{
+  if (idx >= c->clv.size() || !c->clv[idx])
+  {
+    pllhip_set_error("pllhip_put_tip_clv_persite: index %u has no CLV", idx);
+    return -1;
+  }
+  const size_t S = c->sh.states, N = c->sh.sites;
+  // stage the compact [sites][states] vectors in the tail of the parent CLV's
+  // own storage?  No: use a temporary so partially written CLVs never alias.
+  double * tmp = nullptr;
+  HIP_TRY(hipSetDevice(c->sh.device));
+  HIP_TRY(hipMalloc((void **)&tmp, N * S * sizeof(double)));
+  int rc = 0;
+  if (stride == S)
+    rc = h2d(c, tmp, h, N * S * sizeof(double));
+  else
+  {
+    hipError_t e = hipMemcpy2DAsync(tmp, S * sizeof(double), h, stride * sizeof(double),
+                                    S * sizeof(double), N, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { pllhip_set_error("hipMemcpy2DAsync: %s", hipGetErrorString(e)); rc = (int)e; }
+  }
+  if (!rc)
+  {
+    const size_t total = c->clv_elems;
+    k_replicate_tip_clv<<<pllhip_stream_grid(c, total, 256), 256, 0, c->stream>>>(
+        c->clv[idx], tmp, c->sh.sites, c->sh.rate_cats, c->sh.states);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { pllhip_set_error("replicate: %s", hipGetErrorString(e)); rc = (int)e; }
+  }
+  (void)hipFree(tmp);
+  return rc;
+}
+
+extern "C" int pllhip_put_pattern_weights(pllhip_ctx_t * c, const unsigned int * h)
+{
+  return h2d(c, c->pattern_weights, h, (size_t)c->sh.sites * sizeof(unsigned int));
+}
+
+extern "C" int pllhip_put_invariant(pllhip_ctx_t * c, const int * h)
+{
+  HIP_TRY(hipSetDevice(c->sh.device));
+  if (!h)
+  {
+    if (c->invariant) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->invariant)); }
+    c->invariant = nullptr;
+    return 0;
+  }
+  if (!c->invariant) HIP_TRY(hipMalloc((void **)&c->invariant, (size_t)c->sh.sites * sizeof(int)));
+  return h2d(c, c->invariant, h, (size_t)c->sh.sites * sizeof(int));
+}
+
+extern "C" int pllhip_put_rates(pllhip_ctx_t * c, const double * r, const double * w)
+{
+  int rc = 0;
+  if (r) rc = h2d(c, c->rates, r, c->sh.rate_cats * sizeof(double));
+  if (!rc && w) rc = h2d(c, c->rate_weights, w, c->sh.rate_cats * sizeof(double));
+  return rc;
+}
+
+extern "C" int pllhip_put_model(pllhip_ctx_t * c, unsigned int pi, const double * evals,
+                                const double * evecs, const double * inv_evecs,
+                                const double * freqs, double prop_invar)
+{
+  if (pi >= c->sh.rate_matrices) { pllhip_set_error("pllhip_put_model: index %u", pi); return -1; }
+  const size_t S = c->sh.states;
+  int rc = 0;
+  if (evals) rc = h2d(c, c->eigenvals + pi * S, evals, S * sizeof(double));
+  if (!rc && evecs) rc = h2d(c, c->eigenvecs + pi * S * S, evecs, S * S * sizeof(double));
+  if (!rc && inv_evecs) rc = h2d(c, c->inv_eigenvecs + pi * S * S, inv_evecs, S * S * sizeof(double));
+  if (!rc && freqs) rc = h2d(c, c->freqs + pi * S, freqs, S * sizeof(double));
+  if (!rc) rc = h2d(c, c->prop_invar + pi, &prop_invar, sizeof(double));
+  c->h_prop_invar[pi] = prop_invar;
+  c->any_prop_invar = false;
+  for (double p : c->h_prop_invar)
+    if (p > 0) c->any_prop_invar = true;
+  return rc;
+}
+
+extern "C" int pllhip_get_clv(pllhip_ctx_t * c, unsigned int idx, double * h)
+{
+  if (idx >= c->clv.size() || !c->clv[idx])
+  {
+    pllhip_set_error("pllhip_get_clv: index %u has no CLV", idx);
+    return -1;
+  }
+  return d2h(c, h, c->clv[idx], c->clv_elems * sizeof(double));
+}
+
+extern "C" int pllhip_get_scaler(pllhip_ctx_t * c, unsigned int idx, unsigned int * h)
+{
+  if (idx >= c->sh.scale_buffers) { pllhip_set_error("pllhip_get_scaler: index %u", idx); return -1; }
+  return d2h(c, h, pllhip_scaler_ptr(c, (int)idx), c->scaler_elems * sizeof(unsigned int));
+}
+
+extern "C" int pllhip_get_pmatrix(pllhip_ctx_t * c, unsigned int idx, double * h)
+{
+  if (idx >= c->sh.prob_matrices) { pllhip_set_error("pllhip_get_pmatrix: index %u", idx); return -1; }
+  return d2h(c, h, pllhip_pmat_ptr(c, idx), c->pmat_elems * sizeof(double));
+}
+
+extern "C" int pllhip_put_sumtable(pllhip_ctx_t * c, unsigned int slot, const double * h)
+{
+  if (slot >= PLLHIP_SUMTABLE_SLOTS) { pllhip_set_error("sumtable slot %u", slot); return -1; }
+  HIP_TRY(hipSetDevice(c->sh.device));
+  if (!c->sumtable[slot]) HIP_TRY(hipMalloc((void **)&c->sumtable[slot], c->clv_elems * sizeof(double)));
+  return h2d(c, c->sumtable[slot], h, c->clv_elems * sizeof(double));
+}
+
+extern "C" int pllhip_get_sumtable(pllhip_ctx_t * c, unsigned int slot, double * h)
+{
+  if (slot >= PLLHIP_SUMTABLE_SLOTS || !c->sumtable[slot])
+  {
+    pllhip_set_error("sumtable slot %u empty", slot);
+    return -1;
+  }
+  return d2h(c, h, c->sumtable[slot], c->clv_elems * sizeof(double));
+}
+
+extern "C" void * pllhip_dev_clv(pllhip_ctx_t * c, unsigned int idx)
+{
+  return idx < c->clv.size() ? (void *)c->clv[idx] : nullptr;
+}
+
+extern "C" int pllhip_timer_start(pllhip_ctx_t * c)
+{
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  return 0;
+}
+
+extern "C" int pllhip_timer_stop_ms(pllhip_ctx_t * c, float * ms)
+{
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}

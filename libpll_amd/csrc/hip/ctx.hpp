@@ -1,0 +1,133 @@
+// ctx.hpp -- internal: device context shared by the .hip translation units.
+// Not installed; the public surface is include/pllhip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "pllhip.h"
+
+#define PLLHIP_MAX_RATE_CATS 64
+#define PLLHIP_REDUCE_BLOCKS 2048 /* upper bound on blocks of a reducing kernel */
+
+struct ncclComm;
+
+struct pllhip_ctx
+{
+  pllhip_shape_t sh;
+  hipStream_t stream = nullptr;
+
+  size_t span = 0;         // states * rate_cats doubles per site
+  size_t clv_elems = 0;    // sites * span
+  size_t scaler_elems = 0; // sites (per-site mode) or sites * rate_cats
+  size_t tip_stride = 0;   // bytes between two tips' code rows
+  size_t pmat_elems = 0;   // rate_cats * states * states
+
+  // HBM-resident partition data
+  double * clv_arena = nullptr;        // all CLVs back to back
+  std::vector<double *> clv;           // [tips + clv_buffers], nullptr for pattern tips
+  unsigned char * tipchars = nullptr;  // [tips][tip_stride]
+  unsigned int * scaler_arena = nullptr;
+  double * pmatrix = nullptr;          // [prob_matrices][rate_cats][states][states]
+  // model, per rate matrix
+  double * eigenvals = nullptr;        // [rate_matrices][states]
+  double * eigenvecs = nullptr;        // [rate_matrices][states*states]
+  double * inv_eigenvecs = nullptr;
+  double * freqs = nullptr;            // [rate_matrices][states]
+  double * prop_invar = nullptr;       // [rate_matrices]
+  double * rates = nullptr;            // [rate_cats]
+  double * rate_weights = nullptr;     // [rate_cats]
+  unsigned int * pattern_weights = nullptr; // [sites]
+  int * invariant = nullptr;           // [sites] or nullptr
+  bool any_prop_invar = false;
+  std::vector<double> h_prop_invar;
+  unsigned int * tipmap = nullptr;     // [256]
+  unsigned int maxstates = 0;
+  double * sumtable[PLLHIP_SUMTABLE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+
+  // reductions: per-block partial sums, then a fixed-order final pass
+  double * block_partials = nullptr;   // [PLLHIP_REDUCE_BLOCKS][2]
+  double * d_result = nullptr;         // [4]
+  double * h_result = nullptr;         // pinned [4]
+  double * d_persite = nullptr;        // [sites], lazily allocated
+
+  // staging for small per-call parameter arrays
+  void * h_stage = nullptr;            // pinned
+  void * d_stage = nullptr;
+  size_t stage_bytes = 0;
+
+  ncclComm * comm = nullptr;
+  int nranks = 1;
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cus = 256;
+};
+
+void pllhip_set_error(const char * fmt, ...);
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      pllhip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                       __FILE__, __LINE__);                                   \
+      return (int)e_;                                                         \
+    }                                                                         \
+  } while (0)
+
+static inline bool pllhip_is_tip(const pllhip_ctx * c, unsigned int clv_index)
+{
+  return c->sh.pattern_tip && clv_index < c->sh.tips;
+}
+
+static inline unsigned int * pllhip_scaler_ptr(const pllhip_ctx * c, int idx)
+{
+  return idx < 0 ? nullptr : c->scaler_arena + (size_t)idx * c->scaler_elems;
+}
+
+static inline const unsigned char * pllhip_tip_ptr(const pllhip_ctx * c, unsigned int tip)
+{
+  return c->tipchars + (size_t)tip * c->tip_stride;
+}
+
+static inline double * pllhip_pmat_ptr(const pllhip_ctx * c, unsigned int idx)
+{
+  return c->pmatrix + (size_t)idx * c->pmat_elems;
+}
+
+// grid size for a streaming kernel: enough blocks to fill 256 CUs several
+// times over, capped so grid-stride loops amortise the per-thread setup
+static inline unsigned int pllhip_stream_grid(const pllhip_ctx * c, size_t items,
+                                              unsigned int block)
+{
+  size_t need = (items + block - 1) / block;
+  size_t cap = (size_t)c->num_cus * 8;
+  if (need < 1) need = 1;
+  return (unsigned int)(need < cap ? need : cap);
+}
+
+// ---- shared between partials.hip and derivatives.hip ----
+struct PartialsArgs
+{
+  double * __restrict__ parent;
+  const double * __restrict__ left;      // inner child "1" (ii only)
+  const double * __restrict__ right;     // inner child (ii: child 2, ti: the inner one)
+  const unsigned char * __restrict__ ltip; // tip child (ti), tip child 1 (tt)
+  const unsigned char * __restrict__ rtip; // tip child 2 (tt)
+  const double * __restrict__ lmat;      // P of left / tip child  [R][S][S]
+  const double * __restrict__ rmat;      // P of right child
+  unsigned int * pscaler;                // may alias nothing else; nullptr = no scaling
+  const unsigned int * lscaler;
+  const unsigned int * rscaler;
+  const unsigned int * __restrict__ tipmap;
+  unsigned int sites, rate_cats, states, maxstates;
+};
+
+enum { SCALE_NONE = 0, SCALE_SITE = 1, SCALE_RATE = 2 };
+
+// kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
+int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode);
+int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);

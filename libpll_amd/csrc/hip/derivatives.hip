@@ -1,0 +1,415 @@
+// derivatives.hip -- branch-length derivative machinery.
+//
+// (1) sumtable   sum[n,k,j] = (sum_m pi_m Vinv[m,j] Pclv[n,k,m]) * (sum_m V[j,m] Cclv[n,k,m])
+//     replaces pll_core_update_sumtable_ii / _ti (core_derivatives.c:125,277;
+//     AVX2-flag kernels core_derivatives_avx.c:25,462, core_derivatives_avx2.c:24,274).
+//     Observation: with A_k[j][m] = pi_m Vinv_k[m][j] and B_k = V_k this is exactly
+//     the CLV update (A.P) (.) (B.C) without scaling, so the sumtable is produced by
+//     the SAME streaming kernels as pll_update_partials (partials.hip), fed with
+//     two small per-category matrices built by k_build_sumtable_mats.  The table
+//     stays in HBM; 384 B per site for 4x4.
+// (2) derivatives  per site (L, L', L'') = sum_k w_k sum_j sum[n,k,j] * diagp[k,j,0..2]
+//     d = sum_n w_n (-L'/L),  dd = sum_n w_n ((L'/L)^2 - L''/L)
+//     replaces the site loop of pll_core_likelihood_derivatives
+//     (core_derivatives.c:501, AVX2 kernel core_derivatives_avx2.c:523).
+//     Streams the table once per Newton iteration: 132 B per site for 4x4.
+//     The (rate_cats x states x 4) diagptable is built by the host with libm exp,
+//     exactly like core_derivatives.c:560-575, and passed in.
+#include "ctx.hpp"
+#include "numerics.hpp"
+
+struct SumMatArgs
+{
+  double * left;   // [R][S][S]  A_k[j][m] = freqs_k[m] * inv_eigenvecs_k[m][j]
+  double * right;  // [R][S][S]  B_k[j][m] = eigenvecs_k[j][m]
+  const double * eigenvecs;
+  const double * inv_eigenvecs;
+  const double * freqs;
+  unsigned int states, rate_cats;
+  unsigned int params_indices[PLLHIP_MAX_RATE_CATS];
+};
+
+__global__ void k_build_sumtable_mats(SumMatArgs a)
+{
+  const unsigned int S = a.states;
+  const unsigned int total = a.rate_cats * S * S;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += gridDim.x * blockDim.x)
+  {
+    const unsigned int k = t / (S * S), j = (t / S) % S, m = t % S;
+    const size_t pi = a.params_indices[k];
+    a.left[t] = a.freqs[pi * S + m] * a.inv_eigenvecs[pi * S * S + m * S + j];
+    a.right[t] = a.eigenvecs[pi * S * S + j * S + m];
+  }
+}
+
+// per-rate scaling mode: bring every category of a site to the site's minimum
+// scaler, capped at 4 steps (core_derivatives.c:100-118,187-191)
+__global__ __launch_bounds__(256) void k_sumtable_rescale(double * __restrict__ sum,
+                                                          const unsigned int * __restrict__ ps,
+                                                          const unsigned int * __restrict__ cs,
+                                                          unsigned int sites, unsigned int R,
+                                                          unsigned int S)
+{
+  for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < sites;
+       n += (size_t)gridDim.x * blockDim.x)
+  {
+    unsigned int mn = 0xffffffffu;
+    for (unsigned int k = 0; k < R; ++k)
+    {
+      unsigned int v = (ps ? ps[n * R + k] : 0) + (cs ? cs[n * R + k] : 0);
+      mn = v < mn ? v : mn;
+    }
+    for (unsigned int k = 0; k < R; ++k)
+    {
+      unsigned int d = (ps ? ps[n * R + k] : 0) + (cs ? cs[n * R + k] : 0) - mn;
+      if (!d) continue;
+      if (d > PLLHIP_SCALE_RATE_MAXDIFF) d = PLLHIP_SCALE_RATE_MAXDIFF;
+      const double f = d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
+      for (unsigned int j = 0; j < S; ++j) sum[(n * R + k) * S + j] *= f;
+    }
+  }
+}
+
+extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
+                                      int parent_scaler, unsigned int child_clv,
+                                      int child_scaler, const unsigned int * h_params_indices,
+                                      unsigned int slot)
+{
+  HIP_TRY(hipSetDevice(c->sh.device));
+  const unsigned int nodes = (unsigned int)c->clv.size();
+  if (slot >= PLLHIP_SUMTABLE_SLOTS || parent_clv >= nodes || child_clv >= nodes ||
+      parent_scaler >= (int)c->sh.scale_buffers || child_scaler >= (int)c->sh.scale_buffers)
+  {
+    pllhip_set_error("pllhip_update_sumtable: index out of range");
+    return -1;
+  }
+  const bool tp = pllhip_is_tip(c, parent_clv), tc = pllhip_is_tip(c, child_clv);
+  if (tp && tc)
+  {
+    // the reference asserts here (derivatives.c:191-195)
+    pllhip_set_error("pllhip_update_sumtable: tip-tip edge has no sumtable");
+    return -1;
+  }
+  if (!c->sumtable[slot])
+    HIP_TRY(hipMalloc((void **)&c->sumtable[slot], c->clv_elems * sizeof(double)));
+
+  const unsigned int S = c->sh.states, R = c->sh.rate_cats;
+  // the two matrix sets live at the start of the staging buffer's device half
+  if (2 * c->pmat_elems * sizeof(double) > c->stage_bytes)
+  {
+    pllhip_set_error("pllhip_update_sumtable: staging buffer too small");
+    return -1;
+  }
+  SumMatArgs m;
+  m.left = (double *)c->d_stage;
+  m.right = m.left + c->pmat_elems;
+  m.eigenvecs = c->eigenvecs;
+  m.inv_eigenvecs = c->inv_eigenvecs;
+  m.freqs = c->freqs;
+  m.states = S;
+  m.rate_cats = R;
+  for (unsigned int k = 0; k < R; ++k)
+  {
+    if (h_params_indices[k] >= c->sh.rate_matrices)
+    {
+      pllhip_set_error("pllhip_update_sumtable: params index out of range");
+      return -1;
+    }
+    m.params_indices[k] = h_params_indices[k];
+  }
+  k_build_sumtable_mats<<<(R * S * S + 255) / 256, 256, 0, c->stream>>>(m);
+  HIP_TRY(hipGetLastError());
+
+  PartialsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.parent = c->sumtable[slot];
+  a.tipmap = c->tipmap;
+  a.sites = c->sh.sites;
+  a.rate_cats = R;
+  a.states = S;
+  a.maxstates = c->maxstates;
+  const unsigned int * ps = nullptr, * cs = nullptr;
+  int kind;
+  if (tp || tc)
+  {
+    // the tip supplies the pi-weighted "left" factor (core_derivatives.c:413-429);
+    // its matrix rows are A_k when the tip is the parent side.  When the tip is
+    // the CHILD, the reference still takes the left factor from the tip and the
+    // eigenvector factor from the inner CLV (derivatives.c:67-78).
+    kind = 1;
+    a.ltip = pllhip_tip_ptr(c, tp ? parent_clv : child_clv);
+    a.right = c->clv[tp ? child_clv : parent_clv];
+    a.lmat = m.left;
+    a.rmat = m.right;
+    ps = pllhip_scaler_ptr(c, tp ? child_scaler : parent_scaler);
+  }
+  else
+  {
+    kind = 0;
+    a.left = c->clv[parent_clv];
+    a.right = c->clv[child_clv];
+    a.lmat = m.left;
+    a.rmat = m.right;
+    ps = pllhip_scaler_ptr(c, parent_scaler);
+    cs = pllhip_scaler_ptr(c, child_scaler);
+  }
+  if (!a.right || (kind == 0 && !a.left))
+  {
+    pllhip_set_error("pllhip_update_sumtable: CLV missing");
+    return -1;
+  }
+  int rc = pllhip_launch_partials(c, a, kind, SCALE_NONE);
+  if (rc) return rc;
+  if (c->sh.rate_scalers && (ps || cs))
+  {
+    k_sumtable_rescale<<<pllhip_stream_grid(c, a.sites, 256), 256, 0, c->stream>>>(
+        c->sumtable[slot], ps, cs, a.sites, R, S);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+struct DerivArgs
+{
+  const double * __restrict__ sumtable;
+  const double * __restrict__ diagp;      // device copy [R][S][4]
+  const double * __restrict__ rate_weights;
+  const double * __restrict__ freqs;
+  const double * __restrict__ prop_invar;
+  const unsigned int * __restrict__ pattern_weights;
+  const int * __restrict__ invariant;
+  double * __restrict__ block_partials;
+  unsigned int sites, rate_cats, states;
+  unsigned int params_indices[PLLHIP_MAX_RATE_CATS];
+};
+
+__device__ __forceinline__ void block_sum2(double v0, double v1, double * __restrict__ out,
+                                           unsigned int nparts)
+{
+  __shared__ double s_wave[2][16];
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    v0 += __shfl_down(v0, off, 64);
+    v1 += __shfl_down(v1, off, 64);
+  }
+  const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (lane == 0) { s_wave[0][wave] = v0; s_wave[1][wave] = v1; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double t0 = 0.0, t1 = 0.0;
+    for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) { t0 += s_wave[0][w]; t1 += s_wave[1][w]; }
+    out[blockIdx.x] = t0;
+    out[nparts + blockIdx.x] = t1;
+  }
+}
+
+// one lane per (site, rate); RC lanes of a site combine with __shfl
+template <int RC>
+__global__ __launch_bounds__(256) void k_derivatives(DerivArgs a)
+{
+  extern __shared__ double s_diag[]; // [RC][S][4]
+  const unsigned int S = a.states;
+  for (unsigned int t = threadIdx.x; t < RC * S * 4; t += blockDim.x) s_diag[t] = a.diagp[t];
+  __syncthreads();
+  const unsigned int k = threadIdx.x & (RC - 1);
+  const double * dg = s_diag + k * S * 4;
+  const unsigned int pi = a.params_indices[k];
+  const double pinv = a.prop_invar[pi];
+  const double w = a.rate_weights[k];
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int grp0 = lane & ~(unsigned int)(RC - 1);
+
+  double acc_d = 0.0, acc_dd = 0.0;
+  const size_t total = (size_t)a.sites * RC;
+  const size_t total_up = (total + 63) & ~(size_t)63;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  {
+    const bool act = e < total;
+    const size_t ec = act ? e : 0;
+    const size_t n = ec / RC;
+    const double * sm = a.sumtable + ec * S;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    for (unsigned int j = 0; j < S; ++j)
+    {
+      const double s = sm[j];
+      c0 = fma(s, dg[j * 4 + 0], c0);
+      c1 = fma(s, dg[j * 4 + 1], c1);
+      c2 = fma(s, dg[j * 4 + 2], c2);
+    }
+    if (pinv > 0.0)
+    {
+      // core_derivatives.c:481-491
+      const int inv = a.invariant ? a.invariant[n] : -1;
+      const double inv_lk = (inv == -1) ? 0.0 : a.freqs[(size_t)pi * S + inv] * pinv;
+      c0 = c0 * (1.0 - pinv) + inv_lk;
+      c1 = c1 * (1.0 - pinv);
+      c2 = c2 * (1.0 - pinv);
+    }
+    c0 *= w; c1 *= w; c2 *= w;
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RC; ++i)
+    {
+      l0 += __shfl(c0, (int)(grp0 + i), 64);
+      l1 += __shfl(c1, (int)(grp0 + i), 64);
+      l2 += __shfl(c2, (int)(grp0 + i), 64);
+    }
+    if (act && k == 0)
+    {
+      const double d1 = -l1 / l0;
+      const double d2 = d1 * d1 - l2 / l0;
+      const double pw = (double)a.pattern_weights[n];
+      acc_d += pw * d1;
+      acc_dd += pw * d2;
+    }
+  }
+  block_sum2(acc_d, acc_dd, a.block_partials, gridDim.x);
+}
+
+// any rate_cats: one lane per site
+__global__ __launch_bounds__(128) void k_derivatives_gen(DerivArgs a)
+{
+  const unsigned int S = a.states, R = a.rate_cats;
+  double acc_d = 0.0, acc_dd = 0.0;
+  for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < a.sites;
+       n += (size_t)gridDim.x * blockDim.x)
+  {
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+    for (unsigned int k = 0; k < R; ++k)
+    {
+      const double * sm = a.sumtable + (n * R + k) * S;
+      const double * dg = a.diagp + (size_t)k * S * 4;
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+      for (unsigned int j = 0; j < S; ++j)
+      {
+        c0 += sm[j] * dg[j * 4 + 0];
+        c1 += sm[j] * dg[j * 4 + 1];
+        c2 += sm[j] * dg[j * 4 + 2];
+      }
+      const unsigned int pi = a.params_indices[k];
+      const double pinv = a.prop_invar[pi];
+      if (pinv > 0.0)
+      {
+        const int inv = a.invariant ? a.invariant[n] : -1;
+        const double inv_lk = (inv == -1) ? 0.0 : a.freqs[(size_t)pi * S + inv] * pinv;
+        c0 = c0 * (1.0 - pinv) + inv_lk;
+        c1 = c1 * (1.0 - pinv);
+        c2 = c2 * (1.0 - pinv);
+      }
+      l0 += c0 * a.rate_weights[k];
+      l1 += c1 * a.rate_weights[k];
+      l2 += c2 * a.rate_weights[k];
+    }
+    const double d1 = -l1 / l0;
+    const double d2 = d1 * d1 - l2 / l0;
+    const double pw = (double)a.pattern_weights[n];
+    acc_d += pw * d1;
+    acc_dd += pw * d2;
+  }
+  block_sum2(acc_d, acc_dd, a.block_partials, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void k_final_sum2(const double * __restrict__ parts,
+                                                    unsigned int nparts,
+                                                    double * __restrict__ result)
+{
+  __shared__ double s[2][256];
+  double v0 = 0.0, v1 = 0.0;
+  for (unsigned int i = threadIdx.x; i < nparts; i += 256)
+  {
+    v0 += parts[i];
+    v1 += parts[nparts + i];
+  }
+  s[0][threadIdx.x] = v0;
+  s[1][threadIdx.x] = v1;
+  __syncthreads();
+  for (unsigned int w = 128; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w)
+    {
+      s[0][threadIdx.x] += s[0][threadIdx.x + w];
+      s[1][threadIdx.x] += s[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { result[0] = s[0][0]; result[1] = s[1][0]; }
+}
+
+extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot,
+                                             const unsigned int * h_params_indices,
+                                             const double * h_diagptable, double * h_d_f,
+                                             double * h_dd_f)
+{
+  HIP_TRY(hipSetDevice(c->sh.device));
+  if (slot >= PLLHIP_SUMTABLE_SLOTS || !c->sumtable[slot])
+  {
+    pllhip_set_error("pllhip_likelihood_derivatives: sumtable slot %u empty", slot);
+    return -1;
+  }
+  const unsigned int S = c->sh.states, R = c->sh.rate_cats;
+  const size_t dbytes = (size_t)R * S * 4 * sizeof(double);
+  if (dbytes > c->stage_bytes)
+  {
+    pllhip_set_error("pllhip_likelihood_derivatives: diagptable too large");
+    return -1;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream)); // staging buffer free?
+  memcpy(c->h_stage, h_diagptable, dbytes);
+  HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, dbytes, hipMemcpyHostToDevice, c->stream));
+
+  DerivArgs a;
+  a.sumtable = c->sumtable[slot];
+  a.diagp = (const double *)c->d_stage;
+  a.rate_weights = c->rate_weights;
+  a.freqs = c->freqs;
+  a.prop_invar = c->prop_invar;
+  a.pattern_weights = c->pattern_weights;
+  a.invariant = c->invariant;
+  a.block_partials = c->block_partials;
+  a.sites = c->sh.sites;
+  a.rate_cats = R;
+  a.states = S;
+  for (unsigned int k = 0; k < R; ++k)
+  {
+    if (h_params_indices[k] >= c->sh.rate_matrices)
+    {
+      pllhip_set_error("pllhip_likelihood_derivatives: params index out of range");
+      return -1;
+    }
+    a.params_indices[k] = h_params_indices[k];
+  }
+  unsigned int grid;
+  if (R == 1 || R == 2 || R == 4 || R == 8 || R == 16)
+  {
+    grid = pllhip_stream_grid(c, (size_t)a.sites * R, 256);
+    if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    switch (R)
+    {
+      case 1: k_derivatives<1><<<grid, 256, dbytes, c->stream>>>(a); break;
+      case 2: k_derivatives<2><<<grid, 256, dbytes, c->stream>>>(a); break;
+      case 4: k_derivatives<4><<<grid, 256, dbytes, c->stream>>>(a); break;
+      case 8: k_derivatives<8><<<grid, 256, dbytes, c->stream>>>(a); break;
+      default: k_derivatives<16><<<grid, 256, dbytes, c->stream>>>(a); break;
+    }
+  }
+  else
+  {
+    grid = pllhip_stream_grid(c, a.sites, 128);
+    if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    k_derivatives_gen<<<grid, 128, 0, c->stream>>>(a);
+  }
+  HIP_TRY(hipGetLastError());
+  k_final_sum2<<<1, 256, 0, c->stream>>>(c->block_partials, grid, c->d_result);
+  HIP_TRY(hipGetLastError());
+  int rc = pllhip_allreduce_result(c, 2);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *h_d_f = c->h_result[0];
+  *h_dd_f = c->h_result[1];
+  return 0;
+}

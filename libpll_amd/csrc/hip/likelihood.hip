@@ -1,0 +1,504 @@
+// likelihood.hip -- per-site log-likelihood at an edge (or at a root CLV) and
+// its sum over sites.
+//
+// Replaces pll_core_edge_loglikelihood_ii (core_likelihood.c:726; AVX2-flag
+// kernels core_likelihood_avx.c:1079 for 4 states, core_likelihood_avx2.c:333
+// for 20), _ti_4x4 / _ti (core_likelihood.c:211,412; core_likelihood_avx.c:191,
+// core_likelihood_avx2.c:111) and pll_core_root_loglikelihood
+// (core_likelihood.c:25).
+//
+// Mapping: one lane per (site, rate) like the CLV update; the rate_cats lanes
+// of a site exchange their category terms with __shfl and the lane of category
+// 0 adds them in category order (the reference's order), takes the log, applies
+// scalers and the pattern weight.  HBM traffic per site: two CLVs + two scalers
+// + one weight (268 B for 4x4), nothing written unless persite_lnl is asked for.
+//
+// Site sum: per-lane running sums -> wave __shfl_down tree -> LDS -> one double
+// per workgroup -> a second one-workgroup kernel adds the workgroup values in a
+// fixed order, so the result is reproducible run to run (the reference adds
+// sites sequentially; agreement is ~1e-16*sqrt(sites) relative).
+#include "ctx.hpp"
+#include "numerics.hpp"
+
+struct LnlArgs
+{
+  const double * __restrict__ parent;   // CLV carrying the frequencies side
+  const double * __restrict__ child;    // inner child CLV (ii)
+  const unsigned char * __restrict__ tip; // tip child codes (ti)
+  const unsigned int * __restrict__ pscaler;
+  const unsigned int * __restrict__ cscaler;
+  const double * __restrict__ pmat;     // [R][S][S]
+  const double * __restrict__ freqs;    // [rate_matrices][S]
+  const double * __restrict__ prop_invar; // [rate_matrices]
+  const double * __restrict__ rate_weights;
+  const unsigned int * __restrict__ pattern_weights;
+  const int * __restrict__ invariant;   // nullable
+  const unsigned int * __restrict__ tipmap;
+  double * __restrict__ persite;        // nullable
+  double * __restrict__ block_partials; // [gridDim.x]
+  unsigned int sites, rate_cats, states, maxstates;
+  int rate_scalers;
+  unsigned int freqs_indices[PLLHIP_MAX_RATE_CATS];
+};
+
+enum { EDGE_II = 0, EDGE_TI = 1, ROOT = 2 };
+
+// (2^-256)^d for d = 1..4, exact powers of two (core_likelihood_avx.c:1119-1128)
+__device__ __forceinline__ double scale_minlh(unsigned int d)
+{
+  return d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
+}
+
+__device__ __forceinline__ double block_sum_to_partials(double v, double * __restrict__ out)
+{
+  __shared__ double s_wave[16];
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (lane == 0) s_wave[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double t = 0.0;
+    for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) t += s_wave[w];
+    out[blockIdx.x] = t;
+  }
+  return v;
+}
+
+// sums `nparts` workgroup values of `ncomp` interleaved components in fixed order
+__global__ __launch_bounds__(256) void k_final_sum(const double * __restrict__ parts,
+                                                   unsigned int nparts, unsigned int ncomp,
+                                                   double * __restrict__ result)
+{
+  __shared__ double s[256];
+  for (unsigned int comp = 0; comp < ncomp; ++comp)
+  {
+    double v = 0.0;
+    for (unsigned int i = threadIdx.x; i < nparts; i += 256) v += parts[(size_t)comp * nparts + i];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (unsigned int w = 128; w > 0; w >>= 1)
+    {
+      if (threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) result[comp] = s[0];
+    __syncthreads();
+  }
+}
+
+// category term -> weighted contribution (core_likelihood_avx.c:1219-1240)
+template <bool GUARD_POSITIVE>
+__device__ __forceinline__ double category_term(const LnlArgs & a, double terma_r,
+                                                unsigned int k, size_t n, unsigned int rel_scale)
+{
+  if (rel_scale > 0) terma_r *= scale_minlh(rel_scale);
+  if (GUARD_POSITIVE && !(terma_r > 0.0)) return 0.0;
+  const unsigned int fi = a.freqs_indices[k];
+  const double pinv = a.prop_invar[fi];
+  const double w = a.rate_weights[k];
+  if (pinv > 0.0)
+  {
+    const int inv = a.invariant ? a.invariant[n] : -1;
+    const double inv_lk = (inv == -1) ? 0.0 : a.freqs[(size_t)fi * a.states + inv];
+    return w * (terma_r * (1.0 - pinv) + inv_lk * pinv);
+  }
+  return terma_r * w;
+}
+
+__device__ __forceinline__ double site_loglk(const LnlArgs & a, double terma, size_t n,
+                                             unsigned int site_scalings)
+{
+  double lk = log(terma);
+  if (site_scalings) lk += (double)site_scalings * log(PLLHIP_SCALE_THRESHOLD);
+  lk *= (double)a.pattern_weights[n];
+  if (a.persite) a.persite[n] = lk;
+  return lk;
+}
+
+// Per-(site,rate) kernels.  KIND: EDGE_II / EDGE_TI / ROOT;  S4: 4-state vs 20-state
+template <int RC, int KIND, bool S4>
+__global__ __launch_bounds__(256) void k_lnl_fast(LnlArgs a)
+{
+  constexpr unsigned int S = S4 ? 4 : 20;
+  extern __shared__ double smem[];
+  const unsigned int k = threadIdx.x & (RC - 1);
+  const unsigned int fi = a.freqs_indices[k];
+  const double * __restrict__ fr = a.freqs + (size_t)fi * S;
+
+  // stage what every lane of the workgroup shares
+  //   ii: the R P-matrices;  ti: pi-weighted tip row sums per code;  root: nothing
+  double * sm = smem;
+  const unsigned int ncodes = S4 ? 16u : a.maxstates;
+  if (KIND == EDGE_II)
+  {
+    for (unsigned int t = threadIdx.x; t < RC * S * S; t += blockDim.x) sm[t] = a.pmat[t];
+  }
+  else if (KIND == EDGE_TI)
+  {
+    for (unsigned int t = threadIdx.x; t < ncodes * RC * S; t += blockDim.x)
+    {
+      const unsigned int code = t / (RC * S), kk = (t / S) % RC, j = t % S;
+      const double * row = a.pmat + ((size_t)kk * S + j) * S;
+      const double f = a.freqs[(size_t)a.freqs_indices[kk] * S + j];
+      // 4 states: freqs * rowsum (core_likelihood_avx.c:291-301);
+      // 20 states: rowsum * freqs (core_likelihood_avx2.c:225)
+      sm[t] = S4 ? f * masksum4(row, code) : masksum_seq(row, a.tipmap[code], S) * f;
+    }
+  }
+  __syncthreads();
+
+  double acc = 0.0;
+  const size_t total = (size_t)a.sites * RC;
+  const size_t total_up = (total + 63) & ~(size_t)63;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int grp0 = lane & ~(unsigned int)(RC - 1);
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  {
+    const bool act = e < total;
+    const size_t ec = act ? e : 0;
+    const size_t n = ec / RC;
+    const double * pc = a.parent + (size_t)S * ec;
+
+    double terma_r;
+    if (S4)
+    {
+      const double2 * P2 = reinterpret_cast<const double2 *>(pc);
+      const double2 p01 = P2[0], p23 = P2[1];
+      double t0, t1, t2, t3;
+      if (KIND == EDGE_II)
+      {
+        const double2 * C2 = reinterpret_cast<const double2 *>(a.child + (size_t)S * ec);
+        const double2 c01 = C2[0], c23 = C2[1];
+        const double * m = sm + k * 16;
+        // row dot, x pi, x parent (core_likelihood_avx.c:1175-1213)
+        t0 = (fr[0] * dot4(m + 0, c01.x, c01.y, c23.x, c23.y)) * p01.x;
+        t1 = (fr[1] * dot4(m + 4, c01.x, c01.y, c23.x, c23.y)) * p01.y;
+        t2 = (fr[2] * dot4(m + 8, c01.x, c01.y, c23.x, c23.y)) * p23.x;
+        t3 = (fr[3] * dot4(m + 12, c01.x, c01.y, c23.x, c23.y)) * p23.y;
+      }
+      else if (KIND == EDGE_TI)
+      {
+        const unsigned int code = a.tip[n] & 15u;
+        const double * m = sm + (code * RC + k) * 4;
+        t0 = m[0] * p01.x; t1 = m[1] * p01.y; t2 = m[2] * p23.x; t3 = m[3] * p23.y;
+      }
+      else
+      {
+        t0 = fr[0] * p01.x; t1 = fr[1] * p01.y; t2 = fr[2] * p23.x; t3 = fr[3] * p23.y;
+      }
+      terma_r = pairsum4(t0, t1, t2, t3);
+    }
+    else
+    {
+      double P[20];
+      {
+        const double2 * q = reinterpret_cast<const double2 *>(pc);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { const double2 t = q[j]; P[2 * j] = t.x; P[2 * j + 1] = t.y; }
+      }
+      const dview Pv{P};
+      if (KIND == EDGE_II)
+      {
+        double C[20];
+        const double2 * q = reinterpret_cast<const double2 *>(a.child + (size_t)S * ec);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { const double2 t = q[j]; C[2 * j] = t.x; C[2 * j + 1] = t.y; }
+        const dview Cv{C};
+        const double * m = sm + k * 400;
+        // core_likelihood_avx2.c:432-502: chunks of 4 rows, chunk sums added in order
+        terma_r = 0.0;
+#pragma unroll
+        for (int j = 0; j < 20; j += 4)
+        {
+          double t[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            t[r] = (dot_strided4<true>(m + (j + r) * 20, Cv, 20) * fr[j + r]) * P[j + r];
+          terma_r += pairsum4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      else if (KIND == EDGE_TI)
+      {
+        unsigned int code = a.tip[n];
+        if (code >= a.maxstates) code = 0;
+        // core_likelihood_avx2.c:262-276: fused strided dot of lookup . parent
+        terma_r = dot_strided4<true>(sm + ((size_t)code * RC + k) * 20, Pv, 20);
+      }
+      else
+      {
+        terma_r = 0.0;
+        for (int j = 0; j < 20; ++j) terma_r += P[j] * fr[j];
+      }
+    }
+
+    // scalers: per-site count, or per-rate counts reduced to min + capped rest
+    unsigned int site_scalings = 0, rel = 0;
+    if (a.rate_scalers)
+    {
+      unsigned int mine = 0;
+      if (KIND != ROOT)
+      {
+        if (a.pscaler) mine += a.pscaler[ec];
+        if (KIND == EDGE_II && a.cscaler) mine += a.cscaler[ec];
+      }
+      unsigned int mn = mine;
+      for (unsigned int off = 1; off < RC; off <<= 1)
+      {
+        const unsigned int o = (unsigned int)__shfl_xor((int)mn, (int)off, 64);
+        mn = o < mn ? o : mn;
+      }
+      site_scalings = mn;
+      rel = mine - mn;
+      if (rel > PLLHIP_SCALE_RATE_MAXDIFF) rel = PLLHIP_SCALE_RATE_MAXDIFF;
+      if (KIND == ROOT)
+      {
+        // the root kernel ignores per-rate scalers and reads scaler[n] only
+        // (core_likelihood.c:197-198)
+        site_scalings = a.pscaler ? a.pscaler[n] : 0;
+        rel = 0;
+      }
+    }
+    else
+    {
+      if (a.pscaler) site_scalings += a.pscaler[n];
+      if (KIND == EDGE_II && a.cscaler) site_scalings += a.cscaler[n];
+    }
+
+    const double contrib = (S4 && KIND != ROOT) ? category_term<true>(a, terma_r, k, n, rel)
+                                                : category_term<false>(a, terma_r, k, n, rel);
+    // category 0's lane adds the RC contributions in category order
+    double terma = 0.0;
+#pragma unroll
+    for (int i = 0; i < RC; ++i) terma += __shfl(contrib, (int)(grp0 + i), 64);
+    if (act && k == 0) acc += site_loglk(a, terma, n, site_scalings);
+  }
+  block_sum_to_partials(acc, a.block_partials);
+}
+
+// any states / any rate_cats: one lane per site
+template <int KIND>
+__global__ __launch_bounds__(128) void k_lnl_gen(LnlArgs a)
+{
+  const unsigned int S = a.states, R = a.rate_cats;
+  double acc = 0.0;
+  for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < a.sites;
+       n += (size_t)gridDim.x * blockDim.x)
+  {
+    unsigned int rs[PLLHIP_MAX_RATE_CATS];
+    unsigned int site_scalings = 0;
+    if (a.rate_scalers && KIND != ROOT)
+    {
+      unsigned int mn = 0xffffffffu;
+      for (unsigned int k = 0; k < R; ++k)
+      {
+        unsigned int v = a.pscaler ? a.pscaler[n * R + k] : 0;
+        if (KIND == EDGE_II && a.cscaler) v += a.cscaler[n * R + k];
+        rs[k] = v;
+        mn = v < mn ? v : mn;
+      }
+      site_scalings = mn;
+      for (unsigned int k = 0; k < R; ++k)
+      {
+        const unsigned int d = rs[k] - mn;
+        rs[k] = d > PLLHIP_SCALE_RATE_MAXDIFF ? PLLHIP_SCALE_RATE_MAXDIFF : d;
+      }
+    }
+    else
+    {
+      for (unsigned int k = 0; k < R; ++k) rs[k] = 0;
+      if (a.pscaler) site_scalings += a.pscaler[n];
+      if (KIND == EDGE_II && a.cscaler) site_scalings += a.cscaler[n];
+    }
+    unsigned int mask = 0;
+    if (KIND == EDGE_TI)
+    {
+      const unsigned int c = a.tip[n];
+      mask = (S == 4) ? c : a.tipmap[c];
+    }
+    double terma = 0.0;
+    for (unsigned int k = 0; k < R; ++k)
+    {
+      const double * fr = a.freqs + (size_t)a.freqs_indices[k] * S;
+      const double * pc = a.parent + (n * R + k) * S;
+      const double * cc = (KIND == EDGE_II) ? a.child + (n * R + k) * S : nullptr;
+      const double * m = a.pmat + (size_t)k * S * S;
+      double terma_r = 0.0;
+      for (unsigned int j = 0; j < S; ++j)
+      {
+        if (KIND == ROOT)
+          terma_r += pc[j] * fr[j];
+        else
+        {
+          double termb = 0.0;
+          if (KIND == EDGE_II)
+            for (unsigned int q = 0; q < S; ++q) termb += m[j * S + q] * cc[q];
+          else
+            for (unsigned int q = 0; q < S; ++q)
+              if ((mask >> q) & 1u) termb += m[j * S + q];
+          terma_r += pc[j] * fr[j] * termb; // core_likelihood.c:955
+        }
+      }
+      terma += category_term<false>(a, terma_r, k, n, rs[k]);
+    }
+    acc += site_loglk(a, terma, n, site_scalings);
+  }
+  block_sum_to_partials(acc, a.block_partials);
+}
+
+#define LAUNCH_LNL(RCV, KINDV)                                                            \
+  do {                                                                                    \
+    if (s4) k_lnl_fast<RCV, KINDV, true><<<grid, 256, lds, c->stream>>>(a);               \
+    else k_lnl_fast<RCV, KINDV, false><<<grid, 256, lds, c->stream>>>(a);                 \
+  } while (0)
+
+#define LAUNCH_LNL_RC(KINDV)                      \
+  do {                                            \
+    switch (R) {                                  \
+      case 1: LAUNCH_LNL(1, KINDV); break;        \
+      case 2: LAUNCH_LNL(2, KINDV); break;        \
+      case 4: LAUNCH_LNL(4, KINDV); break;        \
+      case 8: LAUNCH_LNL(8, KINDV); break;        \
+      default: break;                             \
+    }                                             \
+  } while (0)
+
+static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, double * h_lnl)
+{
+  HIP_TRY(hipSetDevice(c->sh.device));
+  const unsigned int S = c->sh.states, R = c->sh.rate_cats;
+  a.freqs = c->freqs;
+  a.prop_invar = c->prop_invar;
+  a.rate_weights = c->rate_weights;
+  a.pattern_weights = c->pattern_weights;
+  a.invariant = c->invariant;
+  a.tipmap = c->tipmap;
+  a.sites = c->sh.sites;
+  a.rate_cats = R;
+  a.states = S;
+  a.maxstates = c->maxstates;
+  a.rate_scalers = c->sh.rate_scalers;
+  a.block_partials = c->block_partials;
+  a.persite = nullptr;
+  if (h_persite)
+  {
+    if (!c->d_persite) HIP_TRY(hipMalloc((void **)&c->d_persite, (size_t)c->sh.sites * sizeof(double)));
+    a.persite = c->d_persite;
+  }
+
+  unsigned int grid;
+  const bool fast = (S == 4 || S == 20) && (R == 1 || R == 2 || R == 4 || R == 8);
+  if (fast)
+  {
+    const bool s4 = (S == 4);
+    grid = pllhip_stream_grid(c, (size_t)a.sites * R, 256);
+    if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    size_t lds = 0;
+    if (kind == EDGE_II) lds = (size_t)R * S * S * sizeof(double);
+    if (kind == EDGE_TI) lds = (size_t)(s4 ? 16u : c->maxstates) * R * S * sizeof(double);
+    if (kind == EDGE_II) LAUNCH_LNL_RC(EDGE_II);
+    if (kind == EDGE_TI) LAUNCH_LNL_RC(EDGE_TI);
+    if (kind == ROOT) LAUNCH_LNL_RC(ROOT);
+  }
+  else
+  {
+    grid = pllhip_stream_grid(c, a.sites, 128);
+    if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    if (kind == EDGE_II) k_lnl_gen<EDGE_II><<<grid, 128, 0, c->stream>>>(a);
+    if (kind == EDGE_TI) k_lnl_gen<EDGE_TI><<<grid, 128, 0, c->stream>>>(a);
+    if (kind == ROOT) k_lnl_gen<ROOT><<<grid, 128, 0, c->stream>>>(a);
+  }
+  HIP_TRY(hipGetLastError());
+  k_final_sum<<<1, 256, 0, c->stream>>>(c->block_partials, grid, 1, c->d_result);
+  HIP_TRY(hipGetLastError());
+  int rc = pllhip_allreduce_result(c, 1);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (h_persite)
+    HIP_TRY(hipMemcpyAsync(h_persite, c->d_persite, (size_t)c->sh.sites * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *h_lnl = c->h_result[0];
+  return 0;
+}
+
+static int fill_freqs_indices(pllhip_ctx * c, LnlArgs & a, const unsigned int * h)
+{
+  for (unsigned int k = 0; k < c->sh.rate_cats; ++k)
+  {
+    if (h[k] >= c->sh.rate_matrices)
+    {
+      pllhip_set_error("freqs index %u out of range", h[k]);
+      return -1;
+    }
+    a.freqs_indices[k] = h[k];
+  }
+  return 0;
+}
+
+extern "C" int pllhip_edge_loglikelihood(pllhip_ctx_t * c, unsigned int parent_clv,
+                                         int parent_scaler, unsigned int child_clv,
+                                         int child_scaler, unsigned int matrix_index,
+                                         const unsigned int * h_freqs_indices,
+                                         double * h_persite_lnl, double * h_lnl)
+{
+  const unsigned int nodes = (unsigned int)c->clv.size();
+  if (parent_clv >= nodes || child_clv >= nodes || matrix_index >= c->sh.prob_matrices ||
+      parent_scaler >= (int)c->sh.scale_buffers || child_scaler >= (int)c->sh.scale_buffers)
+  {
+    pllhip_set_error("pllhip_edge_loglikelihood: index out of range");
+    return -1;
+  }
+  LnlArgs a;
+  memset(&a, 0, sizeof(a));
+  if (fill_freqs_indices(c, a, h_freqs_indices)) return -1;
+  a.pmat = pllhip_pmat_ptr(c, matrix_index);
+  const bool tp = pllhip_is_tip(c, parent_clv), tc = pllhip_is_tip(c, child_clv);
+  if (tp && tc)
+  {
+    pllhip_set_error("pllhip_edge_loglikelihood: both ends are pattern tips");
+    return -1;
+  }
+  int kind;
+  if (tp || tc)
+  {
+    // the inner node plays "parent", only its scaler counts (likelihood.c:489-501)
+    kind = EDGE_TI;
+    a.parent = c->clv[tp ? child_clv : parent_clv];
+    a.pscaler = pllhip_scaler_ptr(c, tp ? child_scaler : parent_scaler);
+    a.tip = pllhip_tip_ptr(c, tp ? parent_clv : child_clv);
+    if (c->sh.states != 4 && c->maxstates == 0)
+    {
+      pllhip_set_error("pllhip_edge_loglikelihood: tipmap not uploaded");
+      return -1;
+    }
+  }
+  else
+  {
+    kind = EDGE_II;
+    a.parent = c->clv[parent_clv];
+    a.child = c->clv[child_clv];
+    a.pscaler = pllhip_scaler_ptr(c, parent_scaler);
+    a.cscaler = pllhip_scaler_ptr(c, child_scaler);
+  }
+  return run_lnl(c, a, kind, h_persite_lnl, h_lnl);
+}
+
+extern "C" int pllhip_root_loglikelihood(pllhip_ctx_t * c, unsigned int clv_index,
+                                         int scaler_index, const unsigned int * h_freqs_indices,
+                                         double * h_persite_lnl, double * h_lnl)
+{
+  if (clv_index >= c->clv.size() || !c->clv[clv_index] ||
+      scaler_index >= (int)c->sh.scale_buffers)
+  {
+    pllhip_set_error("pllhip_root_loglikelihood: index out of range");
+    return -1;
+  }
+  LnlArgs a;
+  memset(&a, 0, sizeof(a));
+  if (fill_freqs_indices(c, a, h_freqs_indices)) return -1;
+  a.parent = c->clv[clv_index];
+  a.pscaler = pllhip_scaler_ptr(c, scaler_index);
+  return run_lnl(c, a, ROOT, h_persite_lnl, h_lnl);
+}

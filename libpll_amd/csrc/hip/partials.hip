@@ -1,0 +1,600 @@
+// partials.hip -- Felsenstein pruning: parent CLV <- (P_l . left) (.) (P_r . right)
+//
+// Replaces pll_update_partials' op loop (partials.c:177) and the kernels
+//   inner-inner  pll_core_update_partial_ii  core_partials.c:510
+//                AVX2-flag path: 4 states core_partials_avx.c:366, 20 states core_partials_avx2.c:568
+//   tip-inner    pll_core_update_partial_ti  core_partials.c:354
+//                AVX2-flag path: core_partials_avx.c:899 (4), :1097 (20)
+//   tip-tip      pll_core_create_lookup + pll_core_update_partial_tt
+//                core_partials.c:725,82; AVX2-flag path core_partials_avx.c:262,146,581,531
+//
+// Mapping: one lane per (site, rate category).  CLVs are [site][rate][state]
+// with state fastest, so lane e reads bytes [e*8*S, (e+1)*8*S): a wave streams
+// 64*8*S contiguous bytes per child with 16-byte loads.  The P-matrices of the
+// lane's rate category sit in VGPRs (4 states: 2 x 16 doubles, loaded once per
+// lane and reused over the grid-stride loop) or in LDS (20+ states).
+// Per-site scaling needs "all rate_cats x states entries < 2^-256": each lane
+// tests its own states, then one __ballot gives every lane the bits of its
+// rate_cats neighbours (rate_cats is a power of two <= 16 in the fast kernels,
+// so a site never straddles a wave).
+//
+// Roofline: pure HBM stream.  4 states: 396 B and 240 flop per site-update
+// (0.6 flop/B); nothing but the child CLVs, the parent CLV and 12 B of
+// scalers moves.  Tip lookups (<= 15 KB) live in LDS and are built by the
+// workgroup itself, so a tip-tip op reads 2 B/site and writes the CLV.
+//
+// Arithmetic order is the reference's: see numerics.hpp.
+#include "ctx.hpp"
+#include "numerics.hpp"
+
+
+template <int RC>
+__device__ __forceinline__ bool site_all(bool lane_flag)
+{
+  // true iff lane_flag holds on all RC lanes of this lane's site
+  const unsigned long long b = __ballot(lane_flag);
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int grp = (unsigned int)(b >> (lane & ~(unsigned int)(RC - 1)));
+  const unsigned int full = (RC >= 32) ? 0xffffffffu : ((1u << RC) - 1u);
+  return (grp & full) == full;
+}
+
+template <int MODE, int RC>
+__device__ __forceinline__ void finish4(const PartialsArgs & a, size_t e, bool act, unsigned int k,
+                                        double p0, double p1, double p2, double p3,
+                                        unsigned int base_scale)
+{
+  // scaling rule of core_partials_avx.c:486-527
+  const bool small = (p0 < PLLHIP_SCALE_THRESHOLD) & (p1 < PLLHIP_SCALE_THRESHOLD) &
+                     (p2 < PLLHIP_SCALE_THRESHOLD) & (p3 < PLLHIP_SCALE_THRESHOLD);
+  bool scale = false;
+  if (MODE == SCALE_RATE) scale = small;
+  if (MODE == SCALE_SITE) scale = site_all<RC>(small || !act);
+  if (scale)
+  {
+    p0 *= PLLHIP_SCALE_FACTOR; p1 *= PLLHIP_SCALE_FACTOR;
+    p2 *= PLLHIP_SCALE_FACTOR; p3 *= PLLHIP_SCALE_FACTOR;
+  }
+  if (!act) return;
+  double2 * out = reinterpret_cast<double2 *>(a.parent + 4 * e);
+  out[0] = make_double2(p0, p1);
+  out[1] = make_double2(p2, p3);
+  if (MODE == SCALE_RATE) a.pscaler[e] = base_scale + (scale ? 1u : 0u);
+  if (MODE == SCALE_SITE && k == 0) a.pscaler[e / RC] = base_scale + (scale ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------- 4 states
+
+template <int RC, int MODE>
+__global__ __launch_bounds__(256) void k_dna_ii(PartialsArgs a)
+{
+  const unsigned int k = threadIdx.x & (RC - 1);
+  double pl[16], pr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { pl[i] = a.lmat[k * 16 + i]; pr[i] = a.rmat[k * 16 + i]; }
+
+  const size_t total = (size_t)a.sites * RC;
+  const size_t total_up = (total + 63) & ~(size_t)63;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  {
+    const bool act = e < total;
+    const size_t ec = act ? e : 0;
+    const double2 * L = reinterpret_cast<const double2 *>(a.left + 4 * ec);
+    const double2 * R = reinterpret_cast<const double2 *>(a.right + 4 * ec);
+    const double2 l01 = L[0], l23 = L[1], r01 = R[0], r23 = R[1];
+    unsigned int base = 0;
+    if (MODE != SCALE_NONE)
+    {
+      const size_t si = (MODE == SCALE_RATE) ? ec : ec / RC;
+      if (a.lscaler) base += a.lscaler[si];
+      if (a.rscaler) base += a.rscaler[si];
+    }
+    double p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      p[i] = dot4(pl + 4 * i, l01.x, l01.y, l23.x, l23.y) *
+             dot4(pr + 4 * i, r01.x, r01.y, r23.x, r23.y);
+    finish4<MODE, RC>(a, e, act, k, p[0], p[1], p[2], p[3], base);
+  }
+}
+
+// row sums of one P-matrix for the 16 DNA ambiguity codes, in LDS:
+// tab[(code * RC + k) * 4 + i] = sum_{j in code} P[k][i][j]
+template <int RC>
+__device__ __forceinline__ void build_tip_table4(double * tab, const double * __restrict__ mat)
+{
+  for (unsigned int t = threadIdx.x; t < 16 * RC * 4; t += blockDim.x)
+  {
+    const unsigned int code = t / (RC * 4), ki = t % (RC * 4);
+    tab[t] = masksum4(mat + ki * 4, code);
+  }
+}
+
+template <int RC, int MODE>
+__global__ __launch_bounds__(256) void k_dna_ti(PartialsArgs a)
+{
+  __shared__ double tab[16 * RC * 4];
+  build_tip_table4<RC>(tab, a.lmat);
+  const unsigned int k = threadIdx.x & (RC - 1);
+  double pr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pr[i] = a.rmat[k * 16 + i];
+  __syncthreads();
+
+  const size_t total = (size_t)a.sites * RC;
+  const size_t total_up = (total + 63) & ~(size_t)63;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  {
+    const bool act = e < total;
+    const size_t ec = act ? e : 0;
+    const double2 * R = reinterpret_cast<const double2 *>(a.right + 4 * ec);
+    const double2 r01 = R[0], r23 = R[1];
+    const unsigned int code = a.ltip[ec / RC] & 15u;
+    unsigned int base = 0;
+    if (MODE != SCALE_NONE && a.rscaler) base = a.rscaler[(MODE == SCALE_RATE) ? ec : ec / RC];
+    const double * tl = tab + (code * RC + k) * 4;
+    double p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = tl[i] * dot4(pr + 4 * i, r01.x, r01.y, r23.x, r23.y);
+    finish4<MODE, RC>(a, e, act, k, p[0], p[1], p[2], p[3], base);
+  }
+}
+
+template <int RC, int MODE>
+__global__ __launch_bounds__(256) void k_dna_tt(PartialsArgs a)
+{
+  // The reference materialises a 256-entry pair table (core_partials_avx.c:262);
+  // the two 16-entry row-sum tables give the same products without it.
+  __shared__ double tabl[16 * RC * 4];
+  __shared__ double tabr[16 * RC * 4];
+  build_tip_table4<RC>(tabl, a.lmat);
+  build_tip_table4<RC>(tabr, a.rmat);
+  __syncthreads();
+  const unsigned int k = threadIdx.x & (RC - 1);
+  const size_t total = (size_t)a.sites * RC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += stride)
+  {
+    const size_t n = e / RC;
+    const unsigned int cl = a.ltip[n] & 15u, cr = a.rtip[n] & 15u;
+    const double * tl = tabl + (cl * RC + k) * 4;
+    const double * tr = tabr + (cr * RC + k) * 4;
+    double2 * out = reinterpret_cast<double2 *>(a.parent + 4 * e);
+    out[0] = make_double2(tl[0] * tr[0], tl[1] * tr[1]);
+    out[1] = make_double2(tl[2] * tr[2], tl[3] * tr[3]);
+    // no scaling test on tip-tip; the scaler is cleared (core_partials_avx.c:598-599)
+    if (MODE == SCALE_RATE) a.pscaler[e] = 0u;
+    if (MODE == SCALE_SITE && k == 0) a.pscaler[n] = 0u;
+  }
+}
+
+// ------------------------------------------------- any state count (fallback)
+//
+// One lane per SITE, looping over rate categories and states; P-matrices and
+// tip tables are read through L1/L2.  Used for state counts without a
+// dedicated kernel and for rate_cats that are not a power of two <= 16.
+// Orders: 4 states pairwise; 20 states the AVX2-flag order (ii fused, ti not);
+// otherwise left-to-right like the plain C kernels.
+
+__device__ __forceinline__ double gen_dot(const double * __restrict__ row, const double * v,
+                                          unsigned int S, bool fused)
+{
+  const dview vv{v};
+  if (S == 4) return dot4(row, v[0], v[1], v[2], v[3]);
+  if (S == 20) return fused ? dot_strided4<true>(row, vv, S) : dot_strided4<false>(row, vv, S);
+  return dot_seq(row, vv, S);
+}
+
+__device__ __forceinline__ double gen_tipsum(const double * __restrict__ row, unsigned int mask,
+                                             unsigned int S)
+{
+  return (S == 4) ? masksum4(row, mask) : masksum_seq(row, mask, S);
+}
+
+template <int KIND> // 0 = ii, 1 = ti, 2 = tt
+__global__ __launch_bounds__(128) void k_gen_partials(PartialsArgs a, int mode)
+{
+  const unsigned int S = a.states, R = a.rate_cats;
+  const size_t span = (size_t)S * R;
+  for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < a.sites;
+       n += (size_t)gridDim.x * blockDim.x)
+  {
+    double * par = a.parent + n * span;
+    const double * lc = (KIND == 0) ? a.left + n * span : nullptr;
+    const double * rc = (KIND != 2) ? a.right + n * span : nullptr;
+    unsigned int lmask = 0, rmask = 0;
+    if (KIND >= 1)
+    {
+      const unsigned int c = a.ltip[n];
+      lmask = (S == 4) ? c : a.tipmap[c];
+    }
+    if (KIND == 2)
+    {
+      const unsigned int c = a.rtip[n];
+      rmask = (S == 4) ? c : a.tipmap[c];
+    }
+    bool site_small = true;
+    for (unsigned int k = 0; k < R; ++k)
+    {
+      const double * lm = a.lmat + (size_t)k * S * S;
+      const double * rm = a.rmat + (size_t)k * S * S;
+      bool rate_small = true;
+      for (unsigned int i = 0; i < S; ++i)
+      {
+        const double x = (KIND == 0) ? gen_dot(lm + i * S, lc + k * S, S, true)
+                                     : gen_tipsum(lm + i * S, lmask, S);
+        const double y = (KIND == 2) ? gen_tipsum(rm + i * S, rmask, S)
+                                     : gen_dot(rm + i * S, rc + k * S, S, KIND == 0);
+        const double p = x * y;
+        par[k * S + i] = p;
+        rate_small = rate_small && (p < PLLHIP_SCALE_THRESHOLD);
+      }
+      if (KIND != 2 && mode == SCALE_RATE)
+      {
+        unsigned int base = 0;
+        if (KIND == 0 && a.lscaler) base += a.lscaler[n * R + k];
+        if (a.rscaler) base += a.rscaler[n * R + k];
+        if (rate_small)
+          for (unsigned int i = 0; i < S; ++i) par[k * S + i] *= PLLHIP_SCALE_FACTOR;
+        a.pscaler[n * R + k] = base + (rate_small ? 1u : 0u);
+      }
+      site_small = site_small && rate_small;
+    }
+    if (KIND == 2)
+    {
+      if (mode == SCALE_SITE) a.pscaler[n] = 0u;
+      if (mode == SCALE_RATE)
+        for (unsigned int k = 0; k < R; ++k) a.pscaler[n * R + k] = 0u;
+    }
+    else if (mode == SCALE_SITE)
+    {
+      unsigned int base = 0;
+      if (KIND == 0 && a.lscaler) base += a.lscaler[n];
+      if (a.rscaler) base += a.rscaler[n];
+      if (site_small)
+        for (unsigned int t = 0; t < span; ++t) par[t] *= PLLHIP_SCALE_FACTOR;
+      a.pscaler[n] = base + (site_small ? 1u : 0u);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 20 states
+//
+// Vector (non-MFMA) kernels that reproduce the AVX2-flag arithmetic exactly:
+// one lane per (site, rate); the lane keeps both child vectors in registers
+// and walks the 20 rows of P_l / P_r, which sit in LDS ([R][20][20] each,
+// 25.6 KB for 4 categories).  Lanes of one wave read at most RC distinct LDS
+// addresses per instruction (one per rate), rows padded so the RC addresses
+// fall in different banks.
+
+#define AA_S 20
+#define AA_ROWPAD 20 /* row stride in doubles */
+#define AA_MATPAD (AA_S * AA_ROWPAD + 2) /* matrix stride: +2 doubles skews banks between rates */
+
+template <int RC>
+__device__ __forceinline__ void aa_stage_matrix(double * dst, const double * __restrict__ src)
+{
+  for (unsigned int t = threadIdx.x; t < RC * AA_S * AA_S; t += blockDim.x)
+  {
+    const unsigned int k = t / (AA_S * AA_S), ij = t % (AA_S * AA_S);
+    dst[k * AA_MATPAD + ij] = src[t];
+  }
+}
+
+struct reg20
+{
+  double v[AA_S];
+  __device__ __forceinline__ double operator[](unsigned int j) const { return v[j]; }
+};
+
+__device__ __forceinline__ void aa_load(reg20 & r, const double * __restrict__ p)
+{
+  const double2 * q = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+  for (int j = 0; j < AA_S / 2; ++j)
+  {
+    const double2 t = q[j];
+    r.v[2 * j] = t.x;
+    r.v[2 * j + 1] = t.y;
+  }
+}
+
+template <int MODE, int RC>
+__device__ __forceinline__ void aa_finish(const PartialsArgs & a, size_t e, bool act,
+                                          unsigned int k, reg20 & p, bool small,
+                                          unsigned int base_scale)
+{
+  bool scale = false;
+  if (MODE == SCALE_RATE) scale = small;
+  if (MODE == SCALE_SITE) scale = site_all<RC>(small || !act);
+  if (!act) return;
+  double2 * out = reinterpret_cast<double2 *>(a.parent + (size_t)AA_S * e);
+#pragma unroll
+  for (int j = 0; j < AA_S / 2; ++j)
+  {
+    double x = p.v[2 * j], y = p.v[2 * j + 1];
+    if (scale) { x *= PLLHIP_SCALE_FACTOR; y *= PLLHIP_SCALE_FACTOR; }
+    out[j] = make_double2(x, y);
+  }
+  if (MODE == SCALE_RATE) a.pscaler[e] = base_scale + (scale ? 1u : 0u);
+  if (MODE == SCALE_SITE && k == 0) a.pscaler[e / RC] = base_scale + (scale ? 1u : 0u);
+}
+
+template <int RC, int MODE>
+__global__ __launch_bounds__(256) void k_aa_ii(PartialsArgs a)
+{
+  extern __shared__ double smem[];
+  double * sl = smem;
+  double * sr = smem + RC * AA_MATPAD;
+  aa_stage_matrix<RC>(sl, a.lmat);
+  aa_stage_matrix<RC>(sr, a.rmat);
+  __syncthreads();
+  const unsigned int k = threadIdx.x & (RC - 1);
+  const double * ml = sl + k * AA_MATPAD;
+  const double * mr = sr + k * AA_MATPAD;
+
+  const size_t total = (size_t)a.sites * RC;
+  const size_t total_up = (total + 63) & ~(size_t)63;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  {
+    const bool act = e < total;
+    const size_t ec = act ? e : 0;
+    reg20 L, R, P;
+    aa_load(L, a.left + (size_t)AA_S * ec);
+    aa_load(R, a.right + (size_t)AA_S * ec);
+    unsigned int base = 0;
+    if (MODE != SCALE_NONE)
+    {
+      const size_t si = (MODE == SCALE_RATE) ? ec : ec / RC;
+      if (a.lscaler) base += a.lscaler[si];
+      if (a.rscaler) base += a.rscaler[si];
+    }
+    bool small = true;
+#pragma unroll
+    for (int i = 0; i < AA_S; ++i)
+    {
+      const double x = dot_strided4<true>(ml + i * AA_ROWPAD, L, AA_S);
+      const double y = dot_strided4<true>(mr + i * AA_ROWPAD, R, AA_S);
+      P.v[i] = x * y;
+      small = small && (P.v[i] < PLLHIP_SCALE_THRESHOLD);
+    }
+    aa_finish<MODE, RC>(a, e, act, k, P, small, base);
+  }
+}
+
+// tip row sums for every code of the tipmap: tab[(code*RC + k)*20 + i]
+template <int RC>
+__device__ __forceinline__ void aa_build_tip_table(double * tab, const double * __restrict__ mat,
+                                                   const unsigned int * __restrict__ tipmap,
+                                                   unsigned int maxstates)
+{
+  for (unsigned int t = threadIdx.x; t < maxstates * RC * AA_S; t += blockDim.x)
+  {
+    const unsigned int code = t / (RC * AA_S), ki = t % (RC * AA_S);
+    tab[t] = masksum_seq(mat + (size_t)ki * AA_S, tipmap[code], AA_S);
+  }
+}
+
+template <int RC, int MODE>
+__global__ __launch_bounds__(256) void k_aa_ti(PartialsArgs a)
+{
+  extern __shared__ double smem[];
+  double * sr = smem;                       // [RC] padded matrices
+  double * tab = smem + RC * AA_MATPAD;     // [maxstates][RC][20]
+  aa_stage_matrix<RC>(sr, a.rmat);
+  aa_build_tip_table<RC>(tab, a.lmat, a.tipmap, a.maxstates);
+  __syncthreads();
+  const unsigned int k = threadIdx.x & (RC - 1);
+  const double * mr = sr + k * AA_MATPAD;
+
+  const size_t total = (size_t)a.sites * RC;
+  const size_t total_up = (total + 63) & ~(size_t)63;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  {
+    const bool act = e < total;
+    const size_t ec = act ? e : 0;
+    reg20 R, P;
+    aa_load(R, a.right + (size_t)AA_S * ec);
+    unsigned int code = a.ltip[ec / RC];
+    if (code >= a.maxstates) code = 0;
+    const double * tl = tab + ((size_t)code * RC + k) * AA_S;
+    unsigned int base = 0;
+    if (MODE != SCALE_NONE && a.rscaler) base = a.rscaler[(MODE == SCALE_RATE) ? ec : ec / RC];
+    bool small = true;
+#pragma unroll
+    for (int i = 0; i < AA_S; ++i)
+    {
+      // the AVX2 flag runs the AVX (mul, add) tip-inner kernel: core_partials.c:428-443
+      const double y = dot_strided4<false>(mr + i * AA_ROWPAD, R, AA_S);
+      P.v[i] = tl[i] * y;
+      small = small && (P.v[i] < PLLHIP_SCALE_THRESHOLD);
+    }
+    aa_finish<MODE, RC>(a, e, act, k, P, small, base);
+  }
+}
+
+template <int RC, int MODE>
+__global__ __launch_bounds__(256) void k_aa_tt(PartialsArgs a)
+{
+  extern __shared__ double smem[];
+  double * tabl = smem;
+  double * tabr = smem + (size_t)a.maxstates * RC * AA_S;
+  aa_build_tip_table<RC>(tabl, a.lmat, a.tipmap, a.maxstates);
+  aa_build_tip_table<RC>(tabr, a.rmat, a.tipmap, a.maxstates);
+  __syncthreads();
+  const unsigned int k = threadIdx.x & (RC - 1);
+  const size_t total = (size_t)a.sites * RC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += stride)
+  {
+    const size_t n = e / RC;
+    unsigned int cl = a.ltip[n], cr = a.rtip[n];
+    if (cl >= a.maxstates) cl = 0;
+    if (cr >= a.maxstates) cr = 0;
+    const double * tl = tabl + ((size_t)cl * RC + k) * AA_S;
+    const double * tr = tabr + ((size_t)cr * RC + k) * AA_S;
+    double2 * out = reinterpret_cast<double2 *>(a.parent + (size_t)AA_S * e);
+#pragma unroll
+    for (int j = 0; j < AA_S / 2; ++j)
+      out[j] = make_double2(tl[2 * j] * tr[2 * j], tl[2 * j + 1] * tr[2 * j + 1]);
+    if (MODE == SCALE_RATE) a.pscaler[e] = 0u;
+    if (MODE == SCALE_SITE && k == 0) a.pscaler[n] = 0u;
+  }
+}
+
+// ---------------------------------------------------------------- dispatch
+
+#define LAUNCH_RC_MODE(KERNEL, rc, mode, grid, block, lds, stream, args)          \
+  do {                                                                            \
+    switch ((rc) * 4 + (mode)) {                                                  \
+      case 1 * 4 + 0: KERNEL<1, 0><<<grid, block, lds, stream>>>(args); break;    \
+      case 1 * 4 + 1: KERNEL<1, 1><<<grid, block, lds, stream>>>(args); break;    \
+      case 1 * 4 + 2: KERNEL<1, 2><<<grid, block, lds, stream>>>(args); break;    \
+      case 2 * 4 + 0: KERNEL<2, 0><<<grid, block, lds, stream>>>(args); break;    \
+      case 2 * 4 + 1: KERNEL<2, 1><<<grid, block, lds, stream>>>(args); break;    \
+      case 2 * 4 + 2: KERNEL<2, 2><<<grid, block, lds, stream>>>(args); break;    \
+      case 4 * 4 + 0: KERNEL<4, 0><<<grid, block, lds, stream>>>(args); break;    \
+      case 4 * 4 + 1: KERNEL<4, 1><<<grid, block, lds, stream>>>(args); break;    \
+      case 4 * 4 + 2: KERNEL<4, 2><<<grid, block, lds, stream>>>(args); break;    \
+      case 8 * 4 + 0: KERNEL<8, 0><<<grid, block, lds, stream>>>(args); break;    \
+      case 8 * 4 + 1: KERNEL<8, 1><<<grid, block, lds, stream>>>(args); break;    \
+      case 8 * 4 + 2: KERNEL<8, 2><<<grid, block, lds, stream>>>(args); break;    \
+      case 16 * 4 + 0: KERNEL<16, 0><<<grid, block, lds, stream>>>(args); break;  \
+      case 16 * 4 + 1: KERNEL<16, 1><<<grid, block, lds, stream>>>(args); break;  \
+      case 16 * 4 + 2: KERNEL<16, 2><<<grid, block, lds, stream>>>(args); break;  \
+      default: break;                                                             \
+    }                                                                             \
+  } while (0)
+
+static bool fast_rc(unsigned int rc)
+{
+  return rc == 1 || rc == 2 || rc == 4 || rc == 8 || rc == 16;
+}
+
+// kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
+int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode)
+{
+  const unsigned int R = a.rate_cats;
+  const size_t items = (size_t)a.sites * R;
+  hipStream_t s = c->stream;
+
+  if (a.states == 4 && fast_rc(R))
+  {
+    const unsigned int grid = pllhip_stream_grid(c, items, 256);
+    if (kind == 0) LAUNCH_RC_MODE(k_dna_ii, R, mode, grid, 256, 0, s, a);
+    if (kind == 1) LAUNCH_RC_MODE(k_dna_ti, R, mode, grid, 256, 0, s, a);
+    if (kind == 2) LAUNCH_RC_MODE(k_dna_tt, R, mode, grid, 256, 0, s, a);
+  }
+  else if (a.states == 20 && fast_rc(R) && R <= 8)
+  {
+    const unsigned int grid = pllhip_stream_grid(c, items, 256);
+    const size_t mat = (size_t)R * AA_MATPAD * sizeof(double);
+    const size_t tab = (size_t)c->maxstates * R * AA_S * sizeof(double);
+    if (kind == 0) LAUNCH_RC_MODE(k_aa_ii, R, mode, grid, 256, 2 * mat, s, a);
+    if (kind == 1) LAUNCH_RC_MODE(k_aa_ti, R, mode, grid, 256, mat + tab, s, a);
+    if (kind == 2) LAUNCH_RC_MODE(k_aa_tt, R, mode, grid, 256, 2 * tab, s, a);
+  }
+  else
+  {
+    const unsigned int grid = pllhip_stream_grid(c, a.sites, 128);
+    if (kind == 0) k_gen_partials<0><<<grid, 128, 0, s>>>(a, mode);
+    if (kind == 1) k_gen_partials<1><<<grid, 128, 0, s>>>(a, mode);
+    if (kind == 2) k_gen_partials<2><<<grid, 128, 0, s>>>(a, mode);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_op(pllhip_ctx * c, const pllhip_op_t & op)
+{
+  const unsigned int nodes = (unsigned int)c->clv.size();
+  if (op.parent_clv >= nodes || op.child1_clv >= nodes || op.child2_clv >= nodes ||
+      !c->clv[op.parent_clv])
+  {
+    pllhip_set_error("pllhip_update_partials: clv index out of range or parent is a tip");
+    return -1;
+  }
+  if (op.child1_matrix >= c->sh.prob_matrices || op.child2_matrix >= c->sh.prob_matrices)
+  {
+    pllhip_set_error("pllhip_update_partials: matrix index out of range");
+    return -1;
+  }
+  const int nsc = (int)c->sh.scale_buffers;
+  if (op.parent_scaler >= nsc || op.child1_scaler >= nsc || op.child2_scaler >= nsc)
+  {
+    pllhip_set_error("pllhip_update_partials: scaler index out of range");
+    return -1;
+  }
+
+  const bool t1 = pllhip_is_tip(c, op.child1_clv), t2 = pllhip_is_tip(c, op.child2_clv);
+  PartialsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.parent = c->clv[op.parent_clv];
+  a.pscaler = pllhip_scaler_ptr(c, op.parent_scaler);
+  a.tipmap = c->tipmap;
+  a.sites = c->sh.sites;
+  a.rate_cats = c->sh.rate_cats;
+  a.states = c->sh.states;
+  a.maxstates = c->maxstates;
+  int kind;
+  if (t1 && t2)
+  {
+    kind = 2;
+    a.ltip = pllhip_tip_ptr(c, op.child1_clv);
+    a.rtip = pllhip_tip_ptr(c, op.child2_clv);
+    a.lmat = pllhip_pmat_ptr(c, op.child1_matrix);
+    a.rmat = pllhip_pmat_ptr(c, op.child2_matrix);
+  }
+  else if (t1 || t2)
+  {
+    // the tip is always presented as the "left" child (partials.c:91-112)
+    kind = 1;
+    const unsigned int tip = t1 ? op.child1_clv : op.child2_clv;
+    const unsigned int inner = t1 ? op.child2_clv : op.child1_clv;
+    a.ltip = pllhip_tip_ptr(c, tip);
+    a.right = c->clv[inner];
+    a.lmat = pllhip_pmat_ptr(c, t1 ? op.child1_matrix : op.child2_matrix);
+    a.rmat = pllhip_pmat_ptr(c, t1 ? op.child2_matrix : op.child1_matrix);
+    a.rscaler = pllhip_scaler_ptr(c, t1 ? op.child2_scaler : op.child1_scaler);
+  }
+  else
+  {
+    kind = 0;
+    a.left = c->clv[op.child1_clv];
+    a.right = c->clv[op.child2_clv];
+    a.lmat = pllhip_pmat_ptr(c, op.child1_matrix);
+    a.rmat = pllhip_pmat_ptr(c, op.child2_matrix);
+    a.lscaler = pllhip_scaler_ptr(c, op.child1_scaler);
+    a.rscaler = pllhip_scaler_ptr(c, op.child2_scaler);
+  }
+  if ((kind == 0 && (!a.left || !a.right)) || (kind == 1 && !a.right))
+  {
+    pllhip_set_error("pllhip_update_partials: child CLV missing");
+    return -1;
+  }
+  if (kind >= 1 && a.states != 4 && c->maxstates == 0)
+  {
+    pllhip_set_error("pllhip_update_partials: tipmap not uploaded");
+    return -1;
+  }
+
+  const int mode = !a.pscaler ? SCALE_NONE : (c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE);
+  return pllhip_launch_partials(c, a, kind, mode);
+}
+
+extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)
+{
+  HIP_TRY(hipSetDevice(c->sh.device));
+  // strictly in list order on one stream: unrooted trees reuse CLV slots, so
+  // dependencies follow buffer indices, not tree shape (partials.c:184-212)
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    int rc = launch_op(c, ops[i]);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,183 @@
+/* hotpath.c -- the partition-level likelihood API: thin argument checks, then
+ * straight into the HIP shim.
+ *
+ * Replaces pll_update_partials (partials.c:177), pll_compute_edge_loglikelihood
+ * (likelihood.c:478), pll_compute_root_loglikelihood (likelihood.c:121),
+ * pll_update_sumtable (derivatives.c:164) and
+ * pll_compute_likelihood_derivatives (derivatives.c:243).  The tip-tip /
+ * tip-inner / inner-inner case split the reference does here is made by the
+ * shim from the same rule (clv index < tips under PLL_ATTRIB_PATTERN_TIP).
+ */
+#include <stdio.h>
+
+#include "internal.h"
+
+/* pll_operation_t and pllhip_op_t are the same eight 32-bit fields */
+typedef char op_layout_check[(sizeof(pll_operation_t) == sizeof(pllhip_op_t)) ? 1 : -1];
+
+void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops, unsigned int count)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  unsigned int i;
+  int rc;
+  if (!pll_amd_flush_model(p)) return;
+  rc = pllhip_update_partials(q->ctx, (const pllhip_op_t *)ops, count);
+  if (rc)
+  {
+    /* void function: errors are reported through pll_errno only, as in the reference */
+    pll_amd_fail_hip(rc, "CLV update");
+    return;
+  }
+  if (pll_amd_mirror_mode)
+    for (i = 0; i < count; ++i)
+    {
+      pll_amd_sync_clv(p, ops[i].parent_clv_index);
+      if (ops[i].parent_scaler_index != PLL_SCALE_BUFFER_NONE)
+        pll_amd_sync_scaler(p, (unsigned int)ops[i].parent_scaler_index);
+    }
+}
+
+double pll_compute_edge_loglikelihood(pll_partition_t * p, unsigned int parent_clv_index,
+                                      int parent_scaler_index, unsigned int child_clv_index,
+                                      int child_scaler_index, unsigned int matrix_index,
+                                      const unsigned int * freqs_indices, double * persite_lnl)
+{
+  double lnl = -INFINITY;
+  int rc;
+  if (!pll_amd_flush_model(p)) return -INFINITY;
+  rc = pllhip_edge_loglikelihood(pll_amd_priv(p)->ctx, parent_clv_index, parent_scaler_index,
+                                 child_clv_index, child_scaler_index, matrix_index,
+                                 freqs_indices, persite_lnl, &lnl);
+  if (rc)
+  {
+    pll_amd_fail_hip(rc, "edge log-likelihood");
+    return -INFINITY;
+  }
+  return lnl;
+}
+
+double pll_compute_root_loglikelihood(pll_partition_t * p, unsigned int clv_index,
+                                      int scaler_index, const unsigned int * freqs_indices,
+                                      double * persite_lnl)
+{
+  double lnl = -INFINITY;
+  int rc;
+  if (!pll_amd_flush_model(p)) return -INFINITY;
+  rc = pllhip_root_loglikelihood(pll_amd_priv(p)->ctx, clv_index, scaler_index, freqs_indices,
+                                 persite_lnl, &lnl);
+  if (rc)
+  {
+    pll_amd_fail_hip(rc, "root log-likelihood");
+    return -INFINITY;
+  }
+  return lnl;
+}
+
+/* The caller's sumtable pointer is only a KEY here: the table itself is kept
+ * in one of a few device slots (least recently produced slot is recycled). */
+static int slot_of(pll_amd_partition_t * q, const double * key)
+{
+  unsigned int s;
+  for (s = 0; s < PLLHIP_SUMTABLE_SLOTS; ++s)
+    if (q->sumtable_key[s] == key) return (int)s;
+  return -1;
+}
+
+int pll_update_sumtable(pll_partition_t * p, unsigned int parent_clv_index,
+                        unsigned int child_clv_index, int parent_scaler_index,
+                        int child_scaler_index, const unsigned int * params_indices,
+                        double * sumtable)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  int slot, rc;
+  unsigned int n;
+  if (!sumtable)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "sumtable is NULL");
+    return PLL_FAILURE;
+  }
+  for (n = 0; n < p->rate_cats; ++n)
+    if (!p->eigen_decomp_valid[params_indices[n]])
+      if (!pll_update_eigen(p, params_indices[n])) return PLL_FAILURE;
+  if (!pll_amd_flush_model(p)) return PLL_FAILURE;
+  slot = slot_of(q, sumtable);
+  if (slot < 0)
+  {
+    slot = (int)(q->sumtable_next++ % PLLHIP_SUMTABLE_SLOTS);
+    q->sumtable_key[slot] = sumtable;
+  }
+  rc = pllhip_update_sumtable(q->ctx, parent_clv_index, parent_scaler_index, child_clv_index,
+                              child_scaler_index, params_indices, (unsigned int)slot);
+  if (rc)
+  {
+    q->sumtable_key[slot] = NULL;
+    return pll_amd_fail_hip(rc, "sumtable update");
+  }
+  if (pll_amd_mirror_mode) return pll_amd_sync_sumtable(p, sumtable);
+  return PLL_SUCCESS;
+}
+
+int pll_amd_sync_sumtable(pll_partition_t * p, double * sumtable)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  int slot = slot_of(q, sumtable), rc;
+  if (slot < 0)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "no device sumtable is associated with this buffer");
+    return PLL_FAILURE;
+  }
+  if ((rc = pllhip_get_sumtable(q->ctx, (unsigned int)slot, sumtable)))
+    return pll_amd_fail_hip(rc, "sumtable download");
+  return PLL_SUCCESS;
+}
+
+int pll_compute_likelihood_derivatives(pll_partition_t * p, int parent_scaler_index,
+                                       int child_scaler_index, double branch_length,
+                                       const unsigned int * params_indices,
+                                       const double * sumtable, double * d_f, double * dd_f)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  const unsigned int S = p->states, R = p->rate_cats;
+  unsigned int i, j;
+  int slot, rc;
+  double * diag;
+  (void)parent_scaler_index; /* scalers only enter through asc-bias terms (core_derivatives.c:683) */
+  (void)child_scaler_index;
+
+  if (!pll_amd_flush_model(p)) return PLL_FAILURE;
+  slot = slot_of(q, sumtable);
+  if (slot < 0)
+  {
+    /* a table the caller filled itself: take the host contents */
+    slot = (int)(q->sumtable_next++ % PLLHIP_SUMTABLE_SLOTS);
+    if ((rc = pllhip_put_sumtable(q->ctx, (unsigned int)slot, sumtable)))
+      return pll_amd_fail_hip(rc, "sumtable upload");
+    q->sumtable_key[slot] = sumtable;
+  }
+
+  /* e^{lambda r t}, its first and second t-derivative per (category, state):
+     core_derivatives.c:560-575, same expression order, libm exp */
+  diag = (double *)malloc((size_t)R * S * 4 * sizeof(double));
+  if (!diag)
+  {
+    pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate memory for diagptable");
+    return PLL_FAILURE;
+  }
+  for (i = 0; i < R; ++i)
+  {
+    const double * ev = p->eigenvals[params_indices[i]];
+    const double ki = p->rates[i] / (1.0 - p->prop_invar[params_indices[i]]);
+    double * dp = diag + (size_t)i * S * 4;
+    for (j = 0; j < S; ++j, dp += 4)
+    {
+      dp[0] = exp(ev[j] * ki * branch_length);
+      dp[1] = ev[j] * ki * dp[0];
+      dp[2] = ev[j] * ki * ev[j] * ki * dp[0];
+      dp[3] = 0;
+    }
+  }
+  rc = pllhip_likelihood_derivatives(q->ctx, (unsigned int)slot, params_indices, diag, d_f, dd_f);
+  free(diag);
+  if (rc) return pll_amd_fail_hip(rc, "likelihood derivatives");
+  return PLL_SUCCESS;
+}

@@ -1,0 +1,525 @@
+/* partition.c -- the partition container: creation, destruction, tip data,
+ * pattern weights, host mirrors.
+ *
+ * Replaces the container half of the reference's pll.c (pll_partition_create
+ * pll.c:399, pll_partition_destroy :820, pll_set_tip_states :966,
+ * pll_set_tip_clv :1001, pll_set_pattern_weights :1047, create_charmap :272,
+ * update_charmap :136).  Small model arrays live on the host exactly as in the
+ * reference (clients read them); CLVs, scalers, tip codes and P-matrices live
+ * in HBM behind partition->ctx, with host mirrors filled on request.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "internal.h"
+
+__thread int pll_errno;
+__thread char pll_errmsg[200] = {0};
+
+int pll_amd_mirror_mode = 0;
+static int g_device = -1;
+
+void pll_amd_set_error(int code, const char * fmt, ...)
+{
+  va_list ap;
+  pll_errno = code;
+  va_start(ap, fmt);
+  vsnprintf(pll_errmsg, sizeof(pll_errmsg), fmt, ap);
+  va_end(ap);
+}
+
+int pll_amd_fail_hip(int rc, const char * what)
+{
+  pll_amd_set_error(PLL_ERROR_HIP_RUNTIME, "%s: %s (rc=%d)", what, pllhip_last_error(), rc);
+  return PLL_FAILURE;
+}
+
+void * pll_aligned_alloc(size_t size, size_t alignment)
+{
+  void * mem = NULL;
+  if (alignment < sizeof(void *)) alignment = sizeof(void *);
+  if (posix_memalign(&mem, alignment, size ? size : alignment)) return NULL;
+  return mem;
+}
+
+void pll_aligned_free(void * ptr) { free(ptr); }
+
+int pll_amd_device_count(void)
+{
+  int n = 0;
+  if (pllhip_device_count(&n)) return 0;
+  return n;
+}
+
+int pll_amd_set_device(int device)
+{
+  g_device = device;
+  return PLL_SUCCESS;
+}
+
+void pll_amd_set_mirror_mode(int on) { pll_amd_mirror_mode = on ? 1 : 0; }
+
+static int default_device(void)
+{
+  if (g_device >= 0) return g_device;
+  const char * e = getenv("PLL_AMD_DEVICE");
+  if (!e || !*e) e = getenv("LOCAL_RANK");
+  if (e && *e)
+  {
+    int d = atoi(e);
+    int n = pll_amd_device_count();
+    if (n > 0) return d % n;
+  }
+  return 0;
+}
+
+static void free_ptr_array(void ** a, unsigned int n)
+{
+  unsigned int i;
+  if (!a) return;
+  for (i = 0; i < n; ++i) free(a[i]);
+  free(a);
+}
+
+void pll_partition_destroy(pll_partition_t * p)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  unsigned int nodes;
+  if (!p) return;
+  nodes = p->tips + p->clv_buffers;
+  if (q->ctx) pllhip_ctx_destroy(q->ctx);
+  free_ptr_array((void **)p->clv, nodes);
+  if (p->pmatrix)
+  {
+    free(p->pmatrix[0]);
+    free(p->pmatrix);
+  }
+  free(p->rates);
+  free(p->rate_weights);
+  free_ptr_array((void **)p->subst_params, p->rate_matrices);
+  free_ptr_array((void **)p->scale_buffer, p->scale_buffers);
+  free_ptr_array((void **)p->frequencies, p->rate_matrices);
+  free(p->prop_invar);
+  free(p->invariant);
+  free(p->pattern_weights);
+  free(p->eigen_decomp_valid);
+  free_ptr_array((void **)p->eigenvecs, p->rate_matrices);
+  free_ptr_array((void **)p->inv_eigenvecs, p->rate_matrices);
+  free_ptr_array((void **)p->eigenvals, p->rate_matrices);
+  free_ptr_array((void **)p->tipchars, p->tips);
+  free(p->charmap);
+  free(p->tipmap);
+  free(p->ttlookup);
+  free(q->model_dirty);
+  q->magic = 0;
+  free(q);
+}
+
+static double ** alloc_rows(unsigned int rows, size_t cols)
+{
+  unsigned int i;
+  double ** a = (double **)calloc(rows ? rows : 1, sizeof(double *));
+  if (!a) return NULL;
+  for (i = 0; i < rows; ++i)
+    if (!(a[i] = (double *)pll_aligned_alloc(cols * sizeof(double), PLL_ALIGNMENT_HIP)))
+    {
+      free_ptr_array((void **)a, rows);
+      return NULL;
+    }
+    else
+      memset(a[i], 0, cols * sizeof(double));
+  return a;
+}
+
+pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffers,
+                                       unsigned int states, unsigned int sites,
+                                       unsigned int rate_matrices, unsigned int prob_matrices,
+                                       unsigned int rate_cats, unsigned int scale_buffers,
+                                       unsigned int attributes)
+{
+  unsigned int i;
+  pll_amd_partition_t * q;
+  pll_partition_t * p;
+  pllhip_shape_t sh;
+  int rc, ndev = 0;
+
+  /* at most one ISA flag, as in the reference (pll.c:413-418); the flag itself
+     selects nothing here */
+  if (__builtin_popcount(attributes & PLL_ATTRIB_ARCH_MASK) > 1)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "Multiple architecture flags specified.");
+    return NULL;
+  }
+  if (attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG))
+  {
+    pll_amd_set_error(PLL_ERROR_AB_NOSUPPORT,
+                      "Ascertainment bias correction is not part of the HIP hot path.");
+    return NULL;
+  }
+  if (!states || !sites || !rate_cats || !rate_matrices || (tips + clv_buffers) == 0)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "Empty partition dimensions.");
+    return NULL;
+  }
+
+  /* no device, no partition: this library has no CPU compute path */
+  if (pllhip_device_count(&ndev) || ndev <= 0)
+  {
+    pll_amd_set_error(PLL_ERROR_HIP_NODEVICE, "No HIP device available: %s",
+                      pllhip_last_error());
+    return NULL;
+  }
+
+  q = (pll_amd_partition_t *)calloc(1, sizeof(pll_amd_partition_t));
+  if (!q)
+  {
+    pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate memory for partition.");
+    return NULL;
+  }
+  p = &q->pub;
+  q->magic = PLL_AMD_MAGIC;
+
+  p->tips = tips;
+  p->clv_buffers = clv_buffers;
+  p->states = states;
+  p->sites = sites;
+  p->pattern_weight_sum = sites;
+  p->rate_matrices = rate_matrices;
+  p->prob_matrices = prob_matrices;
+  p->rate_cats = rate_cats;
+  p->scale_buffers = scale_buffers;
+  p->attributes = attributes;
+  p->alignment = PLL_ALIGNMENT_HIP;
+  p->states_padded = states;
+  p->asc_bias_alloc = 0;
+  q->sites_alloc = sites;
+
+  /* host-side arrays the reference exposes; CLV / scaler mirrors start NULL */
+  p->eigen_decomp_valid = (int *)calloc(rate_matrices, sizeof(int));
+  p->clv = (double **)calloc(tips + clv_buffers, sizeof(double *));
+  p->scale_buffer = (unsigned int **)calloc(scale_buffers ? scale_buffers : 1,
+                                            sizeof(unsigned int *));
+  p->pmatrix = (double **)calloc(prob_matrices ? prob_matrices : 1, sizeof(double *));
+  p->eigenvecs = alloc_rows(rate_matrices, (size_t)states * states);
+  p->inv_eigenvecs = alloc_rows(rate_matrices, (size_t)states * states);
+  p->eigenvals = alloc_rows(rate_matrices, states);
+  p->subst_params = alloc_rows(rate_matrices, (size_t)states * (states - 1) / 2 + 1);
+  p->frequencies = alloc_rows(rate_matrices, states);
+  p->rates = (double *)calloc(rate_cats, sizeof(double));
+  p->rate_weights = (double *)calloc(rate_cats, sizeof(double));
+  p->prop_invar = (double *)calloc(rate_matrices, sizeof(double));
+  p->pattern_weights = (unsigned int *)malloc((size_t)sites * sizeof(unsigned int));
+  q->model_dirty = (int *)calloc(rate_matrices, sizeof(int));
+  if (!p->eigen_decomp_valid || !p->clv || !p->scale_buffer || !p->pmatrix || !p->eigenvecs ||
+      !p->inv_eigenvecs || !p->eigenvals || !p->subst_params || !p->frequencies || !p->rates ||
+      !p->rate_weights || !p->prop_invar || !p->pattern_weights || !q->model_dirty)
+    goto oom;
+  if (prob_matrices)
+  {
+    /* one contiguous block like the reference (pll.c:559-579) */
+    const size_t per = (size_t)states * states * rate_cats;
+    p->pmatrix[0] = (double *)pll_aligned_alloc(prob_matrices * per * sizeof(double),
+                                                PLL_ALIGNMENT_HIP);
+    if (!p->pmatrix[0]) goto oom;
+    memset(p->pmatrix[0], 0, prob_matrices * per * sizeof(double));
+    for (i = 1; i < prob_matrices; ++i) p->pmatrix[i] = p->pmatrix[i - 1] + per;
+  }
+  /* defaults (pll.c:742-748, 773-786) */
+  for (i = 0; i < rate_cats; ++i) p->rate_weights[i] = 1.0 / rate_cats;
+  for (i = 0; i < sites; ++i) p->pattern_weights[i] = 1;
+  for (i = 0; i < rate_matrices; ++i) q->model_dirty[i] = 1;
+  q->rates_dirty = 1;
+
+  memset(&sh, 0, sizeof(sh));
+  sh.device = default_device();
+  sh.states = states;
+  sh.rate_cats = rate_cats;
+  sh.sites = q->sites_alloc;
+  sh.tips = tips;
+  sh.clv_buffers = clv_buffers;
+  sh.rate_matrices = rate_matrices;
+  sh.prob_matrices = prob_matrices;
+  sh.scale_buffers = scale_buffers;
+  sh.pattern_tip = (attributes & PLL_ATTRIB_PATTERN_TIP) ? 1 : 0;
+  sh.rate_scalers = (attributes & PLL_ATTRIB_RATE_SCALERS) ? 1 : 0;
+  rc = pllhip_ctx_create(&sh, &q->ctx);
+  if (rc)
+  {
+    pll_amd_set_error(rc == -1 ? PLL_ERROR_HIP_UNSUPPORTED : PLL_ERROR_HIP_RUNTIME,
+                      "Cannot create device context: %s", pllhip_last_error());
+    q->ctx = NULL;
+    pll_partition_destroy(p);
+    return NULL;
+  }
+  return p;
+
+oom:
+  pll_partition_destroy(p);
+  pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Unable to allocate enough memory.");
+  return NULL;
+}
+
+/* ---- tip encoding ------------------------------------------------------- */
+
+/* Assign 1-byte codes to the distinct state masks of `map`, in ASCII order of
+ * first appearance, extending an existing tipmap (create_charmap pll.c:305-325,
+ * update_charmap pll.c:136-260).  4-state data is not remapped: the code is the
+ * ambiguity mask itself and maxstates = largest mask + 1. */
+static int merge_charmap(pll_partition_t * p, const unsigned int * map)
+{
+  unsigned int i, j, known = 0, fresh = 0;
+  unsigned int seen[PLL_ASCII_SIZE];
+  unsigned int nseen = 0;
+
+  if (!p->charmap)
+  {
+    p->charmap = (unsigned char *)calloc(PLL_ASCII_SIZE, 1);
+    p->tipmap = (unsigned int *)calloc(PLL_ASCII_SIZE, sizeof(unsigned int));
+    p->tipchars = (unsigned char **)calloc(p->tips, sizeof(unsigned char *));
+    if (!p->charmap || !p->tipmap || !p->tipchars)
+    {
+      pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate charmap for tip-tip precomputation.");
+      return PLL_FAILURE;
+    }
+    for (i = 0; i < p->tips; ++i)
+      if (!(p->tipchars[i] = (unsigned char *)calloc(pll_amd_priv(p)->sites_alloc, 1)))
+      {
+        pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate space for storing tip characters.");
+        return PLL_FAILURE;
+      }
+    p->maxstates = 0;
+  }
+  else
+    while (known < PLL_ASCII_SIZE && p->tipmap[known]) ++known;
+
+  /* count masks not yet in the tipmap */
+  for (i = 0; i < PLL_ASCII_SIZE; ++i)
+  {
+    if (!map[i]) continue;
+    for (j = 0; j < known; ++j)
+      if (p->tipmap[j] == map[i]) break;
+    if (j < known) continue;
+    for (j = 0; j < nseen; ++j)
+      if (seen[j] == map[i]) break;
+    if (j == nseen) { seen[nseen++] = map[i]; ++fresh; }
+  }
+  if (known + fresh >= PLL_ASCII_SIZE)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID,
+                      "Cannot specify 256 or more states with PLL_ATTRIB_PATTERN_TIP.");
+    return PLL_FAILURE;
+  }
+
+  memset(p->charmap, 0, PLL_ASCII_SIZE);
+  for (i = 0; i < PLL_ASCII_SIZE; ++i)
+  {
+    unsigned int code;
+    if (!map[i]) continue;
+    for (code = 0; code < known; ++code)
+      if (p->tipmap[code] == map[i]) break;
+    if (code == known) p->tipmap[known++] = map[i];
+    p->charmap[i] = (unsigned char)code;
+  }
+
+  if (fresh || !p->maxstates)
+  {
+    if (p->states == 4)
+    {
+      unsigned int top = 0;
+      for (i = 0; i < known; ++i)
+        if (p->tipmap[i] > top) top = p->tipmap[i];
+      p->maxstates = top + 1;
+    }
+    else
+      p->maxstates = known;
+    pll_amd_priv(p)->tipmap_dirty = 1;
+  }
+  return PLL_SUCCESS;
+}
+
+static int illegal_state(char c)
+{
+  pll_amd_set_error(PLL_ERROR_TIPDATA_ILLEGALSTATE, "Illegal state code in tip \"%c\"", c);
+  return PLL_FAILURE;
+}
+
+int pll_set_tip_states(pll_partition_t * p, unsigned int tip_index, const unsigned int * map,
+                       const char * sequence)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  unsigned int i, j;
+  int rc;
+
+  if (tip_index >= p->tips)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "Tip index %u out of range", tip_index);
+    return PLL_FAILURE;
+  }
+
+  if (p->attributes & PLL_ATTRIB_PATTERN_TIP)
+  {
+    unsigned char * codes;
+    if (!merge_charmap(p, map)) return PLL_FAILURE;
+    codes = p->tipchars[tip_index];
+    for (i = 0; i < p->sites; ++i)
+    {
+      const unsigned int m = map[(unsigned char)sequence[i]];
+      if (!m) return illegal_state(sequence[i]);
+      /* 4 states: the mask is the code (pll.c:825-845); else the charmap code (pll.c:862-883) */
+      codes[i] = (p->states == 4) ? (unsigned char)m : p->charmap[(unsigned char)sequence[i]];
+    }
+    if ((rc = pllhip_put_tipchars(q->ctx, tip_index, codes)))
+      return pll_amd_fail_hip(rc, "upload of tip characters");
+    return PLL_SUCCESS;
+  }
+
+  /* tip as CLV: one 0/1 vector per site, replicated over the categories on the
+     device (set_tipclv pll.c:905-939) */
+  {
+    const unsigned int S = p->states;
+    double * v = (double *)malloc((size_t)p->sites * S * sizeof(double));
+    if (!v)
+    {
+      pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate tip vector staging.");
+      return PLL_FAILURE;
+    }
+    for (i = 0; i < p->sites; ++i)
+    {
+      unsigned int m = map[(unsigned char)sequence[i]];
+      if (!m)
+      {
+        free(v);
+        return illegal_state(sequence[i]);
+      }
+      for (j = 0; j < S; ++j, m >>= 1) v[(size_t)i * S + j] = (double)(m & 1u);
+    }
+    rc = pllhip_put_tip_clv_persite(q->ctx, tip_index, v, S);
+    free(v);
+    if (rc) return pll_amd_fail_hip(rc, "upload of tip CLV");
+  }
+  return PLL_SUCCESS;
+}
+
+int pll_set_tip_clv(pll_partition_t * p, unsigned int tip_index, const double * clv, int padding)
+{
+  int rc;
+  (void)padding; /* states_padded == states here, both layouts coincide */
+  if (p->attributes & PLL_ATTRIB_PATTERN_TIP)
+  {
+    pll_amd_set_error(PLL_ERROR_TIPDATA_ILLEGALFUNCTION,
+                      "Cannot use pll_set_tip_clv with PLL_ATTRIB_PATTERN_TIP.");
+    return PLL_FAILURE;
+  }
+  if (tip_index >= p->tips + p->clv_buffers)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "CLV index %u out of range", tip_index);
+    return PLL_FAILURE;
+  }
+  rc = pllhip_put_tip_clv_persite(pll_amd_priv(p)->ctx, tip_index, clv, p->states);
+  if (rc) return pll_amd_fail_hip(rc, "upload of tip CLV");
+  return PLL_SUCCESS;
+}
+
+void pll_set_pattern_weights(pll_partition_t * p, const unsigned int * w)
+{
+  unsigned int i;
+  int rc;
+  memcpy(p->pattern_weights, w, (size_t)p->sites * sizeof(unsigned int));
+  p->pattern_weight_sum = 0;
+  for (i = 0; i < p->sites; ++i) p->pattern_weight_sum += w[i];
+  rc = pllhip_put_pattern_weights(pll_amd_priv(p)->ctx, p->pattern_weights);
+  if (rc) pll_amd_fail_hip(rc, "upload of pattern weights");
+}
+
+/* ---- host mirrors -------------------------------------------------------- */
+
+int pll_amd_sync_clv(pll_partition_t * p, unsigned int idx)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  const size_t n = (size_t)q->sites_alloc * p->rate_cats * p->states;
+  int rc;
+  if (idx >= p->tips + p->clv_buffers ||
+      ((p->attributes & PLL_ATTRIB_PATTERN_TIP) && idx < p->tips))
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "CLV index %u has no CLV", idx);
+    return PLL_FAILURE;
+  }
+  if (!p->clv[idx] && !(p->clv[idx] = (double *)pll_aligned_alloc(n * sizeof(double),
+                                                                 PLL_ALIGNMENT_HIP)))
+  {
+    pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate CLV mirror.");
+    return PLL_FAILURE;
+  }
+  if ((rc = pllhip_get_clv(q->ctx, idx, p->clv[idx]))) return pll_amd_fail_hip(rc, "CLV download");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_sync_scaler(pll_partition_t * p, unsigned int idx)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  const size_t n = (size_t)q->sites_alloc *
+                   ((p->attributes & PLL_ATTRIB_RATE_SCALERS) ? p->rate_cats : 1);
+  int rc;
+  if (idx >= p->scale_buffers)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "Scaler index %u out of range", idx);
+    return PLL_FAILURE;
+  }
+  if (!p->scale_buffer[idx] &&
+      !(p->scale_buffer[idx] = (unsigned int *)calloc(n, sizeof(unsigned int))))
+  {
+    pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate scaler mirror.");
+    return PLL_FAILURE;
+  }
+  if ((rc = pllhip_get_scaler(q->ctx, idx, p->scale_buffer[idx])))
+    return pll_amd_fail_hip(rc, "scaler download");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_sync_pmatrix(pll_partition_t * p, unsigned int idx)
+{
+  int rc;
+  if (idx >= p->prob_matrices)
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "P-matrix index %u out of range", idx);
+    return PLL_FAILURE;
+  }
+  if ((rc = pllhip_get_pmatrix(pll_amd_priv(p)->ctx, idx, p->pmatrix[idx])))
+    return pll_amd_fail_hip(rc, "P-matrix download");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_wait(pll_partition_t * p)
+{
+  int rc = pllhip_wait(pll_amd_priv(p)->ctx);
+  if (rc) return pll_amd_fail_hip(rc, "stream synchronize");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_comm_unique_id(void * id)
+{
+  int rc = pllhip_comm_unique_id(id);
+  if (rc) return pll_amd_fail_hip(rc, "RCCL unique id");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_comm_init(pll_partition_t * p, int rank, int nranks, const void * id)
+{
+  int rc = pllhip_comm_init(pll_amd_priv(p)->ctx, rank, nranks, id);
+  if (rc) return pll_amd_fail_hip(rc, "RCCL communicator");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_timer_start(pll_partition_t * p)
+{
+  int rc = pllhip_timer_start(pll_amd_priv(p)->ctx);
+  if (rc) return pll_amd_fail_hip(rc, "timer start");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_timer_stop_ms(pll_partition_t * p, float * ms)
+{
+  int rc = pllhip_timer_stop_ms(pll_amd_priv(p)->ctx, ms);
+  if (rc) return pll_amd_fail_hip(rc, "timer stop");
+  return PLL_SUCCESS;
+}

@@ -1,0 +1,281 @@
+"""Synthetic phylogenetic workloads: tree shapes as pll_operation_t lists,
+alignments, models.  Host-side numpy only; nothing here touches the GPU.
+
+The reference builds op lists with pll_utree_traverse + pll_utree_create_operations
+(utree.c:403,284; out of scope here) or by hand in its tests
+(test/src/00010_NMDU_lkcalc.c:151-175).  We build them by hand the same way:
+
+  node numbering   tips 0..T-1, inner nodes T..2T-3 (one CLV buffer each)
+  scalers          inner node v uses scale buffer v-T
+  P-matrices       the edge above node v uses matrix index v
+  ops              every inner node once, children before parents
+  root edge        the single edge joining the last two subtrees (unrooted tree)
+
+SURVEY.md section 8(d) fixes the generator: splitmix64 stream, seed 42, branch
+lengths U(0.01, 0.2), GTR rates / frequencies below, Gamma alpha 0.7 with 4
+mean-discretised categories, 2 % fully ambiguous characters.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .pllapi import OPS_DTYPE, SCALE_BUFFER_NONE
+
+GTR_RATES = np.array([1.2, 3.1, 0.9, 1.1, 3.4, 1.0])
+GTR_FREQS = np.array([0.28, 0.22, 0.24, 0.26])
+GAMMA_ALPHA = 0.7
+DNA_CHARS = b"ACGT"
+AA_CHARS = b"ARNDCQEGHILKMFPSTWYV"
+
+
+class SplitMix64:
+    """The splitmix64 generator (Steele, Lea & Flood 2014): tiny, seedable and
+    identical in every language a caller may reimplement it in."""
+
+    def __init__(self, seed):
+        self.x = np.uint64(seed)
+
+    def next_u64(self):
+        with np.errstate(over="ignore"):
+            self.x = self.x + np.uint64(0x9E3779B97F4A7C15)
+            z = self.x
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            return z ^ (z >> np.uint64(31))
+
+    def uniform(self, lo=0.0, hi=1.0):
+        return lo + (hi - lo) * (int(self.next_u64() >> np.uint64(11)) / float(1 << 53))
+
+    def below(self, n):
+        return int(self.next_u64() % np.uint64(n))
+
+
+@dataclass
+class TreePlan:
+    tips: int
+    ops: np.ndarray                 # OPS_DTYPE, post-order
+    matrix_indices: np.ndarray      # every edge's matrix index
+    branch_lengths: np.ndarray      # same length
+    root_edge: tuple                # (parent_clv, parent_scaler, child_clv, child_scaler, matrix)
+    parent_of: dict = field(default_factory=dict)   # node -> (parent node), for simulation
+    shape: str = ""
+
+    @property
+    def clv_buffers(self):
+        return self.tips - 2
+
+    @property
+    def scale_buffers(self):
+        return self.tips - 2
+
+    @property
+    def prob_matrices(self):
+        return 2 * self.tips - 2
+
+    def op_kinds(self):
+        """(tip-tip, tip-inner, inner-inner) op counts under PATTERN_TIP."""
+        t = self.tips
+        c1 = self.ops["child1_clv_index"] < t
+        c2 = self.ops["child2_clv_index"] < t
+        return int((c1 & c2).sum()), int((c1 ^ c2).sum()), int((~c1 & ~c2).sum())
+
+
+def _scaler_of(node, tips, use_scalers):
+    return node - tips if (use_scalers and node >= tips) else SCALE_BUFFER_NONE
+
+
+def _assemble(tips, joins, last_two, rng, shape, use_scalers=True, branch=None):
+    ops = np.zeros(len(joins), dtype=OPS_DTYPE)
+    parent_of = {}
+    for i, (parent, a, b) in enumerate(joins):
+        ops[i] = (parent, _scaler_of(parent, tips, use_scalers),
+                  a, a, _scaler_of(a, tips, use_scalers),
+                  b, b, _scaler_of(b, tips, use_scalers))
+        parent_of[a] = parent
+        parent_of[b] = parent
+    u, v = last_two
+    # the root edge uses u's matrix slot; v's slot stays unused
+    parent_of[v] = u
+    edges = sorted(set(parent_of.keys()) - {v}) + [u]
+    edges = sorted(set(edges))
+    mi = np.array(edges, dtype=np.uint32)
+    if branch is None:
+        bl = np.array([rng.uniform(0.01, 0.2) for _ in edges])
+    else:
+        bl = np.full(len(edges), float(branch))
+    root = (u, _scaler_of(u, tips, use_scalers), v, _scaler_of(v, tips, use_scalers), u)
+    return TreePlan(tips, ops, mi, bl, root, parent_of, shape)
+
+
+def balanced_tree(tips, seed=42, use_scalers=True, branch=None):
+    """Perfectly balanced binary tree over `tips` (a power of two >= 4),
+    unrooted at the top split: T/2 tip-tip ops, then T/2-2 inner-inner ops."""
+    assert tips >= 4 and tips & (tips - 1) == 0
+    rng = SplitMix64(seed)
+    level = list(range(tips))
+    nxt = tips
+    joins = []
+    while len(level) > 2:
+        new = []
+        for i in range(0, len(level), 2):
+            joins.append((nxt, level[i], level[i + 1]))
+            new.append(nxt)
+            nxt += 1
+        level = new
+    return _assemble(tips, joins, (level[0], level[1]), rng, "balanced", use_scalers, branch)
+
+
+def caterpillar_tree(tips, seed=42, use_scalers=True, branch=None):
+    """Ladder: ((((t0,t1),t2),t3)...); the root edge joins the last inner node
+    and the last tip.  Depth = tips-2, which drives scaler counts up."""
+    assert tips >= 3
+    rng = SplitMix64(seed)
+    joins = [(tips, 0, 1)]
+    for k in range(1, tips - 2):
+        joins.append((tips + k, tips + k - 1, k + 1))
+    return _assemble(tips, joins, (2 * tips - 3, tips - 1), rng, "caterpillar", use_scalers, branch)
+
+
+def random_tree(tips, seed=42, use_scalers=True, branch=None):
+    """Random joining order (Yule-like topology)."""
+    assert tips >= 3
+    rng = SplitMix64(seed)
+    active = list(range(tips))
+    nxt = tips
+    joins = []
+    while len(active) > 2:
+        i = rng.below(len(active))
+        a = active.pop(i)
+        j = rng.below(len(active))
+        b = active.pop(j)
+        joins.append((nxt, a, b))
+        active.append(nxt)
+        nxt += 1
+    u, v = active
+    if u < tips and v >= tips:
+        u, v = v, u
+    return _assemble(tips, joins, (u, v), rng, "random", use_scalers, branch)
+
+
+# ---- models ---------------------------------------------------------------------
+
+def q_matrix(rates, freqs):
+    """Reversible rate matrix normalised to one substitution per unit time."""
+    n = len(freqs)
+    q = np.zeros((n, n))
+    k = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            q[i, j] = rates[k] * freqs[j]
+            q[j, i] = rates[k] * freqs[i]
+            k += 1
+    q -= np.diag(q.sum(axis=1))
+    return q / -(freqs * np.diag(q)).sum()
+
+
+def transition_matrix(q, t):
+    w, v = np.linalg.eig(q)
+    p = (v * np.exp(w * t)) @ np.linalg.inv(v)
+    p = np.clip(p.real, 0.0, None)
+    return p / p.sum(axis=1, keepdims=True)
+
+
+# ---- alignments -------------------------------------------------------------------
+
+def random_alignment(tips, sites, states=4, seed=42, gap_frac=0.02):
+    """i.i.d. uniform tip characters with `gap_frac` fully ambiguous ('-').
+    Returns a list of `tips` bytes objects of length `sites`."""
+    chars = np.frombuffer(DNA_CHARS if states == 4 else AA_CHARS, dtype=np.uint8)
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(tips):
+        s = chars[rng.integers(0, len(chars), size=sites)]
+        if gap_frac > 0:
+            s = np.where(rng.random(sites) < gap_frac, np.uint8(ord("-")), s)
+        out.append(s.astype(np.uint8).tobytes())
+    return out
+
+
+def simulated_alignment(plan, sites, rates, freqs, cat_rates, seed=42, gap_frac=0.02):
+    """Evolve `sites` characters down the tree under the model (root state from
+    the stationary distribution at node root_edge[0], one Gamma category per
+    site), so that CLVs shrink the way they do on real data."""
+    states = len(freqs)
+    chars = np.frombuffer(DNA_CHARS if states == 4 else AA_CHARS, dtype=np.uint8)
+    rng = np.random.default_rng(seed)
+    q = q_matrix(rates, freqs)
+    cat = rng.integers(0, len(cat_rates), size=sites)
+    blen = dict(zip(plan.matrix_indices.tolist(), plan.branch_lengths.tolist()))
+    u, _, v, _, m = plan.root_edge
+    state = {u: rng.choice(states, size=sites, p=freqs / freqs.sum())}
+    children = {}
+    for node, par in plan.parent_of.items():
+        children.setdefault(par, []).append(node)
+    stack = [u]
+    while stack:
+        par = stack.pop()
+        for ch in children.get(par, []):
+            t = blen[m] if (par == u and ch == v) else blen[ch]
+            new = np.empty(sites, dtype=np.int64)
+            for k, r in enumerate(cat_rates):
+                sel = np.nonzero(cat == k)[0]
+                if not len(sel):
+                    continue
+                cum = np.cumsum(transition_matrix(q, t * r), axis=1)
+                draw = rng.random(len(sel))
+                new[sel] = (draw[:, None] > cum[state[par][sel]]).sum(axis=1).clip(0, states - 1)
+            state[ch] = new
+            stack.append(ch)
+        if par >= plan.tips:
+            del state[par]
+    out = []
+    for tip in range(plan.tips):
+        s = chars[state[tip]]
+        if gap_frac > 0:
+            s = np.where(rng.random(sites) < gap_frac, np.uint8(ord("-")), s)
+        out.append(s.astype(np.uint8).tobytes())
+    return out
+
+
+# ---- site sharding (multi-GPU) -------------------------------------------------------
+
+def shard_bounds(sites, nranks, granule=256):
+    """Contiguous site ranges for `nranks` devices, boundaries on multiples of
+    `granule` sites (keeps every per-site array 16-byte aligned).  Returns
+    nranks+1 offsets."""
+    per = -(-sites // nranks)
+    per = -(-per // granule) * granule
+    return [min(sites, r * per) for r in range(nranks)] + [sites]
+
+
+# ---- one-call setup used by tests and bench.py -----------------------------------------
+
+def setup_partition(lib, plan, seqs, states=4, rate_cats=4, attributes=0, alpha=GAMMA_ALPHA,
+                    rates=None, freqs=None, pattern_weights=None, pinv=0.0, site_range=None):
+    """Create a partition on `lib` (product or reference), load model and tips,
+    compute all P-matrices.  `site_range` = (lo, hi) keeps only those alignment
+    columns (site sharding)."""
+    if site_range is not None:
+        lo, hi = site_range
+        seqs = [s[lo:hi] for s in seqs]
+        if pattern_weights is not None:
+            pattern_weights = pattern_weights[lo:hi]
+    sites = len(seqs[0])
+    if rates is None:
+        rates = GTR_RATES if states == 4 else lib.aa_model("lg")[0]
+    if freqs is None:
+        freqs = GTR_FREQS if states == 4 else lib.aa_model("lg")[1]
+    p = lib.partition_create(plan.tips, plan.clv_buffers, states, sites, 1, plan.prob_matrices,
+                             rate_cats, plan.scale_buffers, attributes)
+    p.set_frequencies(0, freqs)
+    p.set_subst_params(0, rates)
+    p.set_category_rates(lib.compute_gamma_cats(alpha, rate_cats))
+    cmap = lib.map("nt" if states == 4 else "aa")
+    for i, s in enumerate(seqs):
+        p.set_tip_states(i, cmap, s)
+    if pattern_weights is not None:
+        p.set_pattern_weights(pattern_weights)
+    if pinv > 0:
+        p.update_invariant_sites_proportion(0, pinv)
+    p.update_prob_matrices([0] * rate_cats, plan.matrix_indices, plan.branch_lengths)
+    return p
