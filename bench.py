@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Felsenstein-pruning hot path on MI355X.
+
+Metric (BASELINE.json): M CLV-site-updates/s, states x rates stated.
+One "step" = one full likelihood evaluation of the tree through the C API:
+pll_update_partials over all taxa-2 operations + pll_compute_edge_loglikelihood
+at the root edge (which contains the device->host read of lnL and, for N>1,
+the RCCL all-reduce).  A site-update = one alignment site of one
+pll_operation_t (all rate categories and states, scaler included).
+
+Workload at N=1 = BASELINE.json configs[1]: 4-state GTR, 4 Gamma rates,
+1,000,000 synthetic sites, 64-taxon balanced tree, PLL_ATTRIB_PATTERN_TIP,
+per-site scalers.  For N>1 every rank holds its own 1,000,000-site shard of an
+N x 1,000,000-site alignment (weak scaling, no data-path collective; one
+8-byte RCCL all-reduce of lnL per step).
+
+Inputs are resident in HBM before the timed region starts.  `roofline` is for
+the dominant kernel, the 4-state inner-inner CLV update: 396 algorithmic
+bytes per site-update x sites per launch / the launch's average
+duration from HIP events on the partition's own stream, against 8 TB/s.
+`cpu_baseline` times the reference's AVX2-flag path (oracle/_ref, built from
+the reference sources in the dev container) on one host core over a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sites", type=int, default=1_000_000, help="sites per GPU")
+    ap.add_argument("--taxa", type=int, default=64)
+    ap.add_argument("--states", type=int, default=4, choices=(4, 20))
+    ap.add_argument("--rate-cats", type=int, default=4)
+    ap.add_argument("--tip-clv", action="store_true", help="tips as CLVs (all ops inner-inner)")
+    ap.add_argument("--rate-scalers", action="store_true")
+    ap.add_argument("--alignment", default="simulated", choices=("simulated", "random"))
+    ap.add_argument("--cpu-sites", type=int, default=100_000,
+                    help="sample size for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    # torch first: it carries its own HIP runtime; loading it before our library
+    # makes both share one runtime instance in this process.
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, root)
+    import libpll_amd
+    from libpll_amd import workload as W
+    from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_ARCH_AVX2,
+                                   PllLibrary)
+
+    amd = libpll_amd.load()
+    amd.lib.pll_amd_set_device(local_rank)
+
+    S, R, T = args.states, args.rate_cats, args.taxa
+    attrs = (0 if args.tip_clv else ATTRIB_PATTERN_TIP) | \
+            (ATTRIB_RATE_SCALERS if args.rate_scalers else 0)
+    plan = W.balanced_tree(T, seed=42)
+    total_sites = args.sites * world
+    cat_rates = amd.compute_gamma_cats(W.GAMMA_ALPHA, R)
+    rates = W.GTR_RATES if S == 4 else amd.aa_model("lg")[0]
+    freqs = W.GTR_FREQS if S == 4 else amd.aa_model("lg")[1]
+
+    # each rank generates only its own shard (seeded by rank): [lo, hi) of the
+    # conceptual total alignment
+    lo, hi = W.shard_bounds(total_sites, world)[rank:rank + 2]
+    if args.alignment == "simulated":
+        seqs = W.simulated_alignment(plan, hi - lo, rates, freqs, cat_rates, seed=42 + rank)
+    else:
+        seqs = W.random_alignment(T, hi - lo, S, seed=42 + rank)
+
+    part = W.setup_partition(amd, plan, seqs, S, R, attrs)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            import ctypes
+            buf = ctypes.create_string_buffer(128)
+            if not amd.lib.pll_amd_comm_unique_id(buf):
+                raise SystemExit("pll_amd_comm_unique_id failed: " + amd.errmsg())
+            uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        part.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+
+    fi = [0] * R
+
+    def step():
+        part.update_partials(plan.ops)
+        return part.compute_edge_loglikelihood(*plan.root_edge, fi)
+
+    def sync():
+        part.wait()
+        torch.cuda.synchronize()
+
+    lnl = None
+    for _ in range(args.warmup):
+        lnl = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lnl = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ops_per_eval = len(plan.ops)
+    site_updates = float(ops_per_eval) * total_sites * args.steps
+    value = site_updates / elapsed / 1e6
+
+    # ---- roofline leg: per-launch durations of the same steps, HIP events on
+    # the partition's stream (separate pass so event records do not sit inside
+    # the region `value` is computed from)
+    part.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    prof = part.profile_read()
+    part.profile_enable(False)
+    kinds = {"ii": prof["partials_ii"], "ti": prof["partials_ti"], "tt": prof["partials_tt"]}
+    dom = max(kinds, key=lambda k: kinds[k][1])
+    n_launch, tot_ms = kinds[dom]
+    roofline = None
+    if n_launch:
+        avg_s = tot_ms / n_launch / 1e3
+        algo_bytes = BYTES_PER_SITE[dom][S] * (hi - lo)
+        achieved = algo_bytes / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "pll_core_update_partial_%s (%d states)" % (dom, S),
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_site_update": BYTES_PER_SITE[dom][S],
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": n_launch}
+    per_kernel = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2) if v[0] else None}
+                  for k, v in prof.items() if v[0]}
+
+    # ---- CPU baseline (rank 0, N=1 only): the reference library on a sample
+    cpu = None
+    lnl_rel_err = None
+    ref_path = os.path.join(root, "oracle", "_ref", "libpll_ref.so")
+    if rank == 0 and world == 1 and args.cpu_sites > 0 and os.path.exists(ref_path):
+        ref = PllLibrary(ref_path)
+        n = min(args.cpu_sites, hi - lo)
+        sample = [s[:n] for s in seqs]
+        rp = W.setup_partition(ref, plan, sample, S, R, attrs | ATTRIB_ARCH_AVX2)
+        rp.update_partials(plan.ops)  # warm-up
+        t1 = time.perf_counter()
+        for _ in range(args.cpu_reps):
+            rp.update_partials(plan.ops)
+            ref_lnl = rp.compute_edge_loglikelihood(*plan.root_edge, fi)
+        dt = time.perf_counter() - t1
+        cpu = {"value": round(ops_per_eval * n * args.cpu_reps / dt / 1e6, 2),
+               "unit": "M CLV-site-updates/s", "cores": 1, "kind": "reference",
+               "sample": "%d of %d sites, same tree/ops, %d evaluations, PLL_ATTRIB_ARCH_AVX2"
+                         % (n, hi - lo, args.cpu_reps)}
+        # lnL parity on the same sample through the HIP path
+        gp = W.setup_partition(amd, plan, sample, S, R, attrs)
+        gp.update_partials(plan.ops)
+        g_lnl = gp.compute_edge_loglikelihood(*plan.root_edge, fi)
+        lnl_rel_err = abs(g_lnl - ref_lnl) / abs(ref_lnl)
+        gp.destroy()
+        rp.destroy()
+
+    if rank == 0:
+        tt, ti, ii = plan.op_kinds() if not args.tip_clv else (0, 0, ops_per_eval)
+        out = {
+            "metric": "M CLV-site-updates/s (%dx%d states x rates)" % (S, R),
+            "value": round(value, 2), "unit": "M CLV-site-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (%s alignment, seed 42)" % args.alignment,
+            "config": {"workload": "%d-state %s, %d Gamma rates, %d sites/GPU, %d-taxon balanced "
+                                   "tree, %s, %s scalers; step = pll_update_partials(%d ops: %d "
+                                   "tip-tip, %d tip-inner, %d inner-inner) + "
+                                   "pll_compute_edge_loglikelihood"
+                                   % (S, "GTR" if S == 4 else "LG", R, args.sites, T,
+                                      "tip CLVs" if args.tip_clv else "PATTERN_TIP",
+                                      "per-rate" if args.rate_scalers else "per-site",
+                                      ops_per_eval, tt, ti, ii),
+                       "sites_total": total_sites, "parallelism": "site-sharded x%d" % world},
+            "lnl": lnl, "lnl_rel_err_vs_reference": lnl_rel_err,
+            "roofline": roofline, "kernels": per_kernel, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    part.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -319,6 +319,15 @@ PLL_EXPORT int pll_amd_eigen_decompose(unsigned int n, const double * subst_para
 PLL_EXPORT int pll_amd_timer_start(pll_partition_t * partition);
 PLL_EXPORT int pll_amd_timer_stop_ms(pll_partition_t * partition, float * ms);
 
+/* Per-kernel-class launch timing (HIP events around every hot-kernel launch
+ * while enabled).  Arrays have PLL_AMD_PROF_KINDS entries, indexed
+ * 0 = CLV update inner-inner, 1 = tip-inner, 2 = tip-tip, 3 = log-likelihood,
+ * 4 = sumtable, 5 = derivatives, 6 = P-matrices. */
+#define PLL_AMD_PROF_KINDS 7
+PLL_EXPORT int pll_amd_profile_enable(pll_partition_t * partition, int on);
+PLL_EXPORT int pll_amd_profile_read(pll_partition_t * partition, unsigned int * launches,
+                                    double * total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -176,6 +176,22 @@ PLLHIP_EXPORT int pllhip_comm_init(pllhip_ctx_t * ctx, int rank, int nranks,
 PLLHIP_EXPORT int pllhip_timer_start(pllhip_ctx_t * ctx);
 PLLHIP_EXPORT int pllhip_timer_stop_ms(pllhip_ctx_t * ctx, float * ms);
 
+/* Per-launch kernel timing for bench.py's roofline figure: while enabled, every
+ * launch of the hot kernels is bracketed by a HIP event pair on the context's
+ * stream.  pllhip_profile_read drains the stream and returns, per kernel class,
+ * the number of launches and their summed duration since the last reset. */
+#define PLLHIP_PROF_PARTIALS_II 0
+#define PLLHIP_PROF_PARTIALS_TI 1
+#define PLLHIP_PROF_PARTIALS_TT 2
+#define PLLHIP_PROF_LNL 3
+#define PLLHIP_PROF_SUMTABLE 4
+#define PLLHIP_PROF_DERIVATIVES 5
+#define PLLHIP_PROF_PMATRIX 6
+#define PLLHIP_PROF_KINDS 7
+PLLHIP_EXPORT int pllhip_profile_enable(pllhip_ctx_t * ctx, int on);
+PLLHIP_EXPORT int pllhip_profile_read(pllhip_ctx_t * ctx, unsigned int * launches /*[KINDS]*/,
+                                      double * total_ms /*[KINDS]*/);
+
 /* raw device pointer of a CLV (for tools that share HBM buffers, e.g. a
  * torch tensor wrapped around it); NULL if out of range */
 PLLHIP_EXPORT void * pllhip_dev_clv(pllhip_ctx_t * ctx, unsigned int clv_index);

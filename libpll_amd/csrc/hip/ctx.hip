@@ -247,6 +247,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -439,6 +440,53 @@ extern "C" int pllhip_get_sumtable(pllhip_ctx_t * c, unsigned int slot, double *
 extern "C" void * pllhip_dev_clv(pllhip_ctx_t * c, unsigned int idx)
 {
   return idx < c->clv.size() ? (void *)c->clv[idx] : nullptr;
+}
+
+// ---- per-launch profiling ----
+pllhip_prof_scope::pllhip_prof_scope(pllhip_ctx * ctx, int kind) : c(ctx), slot(0), on(false)
+{
+  if (!c->profiling) return;
+  if (c->prof_used * 2 + 2 > c->prof_events.size())
+  {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    c->prof_events.push_back(a);
+    c->prof_events.push_back(b);
+    c->prof_kind.push_back(kind);
+  }
+  slot = c->prof_used++;
+  c->prof_kind[slot] = kind;
+  on = (hipEventRecord(c->prof_events[2 * slot], c->stream) == hipSuccess);
+}
+
+void pllhip_prof_scope::stop()
+{
+  if (on) (void)hipEventRecord(c->prof_events[2 * slot + 1], c->stream);
+  on = false;
+}
+
+extern "C" int pllhip_profile_enable(pllhip_ctx_t * c, int on)
+{
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->profiling = on != 0;
+  c->prof_used = 0;
+  return 0;
+}
+
+extern "C" int pllhip_profile_read(pllhip_ctx_t * c, unsigned int * launches, double * total_ms)
+{
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < PLLHIP_PROF_KINDS; ++k) { launches[k] = 0; total_ms[k] = 0.0; }
+  for (size_t i = 0; i < c->prof_used; ++i)
+  {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+    const int k = c->prof_kind[i];
+    launches[k] += 1;
+    total_ms[k] += ms;
+  }
+  c->prof_used = 0;
+  return 0;
 }
 
 extern "C" int pllhip_timer_start(pllhip_ctx_t * c)

@@ -64,6 +64,23 @@ struct pllhip_ctx
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cus = 256;
+
+  // optional per-launch timing (pllhip_profile_*): one event pair per launch
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;   // pairs
+  std::vector<int> prof_kind;            // PLLHIP_PROF_* per pair
+  size_t prof_used = 0;                  // pairs in use
+};
+
+// RAII helper: brackets one kernel launch with events when profiling is on
+struct pllhip_prof_scope
+{
+  pllhip_ctx * c;
+  size_t slot;
+  bool on;
+  pllhip_prof_scope(pllhip_ctx * ctx, int kind);
+  void stop();
+  ~pllhip_prof_scope() { stop(); }
 };
 
 void pllhip_set_error(const char * fmt, ...);
@@ -129,5 +146,6 @@ struct PartialsArgs
 enum { SCALE_NONE = 0, SCALE_SITE = 1, SCALE_RATE = 2 };
 
 // kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
-int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode);
+int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode,
+                           int prof_kind);
 int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);

@@ -159,7 +159,7 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
     pllhip_set_error("pllhip_update_sumtable: CLV missing");
     return -1;
   }
-  int rc = pllhip_launch_partials(c, a, kind, SCALE_NONE);
+  int rc = pllhip_launch_partials(c, a, kind, SCALE_NONE, PLLHIP_PROF_SUMTABLE);
   if (rc) return rc;
   if (c->sh.rate_scalers && (ps || cs))
   {
@@ -382,6 +382,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     a.params_indices[k] = h_params_indices[k];
   }
   unsigned int grid;
+  pllhip_prof_scope prof(c, PLLHIP_PROF_DERIVATIVES);
   if (R == 1 || R == 2 || R == 4 || R == 8 || R == 16)
   {
     grid = pllhip_stream_grid(c, (size_t)a.sites * R, 256);
@@ -402,6 +403,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     k_derivatives_gen<<<grid, 128, 0, c->stream>>>(a);
   }
   HIP_TRY(hipGetLastError());
+  prof.stop();
   k_final_sum2<<<1, 256, 0, c->stream>>>(c->block_partials, grid, c->d_result);
   HIP_TRY(hipGetLastError());
   int rc = pllhip_allreduce_result(c, 2);

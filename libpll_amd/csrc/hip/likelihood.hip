@@ -388,6 +388,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   }
 
   unsigned int grid;
+  pllhip_prof_scope prof(c, PLLHIP_PROF_LNL);
   const bool fast = (S == 4 || S == 20) && (R == 1 || R == 2 || R == 4 || R == 8);
   if (fast)
   {
@@ -410,6 +411,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
     if (kind == ROOT) k_lnl_gen<ROOT><<<grid, 128, 0, c->stream>>>(a);
   }
   HIP_TRY(hipGetLastError());
+  prof.stop();
   k_final_sum<<<1, 256, 0, c->stream>>>(c->block_partials, grid, 1, c->d_result);
   HIP_TRY(hipGetLastError());
   int rc = pllhip_allreduce_result(c, 1);

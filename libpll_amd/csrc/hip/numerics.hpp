@@ -4,7 +4,10 @@
 // where fma() is spelled out.  That is what lets CLVs and scaler counts match
 // the reference's AVX (mul,add) and AVX2 (fmadd) kernels bit for bit.
 #pragma once
+#ifndef PLLHIP_NUMERICS_HOST_BUILD /* oracle/check_expm1.cpp builds this header for the host */
 #include <hip/hip_runtime.h>
+#endif
+#include <math.h>
 #include <stdint.h>
 
 #define PLLHIP_SCALE_FACTOR 0x1p+256

@@ -476,11 +476,13 @@ static bool fast_rc(unsigned int rc)
 }
 
 // kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
-int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode)
+int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode,
+                           int prof_kind)
 {
   const unsigned int R = a.rate_cats;
   const size_t items = (size_t)a.sites * R;
   hipStream_t s = c->stream;
+  pllhip_prof_scope prof(c, prof_kind >= 0 ? prof_kind : PLLHIP_PROF_PARTIALS_II + kind);
 
   if (a.states == 4 && fast_rc(R))
   {
@@ -583,7 +585,7 @@ static int launch_op(pllhip_ctx * c, const pllhip_op_t & op)
   }
 
   const int mode = !a.pscaler ? SCALE_NONE : (c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE);
-  return pllhip_launch_partials(c, a, kind, mode);
+  return pllhip_launch_partials(c, a, kind, mode, -1);
 }
 
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)

@@ -523,3 +523,17 @@ int pll_amd_timer_stop_ms(pll_partition_t * p, float * ms)
   if (rc) return pll_amd_fail_hip(rc, "timer stop");
   return PLL_SUCCESS;
 }
+
+int pll_amd_profile_enable(pll_partition_t * p, int on)
+{
+  int rc = pllhip_profile_enable(pll_amd_priv(p)->ctx, on);
+  if (rc) return pll_amd_fail_hip(rc, "profile enable");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_profile_read(pll_partition_t * p, unsigned int * launches, double * total_ms)
+{
+  int rc = pllhip_profile_read(pll_amd_priv(p)->ctx, launches, total_ms);
+  if (rc) return pll_amd_fail_hip(rc, "profile read");
+  return PLL_SUCCESS;
+}

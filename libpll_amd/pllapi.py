@@ -144,6 +144,8 @@ class PllLibrary:
             lib.pll_amd_timer_stop_ms.argtypes = [_PP, C.POINTER(C.c_float)]
             lib.pll_amd_comm_unique_id.argtypes = [C.c_void_p]
             lib.pll_amd_comm_init.argtypes = [_PP, C.c_int, C.c_int, C.c_void_p]
+            lib.pll_amd_profile_enable.argtypes = [_PP, C.c_int]
+            lib.pll_amd_profile_read.argtypes = [_PP, _up, _dp]
             lib.pll_amd_eigen_decompose.argtypes = [C.c_uint, _dp, _dp, _dp, _dp, _dp]
 
     # -- library-level helpers -------------------------------------------------
@@ -346,6 +348,18 @@ class Partition:
         ms = C.c_float()
         self._check(self.lib.pll_amd_timer_stop_ms(self.ptr, C.byref(ms)), "pll_amd_timer_stop_ms")
         return ms.value
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.pll_amd_profile_enable(self.ptr, 1 if on else 0), "pll_amd_profile_enable")
+
+    def profile_read(self):
+        """{kind: (launches, total_ms)} since the last read."""
+        n = np.zeros(7, dtype=np.uint32)
+        ms = np.zeros(7)
+        self._check(self.lib.pll_amd_profile_read(self.ptr, _u(n), _d(ms)), "pll_amd_profile_read")
+        names = ("partials_ii", "partials_ti", "partials_tt", "lnl", "sumtable", "derivatives",
+                 "pmatrix")
+        return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(names)}
 
     def comm_init(self, rank, nranks, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)

@@ -1,0 +1,69 @@
+"""pytest configuration.
+
+Markers
+  gpu      needs a real MI355X (selected with ``-m gpu`` on the GPU box); these are
+           the parity tests proper and call the product through its C-ABI.
+  (none)   CPU-only: oracle vs golden vectors / reference build, host logic,
+           symbol exports, gloo multi-process sharding.
+
+The product library and the CPU checkers are built on demand (make) when their
+shared objects are missing, so a fresh checkout can run ``pytest`` directly.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+LIB = os.path.join(ROOT, "libpll_amd", "libpll_amd.so")
+ORACLE = os.path.join(ROOT, "oracle", "liboracle.so")
+REF = os.path.join(ROOT, "oracle", "_ref", "libpll_ref.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (run with -m gpu)")
+
+
+def _make(target, cwd=ROOT):
+    subprocess.run(["make", "-j4", target], cwd=cwd, check=True, stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="session")
+def amd():
+    """The product library.  Missing library = hard failure, never a skip."""
+    if not os.path.exists(LIB):
+        _make("lib")
+    import libpll_amd
+    return libpll_amd.load()
+
+
+@pytest.fixture(scope="session")
+def gpu(amd):
+    """The product library with a visible device; fails loudly without one."""
+    n = amd.device_count()
+    assert n > 0, "no HIP device visible: the gpu-marked tests must run on a GPU box"
+    return amd
+
+
+@pytest.fixture(scope="session")
+def orc():
+    if not os.path.exists(ORACLE):
+        _make("oracle", os.path.join(ROOT, "oracle"))
+    from oracle_api import Oracle
+    return Oracle(ORACLE)
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The genuine reference, built in place from /root/reference by
+    oracle/Makefile (dev container) or shipped prebuilt (GPU box)."""
+    if not os.path.exists(REF) and os.path.exists("/root/reference/src/pll.h"):
+        _make("ref", os.path.join(ROOT, "oracle"))
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/libpll_ref.so not available")
+    from libpll_amd.pllapi import PllLibrary
+    return PllLibrary(REF)

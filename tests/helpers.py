@@ -1,0 +1,148 @@
+"""Shared builders for the parity tests: one description of a case, applied
+identically to a pll-API library (product or reference) and to the oracle."""
+import numpy as np
+
+from libpll_amd import workload as W
+from libpll_amd.pllapi import ATTRIB_PATTERN_TIP
+from oracle_api import OracleRun
+
+TREES = {"balanced": W.balanced_tree, "caterpillar": W.caterpillar_tree, "random": W.random_tree}
+
+
+def make_case(states=4, shape="balanced", tips=16, sites=200, rate_cats=4, seed=1, alpha=0.7,
+              gap_frac=0.05, weights=True, branch=None, ambiguity=True):
+    """A tree + alignment + model description (plain data)."""
+    plan = TREES[shape](tips, seed=seed, branch=branch)
+    rng = np.random.default_rng(seed)
+    seqs = None
+    if states in (4, 20):
+        seqs = W.random_alignment(tips, sites, states, seed=seed + 100, gap_frac=gap_frac)
+        if ambiguity:
+            extra = b"RYKMSWBDHVN" if states == 4 else b"BZX"
+            seqs = [bytearray(s) for s in seqs]
+            for s in seqs:
+                for pos in rng.integers(0, sites, size=max(1, sites // 25)):
+                    s[pos] = extra[rng.integers(0, len(extra))]
+            seqs = [bytes(s) for s in seqs]
+    pw = rng.integers(1, 4, size=sites).astype(np.uint32) if weights else None
+    if states == 4:
+        rates, freqs = W.GTR_RATES, W.GTR_FREQS
+    else:
+        rates = rng.uniform(0.3, 4.0, states * (states - 1) // 2)
+        freqs = rng.dirichlet(np.ones(states) * 8)
+    return dict(states=states, plan=plan, seqs=seqs, sites=sites, rate_cats=rate_cats,
+                alpha=alpha, pw=pw, rates=rates, freqs=freqs, seed=seed, tips=tips, cmap=None)
+
+
+def odd_state_case(states, tips=9, sites=30, seed=3):
+    """5- or 7-state data over the alphabet A.. with a hand-made character map."""
+    case = make_case(states, "random", tips, sites, seed=seed)
+    rng = np.random.default_rng(seed)
+    alphabet = b"ABCDEFGHIJ"[:states]
+    chars = np.frombuffer(alphabet, dtype=np.uint8)
+    case["seqs"] = [chars[rng.integers(0, states, sites)].tobytes() for _ in range(tips)]
+    cmap = np.zeros(256, dtype=np.uint32)
+    for i, ch in enumerate(alphabet):
+        cmap[ch] = 1 << i
+    cmap[ord("-")] = (1 << states) - 1
+    for s in range(0, tips, 3):
+        b = bytearray(case["seqs"][s])
+        b[s % sites] = ord("-")
+        case["seqs"][s] = bytes(b)
+    case["cmap"] = cmap
+    return case
+
+
+def case_map(lib, case):
+    if case["cmap"] is not None:
+        return case["cmap"]
+    return lib.map("nt" if case["states"] == 4 else "aa")
+
+
+def build_partition(lib, case, attrs, pinv=0.0):
+    """Create + fill a partition on `lib`; returns it with P-matrices computed."""
+    plan, S, R = case["plan"], case["states"], case["rate_cats"]
+    if lib.is_amd:
+        attrs &= ~0xF
+    p = lib.partition_create(plan.tips, plan.clv_buffers, S, case["sites"], 1, plan.prob_matrices,
+                             R, plan.scale_buffers, attrs)
+    p.set_frequencies(0, case["freqs"])
+    p.set_subst_params(0, case["rates"])
+    p.set_category_rates(lib.compute_gamma_cats(case["alpha"], R))
+    cmap = case_map(lib, case)
+    for i, s in enumerate(case["seqs"]):
+        p.set_tip_states(i, cmap, s)
+    if case["pw"] is not None:
+        p.set_pattern_weights(case["pw"])
+    if pinv > 0:
+        p.update_invariant_sites_proportion(0, pinv)
+    p.update_prob_matrices([0] * R, plan.matrix_indices, plan.branch_lengths)
+    return p
+
+
+def model_of(part, lib, case, pinv=0.0):
+    """Model arrays as the partition holds them on the host (eigen system from
+    pll_update_eigen, category rates from pll_compute_gamma_cats)."""
+    vals, vecs, inv = part.get_eigen(0)
+    S, R = case["states"], case["rate_cats"]
+    fr = np.ctypeslib.as_array(part.s.frequencies[0], shape=(part.s.states_padded,)).copy()[:S]
+    return dict(states=S, rate_cats=R, rates=lib.compute_gamma_cats(case["alpha"], R),
+                rate_weights=np.full(R, 1.0 / R), eigenvals=vals, eigenvecs=vecs,
+                inv_eigenvecs=inv, freqs=fr, pinv=pinv)
+
+
+def encode_tips(part):
+    """(tipcodes[tips][sites] uint8, tipmap) as the partition encoded them."""
+    s = part.s
+    codes = np.stack([np.ctypeslib.as_array(s.tipchars[i], shape=(s.sites,)).copy()
+                      for i in range(s.tips)])
+    tipmap = np.ctypeslib.as_array(s.tipmap, shape=(256,)).copy()
+    return codes, tipmap
+
+
+def tip_clvs(case, cmap):
+    """0/1 tip CLVs [tips][sites][R][S] from the character map (pll.c:905-939)."""
+    S, R = case["states"], case["rate_cats"]
+    out = np.zeros((case["tips"], case["sites"], R, S))
+    for i, seq in enumerate(case["seqs"]):
+        masks = cmap[np.frombuffer(seq, dtype=np.uint8)]
+        bits = (masks[:, None] >> np.arange(S)[None, :]) & 1
+        out[i] = bits[:, None, :].astype(np.float64)
+    return out
+
+
+def invariant_of(part):
+    s = part.s
+    if not s.invariant:
+        return None
+    return np.ctypeslib.as_array(s.invariant, shape=(s.sites,)).copy()
+
+
+def oracle_run(orc, lib, part, case, attrs, pinv=0.0):
+    model = model_of(part, lib, case, pinv)
+    inv = invariant_of(part) if pinv > 0 else None
+    if attrs & ATTRIB_PATTERN_TIP:
+        codes, tipmap = encode_tips(part)
+        return OracleRun(orc, model, case["plan"], attrs, tipcodes=codes, tipmap=tipmap,
+                         pattern_weights=case["pw"], invariant=inv)
+    return OracleRun(orc, model, case["plan"], attrs, tipclvs=tip_clvs(case, case_map(lib, case)),
+                     pattern_weights=case["pw"], invariant=inv)
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and bool((a.view(np.uint64) == b.view(np.uint64)).all())
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
+
+
+def sumtable_err(a, b):
+    """max |a-b| relative to the largest entry of the same (site, rate) block:
+    entries that are analytically zero (gap columns) carry only rounding noise."""
+    scale = np.abs(b).max(axis=2, keepdims=True) + 1e-300
+    return float(np.max(np.abs(a - b) / scale))

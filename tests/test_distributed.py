@@ -1,0 +1,83 @@
+"""world_size-2 run of the site-sharding scheme on CPU (gloo).
+
+The multi-GPU path shards alignment columns across ranks with no data-path
+collective; the only exchange is a sum of per-shard lnL (and of d/dd).  Here
+two processes each evaluate their shard -- through the oracle, since there is no
+GPU -- using the same shard_bounds / site_range code bench.py and the product
+use, all-reduce the scalar over gloo and must reproduce the unsharded value.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from libpll_amd import workload as W
+from libpll_amd.pllapi import PllLibrary, ATTRIB_PATTERN_TIP
+from oracle_api import Oracle, OracleRun
+from helpers import make_case
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+orc = Oracle(os.path.join(sys.argv[1], "oracle", "liboracle.so"))
+amd = PllLibrary(os.path.join(sys.argv[1], "libpll_amd", "libpll_amd.so"))
+case = make_case(4, "random", 10, 1000, seed=11)
+S, R, plan = 4, 4, case["plan"]
+dp = lambda a: a.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))
+vals, vecs, inv = np.zeros(S), np.zeros((S, S)), np.zeros((S, S))
+rates = np.ascontiguousarray(case["rates"]); freqs = np.ascontiguousarray(case["freqs"])
+assert amd.lib.pll_amd_eigen_decompose(S, dp(rates), dp(freqs), dp(vals), dp(vecs), dp(inv))
+model = dict(states=S, rate_cats=R, rates=amd.compute_gamma_cats(0.7, R),
+             rate_weights=np.full(R, 0.25), eigenvals=vals, eigenvecs=vecs, inv_eigenvecs=inv,
+             freqs=freqs, pinv=0.0)
+cmap = amd.map("nt")
+codes = np.stack([cmap[np.frombuffer(s, dtype=np.uint8)].astype(np.uint8) for s in case["seqs"]])
+
+def evaluate(lo, hi):
+    o = OracleRun(orc, model, plan, ATTRIB_PATTERN_TIP, tipcodes=codes[:, lo:hi],
+                  tipmap=np.zeros(256, dtype=np.uint32), pattern_weights=case["pw"][lo:hi])
+    o.update_partials()
+    e = plan.root_edge
+    lnl = o.edge_loglikelihood(*e)
+    d, dd = o.derivatives(o.sumtable(e[0], e[2], e[1], e[3]), 0.1)
+    return np.array([lnl, d, dd])
+
+b = W.shard_bounds(1000, world, granule=256)
+mine = torch.from_numpy(evaluate(b[rank], b[rank + 1]))
+dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+full = evaluate(0, 1000)
+err = float(np.max(np.abs(mine.numpy() - full) / np.abs(full)))
+assert err < 1e-13, (mine, full)
+if rank == 0:
+    print("SHARDED_OK bounds=%s err=%.2e" % (b, err))
+dist.destroy_process_group()
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_site_sharding_two_ranks_gloo(tmp_path, orc, amd):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(free_port()), str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "SHARDED_OK" in out.stdout

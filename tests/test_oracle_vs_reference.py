@@ -1,0 +1,116 @@
+"""Pins the oracle: every restated kernel against the genuine reference
+(oracle/_ref/libpll_ref.so, AVX2 flag = the path north_star names).  4- and
+20-state results must be bit-identical; other state counts follow the plain-C
+order and are compared against the reference's CPU flag."""
+import numpy as np
+import pytest
+
+from helpers import (make_case, odd_state_case, build_partition, oracle_run, bits_equal, rel_err,
+                     sumtable_err)
+from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_ARCH_AVX2,
+                               ATTRIB_ARCH_CPU)
+
+CASES = [
+    (4, "balanced", 16, 97), (4, "random", 23, 64), (4, "caterpillar", 40, 33),
+    (20, "balanced", 8, 41), (20, "random", 11, 29),
+]
+
+
+def check_against(o, p, plan, R, clv_bits=True):
+    for mi in plan.matrix_indices:
+        assert bits_equal(o.pmat[int(mi)], p.get_pmatrix(int(mi))), "P-matrix %d" % mi
+    p.update_partials(plan.ops)
+    o.update_partials()
+    for op in plan.ops:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        assert bits_equal(o.clv[node], p.get_clv(node)), "CLV %d" % node
+        if sc >= 0:
+            assert (o.scalers[sc] == p.get_scaler(sc)).all(), "scaler %d" % sc
+    lnl_r, ps_r = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+    lnl_o, ps_o = o.edge_loglikelihood(*plan.root_edge, persite=True)
+    assert bits_equal(ps_o, ps_r)
+    assert lnl_o == lnl_r
+
+
+@pytest.mark.parametrize("states,shape,tips,sites", CASES)
+@pytest.mark.parametrize("pattern_tip", [0, ATTRIB_PATTERN_TIP])
+@pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
+def test_full_evaluation_bit_exact(ref, orc, states, shape, tips, sites, pattern_tip, rate_scalers):
+    attrs = pattern_tip | rate_scalers | ATTRIB_ARCH_AVX2
+    case = make_case(states, shape, tips, sites, seed=tips + sites)
+    if states == 20:
+        case["rates"], case["freqs"] = ref.aa_model("lg")
+    p = build_partition(ref, case, attrs)
+    o = oracle_run(orc, ref, p, case, attrs)
+    plan = case["plan"]
+    check_against(o, p, plan, 4)
+    # derivatives: the SIMD kernels reorder sums, so tolerance not bits
+    e = plan.root_edge
+    st = p.alloc_sumtable()
+    p.update_sumtable(e[0], e[2], e[1], e[3], [0] * 4, st)
+    so = o.sumtable(e[0], e[2], e[1], e[3])
+    assert sumtable_err(so, p.get_sumtable(st)) < 1e-12
+    for t in (0.01, 0.2, 1.5):
+        d_r = p.compute_likelihood_derivatives(e[1], e[3], t, [0] * 4, st)
+        d_o = o.derivatives(so, t)
+        assert rel_err(d_o, d_r) < 1e-10
+    p.destroy()
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_invariant_sites(ref, orc, states):
+    """+I model: prop_invar enters P-matrices, lnL and derivatives."""
+    attrs = ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2
+    case = make_case(states, "random", 7, 120, seed=9, gap_frac=0.0, ambiguity=False)
+    # make a third of the columns constant so invariant[] is populated
+    seqs = [bytearray(s) for s in case["seqs"]]
+    for col in range(0, 120, 3):
+        for s in seqs:
+            s[col] = seqs[0][col]
+    case["seqs"] = [bytes(s) for s in seqs]
+    if states == 20:
+        case["rates"], case["freqs"] = ref.aa_model("wag")
+    p = build_partition(ref, case, attrs, pinv=0.3)
+    o = oracle_run(orc, ref, p, case, attrs, pinv=0.3)
+    assert (o.invariant >= 0).sum() >= 40
+    check_against(o, p, case["plan"], 4)
+    p.destroy()
+
+
+@pytest.mark.parametrize("states,tips,expect_min", [(4, 700, 4), (20, 400, 5)])
+@pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
+def test_deep_tree_scalers(ref, orc, states, tips, expect_min, rate_scalers):
+    """Deep caterpillars drive the scaler counts up (stand-in for the reference's
+    `scaling` test, whose 2000-taxon tree file is not available offline)."""
+    attrs = ATTRIB_PATTERN_TIP | rate_scalers | ATTRIB_ARCH_AVX2
+    case = make_case(states, "caterpillar", tips, 8, seed=5, alpha=0.5, branch=0.5, weights=False,
+                     ambiguity=False, gap_frac=0.0)
+    if states == 20:
+        case["rates"], case["freqs"] = ref.aa_model("lg")
+    p = build_partition(ref, case, attrs)
+    o = oracle_run(orc, ref, p, case, attrs)
+    plan = case["plan"]
+    p.update_partials(plan.ops)
+    o.update_partials()
+    last = int(plan.ops[-1]["parent_scaler_index"])
+    sr = p.get_scaler(last)
+    assert sr.min() >= expect_min, "fixture no longer exercises scaling: %s" % sr
+    for op in list(plan.ops[::37]) + [plan.ops[-1]]:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        assert (o.scalers[sc] == p.get_scaler(sc)).all()
+        assert bits_equal(o.clv[node], p.get_clv(node))
+    lnl_r = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4)
+    lnl_o = o.edge_loglikelihood(*plan.root_edge)
+    assert lnl_o == lnl_r
+    p.destroy()
+
+
+@pytest.mark.parametrize("states", [5, 7])
+def test_odd_states_generic_order(ref, orc, states):
+    """No dedicated SIMD kernel exists for these: compare with the CPU flag."""
+    attrs = ATTRIB_ARCH_CPU
+    case = odd_state_case(states)
+    p = build_partition(ref, case, attrs)
+    o = oracle_run(orc, ref, p, case, attrs)
+    check_against(o, p, case["plan"], 4)
+    p.destroy()
