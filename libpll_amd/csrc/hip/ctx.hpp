@@ -51,6 +51,7 @@ struct pllhip_ctx
   // reductions: per-block partial sums, then a fixed-order final pass
   double * block_partials = nullptr;   // [PLLHIP_REDUCE_BLOCKS][2]
   double * d_result = nullptr;         // [4]
+  unsigned int * d_zero = nullptr;     // [4] zeros
   double * h_result = nullptr;         // pinned [4]
   double * d_persite = nullptr;        // [sites], lazily allocated
 
@@ -117,6 +118,15 @@ static inline double * pllhip_pmat_ptr(const pllhip_ctx * c, unsigned int idx)
 
 // grid size for a streaming kernel: enough blocks to fill 256 CUs several
 // times over, capped so grid-stride loops amortise the per-thread setup
+// Streams that cannot be reused from cache before they are evicted (one CLV
+// bigger than a quarter of the 256 MiB Infinity Cache) use non-temporal loads
+// and stores; smaller partitions keep the default policy so a parent written by
+// one op is still on-die when the next op reads it.
+static inline bool pllhip_use_nt(const pllhip_ctx * c)
+{
+  return c->clv_elems * sizeof(double) >= ((size_t)64 << 20);
+}
+
 static inline unsigned int pllhip_stream_grid(const pllhip_ctx * c, size_t items,
                                               unsigned int block)
 {
@@ -140,6 +150,7 @@ struct PartialsArgs
   const unsigned int * lscaler;
   const unsigned int * rscaler;
   const unsigned int * __restrict__ tipmap;
+  const unsigned int * zero;             // one device word holding 0 (stand-in for absent scalers)
   unsigned int sites, rate_cats, states, maxstates;
 };
 

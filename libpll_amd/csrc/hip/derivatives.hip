@@ -125,6 +125,7 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
   memset(&a, 0, sizeof(a));
   a.parent = c->sumtable[slot];
   a.tipmap = c->tipmap;
+  a.zero = c->d_zero;
   a.sites = c->sh.sites;
   a.rate_cats = R;
   a.states = S;

@@ -34,6 +34,7 @@ struct LnlArgs
   const unsigned int * __restrict__ pattern_weights;
   const int * __restrict__ invariant;   // nullable
   const unsigned int * __restrict__ tipmap;
+  const unsigned int * zero;            // device word holding 0
   double * __restrict__ persite;        // nullable
   double * __restrict__ block_partials; // [gridDim.x]
   unsigned int sites, rate_cats, states, maxstates;
@@ -277,6 +278,147 @@ __global__ __launch_bounds__(256) void k_lnl_fast(LnlArgs a)
   block_sum_to_partials(acc, a.block_partials);
 }
 
+// 4 states: one lane per 16 bytes (two states), lane pairs joined by DPP -- the
+// same mapping as the CLV kernels (partials.hip), so every load instruction of
+// a wave is one contiguous KiB.  W = 2*RC lanes make one site.
+//
+// A wave works in rounds of 64 sites: W sub-steps of 64/W sites each.  In
+// sub-step j the lanes with (lane % W) == j keep their site's category sum, so
+// after the round every lane owns ONE distinct site and the expensive tail
+// (log, scaler term, weight, optional per-site store) runs once per site
+// instead of once per lane -- f64 VALU ops cost 4 cycles per wave on CDNA4 and
+// a redundant log on all 8 lanes of a site made the kernel VALU-bound.
+template <int RC, int KIND, bool NT>
+__global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
+{
+  constexpr unsigned int W = 2 * RC;        // lanes per site
+  constexpr unsigned int SPS = 64 / W;      // sites per sub-step
+  extern __shared__ double smem[]; // EDGE_TI: pi-weighted tip row sums [16][RC][4]
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int h = lane & 1u;
+  const unsigned int k = (lane >> 1) & (RC - 1);
+  const unsigned int fi = a.freqs_indices[k];
+  const double * __restrict__ frk = a.freqs + (size_t)fi * 4;
+  const double fr0 = frk[2 * h], fr1 = frk[2 * h + 1];
+  const double wk = a.rate_weights[k];
+  const double pinv = a.prop_invar[fi];
+  half_rows pm;
+  if (KIND == EDGE_II) pm.load(a.pmat, k, h);
+  if (KIND == EDGE_TI)
+  {
+    for (unsigned int t = threadIdx.x; t < 16 * RC * 4; t += blockDim.x)
+    {
+      const unsigned int code = t / (RC * 4), kk = (t / 4) % RC, j = t % 4;
+      // freqs * rowsum (core_likelihood_avx.c:291-301)
+      smem[t] = a.freqs[(size_t)a.freqs_indices[kk] * 4 + j] *
+                masksum4(a.pmat + ((size_t)kk * 4 + j) * 4, code);
+    }
+    __syncthreads();
+  }
+  const unsigned int * ps_rate = a.pscaler ? a.pscaler : a.zero;
+  const unsigned int * cs_rate = (KIND == EDGE_II && a.cscaler) ? a.cscaler : a.zero;
+  const bool has_ps = a.pscaler != nullptr, has_cs = (KIND == EDGE_II && a.cscaler != nullptr);
+  const bool per_rate = a.rate_scalers && KIND != ROOT;
+
+  double acc = 0.0;
+  const size_t rounds = ((size_t)a.sites + 63) / 64;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const unsigned int grp0 = lane & ~(W - 1);
+  const double2 * __restrict__ P2 = reinterpret_cast<const double2 *>(a.parent);
+  const double2 * __restrict__ C2 = reinterpret_cast<const double2 *>(a.child);
+  const size_t total = (size_t)a.sites * W;
+  for (size_t r = wave; r < rounds; r += nwaves)
+  {
+    double my_terma = 1.0;
+    unsigned int my_rate_min = 0;
+#pragma unroll
+    for (unsigned int j = 0; j < W; ++j)
+    {
+      const size_t g = (r * 64 + (size_t)j * SPS) * W + lane;
+      const bool act = g < total;
+      const size_t gc = act ? g : 0;
+      const size_t n = gc / W, e = gc >> 1;
+      const double2 p = ld16<NT>(P2 + gc);
+      double t0, t1;
+      if (KIND == EDGE_II)
+      {
+        const double2 c = ld16<NT>(C2 + gc);
+        const double2 cp = make_double2(dpp_pair_swap(c.x), dpp_pair_swap(c.y));
+        // row dot, x pi, x parent (core_likelihood_avx.c:1175-1213)
+        t0 = (fr0 * pm.dot(0, c, cp)) * p.x;
+        t1 = (fr1 * pm.dot(1, c, cp)) * p.y;
+      }
+      else if (KIND == EDGE_TI)
+      {
+        const unsigned int code = a.tip[n] & 15u;
+        const double2 m = *reinterpret_cast<const double2 *>(smem + (code * RC + k) * 4 + 2 * h);
+        t0 = m.x * p.x;
+        t1 = m.y * p.y;
+      }
+      else
+      {
+        t0 = fr0 * p.x;
+        t1 = fr1 * p.y;
+      }
+      // (t0 + t1) + (t2 + t3): own pair plus the partner's pair
+      const double s = t0 + t1;
+      double terma_r = s + dpp_pair_swap(s);
+
+      unsigned int mn = 0;
+      if (per_rate)
+      {
+        const unsigned int mine = ps_rate[has_ps ? e : 0] + cs_rate[has_cs ? e : 0];
+        mn = mine;
+        for (unsigned int off = 2; off < W; off <<= 1)
+        {
+          const unsigned int o = (unsigned int)__shfl_xor((int)mn, (int)off, 64);
+          mn = o < mn ? o : mn;
+        }
+        unsigned int rel = mine - mn;
+        if (rel > PLLHIP_SCALE_RATE_MAXDIFF) rel = PLLHIP_SCALE_RATE_MAXDIFF;
+        if (rel > 0) terma_r *= scale_minlh(rel);
+      }
+      // weighted category term (core_likelihood_avx.c:1225-1240); the 4-state
+      // edge kernels skip non-positive terms, the root kernel does not
+      double contrib;
+      if (KIND != ROOT && !(terma_r > 0.0))
+        contrib = 0.0;
+      else if (pinv > 0.0)
+      {
+        const int inv = a.invariant ? a.invariant[n] : -1;
+        const double inv_lk = (inv == -1) ? 0.0 : frk[inv];
+        contrib = wk * (terma_r * (1.0 - pinv) + inv_lk * pinv);
+      }
+      else
+        contrib = terma_r * wk;
+      double terma = 0.0;
+#pragma unroll
+      for (int i = 0; i < RC; ++i) terma += __shfl(contrib, (int)(grp0 + 2 * i), 64);
+      if ((lane & (W - 1)) == j)
+      {
+        my_terma = terma;
+        my_rate_min = mn;
+      }
+    }
+    // lane l now owns site (l % W) * SPS + l / W of this round
+    const size_t n = r * 64 + (size_t)(lane & (W - 1)) * SPS + (lane / W);
+    if (n < a.sites)
+    {
+      unsigned int site_scalings = my_rate_min;
+      if (!per_rate)
+      {
+        // per-site counts; the root kernel reads scaler[n] even in per-rate mode
+        // (core_likelihood.c:197-198)
+        if (a.pscaler) site_scalings += a.pscaler[n];
+        if (KIND == EDGE_II && a.cscaler) site_scalings += a.cscaler[n];
+      }
+      acc += site_loglk(a, my_terma, n, site_scalings);
+    }
+  }
+  block_sum_to_partials(acc, a.block_partials);
+}
+
 // any states / any rate_cats: one lane per site
 template <int KIND>
 __global__ __launch_bounds__(128) void k_lnl_gen(LnlArgs a)
@@ -349,7 +491,8 @@ __global__ __launch_bounds__(128) void k_lnl_gen(LnlArgs a)
 
 #define LAUNCH_LNL(RCV, KINDV)                                                            \
   do {                                                                                    \
-    if (s4) k_lnl_fast<RCV, KINDV, true><<<grid, 256, lds, c->stream>>>(a);               \
+    if (s4 && nt) k_lnl_dna<RCV, KINDV, true><<<grid, 256, lds, c->stream>>>(a);          \
+    else if (s4) k_lnl_dna<RCV, KINDV, false><<<grid, 256, lds, c->stream>>>(a);          \
     else k_lnl_fast<RCV, KINDV, false><<<grid, 256, lds, c->stream>>>(a);                 \
   } while (0)
 
@@ -374,6 +517,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   a.pattern_weights = c->pattern_weights;
   a.invariant = c->invariant;
   a.tipmap = c->tipmap;
+  a.zero = c->d_zero;
   a.sites = c->sh.sites;
   a.rate_cats = R;
   a.states = S;
@@ -393,10 +537,13 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   if (fast)
   {
     const bool s4 = (S == 4);
-    grid = pllhip_stream_grid(c, (size_t)a.sites * R, 256);
+    const bool nt = pllhip_use_nt(c);
+    // 4 states: a wave consumes 64 sites per round
+    grid = s4 ? pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256)
+              : pllhip_stream_grid(c, (size_t)a.sites * R, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
     size_t lds = 0;
-    if (kind == EDGE_II) lds = (size_t)R * S * S * sizeof(double);
+    if (kind == EDGE_II && !s4) lds = (size_t)R * S * S * sizeof(double);
     if (kind == EDGE_TI) lds = (size_t)(s4 ? 16u : c->maxstates) * R * S * sizeof(double);
     if (kind == EDGE_II) LAUNCH_LNL_RC(EDGE_II);
     if (kind == EDGE_TI) LAUNCH_LNL_RC(EDGE_TI);

@@ -200,3 +200,76 @@ struct dview
   const double * p;
   __device__ __forceinline__ double operator[](unsigned int j) const { return p[j]; }
 };
+
+#ifndef PLLHIP_NUMERICS_HOST_BUILD
+// true iff `lane_flag` holds on all W lanes of this lane's aligned group (W = 2..64)
+template <int W>
+__device__ __forceinline__ bool group_all(bool lane_flag)
+{
+  const unsigned long long b = __ballot(lane_flag);
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned long long grp = b >> (lane & ~(unsigned int)(W - 1));
+  const unsigned long long full = (W >= 64) ? ~0ull : ((1ull << W) - 1ull);
+  return (grp & full) == full;
+}
+
+// 16-byte global accesses with a compile-time cache policy
+typedef double pll_v2d __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 ld16(const double2 * p)
+{
+  if (NT)
+  {
+    const pll_v2d v = __builtin_nontemporal_load(reinterpret_cast<const pll_v2d *>(p));
+    return make_double2(v.x, v.y);
+  }
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(double2 * p, double a, double b)
+{
+  if (NT)
+  {
+    const pll_v2d v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<pll_v2d *>(p));
+  }
+  else
+    *p = make_double2(a, b);
+}
+
+// ---- lane-pair helpers of the 4-state kernels (one lane per 16 bytes) ----
+__device__ __forceinline__ double dpp_pair_swap(double v)
+{
+  // quad_perm [1,0,3,2]: every lane reads its xor-1 neighbour
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// matrix rows 2h, 2h+1 of category k, columns split into the lane's own pair
+// (2h, 2h+1) and its partner's: m[r][0..1] own, m[r][2..3] partner
+struct half_rows
+{
+  double m[2][4];
+  __device__ __forceinline__ void load(const double * __restrict__ mat, unsigned int k,
+                                       unsigned int h)
+  {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+    {
+      const double * row = mat + k * 16 + (2 * h + r) * 4;
+      m[r][0] = row[2 * h];
+      m[r][1] = row[2 * h + 1];
+      m[r][2] = row[2 - 2 * h];
+      m[r][3] = row[3 - 2 * h];
+    }
+  }
+  // row r of the matrix times the 4-vector (own.x, own.y | par.x, par.y)
+  __device__ __forceinline__ double dot(int r, double2 own, double2 par) const
+  {
+    return (m[r][0] * own.x + m[r][1] * own.y) + (m[r][2] * par.x + m[r][3] * par.y);
+  }
+};
+
+#endif

@@ -31,71 +31,81 @@
 template <int RC>
 __device__ __forceinline__ bool site_all(bool lane_flag)
 {
-  // true iff lane_flag holds on all RC lanes of this lane's site
-  const unsigned long long b = __ballot(lane_flag);
-  const unsigned int lane = threadIdx.x & 63u;
-  const unsigned int grp = (unsigned int)(b >> (lane & ~(unsigned int)(RC - 1)));
-  const unsigned int full = (RC >= 32) ? 0xffffffffu : ((1u << RC) - 1u);
-  return (grp & full) == full;
-}
-
-template <int MODE, int RC>
-__device__ __forceinline__ void finish4(const PartialsArgs & a, size_t e, bool act, unsigned int k,
-                                        double p0, double p1, double p2, double p3,
-                                        unsigned int base_scale)
-{
-  // scaling rule of core_partials_avx.c:486-527
-  const bool small = (p0 < PLLHIP_SCALE_THRESHOLD) & (p1 < PLLHIP_SCALE_THRESHOLD) &
-                     (p2 < PLLHIP_SCALE_THRESHOLD) & (p3 < PLLHIP_SCALE_THRESHOLD);
-  bool scale = false;
-  if (MODE == SCALE_RATE) scale = small;
-  if (MODE == SCALE_SITE) scale = site_all<RC>(small || !act);
-  if (scale)
-  {
-    p0 *= PLLHIP_SCALE_FACTOR; p1 *= PLLHIP_SCALE_FACTOR;
-    p2 *= PLLHIP_SCALE_FACTOR; p3 *= PLLHIP_SCALE_FACTOR;
-  }
-  if (!act) return;
-  double2 * out = reinterpret_cast<double2 *>(a.parent + 4 * e);
-  out[0] = make_double2(p0, p1);
-  out[1] = make_double2(p2, p3);
-  if (MODE == SCALE_RATE) a.pscaler[e] = base_scale + (scale ? 1u : 0u);
-  if (MODE == SCALE_SITE && k == 0) a.pscaler[e / RC] = base_scale + (scale ? 1u : 0u);
+  return group_all<RC>(lane_flag);
 }
 
 // ---------------------------------------------------------------- 4 states
+//
+// One lane per 16 BYTES (two states): lanes 2m and 2m+1 own one (site, rate)
+// element, so every global load/store instruction of a wave is one contiguous
+// 1 KiB -- whole 128-B lines per instruction, for reads and writes alike.  The
+// pair swaps its two doubles with a DPP quad_perm (VALU, no LDS), after which
+// lane h computes output states 2h and 2h+1.  Summation order is unchanged:
+//   row . v = (m0 v0 + m1 v1) + (m2 v2 + m3 v3)
+// lane 0 forms (own) + (partner), lane 1 forms (own) + (partner) with own =
+// columns 2,3 -- the same two partial sums added in the other order, which is
+// bitwise identical because IEEE addition commutes.
 
-template <int RC, int MODE>
+// W = 2*RC lanes make one site.  Applies the scaling rule of
+// core_partials_avx.c:486-527 and stores this lane's two states.
+template <int MODE, int RC, bool NT>
+__device__ __forceinline__ void finish_half(const PartialsArgs & a, size_t g, bool act,
+                                            double p0, double p1, unsigned int base_scale)
+{
+  const bool small = (p0 < PLLHIP_SCALE_THRESHOLD) & (p1 < PLLHIP_SCALE_THRESHOLD);
+  bool scale = false;
+  if (MODE == SCALE_RATE) scale = group_all<2>(small || !act);
+  if (MODE == SCALE_SITE) scale = group_all<2 * RC>(small || !act);
+  if (scale)
+  {
+    p0 *= PLLHIP_SCALE_FACTOR;
+    p1 *= PLLHIP_SCALE_FACTOR;
+  }
+  if (!act) return;
+  st16<NT>(reinterpret_cast<double2 *>(a.parent) + g, p0, p1);
+  if (MODE == SCALE_RATE && (g & 1) == 0) a.pscaler[g >> 1] = base_scale + (scale ? 1u : 0u);
+  if (MODE == SCALE_SITE && (g & (2 * RC - 1)) == 0)
+    a.pscaler[g / (2 * RC)] = base_scale + (scale ? 1u : 0u);
+}
+
+// scaler counts inherited from the children.  Absent scalers point at a zero
+// word and the loads are unconditional: a load inside a branch makes the
+// compiler wait for it (and for every CLV load in flight) on the spot.
+template <int MODE, int RC>
+__device__ __forceinline__ unsigned int inherited_scale(const PartialsArgs & a, size_t g)
+{
+  if (MODE == SCALE_NONE) return 0;
+  const size_t si = (MODE == SCALE_RATE) ? (g >> 1) : g / (2 * RC);
+  const unsigned int * l = a.lscaler ? a.lscaler : a.zero;
+  const unsigned int * r = a.rscaler ? a.rscaler : a.zero;
+  return l[a.lscaler ? si : 0] + r[a.rscaler ? si : 0];
+}
+
+template <int RC, int MODE, bool NT>
 __global__ __launch_bounds__(256) void k_dna_ii(PartialsArgs a)
 {
-  const unsigned int k = threadIdx.x & (RC - 1);
-  double pl[16], pr[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { pl[i] = a.lmat[k * 16 + i]; pr[i] = a.rmat[k * 16 + i]; }
+  const unsigned int h = threadIdx.x & 1u;
+  const unsigned int k = (threadIdx.x >> 1) & (RC - 1);
+  half_rows pl, pr;
+  pl.load(a.lmat, k, h);
+  pr.load(a.rmat, k, h);
 
-  const size_t total = (size_t)a.sites * RC;
+  const size_t total = (size_t)a.sites * RC * 2;         // 16-byte granules
   const size_t total_up = (total + 63) & ~(size_t)63;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  const double2 * __restrict__ L = reinterpret_cast<const double2 *>(a.left);
+  const double2 * __restrict__ R = reinterpret_cast<const double2 *>(a.right);
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total_up; g += stride)
   {
-    const bool act = e < total;
-    const size_t ec = act ? e : 0;
-    const double2 * L = reinterpret_cast<const double2 *>(a.left + 4 * ec);
-    const double2 * R = reinterpret_cast<const double2 *>(a.right + 4 * ec);
-    const double2 l01 = L[0], l23 = L[1], r01 = R[0], r23 = R[1];
-    unsigned int base = 0;
-    if (MODE != SCALE_NONE)
-    {
-      const size_t si = (MODE == SCALE_RATE) ? ec : ec / RC;
-      if (a.lscaler) base += a.lscaler[si];
-      if (a.rscaler) base += a.rscaler[si];
-    }
-    double p[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      p[i] = dot4(pl + 4 * i, l01.x, l01.y, l23.x, l23.y) *
-             dot4(pr + 4 * i, r01.x, r01.y, r23.x, r23.y);
-    finish4<MODE, RC>(a, e, act, k, p[0], p[1], p[2], p[3], base);
+    const bool act = g < total;
+    const size_t gc = act ? g : 0;
+    const double2 lo = ld16<NT>(L + gc), ro = ld16<NT>(R + gc);
+    const unsigned int base = inherited_scale<MODE, RC>(a, gc);
+    const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
+    const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
+    const double p0 = pl.dot(0, lo, lp) * pr.dot(0, ro, rp);
+    const double p1 = pl.dot(1, lo, lp) * pr.dot(1, ro, rp);
+    finish_half<MODE, RC, NT>(a, g, act, p0, p1, base);
   }
 }
 
@@ -111,38 +121,37 @@ __device__ __forceinline__ void build_tip_table4(double * tab, const double * __
   }
 }
 
-template <int RC, int MODE>
+template <int RC, int MODE, bool NT>
 __global__ __launch_bounds__(256) void k_dna_ti(PartialsArgs a)
 {
   __shared__ double tab[16 * RC * 4];
   build_tip_table4<RC>(tab, a.lmat);
-  const unsigned int k = threadIdx.x & (RC - 1);
-  double pr[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) pr[i] = a.rmat[k * 16 + i];
+  const unsigned int h = threadIdx.x & 1u;
+  const unsigned int k = (threadIdx.x >> 1) & (RC - 1);
+  half_rows pr;
+  pr.load(a.rmat, k, h);
   __syncthreads();
 
-  const size_t total = (size_t)a.sites * RC;
+  const size_t total = (size_t)a.sites * RC * 2;
   const size_t total_up = (total + 63) & ~(size_t)63;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  const double2 * __restrict__ R = reinterpret_cast<const double2 *>(a.right);
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total_up; g += stride)
   {
-    const bool act = e < total;
-    const size_t ec = act ? e : 0;
-    const double2 * R = reinterpret_cast<const double2 *>(a.right + 4 * ec);
-    const double2 r01 = R[0], r23 = R[1];
-    const unsigned int code = a.ltip[ec / RC] & 15u;
-    unsigned int base = 0;
-    if (MODE != SCALE_NONE && a.rscaler) base = a.rscaler[(MODE == SCALE_RATE) ? ec : ec / RC];
-    const double * tl = tab + (code * RC + k) * 4;
-    double p[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = tl[i] * dot4(pr + 4 * i, r01.x, r01.y, r23.x, r23.y);
-    finish4<MODE, RC>(a, e, act, k, p[0], p[1], p[2], p[3], base);
+    const bool act = g < total;
+    const size_t gc = act ? g : 0;
+    const double2 ro = ld16<NT>(R + gc);
+    const unsigned int code = a.ltip[gc / (2 * RC)] & 15u;
+    const unsigned int base = inherited_scale<MODE, RC>(a, gc);
+    const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
+    const double2 tl = *reinterpret_cast<const double2 *>(tab + (code * RC + k) * 4 + 2 * h);
+    const double p0 = tl.x * pr.dot(0, ro, rp);
+    const double p1 = tl.y * pr.dot(1, ro, rp);
+    finish_half<MODE, RC, NT>(a, g, act, p0, p1, base);
   }
 }
 
-template <int RC, int MODE>
+template <int RC, int MODE, bool NT>
 __global__ __launch_bounds__(256) void k_dna_tt(PartialsArgs a)
 {
   // The reference materialises a 256-entry pair table (core_partials_avx.c:262);
@@ -152,21 +161,21 @@ __global__ __launch_bounds__(256) void k_dna_tt(PartialsArgs a)
   build_tip_table4<RC>(tabl, a.lmat);
   build_tip_table4<RC>(tabr, a.rmat);
   __syncthreads();
-  const unsigned int k = threadIdx.x & (RC - 1);
-  const size_t total = (size_t)a.sites * RC;
+  const unsigned int h = threadIdx.x & 1u;
+  const unsigned int k = (threadIdx.x >> 1) & (RC - 1);
+  const size_t total = (size_t)a.sites * RC * 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += stride)
+  double2 * __restrict__ out = reinterpret_cast<double2 *>(a.parent);
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += stride)
   {
-    const size_t n = e / RC;
+    const size_t n = g / (2 * RC);
     const unsigned int cl = a.ltip[n] & 15u, cr = a.rtip[n] & 15u;
-    const double * tl = tabl + (cl * RC + k) * 4;
-    const double * tr = tabr + (cr * RC + k) * 4;
-    double2 * out = reinterpret_cast<double2 *>(a.parent + 4 * e);
-    out[0] = make_double2(tl[0] * tr[0], tl[1] * tr[1]);
-    out[1] = make_double2(tl[2] * tr[2], tl[3] * tr[3]);
+    const double2 tl = *reinterpret_cast<const double2 *>(tabl + (cl * RC + k) * 4 + 2 * h);
+    const double2 tr = *reinterpret_cast<const double2 *>(tabr + (cr * RC + k) * 4 + 2 * h);
+    st16<NT>(out + g, tl.x * tr.x, tl.y * tr.y);
     // no scaling test on tip-tip; the scaler is cleared (core_partials_avx.c:598-599)
-    if (MODE == SCALE_RATE) a.pscaler[e] = 0u;
-    if (MODE == SCALE_SITE && k == 0) a.pscaler[n] = 0u;
+    if (MODE == SCALE_RATE && h == 0) a.pscaler[g >> 1] = 0u;
+    if (MODE == SCALE_SITE && (g & (2 * RC - 1)) == 0) a.pscaler[n] = 0u;
   }
 }
 
@@ -470,6 +479,31 @@ __global__ __launch_bounds__(256) void k_aa_tt(PartialsArgs a)
     }                                                                             \
   } while (0)
 
+#define LAUNCH_RC_MODE_NT(KERNEL, rc, mode, nt, grid, block, lds, stream, args)            \
+  do {                                                                                    \
+    switch (((rc) * 4 + (mode)) * 2 + ((nt) ? 1 : 0)) {                                   \
+      case (1 * 4 + 0) * 2: KERNEL<1, 0, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (1 * 4 + 1) * 2: KERNEL<1, 1, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (1 * 4 + 2) * 2: KERNEL<1, 2, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (2 * 4 + 0) * 2: KERNEL<2, 0, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (2 * 4 + 1) * 2: KERNEL<2, 1, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (2 * 4 + 2) * 2: KERNEL<2, 2, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (4 * 4 + 0) * 2: KERNEL<4, 0, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (4 * 4 + 1) * 2: KERNEL<4, 1, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (4 * 4 + 2) * 2: KERNEL<4, 2, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (8 * 4 + 0) * 2: KERNEL<8, 0, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (8 * 4 + 1) * 2: KERNEL<8, 1, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (8 * 4 + 2) * 2: KERNEL<8, 2, false><<<grid, block, lds, stream>>>(args); break;   \
+      case (16 * 4 + 0) * 2: KERNEL<16, 0, false><<<grid, block, lds, stream>>>(args); break; \
+      case (16 * 4 + 1) * 2: KERNEL<16, 1, false><<<grid, block, lds, stream>>>(args); break; \
+      case (16 * 4 + 2) * 2: KERNEL<16, 2, false><<<grid, block, lds, stream>>>(args); break; \
+      case (4 * 4 + 0) * 2 + 1: KERNEL<4, 0, true><<<grid, block, lds, stream>>>(args); break; \
+      case (4 * 4 + 1) * 2 + 1: KERNEL<4, 1, true><<<grid, block, lds, stream>>>(args); break; \
+      case (4 * 4 + 2) * 2 + 1: KERNEL<4, 2, true><<<grid, block, lds, stream>>>(args); break; \
+      default: break;                                                                     \
+    }                                                                                     \
+  } while (0)
+
 static bool fast_rc(unsigned int rc)
 {
   return rc == 1 || rc == 2 || rc == 4 || rc == 8 || rc == 16;
@@ -486,10 +520,12 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int
 
   if (a.states == 4 && fast_rc(R))
   {
-    const unsigned int grid = pllhip_stream_grid(c, items, 256);
-    if (kind == 0) LAUNCH_RC_MODE(k_dna_ii, R, mode, grid, 256, 0, s, a);
-    if (kind == 1) LAUNCH_RC_MODE(k_dna_ti, R, mode, grid, 256, 0, s, a);
-    if (kind == 2) LAUNCH_RC_MODE(k_dna_tt, R, mode, grid, 256, 0, s, a);
+    const unsigned int grid = pllhip_stream_grid(c, items * 2, 256);
+    // the non-temporal variants exist for the common 4-category case only
+    const bool nt = (R == 4) && pllhip_use_nt(c);
+    if (kind == 0) LAUNCH_RC_MODE_NT(k_dna_ii, R, mode, nt, grid, 256, 0, s, a);
+    if (kind == 1) LAUNCH_RC_MODE_NT(k_dna_ti, R, mode, nt, grid, 256, 0, s, a);
+    if (kind == 2) LAUNCH_RC_MODE_NT(k_dna_tt, R, mode, nt, grid, 256, 0, s, a);
   }
   else if (a.states == 20 && fast_rc(R) && R <= 8)
   {
@@ -538,6 +574,7 @@ static int launch_op(pllhip_ctx * c, const pllhip_op_t & op)
   a.parent = c->clv[op.parent_clv];
   a.pscaler = pllhip_scaler_ptr(c, op.parent_scaler);
   a.tipmap = c->tipmap;
+  a.zero = c->d_zero;
   a.sites = c->sh.sites;
   a.rate_cats = c->sh.rate_cats;
   a.states = c->sh.states;
