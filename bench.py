@@ -31,6 +31,11 @@ import time
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this
+# command (profiles/r1_pmc_*.csv): FETCH_SIZE x 2 (gfx950 counts 128-B requests at
+# 64 B) + WRITE_SIZE, KB -> bytes; 4 states, 1,000,000 sites.  None where no
+# counter pass was taken.
+TRAFFIC_NOTE = {4: 396.5e6}
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
 
@@ -141,27 +146,39 @@ def main():
     site_updates = float(ops_per_eval) * total_sites * args.steps
     value = site_updates / elapsed / 1e6
 
-    # ---- roofline leg: per-launch durations of the same steps, HIP events on
-    # the partition's stream (separate pass so event records do not sit inside
-    # the region `value` is computed from)
+    # ---- roofline leg, for the dominant kernel (the inner-inner CLV update):
+    # HIP events on the partition's own stream around back-to-back launches of
+    # that kernel alone -- the op list restricted to its inner-inner ops, the
+    # same launches as in the timed region -- divided by the launch count.  (A
+    # per-launch event pair would add its own ~2 us to every launch.)
+    c1 = plan.ops["child1_clv_index"] >= T
+    c2 = plan.ops["child2_clv_index"] >= T
+    ii_ops = plan.ops if args.tip_clv else plan.ops[c1 & c2]
+    roofline = None
+    if len(ii_ops):
+        part.update_partials(ii_ops)
+        part.wait()
+        part.timer_start()
+        for _ in range(args.steps):
+            part.update_partials(ii_ops)
+        ms = part.timer_stop_ms()
+        n_launch = len(ii_ops) * args.steps
+        avg_s = ms / n_launch / 1e3
+        algo_bytes = BYTES_PER_SITE["ii"][S] * (hi - lo)
+        achieved = algo_bytes / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "pll_core_update_partial_ii (%d states)" % S,
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": TRAFFIC_NOTE.get(S) if (hi - lo) == 1_000_000 else None,
+                    "bytes_per_site_update": BYTES_PER_SITE["ii"][S],
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": n_launch}
+    # per-class averages with one event pair per launch (diagnostic; each pair
+    # adds ~2 us, so these read high)
     part.profile_enable(True)
-    for _ in range(args.steps):
+    for _ in range(min(args.steps, 5)):
         step()
     prof = part.profile_read()
     part.profile_enable(False)
-    kinds = {"ii": prof["partials_ii"], "ti": prof["partials_ti"], "tt": prof["partials_tt"]}
-    dom = max(kinds, key=lambda k: kinds[k][1])
-    n_launch, tot_ms = kinds[dom]
-    roofline = None
-    if n_launch:
-        avg_s = tot_ms / n_launch / 1e3
-        algo_bytes = BYTES_PER_SITE[dom][S] * (hi - lo)
-        achieved = algo_bytes / avg_s / 1e9
-        roofline = {"bound": "hbm", "kernel": "pll_core_update_partial_%s (%d states)" % (dom, S),
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_site_update": BYTES_PER_SITE[dom][S],
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": n_launch}
     per_kernel = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2) if v[0] else None}
                   for k, v in prof.items() if v[0]}
 

@@ -11,6 +11,7 @@
 //   pmatrix       [prob_matrices][rate_cats][states][states] f64  (KBs; L2-resident)
 #include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <rccl/rccl.h>
@@ -88,6 +89,8 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, shape->device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char * e = getenv("PLLHIP_BLOCKS_PER_CU"))
+    if (atoi(e) > 0) c->blocks_per_cu = atoi(e);
 
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));

@@ -11,7 +11,7 @@
 #include "pllhip.h"
 
 #define PLLHIP_MAX_RATE_CATS 64
-#define PLLHIP_REDUCE_BLOCKS 2048 /* upper bound on blocks of a reducing kernel */
+#define PLLHIP_REDUCE_BLOCKS 65536 /* upper bound on blocks of a reducing kernel */
 
 struct ncclComm;
 
@@ -65,6 +65,12 @@ struct pllhip_ctx
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cus = 256;
+  // Grid cap of the streaming kernels (env PLLHIP_BLOCKS_PER_CU).  Measured on
+  // MI355X, 1,000,000 sites: one pass over the data with as many workgroups as
+  // it takes (3907) runs the 4-state CLV kernel in 65 us; capping the grid so
+  // that every wave makes 2 or 3 grid-stride passes costs 70-72 us.  So the cap
+  // is set where it only matters for alignments beyond ~16 M sites per GPU.
+  int blocks_per_cu = 256;
 
   // optional per-launch timing (pllhip_profile_*): one event pair per launch
   bool profiling = false;
@@ -116,8 +122,6 @@ static inline double * pllhip_pmat_ptr(const pllhip_ctx * c, unsigned int idx)
   return c->pmatrix + (size_t)idx * c->pmat_elems;
 }
 
-// grid size for a streaming kernel: enough blocks to fill 256 CUs several
-// times over, capped so grid-stride loops amortise the per-thread setup
 // Streams that cannot be reused from cache before they are evicted (one CLV
 // bigger than a quarter of the 256 MiB Infinity Cache) use non-temporal loads
 // and stores; smaller partitions keep the default policy so a parent written by
@@ -127,13 +131,20 @@ static inline bool pllhip_use_nt(const pllhip_ctx * c)
   return c->clv_elems * sizeof(double) >= ((size_t)64 << 20);
 }
 
+// Grid size for a streaming kernel over `items` lanes-worth of work: all of it
+// in one pass if that fits the cap (blocks_per_cu x CUs), otherwise the smallest
+// whole number of grid-stride passes, with the grid shrunk so every block does
+// the SAME number of passes -- a last pass that only part of the grid takes
+// showed up as 7 % of the CLV kernel's time.
 static inline unsigned int pllhip_stream_grid(const pllhip_ctx * c, size_t items,
                                               unsigned int block)
 {
   size_t need = (items + block - 1) / block;
-  size_t cap = (size_t)c->num_cus * 8;
+  const size_t cap = (size_t)c->num_cus * c->blocks_per_cu;
   if (need < 1) need = 1;
-  return (unsigned int)(need < cap ? need : cap);
+  if (need <= cap) return (unsigned int)need;
+  const size_t passes = (need + cap - 1) / cap;
+  return (unsigned int)((need + passes - 1) / passes);
 }
 
 // ---- shared between partials.hip and derivatives.hip ----

@@ -46,69 +46,6 @@ __device__ __forceinline__ bool site_all(bool lane_flag)
 // columns 2,3 -- the same two partial sums added in the other order, which is
 // bitwise identical because IEEE addition commutes.
 
-// W = 2*RC lanes make one site.  Applies the scaling rule of
-// core_partials_avx.c:486-527 and stores this lane's two states.
-template <int MODE, int RC, bool NT>
-__device__ __forceinline__ void finish_half(const PartialsArgs & a, size_t g, bool act,
-                                            double p0, double p1, unsigned int base_scale)
-{
-  const bool small = (p0 < PLLHIP_SCALE_THRESHOLD) & (p1 < PLLHIP_SCALE_THRESHOLD);
-  bool scale = false;
-  if (MODE == SCALE_RATE) scale = group_all<2>(small || !act);
-  if (MODE == SCALE_SITE) scale = group_all<2 * RC>(small || !act);
-  if (scale)
-  {
-    p0 *= PLLHIP_SCALE_FACTOR;
-    p1 *= PLLHIP_SCALE_FACTOR;
-  }
-  if (!act) return;
-  st16<NT>(reinterpret_cast<double2 *>(a.parent) + g, p0, p1);
-  if (MODE == SCALE_RATE && (g & 1) == 0) a.pscaler[g >> 1] = base_scale + (scale ? 1u : 0u);
-  if (MODE == SCALE_SITE && (g & (2 * RC - 1)) == 0)
-    a.pscaler[g / (2 * RC)] = base_scale + (scale ? 1u : 0u);
-}
-
-// scaler counts inherited from the children.  Absent scalers point at a zero
-// word and the loads are unconditional: a load inside a branch makes the
-// compiler wait for it (and for every CLV load in flight) on the spot.
-template <int MODE, int RC>
-__device__ __forceinline__ unsigned int inherited_scale(const PartialsArgs & a, size_t g)
-{
-  if (MODE == SCALE_NONE) return 0;
-  const size_t si = (MODE == SCALE_RATE) ? (g >> 1) : g / (2 * RC);
-  const unsigned int * l = a.lscaler ? a.lscaler : a.zero;
-  const unsigned int * r = a.rscaler ? a.rscaler : a.zero;
-  return l[a.lscaler ? si : 0] + r[a.rscaler ? si : 0];
-}
-
-template <int RC, int MODE, bool NT>
-__global__ __launch_bounds__(256) void k_dna_ii(PartialsArgs a)
-{
-  const unsigned int h = threadIdx.x & 1u;
-  const unsigned int k = (threadIdx.x >> 1) & (RC - 1);
-  half_rows pl, pr;
-  pl.load(a.lmat, k, h);
-  pr.load(a.rmat, k, h);
-
-  const size_t total = (size_t)a.sites * RC * 2;         // 16-byte granules
-  const size_t total_up = (total + 63) & ~(size_t)63;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const double2 * __restrict__ L = reinterpret_cast<const double2 *>(a.left);
-  const double2 * __restrict__ R = reinterpret_cast<const double2 *>(a.right);
-  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total_up; g += stride)
-  {
-    const bool act = g < total;
-    const size_t gc = act ? g : 0;
-    const double2 lo = ld16<NT>(L + gc), ro = ld16<NT>(R + gc);
-    const unsigned int base = inherited_scale<MODE, RC>(a, gc);
-    const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
-    const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
-    const double p0 = pl.dot(0, lo, lp) * pr.dot(0, ro, rp);
-    const double p1 = pl.dot(1, lo, lp) * pr.dot(1, ro, rp);
-    finish_half<MODE, RC, NT>(a, g, act, p0, p1, base);
-  }
-}
-
 // row sums of one P-matrix for the 16 DNA ambiguity codes, in LDS:
 // tab[(code * RC + k) * 4 + i] = sum_{j in code} P[k][i][j]
 template <int RC>
@@ -121,61 +58,122 @@ __device__ __forceinline__ void build_tip_table4(double * tab, const double * __
   }
 }
 
-template <int RC, int MODE, bool NT>
-__global__ __launch_bounds__(256) void k_dna_ti(PartialsArgs a)
+// All three 4-state CLV updates.  KIND 0 = inner-inner, 1 = tip-inner, 2 = tip-tip.
+//
+// W = 2*RC lanes make one site; a wave works in ROUNDS of 64 sites = W sub-steps
+// of 64/W sites.  Per round the per-site data (tip codes, inherited scaler
+// counts, the new scaler count) moves once, one element per lane; inside the
+// round the W sub-steps are unrolled, so a wave has 2*W 16-byte CLV loads in
+// flight before its first use -- a tip-tip update, whose only inputs are two
+// bytes per site, would otherwise wait a full memory round trip per KiB stored.
+// Lane l owns site (l % W) * (64/W) + l / W of the round: in sub-step j = l % W
+// its group is exactly that site, so the site's scaling decision is already in
+// the lane when the round ends.
+template <int RC, int MODE, bool NT, int KIND>
+__global__ __launch_bounds__(256) void k_dna_partials(PartialsArgs a)
 {
-  __shared__ double tab[16 * RC * 4];
-  build_tip_table4<RC>(tab, a.lmat);
-  const unsigned int h = threadIdx.x & 1u;
-  const unsigned int k = (threadIdx.x >> 1) & (RC - 1);
-  half_rows pr;
-  pr.load(a.rmat, k, h);
-  __syncthreads();
+  constexpr unsigned int W = 2 * RC;
+  constexpr unsigned int SPS = 64 / W;
+  __shared__ double tabl[KIND >= 1 ? 16 * RC * 4 : 1];
+  __shared__ double tabr[KIND == 2 ? 16 * RC * 4 : 1];
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int h = lane & 1u;
+  const unsigned int k = (lane >> 1) & (RC - 1);
+  half_rows pl, pr;
+  if (KIND == 0) pl.load(a.lmat, k, h);
+  if (KIND <= 1) pr.load(a.rmat, k, h);
+  if (KIND >= 1) build_tip_table4<RC>(tabl, a.lmat);
+  if (KIND == 2) build_tip_table4<RC>(tabr, a.rmat);
+  if (KIND >= 1) __syncthreads();
 
-  const size_t total = (size_t)a.sites * RC * 2;
-  const size_t total_up = (total + 63) & ~(size_t)63;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t sites = a.sites;
+  const size_t total = sites * W; // 16-byte granules
+  const size_t rounds = (sites + 63) / 64;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const unsigned int own = (lane & (W - 1)) * SPS + lane / W; // owned site within a round
+  const double2 * __restrict__ L = reinterpret_cast<const double2 *>(a.left);
   const double2 * __restrict__ R = reinterpret_cast<const double2 *>(a.right);
-  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total_up; g += stride)
-  {
-    const bool act = g < total;
-    const size_t gc = act ? g : 0;
-    const double2 ro = ld16<NT>(R + gc);
-    const unsigned int code = a.ltip[gc / (2 * RC)] & 15u;
-    const unsigned int base = inherited_scale<MODE, RC>(a, gc);
-    const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
-    const double2 tl = *reinterpret_cast<const double2 *>(tab + (code * RC + k) * 4 + 2 * h);
-    const double p0 = tl.x * pr.dot(0, ro, rp);
-    const double p1 = tl.y * pr.dot(1, ro, rp);
-    finish_half<MODE, RC, NT>(a, g, act, p0, p1, base);
-  }
-}
-
-template <int RC, int MODE, bool NT>
-__global__ __launch_bounds__(256) void k_dna_tt(PartialsArgs a)
-{
-  // The reference materialises a 256-entry pair table (core_partials_avx.c:262);
-  // the two 16-entry row-sum tables give the same products without it.
-  __shared__ double tabl[16 * RC * 4];
-  __shared__ double tabr[16 * RC * 4];
-  build_tip_table4<RC>(tabl, a.lmat);
-  build_tip_table4<RC>(tabr, a.rmat);
-  __syncthreads();
-  const unsigned int h = threadIdx.x & 1u;
-  const unsigned int k = (threadIdx.x >> 1) & (RC - 1);
-  const size_t total = (size_t)a.sites * RC * 2;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
   double2 * __restrict__ out = reinterpret_cast<double2 *>(a.parent);
-  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += stride)
+  // absent scalers read a zero word, unconditionally: a load inside a branch
+  // makes the compiler wait for it -- and for every CLV load in flight -- at once
+  const unsigned int * ls = (KIND == 0 && a.lscaler) ? a.lscaler : a.zero;
+  const unsigned int * rs = (KIND <= 1 && a.rscaler) ? a.rscaler : a.zero;
+  const bool has_l = (KIND == 0 && a.lscaler), has_r = (KIND <= 1 && a.rscaler);
+
+  for (size_t r = wave; r < rounds; r += nwaves)
   {
-    const size_t n = g / (2 * RC);
-    const unsigned int cl = a.ltip[n] & 15u, cr = a.rtip[n] & 15u;
-    const double2 tl = *reinterpret_cast<const double2 *>(tabl + (cl * RC + k) * 4 + 2 * h);
-    const double2 tr = *reinterpret_cast<const double2 *>(tabr + (cr * RC + k) * 4 + 2 * h);
-    st16<NT>(out + g, tl.x * tr.x, tl.y * tr.y);
-    // no scaling test on tip-tip; the scaler is cleared (core_partials_avx.c:598-599)
-    if (MODE == SCALE_RATE && h == 0) a.pscaler[g >> 1] = 0u;
-    if (MODE == SCALE_SITE && (g & (2 * RC - 1)) == 0) a.pscaler[n] = 0u;
+    const size_t site0 = r * 64;
+    const size_t n_own = site0 + own;
+    const bool own_ok = n_own < sites;
+    unsigned int codes_l = 0, codes_r = 0, base = 0;
+    if (KIND >= 1) codes_l = (site0 + lane < sites) ? a.ltip[site0 + lane] : 0;
+    if (KIND == 2) codes_r = (site0 + lane < sites) ? a.rtip[site0 + lane] : 0;
+    if (MODE == SCALE_SITE && KIND != 2)
+      base = ls[(has_l && own_ok) ? n_own : 0] + rs[(has_r && own_ok) ? n_own : 0];
+    bool own_scaled = false;
+
+#pragma unroll
+    for (unsigned int j = 0; j < W; ++j)
+    {
+      const size_t g = (site0 + (size_t)j * SPS) * W + lane;
+      const bool act = g < total;
+      const size_t gc = act ? g : 0;
+      const int src = (int)(j * SPS + lane / W); // lane holding this site's per-round data
+      double p0, p1;
+      if (KIND == 0)
+      {
+        const double2 lo = ld16<NT>(L + gc), ro = ld16<NT>(R + gc);
+        const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
+        const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
+        p0 = pl.dot(0, lo, lp) * pr.dot(0, ro, rp);
+        p1 = pl.dot(1, lo, lp) * pr.dot(1, ro, rp);
+      }
+      else if (KIND == 1)
+      {
+        const double2 ro = ld16<NT>(R + gc);
+        const unsigned int code = (unsigned int)__shfl((int)codes_l, src, 64) & 15u;
+        const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
+        const double2 tl = *reinterpret_cast<const double2 *>(tabl + (code * RC + k) * 4 + 2 * h);
+        p0 = tl.x * pr.dot(0, ro, rp);
+        p1 = tl.y * pr.dot(1, ro, rp);
+      }
+      else
+      {
+        // The reference materialises a 256-entry pair table (core_partials_avx.c:262);
+        // the two 16-entry row-sum tables give the same products without it.
+        const unsigned int cl = (unsigned int)__shfl((int)codes_l, src, 64) & 15u;
+        const unsigned int cr = (unsigned int)__shfl((int)codes_r, src, 64) & 15u;
+        const double2 tl = *reinterpret_cast<const double2 *>(tabl + (cl * RC + k) * 4 + 2 * h);
+        const double2 tr = *reinterpret_cast<const double2 *>(tabr + (cr * RC + k) * 4 + 2 * h);
+        p0 = tl.x * tr.x;
+        p1 = tl.y * tr.y;
+      }
+
+      // scaling rule of core_partials_avx.c:486-527; tip-tip never scales and
+      // clears its scaler (core_partials_avx.c:598-599)
+      bool scale = false;
+      if (KIND != 2 && MODE != SCALE_NONE)
+      {
+        const bool small = (p0 < PLLHIP_SCALE_THRESHOLD) & (p1 < PLLHIP_SCALE_THRESHOLD);
+        scale = (MODE == SCALE_RATE) ? group_all<2>(small || !act) : group_all<W>(small || !act);
+        if (scale)
+        {
+          p0 *= PLLHIP_SCALE_FACTOR;
+          p1 *= PLLHIP_SCALE_FACTOR;
+        }
+      }
+      if (act) st16<NT>(out + g, p0, p1);
+      if (MODE == SCALE_RATE)
+      {
+        // one count per (site, rate): 4 bytes per 32 bytes of CLV, kept per sub-step
+        const size_t e = gc >> 1;
+        const unsigned int inh = (KIND == 2) ? 0u : ls[has_l ? e : 0] + rs[has_r ? e : 0];
+        if (act && h == 0) a.pscaler[e] = inh + (scale ? 1u : 0u);
+      }
+      if (MODE == SCALE_SITE && (lane & (W - 1)) == j) own_scaled = scale;
+    }
+    if (MODE == SCALE_SITE && own_ok) a.pscaler[n_own] = base + (own_scaled ? 1u : 0u);
   }
 }
 
@@ -479,29 +477,18 @@ __global__ __launch_bounds__(256) void k_aa_tt(PartialsArgs a)
     }                                                                             \
   } while (0)
 
-#define LAUNCH_RC_MODE_NT(KERNEL, rc, mode, nt, grid, block, lds, stream, args)            \
-  do {                                                                                    \
-    switch (((rc) * 4 + (mode)) * 2 + ((nt) ? 1 : 0)) {                                   \
-      case (1 * 4 + 0) * 2: KERNEL<1, 0, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (1 * 4 + 1) * 2: KERNEL<1, 1, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (1 * 4 + 2) * 2: KERNEL<1, 2, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (2 * 4 + 0) * 2: KERNEL<2, 0, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (2 * 4 + 1) * 2: KERNEL<2, 1, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (2 * 4 + 2) * 2: KERNEL<2, 2, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (4 * 4 + 0) * 2: KERNEL<4, 0, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (4 * 4 + 1) * 2: KERNEL<4, 1, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (4 * 4 + 2) * 2: KERNEL<4, 2, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (8 * 4 + 0) * 2: KERNEL<8, 0, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (8 * 4 + 1) * 2: KERNEL<8, 1, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (8 * 4 + 2) * 2: KERNEL<8, 2, false><<<grid, block, lds, stream>>>(args); break;   \
-      case (16 * 4 + 0) * 2: KERNEL<16, 0, false><<<grid, block, lds, stream>>>(args); break; \
-      case (16 * 4 + 1) * 2: KERNEL<16, 1, false><<<grid, block, lds, stream>>>(args); break; \
-      case (16 * 4 + 2) * 2: KERNEL<16, 2, false><<<grid, block, lds, stream>>>(args); break; \
-      case (4 * 4 + 0) * 2 + 1: KERNEL<4, 0, true><<<grid, block, lds, stream>>>(args); break; \
-      case (4 * 4 + 1) * 2 + 1: KERNEL<4, 1, true><<<grid, block, lds, stream>>>(args); break; \
-      case (4 * 4 + 2) * 2 + 1: KERNEL<4, 2, true><<<grid, block, lds, stream>>>(args); break; \
-      default: break;                                                                     \
-    }                                                                                     \
+#define LAUNCH_DNA_KIND(RCV, MODEV, NTV)                                                   \
+  do {                                                                                     \
+    if (kind == 0) k_dna_partials<RCV, MODEV, NTV, 0><<<grid, 256, 0, s>>>(a);             \
+    else if (kind == 1) k_dna_partials<RCV, MODEV, NTV, 1><<<grid, 256, 0, s>>>(a);        \
+    else k_dna_partials<RCV, MODEV, NTV, 2><<<grid, 256, 0, s>>>(a);                       \
+  } while (0)
+
+#define LAUNCH_DNA_MODE(RCV, NTV)                                 \
+  do {                                                            \
+    if (mode == SCALE_NONE) LAUNCH_DNA_KIND(RCV, 0, NTV);         \
+    else if (mode == SCALE_SITE) LAUNCH_DNA_KIND(RCV, 1, NTV);    \
+    else LAUNCH_DNA_KIND(RCV, 2, NTV);                            \
   } while (0)
 
 static bool fast_rc(unsigned int rc)
@@ -520,12 +507,18 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int
 
   if (a.states == 4 && fast_rc(R))
   {
-    const unsigned int grid = pllhip_stream_grid(c, items * 2, 256);
+    // a wave consumes 64 sites per round
+    const unsigned int grid = pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256);
     // the non-temporal variants exist for the common 4-category case only
     const bool nt = (R == 4) && pllhip_use_nt(c);
-    if (kind == 0) LAUNCH_RC_MODE_NT(k_dna_ii, R, mode, nt, grid, 256, 0, s, a);
-    if (kind == 1) LAUNCH_RC_MODE_NT(k_dna_ti, R, mode, nt, grid, 256, 0, s, a);
-    if (kind == 2) LAUNCH_RC_MODE_NT(k_dna_tt, R, mode, nt, grid, 256, 0, s, a);
+    switch (R)
+    {
+      case 1: LAUNCH_DNA_MODE(1, false); break;
+      case 2: LAUNCH_DNA_MODE(2, false); break;
+      case 4: if (nt) LAUNCH_DNA_MODE(4, true); else LAUNCH_DNA_MODE(4, false); break;
+      case 8: LAUNCH_DNA_MODE(8, false); break;
+      default: LAUNCH_DNA_MODE(16, false); break;
+    }
   }
   else if (a.states == 20 && fast_rc(R) && R <= 8)
   {
