@@ -32,10 +32,10 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this
-# command (profiles/r1_pmc_*.csv): FETCH_SIZE x 2 (gfx950 counts 128-B requests at
+# command (profiles/r1_pmc_hbm_traffic.csv): FETCH_SIZE x 2 (gfx950 counts 128-B requests at
 # 64 B) + WRITE_SIZE, KB -> bytes; 4 states, 1,000,000 sites.  None where no
 # counter pass was taken.
-TRAFFIC_NOTE = {4: 396.5e6}
+TRAFFIC_NOTE = {4: 396.1e6}
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
 
