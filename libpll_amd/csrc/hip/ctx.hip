@@ -89,6 +89,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, shape->device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_BLOCKS_PER_CU"))
     if (atoi(e) > 0) c->blocks_per_cu = atoi(e);
 

@@ -71,6 +71,10 @@ struct pllhip_ctx
   // that every wave makes 2 or 3 grid-stride passes costs 70-72 us.  So the cap
   // is set where it only matters for alignments beyond ~16 M sites per GPU.
   int blocks_per_cu = 256;
+  // 20 states: 1 = bit-exact vector kernels only (env PLLHIP_AA_EXACT=1);
+  // 0 = matrix-core kernels where they exist (last-bit differences, see
+  // partials_aa_mfma.hip)
+  int aa_exact = 0;
 
   // optional per-launch timing (pllhip_profile_*): one event pair per launch
   bool profiling = false;
@@ -171,3 +175,5 @@ enum { SCALE_NONE = 0, SCALE_SITE = 1, SCALE_RATE = 2 };
 int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode,
                            int prof_kind);
 int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);
+// 20-state inner-inner update on the matrix cores; returns 1 if the case is not covered
+int pllhip_launch_aa_ii_mfma(pllhip_ctx * c, const PartialsArgs & a, int mode);

@@ -520,6 +520,10 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int
       default: LAUNCH_DNA_MODE(16, false); break;
     }
   }
+  else if (a.states == 20 && kind == 0 && !c->aa_exact && pllhip_launch_aa_ii_mfma(c, a, mode) == 0)
+  {
+    // launched on the matrix cores (partials_aa_mfma.hip)
+  }
   else if (a.states == 20 && fast_rc(R) && R <= 8)
   {
     const unsigned int grid = pllhip_stream_grid(c, items, 256);

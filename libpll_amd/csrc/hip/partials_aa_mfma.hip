@@ -1,0 +1,278 @@
+// partials_aa_mfma.hip -- 20-state inner-inner CLV update on the f64 matrix cores.
+//
+// Replaces pll_core_update_partial_ii for 20 states (AVX2-flag kernel
+// core_partials_avx2.c:568).  Per (site, rate) the update is two 20x20 . 20
+// mat-vecs and an element-wise product; over many sites that is the dense
+// contraction  X[20 x N] = P_k[20 x 20] . CLV_k[20 x N]  with N = sites, which is
+// what v_mfma_f64_16x16x4_f64 computes (D[16x16] += A[16x4] . B[4x16]).
+//
+// Tiling.  A wave owns a tile of 16 consecutive sites x all RC categories: in HBM
+// that is ONE contiguous block of 16*RC*160 bytes per child (CLV layout
+// [site][rate][state]).  The block is copied by LDS-DMA (global_load_lds_dwordx4,
+// no VGPR staging) into a per-wave LDS image whose 16 site rows are padded by one
+// 16-byte granule (the pad lanes load a dummy granule), so that the B-operand
+// reads -- lane (j = site, q): state 4c+q of site j -- hit 64 different banks.
+//   A operand = P rows:  tile 0 = rows 0..15, tile 1 = rows 16..19 (+12 zero rows)
+//   B operand = CLV:     column j = site j of the tile, k = states 4c..4c+3
+//   5 k-steps cover the 20 input states; 2 row tiles x 5 steps x RC rates x 2
+//   children = 20*RC MFMAs per tile (80 for RC = 4).
+// The accumulator layout (row = q + 4*reg, col = j) is the same for both
+// children, so the product x*y and the "< 2^-256" test are register-local; the
+// per-site AND over the 4 lanes of a column is one __ballot.  The product tile
+// goes back through the same LDS image so the parent CLV is written with
+// contiguous 16-byte-per-lane stores.
+//
+// Roofline.  1932 B and 6320 flop per site-update: 3.3 flop/B, below
+// the f64 machine balance, so HBM bounds it as long as the MFMA pipe (80 x 32
+// cycles per 64 elements per SIMD, 62.5 % useful because of the padded rows)
+// stays under ~35 % busy -- which it does: MFMA time is ~20 % of the HBM time.
+//
+// Numerics.  The matrix core accumulates the 20 products of a row as one chain
+// of fused multiply-adds in state order; the reference's AVX2 kernel uses four
+// interleaved chains and a pairwise tree.  Results agree to ~2e-16 relative but
+// not bitwise, so this kernel is used unless PLLHIP_AA_EXACT=1 asks for the
+// bit-exact vector kernel (partials.hip, k_aa_ii).  Scaler counts still match
+// exactly unless a CLV entry lies within an ulp of 2^-256.
+#include "ctx.hpp"
+#include "numerics.hpp"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define PLL_AS1 __attribute__((address_space(1)))
+#define PLL_AS3 __attribute__((address_space(3)))
+
+namespace
+{
+constexpr int S20 = 20;
+constexpr int PROW = 21; // padded P-matrix row, doubles: 16 rows x 2 k-offsets spread over the banks
+
+template <int RC>
+struct aa_geom
+{
+  static constexpr int ROW_G = RC * 10 + 1;            // 16-B granules per site row incl. the pad
+  static constexpr int TILE_G = 16 * ROW_G;            // granules per tile image
+  static constexpr int N_IT = (TILE_G + 63) / 64;      // wave-instructions to move a tile
+  static constexpr int REGION_B = N_IT * 1024;         // bytes reserved per wave
+  static constexpr int PTAB = 2 * RC * S20 * PROW;     // doubles
+  static constexpr size_t LDS_BYTES = (size_t)PTAB * 8 + 4 * (size_t)REGION_B;
+};
+
+// copy the 16-site tile starting at site0 of `clv` into the wave's LDS image
+template <int RC, bool NT>
+__device__ __forceinline__ void dma_tile(const double * __restrict__ clv, size_t site0, size_t sites,
+                                         char * region, unsigned int lane)
+{
+  using G = aa_geom<RC>;
+#pragma unroll
+  for (int it = 0; it < G::N_IT; ++it)
+  {
+    int P = it * 64 + (int)lane;
+    if (P > G::TILE_G - 1) P = G::TILE_G - 1;
+    const int site = P / G::ROW_G;
+    int col = P - site * G::ROW_G;
+    if (col > G::ROW_G - 2) col = G::ROW_G - 2; // pad granule: re-load the row's last one
+    size_t n = site0 + (size_t)site;
+    if (n >= sites) n = sites - 1;
+    const double * src = clv + (n * (size_t)(RC * 10) + (size_t)col) * 2;
+    __builtin_amdgcn_global_load_lds((const PLL_AS1 void *)src,
+                                     (PLL_AS3 void *)(region + it * 1024), 16, 0, NT ? 2 : 0);
+  }
+}
+
+// x[k][0..3] = rows q, q+4, q+8, q+12 ; x[k][4] = row 16+q   of  P_k . tile column j
+template <int RC>
+__device__ __forceinline__ void tile_matvec(const double * ptab_child, const double (&b)[RC][5],
+                                            unsigned int j, unsigned int q, double (&x)[RC][5])
+{
+#pragma unroll
+  for (int k = 0; k < RC; ++k)
+  {
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const double * pk = ptab_child + (size_t)k * S20 * PROW;
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+    {
+      const double a0 = pk[j * PROW + 4 * c + q];
+      const double a1 = (j < 4) ? pk[(16 + j) * PROW + 4 * c + q] : 0.0;
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[k][c], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[k][c], acc1, 0, 0, 0);
+    }
+    x[k][0] = acc0.x; x[k][1] = acc0.y; x[k][2] = acc0.z; x[k][3] = acc0.w;
+    x[k][4] = acc1.x;
+  }
+}
+
+// all 4 lanes of this lane's tile column (j, j+16, j+32, j+48) have the flag set
+__device__ __forceinline__ bool column_all(bool f, unsigned int j)
+{
+  const unsigned long long b = __ballot(f);
+  const unsigned long long m = 0x0001000100010001ull << j;
+  return (b & m) == m;
+}
+} // namespace
+
+template <int RC, int MODE, bool NT>
+__global__ __launch_bounds__(256) void k_aa_ii_mfma(PartialsArgs a)
+{
+  using G = aa_geom<RC>;
+  extern __shared__ double smem[];
+  double * ptab = smem;
+  // P-matrices of both children, rows padded to PROW doubles
+  for (unsigned int t = threadIdx.x; t < 2u * RC * 400; t += blockDim.x)
+  {
+    const unsigned int child = t / (RC * 400), rem = t % (RC * 400);
+    const unsigned int k = rem / 400, i = (rem / 20) % 20, jj = rem % 20;
+    ptab[((child * RC + k) * S20 + i) * PROW + jj] = (child ? a.rmat : a.lmat)[rem];
+  }
+  __syncthreads();
+
+  const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned int j = lane & 15u, q = lane >> 4;
+  char * region = reinterpret_cast<char *>(smem + G::PTAB) + wave * G::REGION_B;
+  constexpr int ROW_B = G::ROW_G * 16;
+
+  const size_t sites = a.sites;
+  const size_t tiles = (sites + 15) / 16;
+  const size_t nwaves = (size_t)gridDim.x * 4;
+  const unsigned int * ls = a.lscaler ? a.lscaler : a.zero;
+  const unsigned int * rs = a.rscaler ? a.rscaler : a.zero;
+  const bool has_l = a.lscaler != nullptr, has_r = a.rscaler != nullptr;
+
+  for (size_t tile = (size_t)blockIdx.x * 4 + wave; tile < tiles; tile += nwaves)
+  {
+    const size_t site0 = tile * 16;
+    double b[RC][5], x[RC][5], y[RC][5];
+
+    // ---- left child: DMA, fetch B operands, then reuse the image for the right child
+    dma_tile<RC, NT>(a.left, site0, sites, region, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+        b[k][c] = *reinterpret_cast<const double *>(region + j * ROW_B + k * 160 + (4 * c + q) * 8);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dma_tile<RC, NT>(a.right, site0, sites, region, lane);
+    tile_matvec<RC>(ptab, b, j, q, x); // overlaps the right child's DMA
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+        b[k][c] = *reinterpret_cast<const double *>(region + j * ROW_B + k * 160 + (4 * c + q) * 8);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tile_matvec<RC>(ptab + RC * S20 * PROW, b, j, q, y);
+
+    // ---- product + scaling (core_partials_avx2.c:752-800)
+    bool small_site = true;
+    bool small_rate[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+    {
+      small_rate[k] = true;
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+      {
+        x[k][r] = x[k][r] * y[k][r];
+        small_rate[k] = small_rate[k] && (x[k][r] < PLLHIP_SCALE_THRESHOLD);
+      }
+      small_site = small_site && small_rate[k];
+    }
+    const size_t n = site0 + j; // the site of this lane's column
+    if (MODE == SCALE_SITE)
+    {
+      const bool scale = column_all(small_site, j);
+      if (scale)
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+          for (int r = 0; r < 5; ++r) x[k][r] *= PLLHIP_SCALE_FACTOR;
+      if (q == 0 && n < sites)
+        a.pscaler[n] = ls[has_l ? n : 0] + rs[has_r ? n : 0] + (scale ? 1u : 0u);
+    }
+    if (MODE == SCALE_RATE)
+    {
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+      {
+        const bool scale = column_all(small_rate[k], j);
+        if (scale)
+#pragma unroll
+          for (int r = 0; r < 5; ++r) x[k][r] *= PLLHIP_SCALE_FACTOR;
+        if (q == 0 && n < sites)
+          a.pscaler[n * RC + k] = ls[has_l ? n * RC + k : 0] + rs[has_r ? n * RC + k : 0] +
+                                  (scale ? 1u : 0u);
+      }
+    }
+
+    // ---- transpose through the LDS image, store 16 bytes per lane
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+    {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<double *>(region + j * ROW_B + k * 160 + (q + 4 * r) * 8) = x[k][r];
+      *reinterpret_cast<double *>(region + j * ROW_B + k * 160 + (16 + q) * 8) = x[k][4];
+    }
+    double2 * out = reinterpret_cast<double2 *>(a.parent);
+#pragma unroll
+    for (int it = 0; it < G::N_IT; ++it)
+    {
+      const int P = it * 64 + (int)lane;
+      const int site = P / G::ROW_G, col = P - site * G::ROW_G;
+      const size_t ns = site0 + (size_t)site;
+      if (P < G::TILE_G && col < G::ROW_G - 1 && ns < sites)
+      {
+        const double2 v = *reinterpret_cast<const double2 *>(region + P * 16);
+        st16<NT>(out + ns * (size_t)(RC * 10) + (size_t)col, v.x, v.y);
+      }
+    }
+    // the image is reused by the next tile's DMA: its reads must have left LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int RC>
+static int launch_rc(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
+{
+  using G = aa_geom<RC>;
+  const size_t tiles = ((size_t)a.sites + 15) / 16;
+  size_t blocks = (tiles + 3) / 4;
+  // the P-matrix staging (27 KB per workgroup) is amortised over several tiles per wave
+  const size_t cap = (size_t)c->num_cus * 4;
+  if (blocks > cap) blocks = cap;
+  const dim3 grid((unsigned int)blocks), block(256);
+  const size_t lds = G::LDS_BYTES;
+  // more than 64 KB of dynamic LDS has to be requested per kernel
+#define AA_LAUNCH_ONE(KERNEL)                                                                 \
+  do {                                                                                        \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+    hipLaunchKernelGGL(KERNEL, grid, block, lds, c->stream, a);                               \
+  } while (0)
+#define AA_LAUNCH(MODEV)                                                                      \
+  do {                                                                                        \
+    if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true>));                                   \
+    else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false>));                                     \
+  } while (0)
+  if (mode == SCALE_NONE) AA_LAUNCH(0);
+  else if (mode == SCALE_SITE) AA_LAUNCH(1);
+  else AA_LAUNCH(2);
+#undef AA_LAUNCH
+#undef AA_LAUNCH_ONE
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// returns 1 if this kernel does not cover the case (caller falls back)
+int pllhip_launch_aa_ii_mfma(pllhip_ctx * c, const PartialsArgs & a, int mode)
+{
+  const bool nt = pllhip_use_nt(c);
+  switch (a.rate_cats)
+  {
+    case 1: return launch_rc<1>(c, a, mode, nt);
+    case 2: return launch_rc<2>(c, a, mode, nt);
+    case 4: return launch_rc<4>(c, a, mode, nt);
+    default: return 1;
+  }
+}

@@ -111,11 +111,12 @@ def test_oracle_matches_golden(orc, amd, path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", FIXTURES, ids=IDS)
-def test_hip_matches_golden(gpu, path):
+def test_hip_matches_golden(gpu, path, monkeypatch):
     """The product, driven exactly like a reference client, reproduces the
     reference's stored outputs."""
     g = load(path)
     S, R, plan = g["states"], g["rate_cats"], g["plan"]
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")   # the stored outputs are compared bit for bit
     p = gpu.partition_create(plan.tips, plan.clv_buffers, S, g["sites"], 1, plan.prob_matrices, R,
                              plan.scale_buffers, g["attributes"])
     p.set_frequencies(0, g["freqs"])
