@@ -52,6 +52,7 @@ struct pllhip_ctx
   double * block_partials = nullptr;   // [PLLHIP_REDUCE_BLOCKS][2]
   double * d_result = nullptr;         // [4]
   unsigned int * d_zero = nullptr;     // [4] zeros
+  double * d_sink = nullptr;           // [128] write-only scratch
   double * h_result = nullptr;         // pinned [4]
   double * d_persite = nullptr;        // [sites], lazily allocated
 
@@ -166,6 +167,7 @@ struct PartialsArgs
   const unsigned int * rscaler;
   const unsigned int * __restrict__ tipmap;
   const unsigned int * zero;             // one device word holding 0 (stand-in for absent scalers)
+  double * sink;                         // 1 KB scratch that masked-off lanes may store to
   unsigned int sites, rate_cats, states, maxstates;
 };
 

@@ -572,6 +572,7 @@ static int launch_op(pllhip_ctx * c, const pllhip_op_t & op)
   a.pscaler = pllhip_scaler_ptr(c, op.parent_scaler);
   a.tipmap = c->tipmap;
   a.zero = c->d_zero;
+  a.sink = c->d_sink;
   a.sites = c->sh.sites;
   a.rate_cats = c->sh.rate_cats;
   a.states = c->sh.states;

@@ -3,32 +3,42 @@
 // Replaces pll_core_update_partial_ii for 20 states (AVX2-flag kernel
 // core_partials_avx2.c:568).  Per (site, rate) the update is two 20x20 . 20
 // mat-vecs and an element-wise product; over many sites that is the dense
-// contraction  X[20 x N] = P_k[20 x 20] . CLV_k[20 x N]  with N = sites, which is
-// what v_mfma_f64_16x16x4_f64 computes (D[16x16] += A[16x4] . B[4x16]).
+// contraction  X[20 x N] = P_k[20 x 20] . CLV_k[20 x N]  with N = sites.
 //
-// Tiling.  A wave owns a tile of 16 consecutive sites x all RC categories: in HBM
-// that is ONE contiguous block of 16*RC*160 bytes per child (CLV layout
-// [site][rate][state]).  The block is copied by LDS-DMA (global_load_lds_dwordx4,
-// no VGPR staging) into a per-wave LDS image whose 16 site rows are padded by one
-// 16-byte granule (the pad lanes load a dummy granule), so that the B-operand
-// reads -- lane (j = site, q): state 4c+q of site j -- hit 64 different banks.
-//   A operand = P rows:  tile 0 = rows 0..15, tile 1 = rows 16..19 (+12 zero rows)
-//   B operand = CLV:     column j = site j of the tile, k = states 4c..4c+3
-//   5 k-steps cover the 20 input states; 2 row tiles x 5 steps x RC rates x 2
-//   children = 20*RC MFMAs per tile (80 for RC = 4).
-// The accumulator layout (row = q + 4*reg, col = j) is the same for both
-// children, so the product x*y and the "< 2^-256" test are register-local; the
-// per-site AND over the 4 lanes of a column is one __ballot.  The product tile
-// goes back through the same LDS image so the parent CLV is written with
-// contiguous 16-byte-per-lane stores.
+// Instruction choice (measured on MI355X, tools/mfma_f64_bench.hip):
+//   v_mfma_f64_16x16x4_f64     ~136 cycles/instr -> 33-43 TFLOP/s chip-wide, and a
+//                              20-row P needs 2 row tiles (37.5 % of the work is padding)
+//   v_mfma_f64_4x4x4_4b_f64    ~17 cycles/instr  -> 65 TFLOP/s, and 20 = 5 x 4: no padding
+// so the kernel uses the 4-block 4x4x4 form.  Its lane layout (probed with
+// tools/mfma_layout_probe.hip; blk = (lane>>2)&3):
+//   A: lane holds A_blk[i = lane&3][k = lane>>4]
+//   B: lane holds B_blk[k = lane>>4][j = lane&3]
+//   D: lane holds D_blk[i = lane>>4][j = lane&3]
+// With block blk = sites 4blk..4blk+3 of a 16-site tile, B and D are indexed by
+// (site s = lane&15, q = lane>>4): B = state 4c+q of site s, D = state 4g+q of
+// site s.  A = P[4g + (lane&3)][4c + q], the same for all four blocks.
+// 5 row groups x 5 k-chunks = 25 MFMAs per (child, rate); 200 per 16-site tile.
+//
+// Tiling.  A wave owns 16 consecutive sites x all RC categories: ONE contiguous
+// block of 16*RC*160 bytes per child in HBM.  It is copied by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR staging) into a per-wave LDS image whose 16
+// site rows are padded by one 16-byte granule (pad lanes load a dummy granule),
+// so the B-operand reads of a wave hit 64 different banks.  Left child first;
+// once its operands are in registers the image is refilled with the right child
+// while the left products run.  Both children produce the same accumulator
+// layout, so x*y and the "< 2^-256" test are register-local; the per-site AND
+// over the 4 lanes of a column is one __ballot.  The product tile returns through
+// the same image so the parent CLV is written 16 contiguous bytes per lane.
+// P-matrices sit in LDS ([child][rate][20][20], bank-conflict-free for the A
+// pattern); a category's 50 A operands are fetched right before its MFMAs.
+// Two waves per SIMD overlap one wave's DMA wait with the other's MFMAs.
 //
 // Roofline.  1932 B and 6320 flop per site-update: 3.3 flop/B, below
-// the f64 machine balance, so HBM bounds it as long as the MFMA pipe (80 x 32
-// cycles per 64 elements per SIMD, 62.5 % useful because of the padded rows)
-// stays under ~35 % busy -- which it does: MFMA time is ~20 % of the HBM time.
+// the f64 machine balance, so HBM is the bound: 200 MFMAs x 17 cycles per 64
+// elements per SIMD is ~25 % of the time HBM needs for the tile's 31 KB.
 //
-// Numerics.  The matrix core accumulates the 20 products of a row as one chain
-// of fused multiply-adds in state order; the reference's AVX2 kernel uses four
+// Numerics.  The matrix core accumulates the 20 products of a row as a chain of
+// fused multiply-adds in state order; the reference's AVX2 kernel uses four
 // interleaved chains and a pairwise tree.  Results agree to ~2e-16 relative but
 // not bitwise, so this kernel is used unless PLLHIP_AA_EXACT=1 asks for the
 // bit-exact vector kernel (partials.hip, k_aa_ii).  Scaler counts still match
@@ -43,7 +53,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 namespace
 {
 constexpr int S20 = 20;
-constexpr int PROW = 21; // padded P-matrix row, doubles: 16 rows x 2 k-offsets spread over the banks
 
 template <int RC>
 struct aa_geom
@@ -52,7 +61,7 @@ struct aa_geom
   static constexpr int TILE_G = 16 * ROW_G;            // granules per tile image
   static constexpr int N_IT = (TILE_G + 63) / 64;      // wave-instructions to move a tile
   static constexpr int REGION_B = N_IT * 1024;         // bytes reserved per wave
-  static constexpr int PTAB = 2 * RC * S20 * PROW;     // doubles
+  static constexpr int PTAB = 2 * RC * S20 * S20;      // doubles
   static constexpr size_t LDS_BYTES = (size_t)PTAB * 8 + 4 * (size_t)REGION_B;
 };
 
@@ -78,55 +87,67 @@ __device__ __forceinline__ void dma_tile(const double * __restrict__ clv, size_t
   }
 }
 
-// x[k][0..3] = rows q, q+4, q+8, q+12 ; x[k][4] = row 16+q   of  P_k . tile column j
+// B operands of the whole tile: b[k][c] = state 4c+q of (site s, rate k)
+template <int RC>
+__device__ __forceinline__ void read_b_operands(const char * region, unsigned int s, unsigned int q,
+                                                double (&b)[RC][5])
+{
+  constexpr int ROW_B = aa_geom<RC>::ROW_G * 16;
+#pragma unroll
+  for (int k = 0; k < RC; ++k)
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+      b[k][c] = *reinterpret_cast<const double *>(region + s * ROW_B + k * 160 + (4 * c + q) * 8);
+}
+
+// x[k][g] = state 4g+q of  P_k . (column s of the tile), for one child
 template <int RC>
 __device__ __forceinline__ void tile_matvec(const double * ptab_child, const double (&b)[RC][5],
-                                            unsigned int j, unsigned int q, double (&x)[RC][5])
+                                            unsigned int lane, double (&x)[RC][5])
 {
+  const unsigned int i = lane & 3u, q = lane >> 4;
 #pragma unroll
   for (int k = 0; k < RC; ++k)
   {
-    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    const double * pk = ptab_child + (size_t)k * S20 * PROW;
+    const double * pk = ptab_child + (size_t)k * S20 * S20;
+    double a[5][5];
 #pragma unroll
-    for (int c = 0; c < 5; ++c)
+    for (int g = 0; g < 5; ++g)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) a[g][c] = pk[(4 * g + i) * S20 + 4 * c + q];
+#pragma unroll
+    for (int g = 0; g < 5; ++g)
     {
-      const double a0 = pk[j * PROW + 4 * c + q];
-      const double a1 = (j < 4) ? pk[(16 + j) * PROW + 4 * c + q] : 0.0;
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[k][c], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[k][c], acc1, 0, 0, 0);
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g][c], b[k][c], acc, 0, 0, 0);
+      x[k][g] = acc;
     }
-    x[k][0] = acc0.x; x[k][1] = acc0.y; x[k][2] = acc0.z; x[k][3] = acc0.w;
-    x[k][4] = acc1.x;
   }
 }
 
-// all 4 lanes of this lane's tile column (j, j+16, j+32, j+48) have the flag set
-__device__ __forceinline__ bool column_all(bool f, unsigned int j)
+// all 4 lanes of this lane's tile column (s, s+16, s+32, s+48) have the flag set
+__device__ __forceinline__ bool column_all(bool f, unsigned int s)
 {
   const unsigned long long b = __ballot(f);
-  const unsigned long long m = 0x0001000100010001ull << j;
+  const unsigned long long m = 0x0001000100010001ull << s;
   return (b & m) == m;
 }
 } // namespace
 
 template <int RC, int MODE, bool NT>
-__global__ __launch_bounds__(256) void k_aa_ii_mfma(PartialsArgs a)
+__global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsArgs a)
 {
   using G = aa_geom<RC>;
   extern __shared__ double smem[];
-  double * ptab = smem;
-  // P-matrices of both children, rows padded to PROW doubles
+  double * ptab = smem; // [child][rate][20][20]
   for (unsigned int t = threadIdx.x; t < 2u * RC * 400; t += blockDim.x)
-  {
-    const unsigned int child = t / (RC * 400), rem = t % (RC * 400);
-    const unsigned int k = rem / 400, i = (rem / 20) % 20, jj = rem % 20;
-    ptab[((child * RC + k) * S20 + i) * PROW + jj] = (child ? a.rmat : a.lmat)[rem];
-  }
+    ptab[t] = (t < RC * 400u) ? a.lmat[t] : a.rmat[t - RC * 400u];
   __syncthreads();
 
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const unsigned int j = lane & 15u, q = lane >> 4;
+  const unsigned int s = lane & 15u, q = lane >> 4;
   char * region = reinterpret_cast<char *>(smem + G::PTAB) + wave * G::REGION_B;
   constexpr int ROW_B = G::ROW_G * 16;
 
@@ -136,6 +157,7 @@ __global__ __launch_bounds__(256) void k_aa_ii_mfma(PartialsArgs a)
   const unsigned int * ls = a.lscaler ? a.lscaler : a.zero;
   const unsigned int * rs = a.rscaler ? a.rscaler : a.zero;
   const bool has_l = a.lscaler != nullptr, has_r = a.rscaler != nullptr;
+  double2 * out = reinterpret_cast<double2 *>(a.parent);
 
   for (size_t tile = (size_t)blockIdx.x * 4 + wave; tile < tiles; tile += nwaves)
   {
@@ -145,23 +167,15 @@ __global__ __launch_bounds__(256) void k_aa_ii_mfma(PartialsArgs a)
     // ---- left child: DMA, fetch B operands, then reuse the image for the right child
     dma_tile<RC, NT>(a.left, site0, sites, region, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < RC; ++k)
-#pragma unroll
-      for (int c = 0; c < 5; ++c)
-        b[k][c] = *reinterpret_cast<const double *>(region + j * ROW_B + k * 160 + (4 * c + q) * 8);
+    read_b_operands<RC>(region, s, q, b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     dma_tile<RC, NT>(a.right, site0, sites, region, lane);
-    tile_matvec<RC>(ptab, b, j, q, x); // overlaps the right child's DMA
+    tile_matvec<RC>(ptab, b, lane, x); // overlaps the right child's DMA
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < RC; ++k)
-#pragma unroll
-      for (int c = 0; c < 5; ++c)
-        b[k][c] = *reinterpret_cast<const double *>(region + j * ROW_B + k * 160 + (4 * c + q) * 8);
+    read_b_operands<RC>(region, s, q, b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    tile_matvec<RC>(ptab + RC * S20 * PROW, b, j, q, y);
+    tile_matvec<RC>(ptab + RC * S20 * S20, b, lane, y);
 
     // ---- product + scaling (core_partials_avx2.c:752-800)
     bool small_site = true;
@@ -171,22 +185,22 @@ __global__ __launch_bounds__(256) void k_aa_ii_mfma(PartialsArgs a)
     {
       small_rate[k] = true;
 #pragma unroll
-      for (int r = 0; r < 5; ++r)
+      for (int g = 0; g < 5; ++g)
       {
-        x[k][r] = x[k][r] * y[k][r];
-        small_rate[k] = small_rate[k] && (x[k][r] < PLLHIP_SCALE_THRESHOLD);
+        x[k][g] = x[k][g] * y[k][g];
+        small_rate[k] = small_rate[k] && (x[k][g] < PLLHIP_SCALE_THRESHOLD);
       }
       small_site = small_site && small_rate[k];
     }
-    const size_t n = site0 + j; // the site of this lane's column
+    const size_t n = site0 + s; // the site of this lane's column
     if (MODE == SCALE_SITE)
     {
-      const bool scale = column_all(small_site, j);
+      const bool scale = column_all(small_site, s);
       if (scale)
 #pragma unroll
         for (int k = 0; k < RC; ++k)
 #pragma unroll
-          for (int r = 0; r < 5; ++r) x[k][r] *= PLLHIP_SCALE_FACTOR;
+          for (int g = 0; g < 5; ++g) x[k][g] *= PLLHIP_SCALE_FACTOR;
       if (q == 0 && n < sites)
         a.pscaler[n] = ls[has_l ? n : 0] + rs[has_r ? n : 0] + (scale ? 1u : 0u);
     }
@@ -195,10 +209,10 @@ __global__ __launch_bounds__(256) void k_aa_ii_mfma(PartialsArgs a)
 #pragma unroll
       for (int k = 0; k < RC; ++k)
       {
-        const bool scale = column_all(small_rate[k], j);
+        const bool scale = column_all(small_rate[k], s);
         if (scale)
 #pragma unroll
-          for (int r = 0; r < 5; ++r) x[k][r] *= PLLHIP_SCALE_FACTOR;
+          for (int g = 0; g < 5; ++g) x[k][g] *= PLLHIP_SCALE_FACTOR;
         if (q == 0 && n < sites)
           a.pscaler[n * RC + k] = ls[has_l ? n * RC + k : 0] + rs[has_r ? n * RC + k : 0] +
                                   (scale ? 1u : 0u);
@@ -208,13 +222,9 @@ __global__ __launch_bounds__(256) void k_aa_ii_mfma(PartialsArgs a)
     // ---- transpose through the LDS image, store 16 bytes per lane
 #pragma unroll
     for (int k = 0; k < RC; ++k)
-    {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<double *>(region + j * ROW_B + k * 160 + (q + 4 * r) * 8) = x[k][r];
-      *reinterpret_cast<double *>(region + j * ROW_B + k * 160 + (16 + q) * 8) = x[k][4];
-    }
-    double2 * out = reinterpret_cast<double2 *>(a.parent);
+      for (int g = 0; g < 5; ++g)
+        *reinterpret_cast<double *>(region + s * ROW_B + k * 160 + (4 * g + q) * 8) = x[k][g];
 #pragma unroll
     for (int it = 0; it < G::N_IT; ++it)
     {
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void k_aa_ii_mfma(PartialsArgs a)
         st16<NT>(out + ns * (size_t)(RC * 10) + (size_t)col, v.x, v.y);
       }
     }
-    // the image is reused by the next tile's DMA: its reads must have left LDS
+    // the image is refilled by the next tile's DMA: its reads must have left LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
@@ -238,8 +248,9 @@ static int launch_rc(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
   using G = aa_geom<RC>;
   const size_t tiles = ((size_t)a.sites + 15) / 16;
   size_t blocks = (tiles + 3) / 4;
-  // the P-matrix staging (27 KB per workgroup) is amortised over several tiles per wave
-  const size_t cap = (size_t)c->num_cus * 4;
+  // two 4-wave workgroups per CU are resident (71 KB of LDS each); the P-matrix
+  // staging per workgroup is amortised over several tiles per wave
+  const size_t cap = (size_t)c->num_cus * 2;
   if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned int)blocks), block(256);
   const size_t lds = G::LDS_BYTES;
