@@ -53,6 +53,8 @@ struct pllhip_ctx
   double * d_result = nullptr;         // [4]
   unsigned int * d_zero = nullptr;     // [4] zeros
   double * d_sink = nullptr;           // [128] write-only scratch
+  double * d_tiptab = nullptr;         // 20 states: [2][maxstates][rate_cats][20] tip row sums of the current op
+  size_t tiptab_elems = 0;
   double * h_result = nullptr;         // pinned [4]
   double * d_persite = nullptr;        // [sites], lazily allocated
 
@@ -168,6 +170,8 @@ struct PartialsArgs
   const unsigned int * __restrict__ tipmap;
   const unsigned int * zero;             // one device word holding 0 (stand-in for absent scalers)
   double * sink;                         // 1 KB scratch that masked-off lanes may store to
+  const double * ltab;                   // precomputed tip row sums [code][rate][state] (20 states)
+  const double * rtab;
   unsigned int sites, rate_cats, states, maxstates;
 };
 
@@ -179,3 +183,5 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int
 int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);
 // 20-state inner-inner update on the matrix cores; returns 1 if the case is not covered
 int pllhip_launch_aa_ii_mfma(pllhip_ctx * c, const PartialsArgs & a, int mode);
+// 20-state tip-inner (kind 1) / tip-tip (kind 2) fast kernels; returns 1 if not covered
+int pllhip_launch_aa_tip(pllhip_ctx * c, PartialsArgs & a, int kind, int mode);

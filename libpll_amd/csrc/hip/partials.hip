@@ -497,9 +497,10 @@ static bool fast_rc(unsigned int rc)
 }
 
 // kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
-int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode,
+int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, int mode,
                            int prof_kind)
 {
+  PartialsArgs a = a_in;
   const unsigned int R = a.rate_cats;
   const size_t items = (size_t)a.sites * R;
   hipStream_t s = c->stream;
@@ -523,6 +524,10 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int
   else if (a.states == 20 && kind == 0 && !c->aa_exact && pllhip_launch_aa_ii_mfma(c, a, mode) == 0)
   {
     // launched on the matrix cores (partials_aa_mfma.hip)
+  }
+  else if (a.states == 20 && kind >= 1 && !c->aa_exact && pllhip_launch_aa_tip(c, a, kind, mode) == 0)
+  {
+    // tip kernels with precomputed tables (partials_aa_mfma.hip)
   }
   else if (a.states == 20 && fast_rc(R) && R <= 8)
   {

@@ -136,19 +136,27 @@ __device__ __forceinline__ bool column_all(bool f, unsigned int s)
 }
 } // namespace
 
-template <int RC, int MODE, bool NT>
+// KIND 0: inner-inner.  KIND 1: tip-inner -- the left factor is not a mat-vec but
+// a row of the precomputed tip table (a.ltab, [code][rate][state]), which takes
+// the place of the left P-matrix in LDS; the right child goes through the MFMAs.
+template <int RC, int MODE, bool NT, int KIND>
 __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsArgs a)
 {
   using G = aa_geom<RC>;
   extern __shared__ double smem[];
-  double * ptab = smem; // [child][rate][20][20]
-  for (unsigned int t = threadIdx.x; t < 2u * RC * 400; t += blockDim.x)
-    ptab[t] = (t < RC * 400u) ? a.lmat[t] : a.rmat[t - RC * 400u];
+  // LDS: [left part][right P-matrices RC x 20 x 20][4 wave images]
+  //   left part = left P-matrices (KIND 0) or the tip table [maxstates][RC][20] (KIND 1)
+  const unsigned int left_elems = (KIND == 0) ? RC * 400u : a.maxstates * RC * 20u;
+  double * ptab = smem;
+  double * ptab_r = smem + left_elems;
+  for (unsigned int t = threadIdx.x; t < left_elems; t += blockDim.x)
+    ptab[t] = (KIND == 0) ? a.lmat[t] : a.ltab[t];
+  for (unsigned int t = threadIdx.x; t < RC * 400u; t += blockDim.x) ptab_r[t] = a.rmat[t];
   __syncthreads();
 
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned int s = lane & 15u, q = lane >> 4;
-  char * region = reinterpret_cast<char *>(smem + G::PTAB) + wave * G::REGION_B;
+  char * region = reinterpret_cast<char *>(ptab_r + RC * 400) + wave * G::REGION_B;
   constexpr int ROW_B = G::ROW_G * 16;
 
   const size_t sites = a.sites;
@@ -164,18 +172,32 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsArgs a)
     const size_t site0 = tile * 16;
     double b[RC][5], x[RC][5], y[RC][5];
 
-    // ---- left child: DMA, fetch B operands, then reuse the image for the right child
-    dma_tile<RC, NT>(a.left, site0, sites, region, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    read_b_operands<RC>(region, s, q, b);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    dma_tile<RC, NT>(a.right, site0, sites, region, lane);
-    tile_matvec<RC>(ptab, b, lane, x); // overlaps the right child's DMA
+    if (KIND == 0)
+    {
+      // ---- left child: DMA, fetch B operands, then reuse the image for the right child
+      dma_tile<RC, NT>(a.left, site0, sites, region, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      read_b_operands<RC>(region, s, q, b);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dma_tile<RC, NT>(a.right, site0, sites, region, lane);
+      tile_matvec<RC>(ptab, b, lane, x); // overlaps the right child's DMA
+    }
+    else
+    {
+      dma_tile<RC, NT>(a.right, site0, sites, region, lane);
+      // left factor: tip row sums of this column's site, states 4g+q
+      unsigned int code = (site0 + s < sites) ? a.ltip[site0 + s] : 0u;
+      if (code >= a.maxstates) code = 0;
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+#pragma unroll
+        for (int g = 0; g < 5; ++g) x[k][g] = ptab[(code * RC + k) * 20 + 4 * g + q];
+    }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     read_b_operands<RC>(region, s, q, b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    tile_matvec<RC>(ptab + RC * S20 * S20, b, lane, y);
+    tile_matvec<RC>(ptab_r, b, lane, y);
 
     // ---- product + scaling (core_partials_avx2.c:752-800)
     bool small_site = true;
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsArgs a)
 #pragma unroll
           for (int g = 0; g < 5; ++g) x[k][g] *= PLLHIP_SCALE_FACTOR;
       if (q == 0 && n < sites)
-        a.pscaler[n] = ls[has_l ? n : 0] + rs[has_r ? n : 0] + (scale ? 1u : 0u);
+        a.pscaler[n] = (KIND == 0 ? ls[has_l ? n : 0] : 0u) + rs[has_r ? n : 0] + (scale ? 1u : 0u);
     }
     if (MODE == SCALE_RATE)
     {
@@ -214,8 +236,8 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsArgs a)
 #pragma unroll
           for (int g = 0; g < 5; ++g) x[k][g] *= PLLHIP_SCALE_FACTOR;
         if (q == 0 && n < sites)
-          a.pscaler[n * RC + k] = ls[has_l ? n * RC + k : 0] + rs[has_r ? n * RC + k : 0] +
-                                  (scale ? 1u : 0u);
+          a.pscaler[n * RC + k] = (KIND == 0 ? ls[has_l ? n * RC + k : 0] : 0u) +
+                                  rs[has_r ? n * RC + k : 0] + (scale ? 1u : 0u);
       }
     }
 
@@ -242,10 +264,75 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsArgs a)
   }
 }
 
-template <int RC>
+// ---- tip tables, built once per op: tab[code][k][i] = sum_{j in tipmap[code]} P[k][i][j]
+// (core_partials_avx.c:1140-1177); left and right tables back to back
+__global__ __launch_bounds__(256) void k_aa_tip_tables(double * __restrict__ tab,
+                                                       const double * __restrict__ lmat,
+                                                       const double * __restrict__ rmat,
+                                                       const unsigned int * __restrict__ tipmap,
+                                                       unsigned int maxstates, unsigned int rate_cats,
+                                                       int both)
+{
+  const unsigned int per = maxstates * rate_cats * 20;
+  const unsigned int total = both ? 2 * per : per;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x)
+  {
+    const unsigned int side = t / per, u = t % per;
+    const unsigned int code = u / (rate_cats * 20), ki = u % (rate_cats * 20);
+    tab[t] = masksum_seq((side ? rmat : lmat) + (size_t)ki * 20, tipmap[code], 20);
+  }
+}
+
+// tip-tip: parent = ltab[code_l] (.) rtab[code_r].  One lane per 16 bytes, waves
+// in rounds of 64 sites (codes fetched once per round, one site per lane), the
+// GS = 10*RC store instructions of a round each one contiguous KiB.
+template <int RC, int MODE, bool NT>
+__global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsArgs a)
+{
+  constexpr unsigned int GS = RC * 10; // 16-byte granules per site
+  extern __shared__ double smem[];
+  const unsigned int per = a.maxstates * RC * 20;
+  double * tl = smem, * tr = smem + per;
+  for (unsigned int t = threadIdx.x; t < per; t += blockDim.x) { tl[t] = a.ltab[t]; tr[t] = a.rtab[t]; }
+  __syncthreads();
+  const unsigned int lane = threadIdx.x & 63u;
+  const size_t sites = a.sites;
+  const size_t rounds = (sites + 63) / 64;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  double2 * __restrict__ out = reinterpret_cast<double2 *>(a.parent);
+  for (size_t r = wave; r < rounds; r += nwaves)
+  {
+    const size_t site0 = r * 64;
+    unsigned int cl = (site0 + lane < sites) ? a.ltip[site0 + lane] : 0u;
+    unsigned int cr = (site0 + lane < sites) ? a.rtip[site0 + lane] : 0u;
+    if (cl >= a.maxstates) cl = 0;
+    if (cr >= a.maxstates) cr = 0;
+    const size_t gbase = site0 * GS, gend = sites * GS;
+#pragma unroll 10
+    for (unsigned int j = 0; j < GS; ++j)
+    {
+      const unsigned int gg = j * 64 + lane;          // granule within the round
+      const unsigned int sl = gg / GS, rr = gg - sl * GS; // site in round, granule in site
+      const unsigned int c1 = (unsigned int)__shfl((int)cl, (int)sl, 64);
+      const unsigned int c2 = (unsigned int)__shfl((int)cr, (int)sl, 64);
+      const double2 x = *reinterpret_cast<const double2 *>(tl + c1 * RC * 20 + rr * 2);
+      const double2 y = *reinterpret_cast<const double2 *>(tr + c2 * RC * 20 + rr * 2);
+      if (gbase + gg < gend) st16<NT>(out + gbase + gg, x.x * y.x, x.y * y.y);
+    }
+    // no scaling test on tip-tip; the scaler is cleared (core_partials_avx.c:552-553)
+    if (MODE == SCALE_SITE && site0 + lane < sites) a.pscaler[site0 + lane] = 0u;
+    if (MODE == SCALE_RATE)
+      for (unsigned int t = lane; t < 64 * RC; t += 64)
+        if (site0 * RC + t < sites * RC) a.pscaler[site0 * RC + t] = 0u;
+  }
+}
+
+template <int RC, int KIND>
 static int launch_rc(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
 {
   using G = aa_geom<RC>;
+
   const size_t tiles = ((size_t)a.sites + 15) / 16;
   size_t blocks = (tiles + 3) / 4;
   // two 4-wave workgroups per CU are resident (71 KB of LDS each); the P-matrix
@@ -253,7 +340,9 @@ static int launch_rc(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
   const size_t cap = (size_t)c->num_cus * 2;
   if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned int)blocks), block(256);
-  const size_t lds = G::LDS_BYTES;
+  const size_t left_elems = (KIND == 0) ? (size_t)RC * 400 : (size_t)a.maxstates * RC * 20;
+  const size_t lds = (left_elems + (size_t)RC * 400) * sizeof(double) + 4 * (size_t)G::REGION_B;
+  if (lds > 80 * 1024) return 1; // two workgroups per CU must fit
   // more than 64 KB of dynamic LDS has to be requested per kernel
 #define AA_LAUNCH_ONE(KERNEL)                                                                 \
   do {                                                                                        \
@@ -263,8 +352,8 @@ static int launch_rc(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
   } while (0)
 #define AA_LAUNCH(MODEV)                                                                      \
   do {                                                                                        \
-    if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true>));                                   \
-    else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false>));                                     \
+    if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true, KIND>));                             \
+    else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND>));                               \
   } while (0)
   if (mode == SCALE_NONE) AA_LAUNCH(0);
   else if (mode == SCALE_SITE) AA_LAUNCH(1);
@@ -281,9 +370,68 @@ int pllhip_launch_aa_ii_mfma(pllhip_ctx * c, const PartialsArgs & a, int mode)
   const bool nt = pllhip_use_nt(c);
   switch (a.rate_cats)
   {
-    case 1: return launch_rc<1>(c, a, mode, nt);
-    case 2: return launch_rc<2>(c, a, mode, nt);
-    case 4: return launch_rc<4>(c, a, mode, nt);
+    case 1: return launch_rc<1, 0>(c, a, mode, nt);
+    case 2: return launch_rc<2, 0>(c, a, mode, nt);
+    case 4: return launch_rc<4, 0>(c, a, mode, nt);
     default: return 1;
+  }
+}
+
+template <int RC>
+static int launch_tt(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
+{
+  const size_t rounds = ((size_t)a.sites + 63) / 64;
+  size_t blocks = (rounds + 3) / 4;
+  const size_t cap = (size_t)c->num_cus * 8; // 29 KB of table staging per workgroup
+  if (blocks > cap) blocks = cap;
+  const size_t lds = 2 * (size_t)a.maxstates * RC * 20 * sizeof(double);
+  const dim3 grid((unsigned int)blocks), block(256);
+#define TT_LAUNCH(MODEV)                                                                         \
+  do {                                                                                           \
+    if (nt) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, true>), grid, block, lds, c->stream, a);  \
+    else hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false>), grid, block, lds, c->stream, a);    \
+  } while (0)
+  if (mode == SCALE_NONE) TT_LAUNCH(0);
+  else if (mode == SCALE_SITE) TT_LAUNCH(1);
+  else TT_LAUNCH(2);
+#undef TT_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int pllhip_launch_aa_tip(pllhip_ctx * c, PartialsArgs & a, int kind, int mode)
+{
+  const unsigned int R = a.rate_cats;
+  if (!(R == 1 || R == 2 || R == 4) || a.maxstates == 0 || a.maxstates > 32) return 1;
+  const size_t per = (size_t)a.maxstates * R * 20;
+  if (2 * per * sizeof(double) > 60 * 1024) return 1;
+  if (c->tiptab_elems < 2 * per)
+  {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_tiptab) HIP_TRY(hipFree(c->d_tiptab));
+    c->d_tiptab = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->d_tiptab, 2 * per * sizeof(double)));
+    c->tiptab_elems = 2 * per;
+  }
+  k_aa_tip_tables<<<8, 256, 0, c->stream>>>(c->d_tiptab, a.lmat, a.rmat, a.tipmap, a.maxstates, R,
+                                            kind == 2 ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  a.ltab = c->d_tiptab;
+  a.rtab = c->d_tiptab + per;
+  const bool nt = pllhip_use_nt(c);
+  if (kind == 2)
+  {
+    switch (R)
+    {
+      case 1: return launch_tt<1>(c, a, mode, nt);
+      case 2: return launch_tt<2>(c, a, mode, nt);
+      default: return launch_tt<4>(c, a, mode, nt);
+    }
+  }
+  switch (R)
+  {
+    case 1: return launch_rc<1, 1>(c, a, mode, nt);
+    case 2: return launch_rc<2, 1>(c, a, mode, nt);
+    default: return launch_rc<4, 1>(c, a, mode, nt);
   }
 }
