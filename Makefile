@@ -30,7 +30,7 @@ $(BUILD):
 $(BUILD)/host_%.o: libpll_amd/csrc/host/%.c include/pll_amd.h include/pllhip.h libpll_amd/csrc/host/internal.h | $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(BUILD)/hip_%.o: libpll_amd/csrc/hip/%.hip include/pllhip.h libpll_amd/csrc/hip/ctx.hpp libpll_amd/csrc/hip/numerics.hpp | $(BUILD)
+$(BUILD)/hip_%.o: libpll_amd/csrc/hip/%.hip include/pllhip.h $(wildcard libpll_amd/csrc/hip/*.hpp) | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OUT): $(HOST_OBJ) $(HIP_OBJ)

@@ -1,0 +1,97 @@
+// aa_mfma.hpp -- internal: pieces shared by the 20-state matrix-core kernels
+// (partials_aa_mfma.hip, likelihood_aa_mfma.hip).  Layouts and the measured
+// reasons for the instruction choice are documented in partials_aa_mfma.hip.
+#pragma once
+#include "ctx.hpp"
+#include "numerics.hpp"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define PLL_AS1 __attribute__((address_space(1)))
+#define PLL_AS3 __attribute__((address_space(3)))
+
+namespace
+{
+constexpr int S20 = 20;
+
+template <int RC>
+struct aa_geom
+{
+  static constexpr int ROW_G = RC * 10 + 1;            // 16-B granules per site row incl. the pad
+  static constexpr int TILE_G = 16 * ROW_G;            // granules per tile image
+  static constexpr int N_IT = (TILE_G + 63) / 64;      // wave-instructions to move a tile
+  static constexpr int REGION_B = N_IT * 1024;         // bytes reserved per wave
+  static constexpr int PTAB = 2 * RC * S20 * S20;      // doubles
+  static constexpr size_t LDS_BYTES = (size_t)PTAB * 8 + 4 * (size_t)REGION_B;
+};
+
+// copy the 16-site tile starting at site0 of `clv` into the wave's LDS image
+template <int RC, bool NT>
+__device__ __forceinline__ void dma_tile(const double * __restrict__ clv, size_t site0, size_t sites,
+                                         char * region, unsigned int lane)
+{
+  using G = aa_geom<RC>;
+#pragma unroll
+  for (int it = 0; it < G::N_IT; ++it)
+  {
+    int P = it * 64 + (int)lane;
+    if (P > G::TILE_G - 1) P = G::TILE_G - 1;
+    const int site = P / G::ROW_G;
+    int col = P - site * G::ROW_G;
+    if (col > G::ROW_G - 2) col = G::ROW_G - 2; // pad granule: re-load the row's last one
+    size_t n = site0 + (size_t)site;
+    if (n >= sites) n = sites - 1;
+    const double * src = clv + (n * (size_t)(RC * 10) + (size_t)col) * 2;
+    __builtin_amdgcn_global_load_lds((const PLL_AS1 void *)src,
+                                     (PLL_AS3 void *)(region + it * 1024), 16, 0, NT ? 2 : 0);
+  }
+}
+
+// B operands of the whole tile: b[k][c] = state 4c+q of (site s, rate k)
+template <int RC>
+__device__ __forceinline__ void read_b_operands(const char * region, unsigned int s, unsigned int q,
+                                                double (&b)[RC][5])
+{
+  constexpr int ROW_B = aa_geom<RC>::ROW_G * 16;
+#pragma unroll
+  for (int k = 0; k < RC; ++k)
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+      b[k][c] = *reinterpret_cast<const double *>(region + s * ROW_B + k * 160 + (4 * c + q) * 8);
+}
+
+// x[k][g] = state 4g+q of  P_k . (column s of the tile), for one child
+template <int RC>
+__device__ __forceinline__ void tile_matvec(const double * ptab_child, const double (&b)[RC][5],
+                                            unsigned int lane, double (&x)[RC][5])
+{
+  const unsigned int i = lane & 3u, q = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < RC; ++k)
+  {
+    const double * pk = ptab_child + (size_t)k * S20 * S20;
+    double a[5][5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) a[g][c] = pk[(4 * g + i) * S20 + 4 * c + q];
+#pragma unroll
+    for (int g = 0; g < 5; ++g)
+    {
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g][c], b[k][c], acc, 0, 0, 0);
+      x[k][g] = acc;
+    }
+  }
+}
+
+// all 4 lanes of this lane's tile column (s, s+16, s+32, s+48) have the flag set
+__device__ __forceinline__ bool column_all(bool f, unsigned int s)
+{
+  const unsigned long long b = __ballot(f);
+  const unsigned long long m = 0x0001000100010001ull << s;
+  return (b & m) == m;
+}
+} // namespace
+
