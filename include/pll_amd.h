@@ -158,6 +158,9 @@ PLL_EXPORT extern __thread char pll_errmsg[200];
 PLL_EXPORT extern const unsigned int pll_map_bin[256];
 PLL_EXPORT extern const unsigned int pll_map_nt[256];
 PLL_EXPORT extern const unsigned int pll_map_aa[256];
+/* character classes of the (out-of-scope) FASTA / PHYLIP readers, data only */
+PLL_EXPORT extern const unsigned int pll_map_fasta[256];
+PLL_EXPORT extern const unsigned int pll_map_phylip[256];
 
 PLL_EXPORT extern const double pll_aa_rates_lg[190];
 PLL_EXPORT extern const double pll_aa_freqs_lg[20];

@@ -1,0 +1,43 @@
+"""The reference's own self-contained test programs (test/src/*.c, compiled
+UNMODIFIED by oracle/Makefile and linked against libpll_amd.so) must print the
+reference's golden outputs (test/out/*.out, kept as data under
+tests/golden/reference_out/) when run on the GPU -- in every attribute mode the
+reference's runner uses that reaches this library's code path (arch flags are
+accepted and ignored; `tv` selects PLL_ATTRIB_PATTERN_TIP).
+
+This is the drop-in check: same client binary, same expected text."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref")
+OUT = os.path.join(ROOT, "tests", "golden", "reference_out")
+TESTS = ["00010_NMDU_lkcalc", "00011_NMAU_lkcalc", "00012_NMOU_lkcalc", "00020_NMDR_lkcalc",
+         "00021_NMAR_lkcalc", "00022_NMOR_lkcalc", "00030_NMDU_gamma", "00032_NMOU_gamma",
+         "alpha-cats", "derivatives", "derivatives-oddstates", "hky", "pmatrix"]
+MODES = [[], ["tv"], ["avx2"], ["avx2", "tv"], ["avx"], ["sse", "tv"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: "+".join(m) or "cpu")
+@pytest.mark.parametrize("name", TESTS)
+def test_reference_program_output(gpu, name, mode):
+    exe = os.path.join(BIN, "reftest_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("prebuilt reference test program missing (make -C oracle reftests)")
+    env = dict(os.environ, PLLHIP_AA_EXACT="1")
+    run = subprocess.run([exe] + mode, capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    got = run.stdout
+    expected = open(os.path.join(OUT, name + ".out")).read()
+    if got.strip() == "Skip":       # a test may opt out of a mode (test/src/common.c:62-66)
+        assert open(os.path.join(OUT, "skip.out")).read().strip() == "Skip"
+        return
+    if got != expected:
+        gl, el = got.splitlines(), expected.splitlines()
+        diff = [(i, g, e) for i, (g, e) in enumerate(zip(gl, el)) if g != e][:5]
+        raise AssertionError("%s %s: %d/%d lines differ, first: %s"
+                             % (name, mode, sum(g != e for g, e in zip(gl, el)) + abs(len(gl) - len(el)),
+                                len(el), diff))
