@@ -34,7 +34,7 @@ $(BUILD)/hip_%.o: libpll_amd/csrc/hip/%.hip include/pllhip.h $(wildcard libpll_a
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OUT): $(HOST_OBJ) $(HIP_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -Wl,-rpath,/opt/rocm/lib \
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -Wl,-soname,libpll_amd.so -Wl,-rpath,/opt/rocm/lib \
 	    -o $@ $(HOST_OBJ) $(HIP_OBJ) -lm -ldl
 
 oracle:
