@@ -215,7 +215,11 @@ extern "C" int pllhip_comm_unique_id(void * id128)
 
 extern "C" int pllhip_comm_init(pllhip_ctx_t * c, int rank, int nranks, const void * id128)
 {
-  if (nranks <= 1) { c->nranks = 1; return 0; }
+  if (nranks < 1 || rank < 0 || rank >= nranks)
+  {
+    pllhip_set_error("pllhip_comm_init: bad rank %d of %d", rank, nranks);
+    return -1;
+  }
   if (rccl_load()) return -1;
   HIP_TRY(hipSetDevice(c->sh.device));
   ncclUniqueId id;
@@ -230,7 +234,7 @@ extern "C" int pllhip_comm_init(pllhip_ctx_t * c, int rank, int nranks, const vo
 // sum d_result[0..count) over all ranks, in place, on the context's stream
 int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count)
 {
-  if (c->nranks <= 1 || !c->comm) return 0;
+  if (!c->comm) return 0;
   NCCL_TRY(g_rccl.AllReduce(c->d_result, c->d_result, count, ncclDouble, ncclSum,
                             (ncclComm_t)c->comm, c->stream));
   return 0;

@@ -232,6 +232,29 @@ def test_tip_inner_equals_inner_inner(gpu):
         q.destroy()
 
 
+def test_rccl_allreduce_path_single_rank(gpu):
+    """The multi-GPU code path on one GPU: a 1-rank RCCL communicator is created
+    through pll_amd_comm_unique_id / pll_amd_comm_init and every lnL / derivative
+    result then goes through ncclAllReduce on the partition's stream.  With one
+    rank the sum must leave the values unchanged."""
+    import ctypes
+    case = make_case(4, "random", 9, 3000, seed=12)
+    plan = case["plan"]
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    lnl0 = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4)
+    e = plan.root_edge
+    st = p.alloc_sumtable()
+    p.update_sumtable(e[0], e[2], e[1], e[3], [0] * 4, st)
+    d0 = p.compute_likelihood_derivatives(e[1], e[3], 0.2, [0] * 4, st)
+    uid = ctypes.create_string_buffer(128)
+    assert gpu.lib.pll_amd_comm_unique_id(uid), gpu.errmsg()
+    p.comm_init(0, 1, uid.raw)
+    assert p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4) == lnl0
+    assert p.compute_likelihood_derivatives(e[1], e[3], 0.2, [0] * 4, st) == d0
+    p.destroy()
+
+
 def test_error_paths(gpu):
     """Same error behaviour as the reference where it defines one."""
     with pytest.raises(PllError):

@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref")
 OUT = os.path.join(ROOT, "tests", "golden", "reference_out")
-TESTS = ["00010_NMDU_lkcalc", "00011_NMAU_lkcalc", "00012_NMOU_lkcalc", "00020_NMDR_lkcalc",
+TESTS = ["example_unrooted", "00010_NMDU_lkcalc", "00011_NMAU_lkcalc", "00012_NMOU_lkcalc", "00020_NMDR_lkcalc",
          "00021_NMAR_lkcalc", "00022_NMOR_lkcalc", "00030_NMDU_gamma", "00032_NMOU_gamma",
          "alpha-cats", "derivatives", "derivatives-oddstates", "hky", "pmatrix"]
 MODES = [[], ["tv"], ["avx2"], ["avx2", "tv"], ["avx"], ["sse", "tv"]]
@@ -24,6 +24,8 @@ MODES = [[], ["tv"], ["avx2"], ["avx2", "tv"], ["avx"], ["sse", "tv"]]
 @pytest.mark.parametrize("mode", MODES, ids=lambda m: "+".join(m) or "cpu")
 @pytest.mark.parametrize("name", TESTS)
 def test_reference_program_output(gpu, name, mode):
+    if name == "example_unrooted" and mode:
+        pytest.skip("examples/unrooted takes no attribute arguments")
     exe = os.path.join(BIN, "reftest_" + name)
     if not os.path.exists(exe):
         pytest.skip("prebuilt reference test program missing (make -C oracle reftests)")
