@@ -26,6 +26,7 @@
 // Arithmetic order is the reference's: see numerics.hpp.
 #include "ctx.hpp"
 #include "numerics.hpp"
+#include <stdlib.h>
 
 
 template <int RC>
@@ -69,9 +70,19 @@ __device__ __forceinline__ void build_tip_table4(double * tab, const double * __
 // Lane l owns site (l % W) * (64/W) + l / W of the round: in sub-step j = l % W
 // its group is exactly that site, so the site's scaling decision is already in
 // the lane when the round ends.
-template <int RC, int MODE, bool NT, int KIND>
-__global__ __launch_bounds__(256) void k_dna_partials(PartialsArgs a)
+// Several mutually independent ops (one tree level) run in ONE launch:
+// blockIdx.y selects the op.  The op descriptors travel as kernel arguments
+// (24 x 136 B < the 4 KB kernarg segment), so batching needs no staging copy.
+#define PLLHIP_BATCH_MAX 24
+struct PartialsBatch
 {
+  PartialsArgs op[PLLHIP_BATCH_MAX];
+};
+
+template <int RC, int MODE, bool NT, int KIND>
+__global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
+{
+  const PartialsArgs & a = batch.op[blockIdx.y];
   constexpr unsigned int W = 2 * RC;
   constexpr unsigned int SPS = 64 / W;
   __shared__ double tabl[KIND >= 1 ? 16 * RC * 4 : 1];
@@ -479,9 +490,9 @@ __global__ __launch_bounds__(256) void k_aa_tt(PartialsArgs a)
 
 #define LAUNCH_DNA_KIND(RCV, MODEV, NTV)                                                   \
   do {                                                                                     \
-    if (kind == 0) k_dna_partials<RCV, MODEV, NTV, 0><<<grid, 256, 0, s>>>(a);             \
-    else if (kind == 1) k_dna_partials<RCV, MODEV, NTV, 1><<<grid, 256, 0, s>>>(a);        \
-    else k_dna_partials<RCV, MODEV, NTV, 2><<<grid, 256, 0, s>>>(a);                       \
+    if (kind == 0) k_dna_partials<RCV, MODEV, NTV, 0><<<grid, 256, 0, s>>>(b);             \
+    else if (kind == 1) k_dna_partials<RCV, MODEV, NTV, 1><<<grid, 256, 0, s>>>(b);        \
+    else k_dna_partials<RCV, MODEV, NTV, 2><<<grid, 256, 0, s>>>(b);                       \
   } while (0)
 
 #define LAUNCH_DNA_MODE(RCV, NTV)                                 \
@@ -496,6 +507,29 @@ static bool fast_rc(unsigned int rc)
   return rc == 1 || rc == 2 || rc == 4 || rc == 8 || rc == 16;
 }
 
+// 4-state ops of one kind and scaling mode, mutually independent, in one launch
+static int pllhip_launch_dna_batch(pllhip_ctx * c, const PartialsBatch & b, unsigned int count,
+                                   int kind, int mode)
+{
+  const PartialsArgs & a = b.op[0];
+  const unsigned int R = a.rate_cats;
+  hipStream_t s = c->stream;
+  // a wave consumes 64 sites per round
+  const dim3 grid(pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256), count);
+  // the non-temporal variants exist for the common 4-category case only
+  const bool nt = (R == 4) && pllhip_use_nt(c);
+  switch (R)
+  {
+    case 1: LAUNCH_DNA_MODE(1, false); break;
+    case 2: LAUNCH_DNA_MODE(2, false); break;
+    case 4: if (nt) LAUNCH_DNA_MODE(4, true); else LAUNCH_DNA_MODE(4, false); break;
+    case 8: LAUNCH_DNA_MODE(8, false); break;
+    default: LAUNCH_DNA_MODE(16, false); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
 int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, int mode,
                            int prof_kind)
@@ -508,18 +542,10 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, 
 
   if (a.states == 4 && fast_rc(R))
   {
-    // a wave consumes 64 sites per round
-    const unsigned int grid = pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256);
-    // the non-temporal variants exist for the common 4-category case only
-    const bool nt = (R == 4) && pllhip_use_nt(c);
-    switch (R)
-    {
-      case 1: LAUNCH_DNA_MODE(1, false); break;
-      case 2: LAUNCH_DNA_MODE(2, false); break;
-      case 4: if (nt) LAUNCH_DNA_MODE(4, true); else LAUNCH_DNA_MODE(4, false); break;
-      case 8: LAUNCH_DNA_MODE(8, false); break;
-      default: LAUNCH_DNA_MODE(16, false); break;
-    }
+    PartialsBatch b;
+    b.op[0] = a;
+    HIP_TRY(pllhip_launch_dna_batch(c, b, 1, kind, mode) ? hipErrorLaunchFailure : hipSuccess);
+    return 0;
   }
   else if (a.states == 20 && kind == 0 && !c->aa_exact && pllhip_launch_aa_ii_mfma(c, a, mode) == 0)
   {
@@ -549,7 +575,8 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, 
   return 0;
 }
 
-static int launch_op(pllhip_ctx * c, const pllhip_op_t & op)
+// resolves one op into kernel arguments; kind and mode as in pllhip_launch_partials
+static int resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, int & kind, int & mode)
 {
   const unsigned int nodes = (unsigned int)c->clv.size();
   if (op.parent_clv >= nodes || op.child1_clv >= nodes || op.child2_clv >= nodes ||
@@ -571,7 +598,6 @@ static int launch_op(pllhip_ctx * c, const pllhip_op_t & op)
   }
 
   const bool t1 = pllhip_is_tip(c, op.child1_clv), t2 = pllhip_is_tip(c, op.child2_clv);
-  PartialsArgs a;
   memset(&a, 0, sizeof(a));
   a.parent = c->clv[op.parent_clv];
   a.pscaler = pllhip_scaler_ptr(c, op.parent_scaler);
@@ -582,7 +608,6 @@ static int launch_op(pllhip_ctx * c, const pllhip_op_t & op)
   a.rate_cats = c->sh.rate_cats;
   a.states = c->sh.states;
   a.maxstates = c->maxstates;
-  int kind;
   if (t1 && t2)
   {
     kind = 2;
@@ -624,19 +649,73 @@ static int launch_op(pllhip_ctx * c, const pllhip_op_t & op)
     return -1;
   }
 
-  const int mode = !a.pscaler ? SCALE_NONE : (c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE);
-  return pllhip_launch_partials(c, a, kind, mode, -1);
+  mode = !a.pscaler ? SCALE_NONE : (c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE);
+  return 0;
 }
 
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)
 {
   HIP_TRY(hipSetDevice(c->sh.device));
-  // strictly in list order on one stream: unrooted trees reuse CLV slots, so
-  // dependencies follow buffer indices, not tree shape (partials.c:184-212)
+  // Ops execute in list order on one stream.  Unrooted trees reuse CLV slots, so
+  // dependencies follow BUFFER INDICES, not tree shape (partials.c:184-212):
+  // consecutive 4-state ops of the same kind and scaling mode are merged into one
+  // launch as long as none of them touches a CLV or scale buffer another one
+  // writes, and none writes one another reads -- on a balanced tree that is one
+  // launch per level instead of one per node.
+  const char * nb_env = getenv("PLLHIP_NO_BATCH");
+  const bool batchable = c->sh.states == 4 && fast_rc(c->sh.rate_cats) &&
+                         !(nb_env && atoi(nb_env) != 0);
+  PartialsBatch b;
+  unsigned int nb = 0;
+  int bkind = -1, bmode = -1;
+  unsigned int wr_clv[PLLHIP_BATCH_MAX], rd_clv[2 * PLLHIP_BATCH_MAX];
+  int wr_sc[PLLHIP_BATCH_MAX], rd_sc[2 * PLLHIP_BATCH_MAX];
+
+  auto flush = [&]() -> int {
+    if (!nb) return 0;
+    pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II + bkind);
+    int rc = pllhip_launch_dna_batch(c, b, nb, bkind, bmode);
+    nb = 0;
+    return rc;
+  };
+
   for (unsigned int i = 0; i < count; ++i)
   {
-    int rc = launch_op(c, ops[i]);
+    PartialsArgs a;
+    int kind, mode;
+    int rc = resolve_op(c, ops[i], a, kind, mode);
     if (rc) return rc;
+    if (!batchable)
+    {
+      if ((rc = pllhip_launch_partials(c, a, kind, mode, -1))) return rc;
+      continue;
+    }
+    const pllhip_op_t & op = ops[i];
+    bool conflict = nb == PLLHIP_BATCH_MAX || (nb && (kind != bkind || mode != bmode));
+    for (unsigned int j = 0; j < nb && !conflict; ++j)
+    {
+      // RAW / WAW / WAR on CLVs
+      conflict = op.child1_clv == wr_clv[j] || op.child2_clv == wr_clv[j] ||
+                 op.parent_clv == wr_clv[j] || op.parent_clv == rd_clv[2 * j] ||
+                 op.parent_clv == rd_clv[2 * j + 1];
+      // ... and on scale buffers
+      if (wr_sc[j] >= 0)
+        conflict = conflict || op.child1_scaler == wr_sc[j] || op.child2_scaler == wr_sc[j] ||
+                   op.parent_scaler == wr_sc[j];
+      if (op.parent_scaler >= 0)
+        conflict = conflict || op.parent_scaler == rd_sc[2 * j] || op.parent_scaler == rd_sc[2 * j + 1];
+    }
+    if (conflict && (rc = flush())) return rc;
+    b.op[nb] = a;
+    wr_clv[nb] = op.parent_clv;
+    rd_clv[2 * nb] = op.child1_clv;
+    rd_clv[2 * nb + 1] = op.child2_clv;
+    wr_sc[nb] = op.parent_scaler;
+    rd_sc[2 * nb] = op.child1_scaler;
+    rd_sc[2 * nb + 1] = op.child2_scaler;
+    bkind = kind;
+    bmode = mode;
+    ++nb;
   }
-  return 0;
+  return flush();
 }
