@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsArgs a)
       const unsigned int c2 = (unsigned int)__shfl((int)cr, (int)sl, 64);
       const double2 x = *reinterpret_cast<const double2 *>(tl + c1 * RC * 20 + rr * 2);
       const double2 y = *reinterpret_cast<const double2 *>(tr + c2 * RC * 20 + rr * 2);
-      if (gbase + gg < gend) st16<NT>(out + gbase + gg, x.x * y.x, x.y * y.y);
+      // plain stores: a write-only stream is slower with the non-temporal hint (see partials.hip)
+      if (gbase + gg < gend) st16<false>(out + gbase + gg, x.x * y.x, x.y * y.y);
     }
     // no scaling test on tip-tip; the scaler is cleared (core_partials_avx.c:552-553)
     if (MODE == SCALE_SITE && site0 + lane < sites) a.pscaler[site0 + lane] = 0u;
