@@ -39,6 +39,46 @@ TRAFFIC_NOTE = {4: 396.1e6}
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
 
+def _cpu_worker(ref_path, plan, seqs, S, R, attrs, reps, barrier, out, idx):
+    from libpll_amd import workload as W
+    from libpll_amd.pllapi import PllLibrary
+    ref = PllLibrary(ref_path)
+    p = W.setup_partition(ref, plan, seqs, S, R, attrs)
+    p.update_partials(plan.ops)
+    barrier.wait()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p.update_partials(plan.ops)
+        p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    out[idx] = time.perf_counter() - t0
+    barrier.wait()
+
+
+def cpu_all_cores(ref_path, plan, sample, S, R, attrs, cores, reps):
+    """All host cores the standard client way (libpll is single-threaded): `cores`
+    processes, each a partition over sites/cores columns, no shared state.
+    Returns M site-updates/s over the slowest worker's time.  Must run before the
+    GPU is initialised (it forks)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    n = len(sample[0])
+    bounds = [n * i // cores for i in range(cores + 1)]
+    barrier = ctx.Barrier(cores)
+    out = ctx.Array("d", cores)
+    procs = []
+    for i in range(cores):
+        sl = [s[bounds[i]:bounds[i + 1]] for s in sample]
+        procs.append(ctx.Process(target=_cpu_worker,
+                                 args=(ref_path, plan, sl, S, R, attrs, reps, barrier, out, i)))
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    if any(p.exitcode != 0 for p in procs):
+        return None
+    return len(plan.ops) * n * reps / max(out) / 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,9 +91,9 @@ def main():
     ap.add_argument("--tip-clv", action="store_true", help="tips as CLVs (all ops inner-inner)")
     ap.add_argument("--rate-scalers", action="store_true")
     ap.add_argument("--alignment", default="simulated", choices=("simulated", "random"))
-    ap.add_argument("--cpu-sites", type=int, default=100_000,
+    ap.add_argument("--cpu-sites", type=int, default=250_000,
                     help="sample size for the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--cpu-reps", type=int, default=10)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,6 +101,65 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, root)
+    from libpll_amd import workload as W
+    from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_ARCH_AVX2,
+                                   PllLibrary)
+
+    S, R, T = args.states, args.rate_cats, args.taxa
+    attrs = (0 if args.tip_clv else ATTRIB_PATTERN_TIP) | \
+            (ATTRIB_RATE_SCALERS if args.rate_scalers else 0)
+    plan = W.balanced_tree(T, seed=42)
+    total_sites = args.sites * world
+    lo, hi = W.shard_bounds(total_sites, world)[rank:rank + 2]
+    ref_path = os.path.join(root, "oracle", "_ref", "libpll_ref.so")
+    ref = PllLibrary(ref_path) if os.path.exists(ref_path) else None
+    # model tables from whichever library is loadable without a GPU (the reference build
+    # if present, else the product -- both hold the same published numbers)
+    if ref is None:
+        import torch  # noqa: F401  (torch's HIP runtime must be the first one loaded, see below)
+    host_lib = ref if ref is not None else PllLibrary(os.path.join(root, "libpll_amd", "libpll_amd.so"))
+    cat_rates = host_lib.compute_gamma_cats(W.GAMMA_ALPHA, R)
+    rates = W.GTR_RATES if S == 4 else host_lib.aa_model("lg")[0]
+    freqs = W.GTR_FREQS if S == 4 else host_lib.aa_model("lg")[1]
+    # each rank generates only its own shard (seeded by rank): [lo, hi) of the
+    # conceptual total alignment
+    if args.alignment == "simulated":
+        seqs = W.simulated_alignment(plan, hi - lo, rates, freqs, cat_rates, seed=42 + rank)
+    else:
+        seqs = W.random_alignment(T, hi - lo, S, seed=42 + rank)
+    fi = [0] * R
+    ops_per_eval = len(plan.ops)
+
+    # ---- CPU baseline (rank 0, N=1 only), BEFORE anything touches the GPU (its
+    # multi-core leg forks workers): the reference library's AVX2-flag path on a
+    # bounded sample of the same workload, same tree / ops / model.
+    cpu = None
+    cpu_sample = None
+    cpu_ref_lnl = None
+    if rank == 0 and world == 1 and args.cpu_sites > 0 and ref is not None:
+        n = min(args.cpu_sites, hi - lo)
+        cpu_sample = [s[:n] for s in seqs]
+        rp = W.setup_partition(ref, plan, cpu_sample, S, R, attrs | ATTRIB_ARCH_AVX2)
+        rp.update_partials(plan.ops)  # warm-up
+        t1 = time.perf_counter()
+        for _ in range(args.cpu_reps):
+            rp.update_partials(plan.ops)
+            cpu_ref_lnl = rp.compute_edge_loglikelihood(*plan.root_edge, fi)
+        dt = time.perf_counter() - t1
+        rp.destroy()
+        one_core = ops_per_eval * n * args.cpu_reps / dt / 1e6
+        cores = len(os.sched_getaffinity(0))
+        all_cores = cpu_all_cores(ref_path, plan, cpu_sample, S, R, attrs | ATTRIB_ARCH_AVX2, cores,
+                                  args.cpu_reps) if cores > 1 else None
+        cpu = {"value": round(all_cores if all_cores else one_core, 2),
+               "unit": "M CLV-site-updates/s", "cores": cores if all_cores else 1,
+               "kind": "reference", "one_core_value": round(one_core, 2),
+               "sample": "%d of %d sites (sliced over %d processes for the multi-core figure), same "
+                         "tree/ops, %d evaluations, PLL_ATTRIB_ARCH_AVX2"
+                         % (n, hi - lo, cores if all_cores else 1, args.cpu_reps)}
 
     # torch first: it carries its own HIP runtime; loading it before our library
     # makes both share one runtime instance in this process.
@@ -73,32 +172,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    root = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, root)
     import libpll_amd
-    from libpll_amd import workload as W
-    from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_ARCH_AVX2,
-                                   PllLibrary)
-
     amd = libpll_amd.load()
     amd.lib.pll_amd_set_device(local_rank)
-
-    S, R, T = args.states, args.rate_cats, args.taxa
-    attrs = (0 if args.tip_clv else ATTRIB_PATTERN_TIP) | \
-            (ATTRIB_RATE_SCALERS if args.rate_scalers else 0)
-    plan = W.balanced_tree(T, seed=42)
-    total_sites = args.sites * world
-    cat_rates = amd.compute_gamma_cats(W.GAMMA_ALPHA, R)
-    rates = W.GTR_RATES if S == 4 else amd.aa_model("lg")[0]
-    freqs = W.GTR_FREQS if S == 4 else amd.aa_model("lg")[1]
-
-    # each rank generates only its own shard (seeded by rank): [lo, hi) of the
-    # conceptual total alignment
-    lo, hi = W.shard_bounds(total_sites, world)[rank:rank + 2]
-    if args.alignment == "simulated":
-        seqs = W.simulated_alignment(plan, hi - lo, rates, freqs, cat_rates, seed=42 + rank)
-    else:
-        seqs = W.random_alignment(T, hi - lo, S, seed=42 + rank)
 
     part = W.setup_partition(amd, plan, seqs, S, R, attrs)
     if world > 1:
@@ -111,8 +187,6 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
         dist.broadcast(uid, src=0)
         part.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-
-    fi = [0] * R
 
     def step():
         part.update_partials(plan.ops)
@@ -142,7 +216,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ops_per_eval = len(plan.ops)
     site_updates = float(ops_per_eval) * total_sites * args.steps
     value = site_updates / elapsed / 1e6
 
@@ -182,32 +255,14 @@ def main():
     per_kernel = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2) if v[0] else None}
                   for k, v in prof.items() if v[0]}
 
-    # ---- CPU baseline (rank 0, N=1 only): the reference library on a sample
-    cpu = None
+    # ---- lnL parity on the CPU-baseline sample through the HIP path
     lnl_rel_err = None
-    ref_path = os.path.join(root, "oracle", "_ref", "libpll_ref.so")
-    if rank == 0 and world == 1 and args.cpu_sites > 0 and os.path.exists(ref_path):
-        ref = PllLibrary(ref_path)
-        n = min(args.cpu_sites, hi - lo)
-        sample = [s[:n] for s in seqs]
-        rp = W.setup_partition(ref, plan, sample, S, R, attrs | ATTRIB_ARCH_AVX2)
-        rp.update_partials(plan.ops)  # warm-up
-        t1 = time.perf_counter()
-        for _ in range(args.cpu_reps):
-            rp.update_partials(plan.ops)
-            ref_lnl = rp.compute_edge_loglikelihood(*plan.root_edge, fi)
-        dt = time.perf_counter() - t1
-        cpu = {"value": round(ops_per_eval * n * args.cpu_reps / dt / 1e6, 2),
-               "unit": "M CLV-site-updates/s", "cores": 1, "kind": "reference",
-               "sample": "%d of %d sites, same tree/ops, %d evaluations, PLL_ATTRIB_ARCH_AVX2"
-                         % (n, hi - lo, args.cpu_reps)}
-        # lnL parity on the same sample through the HIP path
-        gp = W.setup_partition(amd, plan, sample, S, R, attrs)
+    if cpu is not None:
+        gp = W.setup_partition(amd, plan, cpu_sample, S, R, attrs)
         gp.update_partials(plan.ops)
         g_lnl = gp.compute_edge_loglikelihood(*plan.root_edge, fi)
-        lnl_rel_err = abs(g_lnl - ref_lnl) / abs(ref_lnl)
+        lnl_rel_err = abs(g_lnl - cpu_ref_lnl) / abs(cpu_ref_lnl)
         gp.destroy()
-        rp.destroy()
 
     if rank == 0:
         tt, ti, ii = plan.op_kinds() if not args.tip_clv else (0, 0, ops_per_eval)
