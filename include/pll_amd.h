@@ -92,6 +92,9 @@ extern "C" {
 #define PLL_GAMMA_RATES_MEAN 0
 #define PLL_GAMMA_RATES_MEDIAN 1
 
+#define PLL_TREE_TRAVERSE_POSTORDER 1
+#define PLL_TREE_TRAVERSE_PREORDER 2
+
 /* ---- data types: field order and types are the reference ABI ---- */
 
 /* pll.h:202-244.  Clients read these fields directly, so the layout is frozen.
@@ -149,6 +152,35 @@ typedef struct pll_operation
   unsigned int child2_matrix_index;
   int child2_scaler_index;
 } pll_operation_t;
+
+/* tree nodes as clients build them (pll.h:312-350); layouts frozen.  An inner
+ * node of an unrooted tree is a ring of three pll_unode_t linked by `next`. */
+typedef struct pll_unode_s
+{
+  char * label;
+  double length;
+  unsigned int node_index;
+  unsigned int clv_index;
+  int scaler_index;
+  unsigned int pmatrix_index;
+  struct pll_unode_s * next;
+  struct pll_unode_s * back;
+  void * data;
+} pll_unode_t;
+
+typedef struct pll_rnode_s
+{
+  char * label;
+  double length;
+  unsigned int node_index;
+  unsigned int clv_index;
+  int scaler_index;
+  unsigned int pmatrix_index;
+  struct pll_rnode_s * left;
+  struct pll_rnode_s * right;
+  struct pll_rnode_s * parent;
+  void * data;
+} pll_rnode_t;
 
 /* ---- global data (pll.h:470-522) ---- */
 
@@ -265,6 +297,39 @@ PLL_EXPORT int pll_compute_likelihood_derivatives(pll_partition_t * partition,
                                                   const double * sumtable,
                                                   double * d_f,
                                                   double * dd_f);
+
+/* ---- the steps either side of the path: tree -> op list, and
+ * alignment -> unique site patterns + weights (replaces pll.h:725,731,788,794
+ * and :1735) ---- */
+
+PLL_EXPORT int pll_utree_traverse(pll_unode_t * root,
+                                  int traversal,
+                                  int (*cbtrav)(pll_unode_t *),
+                                  pll_unode_t ** outbuffer,
+                                  unsigned int * trav_size);
+PLL_EXPORT void pll_utree_create_operations(pll_unode_t * const * trav_buffer,
+                                            unsigned int trav_buffer_size,
+                                            double * branches,
+                                            unsigned int * pmatrix_indices,
+                                            pll_operation_t * ops,
+                                            unsigned int * matrix_count,
+                                            unsigned int * ops_count);
+PLL_EXPORT int pll_rtree_traverse(pll_rnode_t * root,
+                                  int traversal,
+                                  int (*cbtrav)(pll_rnode_t *),
+                                  pll_rnode_t ** outbuffer,
+                                  unsigned int * trav_size);
+PLL_EXPORT void pll_rtree_create_operations(pll_rnode_t * const * trav_buffer,
+                                            unsigned int trav_buffer_size,
+                                            double * branches,
+                                            unsigned int * pmatrix_indices,
+                                            pll_operation_t * ops,
+                                            unsigned int * matrix_count,
+                                            unsigned int * ops_count);
+PLL_EXPORT unsigned int * pll_compress_site_patterns(char ** sequence,
+                                                     const unsigned int * map,
+                                                     int count,
+                                                     int * length);
 
 /* ---- support (replaces pll.h:650-664) ---- */
 

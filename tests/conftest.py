@@ -67,3 +67,18 @@ def ref():
         pytest.skip("oracle/_ref/libpll_ref.so not available")
     from libpll_amd.pllapi import PllLibrary
     return PllLibrary(REF)
+
+
+@pytest.fixture(scope="session")
+def ref_tree():
+    """The reference's tree traversal / op-list builders (oracle/_ref/libpll_ref_tree.so)."""
+    import ctypes
+    path = os.path.join(ROOT, "oracle", "_ref", "libpll_ref_tree.so")
+    if not os.path.exists(path) and os.path.exists("/root/reference/src/pll.h"):
+        _make("ref", os.path.join(ROOT, "oracle"))
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libpll_ref_tree.so not available")
+
+    class _L:
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    return _L
