@@ -31,11 +31,12 @@ import time
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this
-# command (profiles/r1_pmc_hbm_traffic.csv): FETCH_SIZE x 2 (gfx950 counts 128-B requests at
-# 64 B) + WRITE_SIZE, KB -> bytes; 4 states, 1,000,000 sites.  None where no
-# counter pass was taken.
-TRAFFIC_NOTE = {4: 396.1e6}
+# HBM bytes per OP of the dominant kernel from rocprofv3 PMC passes of this command
+# (profiles/r1_pmc_hbm_traffic*.csv): FETCH_SIZE x 2 (gfx950 counts 128-B requests
+# at 64 B) + WRITE_SIZE, KB -> bytes, divided by the ops a launch carries.  Valid for
+# the site counts they were taken at; None otherwise.
+TRAFFIC_PER_OP = {4: 396.0e6, 20: 394.4e6}
+TRAFFIC_SITES = {4: 1_000_000, 20: 200_000}
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
 
@@ -233,22 +234,34 @@ def main():
     ii_ops = plan.ops if args.tip_clv else plan.ops[c1 & c2]
     roofline = None
     if len(ii_ops):
+        # how many kernel launches the library makes for this op list (independent
+        # ops of one tree level are batched into one launch, blockIdx.y = op)
+        part.profile_enable(True)
+        part.update_partials(ii_ops)
+        launches_per_pass = part.profile_read()["partials_ii"][0]
+        part.profile_enable(False)
         part.update_partials(ii_ops)
         part.wait()
         part.timer_start()
         for _ in range(args.steps):
             part.update_partials(ii_ops)
         ms = part.timer_stop_ms()
-        n_launch = len(ii_ops) * args.steps
-        avg_s = ms / n_launch / 1e3
-        algo_bytes = BYTES_PER_SITE["ii"][S] * (hi - lo)
-        achieved = algo_bytes / avg_s / 1e9
+        n_launch = launches_per_pass * args.steps
+        n_ops = len(ii_ops) * args.steps
+        avg_launch_s = ms / n_launch / 1e3
+        ops_per_launch = len(ii_ops) / launches_per_pass
+        algo_bytes = BYTES_PER_SITE["ii"][S] * (hi - lo) * ops_per_launch   # per launch
+        achieved = algo_bytes / avg_launch_s / 1e9
+        traffic = TRAFFIC_PER_OP.get(S) if (hi - lo) == TRAFFIC_SITES.get(S) else None
         roofline = {"bound": "hbm", "kernel": "pll_core_update_partial_ii (%d states)" % S,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": TRAFFIC_NOTE.get(S) if (hi - lo) == 1_000_000 else None,
+                    "traffic": traffic * ops_per_launch if traffic else None,
                     "bytes_per_site_update": BYTES_PER_SITE["ii"][S],
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": n_launch}
+                    "site_updates_per_launch": (hi - lo) * ops_per_launch,
+                    "ops_per_launch": round(ops_per_launch, 2),
+                    "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": n_launch,
+                    "avg_op_us": round(ms / n_ops * 1e3, 2)}
     # per-class averages with one event pair per launch (diagnostic; each pair
     # adds ~2 us, so these read high)
     part.profile_enable(True)
