@@ -55,6 +55,19 @@ def _cpu_worker(ref_path, plan, seqs, S, R, attrs, reps, barrier, out, idx):
     barrier.wait()
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the
+    cgroup CPU quota (the GPU box shows 256 logical CPUs but grants 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_all_cores(ref_path, plan, sample, S, R, attrs, cores, reps):
     """All host cores the standard client way (libpll is single-threaded): `cores`
     processes, each a partition over sites/cores columns, no shared state.
@@ -152,7 +165,7 @@ def main():
         dt = time.perf_counter() - t1
         rp.destroy()
         one_core = ops_per_eval * n * args.cpu_reps / dt / 1e6
-        cores = len(os.sched_getaffinity(0))
+        cores = usable_cores()
         # the multi-core leg gets a bigger slice of the same alignment so that every
         # process still has a few thousand sites
         n_all = min(hi - lo, max(n, 4000 * cores))
