@@ -108,6 +108,10 @@ def main():
     ap.add_argument("--cpu-sites", type=int, default=250_000,
                     help="sample size for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-reps", type=int, default=10)
+    ap.add_argument("--tree", default="balanced", choices=("balanced", "random", "caterpillar"))
+    ap.add_argument("--newton", type=int, default=0,
+                    help="also time pll_update_sumtable + N x pll_compute_likelihood_derivatives "
+                         "at the root edge (BASELINE config 5's inner loop)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,7 +129,8 @@ def main():
     S, R, T = args.states, args.rate_cats, args.taxa
     attrs = (0 if args.tip_clv else ATTRIB_PATTERN_TIP) | \
             (ATTRIB_RATE_SCALERS if args.rate_scalers else 0)
-    plan = W.balanced_tree(T, seed=42)
+    plan = {"balanced": W.balanced_tree, "random": W.random_tree,
+            "caterpillar": W.caterpillar_tree}[args.tree](T, seed=42)
     total_sites = args.sites * world
     lo, hi = W.shard_bounds(total_sites, world)[rank:rank + 2]
     ref_path = os.path.join(root, "oracle", "_ref", "libpll_ref.so")
@@ -285,6 +290,29 @@ def main():
     per_kernel = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2) if v[0] else None}
                   for k, v in prof.items() if v[0]}
 
+    # ---- optional: the branch-length optimisation inner loop at the root edge
+    newton = None
+    if args.newton > 0:
+        e = plan.root_edge
+        st = part.alloc_sumtable()
+        part.update_sumtable(e[0], e[2], e[1], e[3], fi, st)
+        part.compute_likelihood_derivatives(e[1], e[3], 0.1, fi, st)
+        part.wait()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            part.update_sumtable(e[0], e[2], e[1], e[3], fi, st)
+        part.wait()
+        t_sum = (time.perf_counter() - t1) / args.steps
+        t1 = time.perf_counter()
+        d = None
+        for i in range(args.steps * args.newton):
+            d = part.compute_likelihood_derivatives(e[1], e[3], 0.05 + 0.01 * (i % 7), fi, st)
+        t_der = (time.perf_counter() - t1) / (args.steps * args.newton)
+        newton = {"sumtable_us": round(t_sum * 1e6, 2), "derivatives_us_per_call": round(t_der * 1e6, 2),
+                  "sumtable_GBs": round(384.0 * (hi - lo) / t_sum / 1e9, 1) if S == 4 else None,
+                  "derivatives_GBs": round((8.0 * S * R + 4) * (hi - lo) / t_der / 1e9, 1),
+                  "last_d_dd": d}
+
     # ---- lnL parity on the CPU-baseline sample through the HIP path
     lnl_rel_err = None
     if cpu is not None:
@@ -303,17 +331,17 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (%s alignment, seed 42)" % args.alignment,
-            "config": {"workload": "%d-state %s, %d Gamma rates, %d sites/GPU, %d-taxon balanced "
+            "config": {"workload": "%d-state %s, %d Gamma rates, %d sites/GPU, %d-taxon %s "
                                    "tree, %s, %s scalers; step = pll_update_partials(%d ops: %d "
                                    "tip-tip, %d tip-inner, %d inner-inner) + "
                                    "pll_compute_edge_loglikelihood"
-                                   % (S, "GTR" if S == 4 else "LG", R, args.sites, T,
+                                   % (S, "GTR" if S == 4 else "LG", R, args.sites, T, args.tree,
                                       "tip CLVs" if args.tip_clv else "PATTERN_TIP",
                                       "per-rate" if args.rate_scalers else "per-site",
                                       ops_per_eval, tt, ti, ii),
                        "sites_total": total_sites, "parallelism": "site-sharded x%d" % world},
             "lnl": lnl, "lnl_rel_err_vs_reference": lnl_rel_err,
-            "roofline": roofline, "kernels": per_kernel, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": per_kernel, "cpu_baseline": cpu, "newton": newton,
         }
         print(json.dumps(out))
     part.destroy()
