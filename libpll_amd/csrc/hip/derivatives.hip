@@ -271,6 +271,84 @@ __global__ __launch_bounds__(256) void k_derivatives(DerivArgs a)
   block_sum2(acc_d, acc_dd, a.block_partials, gridDim.x);
 }
 
+// 4 states: one lane per 16 bytes of the sumtable (two states), 2*RC lanes per
+// site, waves in rounds of 64 sites like the CLV and lnL kernels: every load
+// instruction of a wave is one contiguous KiB and, after a round, each lane
+// finishes ONE site (two f64 divisions per site instead of per lane).
+template <int RC, bool NT>
+__global__ __launch_bounds__(256) void k_derivatives_dna(DerivArgs a)
+{
+  constexpr unsigned int W = 2 * RC, SPS = 64 / W;
+  __shared__ double s_diag[RC * 4 * 4];
+  for (unsigned int t = threadIdx.x; t < RC * 16; t += blockDim.x) s_diag[t] = a.diagp[t];
+  __syncthreads();
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int h = lane & 1u, k = (lane >> 1) & (RC - 1);
+  // diagp[k][j][0..2] for this lane's two states j = 2h, 2h+1
+  double dg[2][3];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dg[jj][t] = s_diag[(k * 4 + 2 * h + jj) * 4 + t];
+  const unsigned int pi = a.params_indices[k];
+  const double pinv = a.prop_invar[pi];
+  const double wk = a.rate_weights[k];
+
+  double acc_d = 0.0, acc_dd = 0.0;
+  const size_t sites = a.sites, total = sites * W;
+  const size_t rounds = (sites + 63) / 64;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const double2 * __restrict__ ST = reinterpret_cast<const double2 *>(a.sumtable);
+  for (size_t r = wave; r < rounds; r += nwaves)
+  {
+    double m0 = 1.0, m1 = 0.0, m2 = 0.0;
+#pragma unroll
+    for (unsigned int j = 0; j < W; ++j)
+    {
+      const size_t g = (r * 64 + (size_t)j * SPS) * W + lane;
+      const size_t gc = g < total ? g : 0;
+      const size_t n = gc / W;
+      const double2 s = ld16<NT>(ST + gc);
+      double c0 = fma(s.y, dg[1][0], s.x * dg[0][0]);
+      double c1 = fma(s.y, dg[1][1], s.x * dg[0][1]);
+      double c2 = fma(s.y, dg[1][2], s.x * dg[0][2]);
+      // the other half of this (site, rate)
+      c0 += dpp_pair_swap(c0);
+      c1 += dpp_pair_swap(c1);
+      c2 += dpp_pair_swap(c2);
+      if (pinv > 0.0)
+      {
+        // core_derivatives.c:481-491
+        const int inv = a.invariant ? a.invariant[n] : -1;
+        const double inv_lk = (inv == -1) ? 0.0 : a.freqs[(size_t)pi * 4 + inv] * pinv;
+        c0 = c0 * (1.0 - pinv) + inv_lk;
+        c1 = c1 * (1.0 - pinv);
+        c2 = c2 * (1.0 - pinv);
+      }
+      c0 *= wk; c1 *= wk; c2 *= wk;
+      // sum the RC categories of the site (lanes 2i of the group hold them)
+      for (unsigned int off = 2; off < W; off <<= 1)
+      {
+        c0 += __shfl_xor(c0, (int)off, 64);
+        c1 += __shfl_xor(c1, (int)off, 64);
+        c2 += __shfl_xor(c2, (int)off, 64);
+      }
+      if ((lane & (W - 1)) == j) { m0 = c0; m1 = c1; m2 = c2; }
+    }
+    const size_t n = r * 64 + (size_t)(lane & (W - 1)) * SPS + lane / W;
+    if (n < sites)
+    {
+      const double d1 = -m1 / m0;
+      const double d2 = d1 * d1 - m2 / m0;
+      const double pw = (double)a.pattern_weights[n];
+      acc_d += pw * d1;
+      acc_dd += pw * d2;
+    }
+  }
+  block_sum2(acc_d, acc_dd, a.block_partials, gridDim.x);
+}
+
 // any rate_cats: one lane per site
 __global__ __launch_bounds__(128) void k_derivatives_gen(DerivArgs a)
 {
@@ -385,7 +463,26 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   }
   unsigned int grid;
   pllhip_prof_scope prof(c, PLLHIP_PROF_DERIVATIVES);
-  if (R == 1 || R == 2 || R == 4 || R == 8 || R == 16)
+  if (S == 4 && (R == 1 || R == 2 || R == 4 || R == 8))
+  {
+    grid = pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256);
+    if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    const bool nt = pllhip_use_nt(c);
+#define DERIV_DNA(RCV)                                                        \
+    do {                                                                      \
+      if (nt) k_derivatives_dna<RCV, true><<<grid, 256, 0, c->stream>>>(a);   \
+      else k_derivatives_dna<RCV, false><<<grid, 256, 0, c->stream>>>(a);     \
+    } while (0)
+    switch (R)
+    {
+      case 1: DERIV_DNA(1); break;
+      case 2: DERIV_DNA(2); break;
+      case 4: DERIV_DNA(4); break;
+      default: DERIV_DNA(8); break;
+    }
+#undef DERIV_DNA
+  }
+  else if (R == 1 || R == 2 || R == 4 || R == 8 || R == 16)
   {
     grid = pllhip_stream_grid(c, (size_t)a.sites * R, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
