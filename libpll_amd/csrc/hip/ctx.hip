@@ -133,7 +133,9 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if ((rc = dev_alloc(&c->d_result, (size_t)4, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->d_zero, (size_t)4, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->d_sink, (size_t)128, true, c->stream))) goto fail;
-  HIP_TRY(hipHostMalloc((void **)&c->h_result, 4 * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&c->h_result, 4 * sizeof(double), hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void **)&c->h_result_dev, c->h_result, 0));
+  if ((rc = dev_alloc(&c->d_counter, (size_t)4, true, c->stream))) goto fail;
 
   c->stage_bytes = 64 * 1024 + (size_t)shape->prob_matrices * 16 +
                    (size_t)(shape->tips + shape->clv_buffers) * sizeof(pllhip_op_t);
@@ -249,7 +251,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   void * bufs[] = {c->clv_arena, c->tipchars, c->scaler_arena, c->pmatrix, c->eigenvals,
                    c->eigenvecs, c->inv_eigenvecs, c->freqs, c->prop_invar, c->rates,
                    c->rate_weights, c->pattern_weights, c->invariant, c->tipmap,
-                   c->block_partials, c->d_result, c->d_zero, c->d_sink, c->d_tiptab, c->d_persite, c->d_stage,
+                   c->block_partials, c->d_result, c->d_counter, c->d_zero, c->d_sink, c->d_tiptab, c->d_persite, c->d_stage,
                    c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3]};
   for (void * p : bufs)
     if (p) (void)hipFree(p);

@@ -55,7 +55,9 @@ struct pllhip_ctx
   double * d_sink = nullptr;           // [128] write-only scratch
   double * d_tiptab = nullptr;         // 20 states: [2][maxstates][rate_cats][20] tip row sums of the current op
   size_t tiptab_elems = 0;
-  double * h_result = nullptr;         // pinned [4]
+  double * h_result = nullptr;         // pinned, host-mapped [4]
+  double * h_result_dev = nullptr;     // device address of h_result
+  unsigned int * d_counter = nullptr;  // arrival counter of the reducing kernels
   double * d_persite = nullptr;        // [sites], lazily allocated
 
   // staging for small per-call parameter arrays

@@ -17,6 +17,7 @@
 //     exactly like core_derivatives.c:560-575, and passed in.
 #include "ctx.hpp"
 #include "numerics.hpp"
+#include "lnl_common.hpp"
 
 struct SumMatArgs
 {
@@ -181,30 +182,15 @@ struct DerivArgs
   const double * __restrict__ prop_invar;
   const unsigned int * __restrict__ pattern_weights;
   const int * __restrict__ invariant;
-  double * __restrict__ block_partials;
+  ReduceOut reduce;
   unsigned int sites, rate_cats, states;
   unsigned int params_indices[PLLHIP_MAX_RATE_CATS];
 };
 
-__device__ __forceinline__ void block_sum2(double v0, double v1, double * __restrict__ out,
-                                           unsigned int nparts)
+__device__ __forceinline__ void block_sum2(double v0, double v1, const ReduceOut & ro)
 {
-  __shared__ double s_wave[2][16];
-  for (int off = 32; off > 0; off >>= 1)
-  {
-    v0 += __shfl_down(v0, off, 64);
-    v1 += __shfl_down(v1, off, 64);
-  }
-  const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  if (lane == 0) { s_wave[0][wave] = v0; s_wave[1][wave] = v1; }
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    double t0 = 0.0, t1 = 0.0;
-    for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) { t0 += s_wave[0][w]; t1 += s_wave[1][w]; }
-    out[blockIdx.x] = t0;
-    out[nparts + blockIdx.x] = t1;
-  }
+  const double two[2] = {v0, v1};
+  grid_sum<2>(two, ro);
 }
 
 // one lane per (site, rate); RC lanes of a site combine with __shfl
@@ -268,7 +254,7 @@ __global__ __launch_bounds__(256) void k_derivatives(DerivArgs a)
       acc_dd += pw * d2;
     }
   }
-  block_sum2(acc_d, acc_dd, a.block_partials, gridDim.x);
+  block_sum2(acc_d, acc_dd, a.reduce);
 }
 
 // 4 states: one lane per 16 bytes of the sumtable (two states), 2*RC lanes per
@@ -346,7 +332,7 @@ __global__ __launch_bounds__(256) void k_derivatives_dna(DerivArgs a)
       acc_dd += pw * d2;
     }
   }
-  block_sum2(acc_d, acc_dd, a.block_partials, gridDim.x);
+  block_sum2(acc_d, acc_dd, a.reduce);
 }
 
 // any rate_cats: one lane per site
@@ -389,33 +375,7 @@ __global__ __launch_bounds__(128) void k_derivatives_gen(DerivArgs a)
     acc_d += pw * d1;
     acc_dd += pw * d2;
   }
-  block_sum2(acc_d, acc_dd, a.block_partials, gridDim.x);
-}
-
-__global__ __launch_bounds__(256) void k_final_sum2(const double * __restrict__ parts,
-                                                    unsigned int nparts,
-                                                    double * __restrict__ result)
-{
-  __shared__ double s[2][256];
-  double v0 = 0.0, v1 = 0.0;
-  for (unsigned int i = threadIdx.x; i < nparts; i += 256)
-  {
-    v0 += parts[i];
-    v1 += parts[nparts + i];
-  }
-  s[0][threadIdx.x] = v0;
-  s[1][threadIdx.x] = v1;
-  __syncthreads();
-  for (unsigned int w = 128; w > 0; w >>= 1)
-  {
-    if (threadIdx.x < w)
-    {
-      s[0][threadIdx.x] += s[0][threadIdx.x + w];
-      s[1][threadIdx.x] += s[1][threadIdx.x + w];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { result[0] = s[0][0]; result[1] = s[1][0]; }
+  block_sum2(acc_d, acc_dd, a.reduce);
 }
 
 extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot,
@@ -448,7 +408,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   a.prop_invar = c->prop_invar;
   a.pattern_weights = c->pattern_weights;
   a.invariant = c->invariant;
-  a.block_partials = c->block_partials;
+  a.reduce = pllhip_reduce_out(c);
   a.sites = c->sh.sites;
   a.rate_cats = R;
   a.states = S;
@@ -503,12 +463,14 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   }
   HIP_TRY(hipGetLastError());
   prof.stop();
-  k_final_sum2<<<1, 256, 0, c->stream>>>(c->block_partials, grid, c->d_result);
-  HIP_TRY(hipGetLastError());
-  int rc = pllhip_allreduce_result(c, 2);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost,
-                         c->stream));
+  (void)grid;
+  if (c->comm)
+  {
+    int rc = pllhip_allreduce_result(c, 2);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   *h_d_f = c->h_result[0];
   *h_dd_f = c->h_result[1];

@@ -22,26 +22,14 @@
 
 #include "lnl_common.hpp"
 
-// sums `nparts` workgroup values of `ncomp` interleaved components in fixed order
-__global__ __launch_bounds__(256) void k_final_sum(const double * __restrict__ parts,
-                                                   unsigned int nparts, unsigned int ncomp,
-                                                   double * __restrict__ result)
+ReduceOut pllhip_reduce_out(pllhip_ctx * c)
 {
-  __shared__ double s[256];
-  for (unsigned int comp = 0; comp < ncomp; ++comp)
-  {
-    double v = 0.0;
-    for (unsigned int i = threadIdx.x; i < nparts; i += 256) v += parts[(size_t)comp * nparts + i];
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (unsigned int w = 128; w > 0; w >>= 1)
-    {
-      if (threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) result[comp] = s[0];
-    __syncthreads();
-  }
+  ReduceOut r;
+  r.partials = c->block_partials;
+  r.counter = c->d_counter;
+  r.result = c->d_result;
+  r.host_result = c->comm ? nullptr : c->h_result_dev;
+  return r;
 }
 
 // Per-(site,rate) kernels.  KIND: EDGE_II / EDGE_TI / ROOT;  S4: 4-state vs 20-state
@@ -202,7 +190,7 @@ __global__ __launch_bounds__(256) void k_lnl_fast(LnlArgs a)
     for (int i = 0; i < RC; ++i) terma += __shfl(contrib, (int)(grp0 + i), 64);
     if (act && k == 0) acc += site_loglk(a, terma, n, site_scalings);
   }
-  block_sum_to_partials(acc, a.block_partials);
+  block_sum_to_partials(acc, a.reduce);
 }
 
 // 4 states: one lane per 16 bytes (two states), lane pairs joined by DPP -- the
@@ -343,7 +331,7 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
       acc += site_loglk(a, my_terma, n, site_scalings);
     }
   }
-  block_sum_to_partials(acc, a.block_partials);
+  block_sum_to_partials(acc, a.reduce);
 }
 
 // any states / any rate_cats: one lane per site
@@ -413,7 +401,7 @@ __global__ __launch_bounds__(128) void k_lnl_gen(LnlArgs a)
     }
     acc += site_loglk(a, terma, n, site_scalings);
   }
-  block_sum_to_partials(acc, a.block_partials);
+  block_sum_to_partials(acc, a.reduce);
 }
 
 #define LAUNCH_LNL(RCV, KINDV)                                                            \
@@ -450,7 +438,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   a.states = S;
   a.maxstates = c->maxstates;
   a.rate_scalers = c->sh.rate_scalers;
-  a.block_partials = c->block_partials;
+  a.reduce = pllhip_reduce_out(c);
   a.persite = nullptr;
   if (h_persite)
   {
@@ -487,11 +475,14 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   }
   HIP_TRY(hipGetLastError());
   prof.stop();
-  k_final_sum<<<1, 256, 0, c->stream>>>(c->block_partials, grid, 1, c->d_result);
-  HIP_TRY(hipGetLastError());
-  int rc = pllhip_allreduce_result(c, 1);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  (void)grid;
+  if (c->comm)
+  {
+    // multi-GPU: sum the per-shard values over xGMI, then fetch
+    int rc = pllhip_allreduce_result(c, 1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
   if (h_persite)
     HIP_TRY(hipMemcpyAsync(h_persite, c->d_persite, (size_t)c->sh.sites * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     // the image is refilled by the next tile's DMA
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  block_sum_to_partials(acc, a.block_partials);
+  block_sum_to_partials(acc, a.reduce);
 }
 
 template <int RC>

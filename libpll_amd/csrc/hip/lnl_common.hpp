@@ -4,6 +4,16 @@
 #include "ctx.hpp"
 #include "numerics.hpp"
 
+// Reduction target shared by the reducing kernels: per-workgroup partial sums,
+// an arrival counter, and where the final value goes.
+struct ReduceOut
+{
+  double * partials;       // [NCOMP][gridDim.x]
+  unsigned int * counter;  // arrival ticket, zero between launches
+  double * result;         // device result [NCOMP] (input of the RCCL all-reduce)
+  double * host_result;    // host-mapped copy (nullptr when an all-reduce follows)
+};
+
 struct LnlArgs
 {
   const double * __restrict__ parent;   // CLV carrying the frequencies side
@@ -20,7 +30,7 @@ struct LnlArgs
   const unsigned int * __restrict__ tipmap;
   const unsigned int * zero;            // device word holding 0
   double * __restrict__ persite;        // nullable
-  double * __restrict__ block_partials; // [gridDim.x]
+  ReduceOut reduce;
   unsigned int sites, rate_cats, states, maxstates;
   int rate_scalers;
   unsigned int freqs_indices[PLLHIP_MAX_RATE_CATS];
@@ -34,20 +44,77 @@ __device__ __forceinline__ double scale_minlh(unsigned int d)
   return d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
 }
 
-__device__ __forceinline__ double block_sum_to_partials(double v, double * __restrict__ out)
+// Sum `v[0..NCOMP)` over the whole grid, reproducibly: lane sums -> wave
+// __shfl_down tree -> LDS -> one value per workgroup in `partials`; the workgroup
+// that arrives LAST (agent-scope release / ticket / acquire, cdna_hip_programming
+// Guideline 16) adds all workgroup values in index order with a fixed tree and
+// publishes the result -- no second kernel launch, same bits every run.
+template <int NCOMP>
+__device__ __forceinline__ void grid_sum(const double (&v_in)[NCOMP], const ReduceOut & ro)
 {
-  __shared__ double s_wave[16];
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __shared__ double s_wave[NCOMP][16];
+  __shared__ double s_tree[NCOMP][256];
+  __shared__ bool s_last;
   const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  if (lane == 0) s_wave[wave] = v;
+  const unsigned int nparts = gridDim.x;
+#pragma unroll
+  for (int cidx = 0; cidx < NCOMP; ++cidx)
+  {
+    double v = v_in[cidx];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) s_wave[cidx][wave] = v;
+  }
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    double t = 0.0;
-    for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) t += s_wave[w];
-    out[blockIdx.x] = t;
+#pragma unroll
+    for (int cidx = 0; cidx < NCOMP; ++cidx)
+    {
+      double t = 0.0;
+      for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) t += s_wave[cidx][w];
+      ro.partials[(size_t)cidx * nparts + blockIdx.x] = t;
+    }
+    __threadfence(); // release: the partial is visible device-wide before the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int ticket = atomicAdd(ro.counter, 1u);
+    s_last = (ticket == nparts - 1);
   }
-  return v;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence(); // acquire: drop stale L1 lines before reading the other workgroups' partials
+#pragma unroll
+  for (int cidx = 0; cidx < NCOMP; ++cidx)
+  {
+    double v = 0.0;
+    for (unsigned int i = threadIdx.x; i < nparts; i += blockDim.x)
+      v += __hip_atomic_load(ro.partials + (size_t)cidx * nparts + i, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    s_tree[cidx][threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (unsigned int w = blockDim.x >> 1; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w)
+#pragma unroll
+      for (int cidx = 0; cidx < NCOMP; ++cidx) s_tree[cidx][threadIdx.x] += s_tree[cidx][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+#pragma unroll
+    for (int cidx = 0; cidx < NCOMP; ++cidx)
+    {
+      ro.result[cidx] = s_tree[cidx][0];
+      if (ro.host_result) ro.host_result[cidx] = s_tree[cidx][0];
+    }
+    *ro.counter = 0u; // ready for the next launch (stream order separates launches)
+  }
+}
+
+__device__ __forceinline__ void block_sum_to_partials(double v, const ReduceOut & ro)
+{
+  const double one[1] = {v};
+  grid_sum<1>(one, ro);
 }
 
 // category term -> weighted contribution (core_likelihood_avx.c:1219-1240)
@@ -79,6 +146,9 @@ __device__ __forceinline__ double site_loglk(const LnlArgs & a, double terma, si
   return lk;
 }
 
+
+// fills a ReduceOut from the context (host_result only when no all-reduce follows)
+ReduceOut pllhip_reduce_out(pllhip_ctx * c);
 
 // 20-state kernels on the matrix cores; returns 1 if the case is not covered
 int pllhip_launch_lnl_aa_mfma(pllhip_ctx * c, const LnlArgs & a, int kind, unsigned int * grid_out);
