@@ -177,13 +177,22 @@ struct PartialsArgs
   unsigned int sites, rate_cats, states, maxstates;
 };
 
+// Several mutually independent ops (one tree level) run in ONE launch:
+// blockIdx.y selects the op.  The op descriptors travel as kernel arguments
+// (24 x 136 B < the 4 KB kernarg segment), so batching needs no staging copy.
+#define PLLHIP_BATCH_MAX 24
+struct PartialsBatch
+{
+  PartialsArgs op[PLLHIP_BATCH_MAX];
+};
+
 enum { SCALE_NONE = 0, SCALE_SITE = 1, SCALE_RATE = 2 };
 
 // kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
 int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode,
                            int prof_kind);
 int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);
-// 20-state inner-inner update on the matrix cores; returns 1 if the case is not covered
-int pllhip_launch_aa_ii_mfma(pllhip_ctx * c, const PartialsArgs & a, int mode);
-// 20-state tip-inner (kind 1) / tip-tip (kind 2) fast kernels; returns 1 if not covered
-int pllhip_launch_aa_tip(pllhip_ctx * c, PartialsArgs & a, int kind, int mode);
+// 20-state fast kernels (matrix cores / round-based tip-tip) for `count` mutually
+// independent ops of one kind and mode; returns 1 if the case is not covered
+bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind);
+int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count, int kind, int mode);

@@ -70,15 +70,6 @@ __device__ __forceinline__ void build_tip_table4(double * tab, const double * __
 // Lane l owns site (l % W) * (64/W) + l / W of the round: in sub-step j = l % W
 // its group is exactly that site, so the site's scaling decision is already in
 // the lane when the round ends.
-// Several mutually independent ops (one tree level) run in ONE launch:
-// blockIdx.y selects the op.  The op descriptors travel as kernel arguments
-// (24 x 136 B < the 4 KB kernarg segment), so batching needs no staging copy.
-#define PLLHIP_BATCH_MAX 24
-struct PartialsBatch
-{
-  PartialsArgs op[PLLHIP_BATCH_MAX];
-};
-
 template <int RC, int MODE, bool NT, int KIND>
 __global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
 {
@@ -549,13 +540,12 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, 
     HIP_TRY(pllhip_launch_dna_batch(c, b, 1, kind, mode) ? hipErrorLaunchFailure : hipSuccess);
     return 0;
   }
-  else if (a.states == 20 && kind == 0 && !c->aa_exact && pllhip_launch_aa_ii_mfma(c, a, mode) == 0)
+  else if (a.states == 20 && pllhip_aa_fast_covers(c, kind))
   {
-    // launched on the matrix cores (partials_aa_mfma.hip)
-  }
-  else if (a.states == 20 && kind >= 1 && !c->aa_exact && pllhip_launch_aa_tip(c, a, kind, mode) == 0)
-  {
-    // tip kernels with precomputed tables (partials_aa_mfma.hip)
+    // matrix-core / round-based kernels (partials_aa_mfma.hip)
+    PartialsBatch b;
+    b.op[0] = a;
+    return pllhip_launch_aa_batch(c, b, 1, kind, mode);
   }
   else if (a.states == 20 && fast_rc(R) && R <= 8)
   {
@@ -665,8 +655,11 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // writes, and none writes one another reads -- on a balanced tree that is one
   // launch per level instead of one per node.
   const char * nb_env = getenv("PLLHIP_NO_BATCH");
-  const bool batchable = c->sh.states == 4 && fast_rc(c->sh.rate_cats) &&
-                         !(nb_env && atoi(nb_env) != 0);
+  const bool no_batch = nb_env && atoi(nb_env) != 0;
+  const bool dna_fast = c->sh.states == 4 && fast_rc(c->sh.rate_cats);
+  const bool aa_fast = c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) &&
+                       (!c->sh.pattern_tip || pllhip_aa_fast_covers(c, 2));
+  const bool batchable = (dna_fast || aa_fast) && !no_batch;
   PartialsBatch b;
   unsigned int nb = 0;
   int bkind = -1, bmode = -1;
@@ -676,7 +669,8 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   auto flush = [&]() -> int {
     if (!nb) return 0;
     pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II + bkind);
-    int rc = pllhip_launch_dna_batch(c, b, nb, bkind, bmode);
+    int rc = dna_fast ? pllhip_launch_dna_batch(c, b, nb, bkind, bmode)
+                      : pllhip_launch_aa_batch(c, b, nb, bkind, bmode);
     nb = 0;
     return rc;
   };

@@ -52,8 +52,9 @@
 // a row of the precomputed tip table (a.ltab, [code][rate][state]), which takes
 // the place of the left P-matrix in LDS; the right child goes through the MFMAs.
 template <int RC, int MODE, bool NT, int KIND>
-__global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsArgs a)
+__global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 {
+  const PartialsArgs & a = batch.op[blockIdx.y];
   using G = aa_geom<RC>;
   extern __shared__ double smem[];
   // LDS: [left part][right P-matrices RC x 20 x 20][4 wave images]
@@ -178,20 +179,20 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsArgs a)
 
 // ---- tip tables, built once per op: tab[code][k][i] = sum_{j in tipmap[code]} P[k][i][j]
 // (core_partials_avx.c:1140-1177); left and right tables back to back
-__global__ __launch_bounds__(256) void k_aa_tip_tables(double * __restrict__ tab,
-                                                       const double * __restrict__ lmat,
-                                                       const double * __restrict__ rmat,
-                                                       const unsigned int * __restrict__ tipmap,
+__global__ __launch_bounds__(256) void k_aa_tip_tables(PartialsBatch batch, double * __restrict__ tab,
                                                        unsigned int maxstates, unsigned int rate_cats,
                                                        int both)
 {
+  // blockIdx.y = op of the batch; its two tables sit back to back in `tab`
+  const PartialsArgs & a = batch.op[blockIdx.y];
   const unsigned int per = maxstates * rate_cats * 20;
   const unsigned int total = both ? 2 * per : per;
+  double * out = tab + (size_t)blockIdx.y * 2 * per;
   for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x)
   {
     const unsigned int side = t / per, u = t % per;
     const unsigned int code = u / (rate_cats * 20), ki = u % (rate_cats * 20);
-    tab[t] = masksum_seq((side ? rmat : lmat) + (size_t)ki * 20, tipmap[code], 20);
+    out[t] = masksum_seq((side ? a.rmat : a.lmat) + (size_t)ki * 20, a.tipmap[code], 20);
   }
 }
 
@@ -199,8 +200,9 @@ __global__ __launch_bounds__(256) void k_aa_tip_tables(double * __restrict__ tab
 // in rounds of 64 sites (codes fetched once per round, one site per lane), the
 // GS = 10*RC store instructions of a round each one contiguous KiB.
 template <int RC, int MODE, bool NT>
-__global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsArgs a)
+__global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsBatch batch)
 {
+  const PartialsArgs & a = batch.op[blockIdx.y];
   constexpr unsigned int GS = RC * 10; // 16-byte granules per site
   extern __shared__ double smem[];
   const unsigned int per = a.maxstates * RC * 20;
@@ -242,17 +244,17 @@ __global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsArgs a)
 }
 
 template <int RC, int KIND>
-static int launch_rc(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
+static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode, bool nt)
 {
   using G = aa_geom<RC>;
-
+  const PartialsArgs & a = b.op[0];
   const size_t tiles = ((size_t)a.sites + 15) / 16;
   size_t blocks = (tiles + 3) / 4;
   // two 4-wave workgroups per CU are resident (71 KB of LDS each); the P-matrix
   // staging per workgroup is amortised over several tiles per wave
   const size_t cap = (size_t)c->num_cus * 2;
   if (blocks > cap) blocks = cap;
-  const dim3 grid((unsigned int)blocks), block(256);
+  const dim3 grid((unsigned int)blocks, count), block(256);
   const size_t left_elems = (KIND == 0) ? (size_t)RC * 400 : (size_t)a.maxstates * RC * 20;
   const size_t lds = (left_elems + (size_t)RC * 400) * sizeof(double) + 4 * (size_t)G::REGION_B;
   if (lds > 80 * 1024) return 1; // two workgroups per CU must fit
@@ -261,7 +263,7 @@ static int launch_rc(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
   do {                                                                                        \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-    hipLaunchKernelGGL(KERNEL, grid, block, lds, c->stream, a);                               \
+    hipLaunchKernelGGL(KERNEL, grid, block, lds, c->stream, b);                               \
   } while (0)
 #define AA_LAUNCH(MODEV)                                                                      \
   do {                                                                                        \
@@ -277,32 +279,20 @@ static int launch_rc(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
   return 0;
 }
 
-// returns 1 if this kernel does not cover the case (caller falls back)
-int pllhip_launch_aa_ii_mfma(pllhip_ctx * c, const PartialsArgs & a, int mode)
-{
-  const bool nt = pllhip_use_nt(c);
-  switch (a.rate_cats)
-  {
-    case 1: return launch_rc<1, 0>(c, a, mode, nt);
-    case 2: return launch_rc<2, 0>(c, a, mode, nt);
-    case 4: return launch_rc<4, 0>(c, a, mode, nt);
-    default: return 1;
-  }
-}
-
 template <int RC>
-static int launch_tt(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
+static int launch_tt(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode, bool nt)
 {
+  const PartialsArgs & a = b.op[0];
   const size_t rounds = ((size_t)a.sites + 63) / 64;
   size_t blocks = (rounds + 3) / 4;
   const size_t cap = (size_t)c->num_cus * 8; // 29 KB of table staging per workgroup
   if (blocks > cap) blocks = cap;
   const size_t lds = 2 * (size_t)a.maxstates * RC * 20 * sizeof(double);
-  const dim3 grid((unsigned int)blocks), block(256);
+  const dim3 grid((unsigned int)blocks, count), block(256);
 #define TT_LAUNCH(MODEV)                                                                         \
   do {                                                                                           \
-    if (nt) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, true>), grid, block, lds, c->stream, a);  \
-    else hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false>), grid, block, lds, c->stream, a);    \
+    if (nt) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, true>), grid, block, lds, c->stream, b);  \
+    else hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false>), grid, block, lds, c->stream, b);    \
   } while (0)
   if (mode == SCALE_NONE) TT_LAUNCH(0);
   else if (mode == SCALE_SITE) TT_LAUNCH(1);
@@ -312,39 +302,64 @@ static int launch_tt(pllhip_ctx * c, const PartialsArgs & a, int mode, bool nt)
   return 0;
 }
 
-int pllhip_launch_aa_tip(pllhip_ctx * c, PartialsArgs & a, int kind, int mode)
+bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind)
 {
-  const unsigned int R = a.rate_cats;
-  if (!(R == 1 || R == 2 || R == 4) || a.maxstates == 0 || a.maxstates > 32) return 1;
-  const size_t per = (size_t)a.maxstates * R * 20;
-  if (2 * per * sizeof(double) > 60 * 1024) return 1;
-  if (c->tiptab_elems < 2 * per)
-  {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_tiptab) HIP_TRY(hipFree(c->d_tiptab));
-    c->d_tiptab = nullptr;
-    HIP_TRY(hipMalloc((void **)&c->d_tiptab, 2 * per * sizeof(double)));
-    c->tiptab_elems = 2 * per;
-  }
-  k_aa_tip_tables<<<8, 256, 0, c->stream>>>(c->d_tiptab, a.lmat, a.rmat, a.tipmap, a.maxstates, R,
-                                            kind == 2 ? 1 : 0);
-  HIP_TRY(hipGetLastError());
-  a.ltab = c->d_tiptab;
-  a.rtab = c->d_tiptab + per;
+  const unsigned int R = c->sh.rate_cats;
+  if (c->aa_exact || c->sh.states != 20 || !(R == 1 || R == 2 || R == 4)) return false;
+  if (kind == 0) return true;
+  // tip kinds: both tables of an op must fit the workgroup's LDS next to its other data
+  return c->maxstates > 0 && c->maxstates <= 32 &&
+         2 * (size_t)c->maxstates * R * 20 * sizeof(double) <= 60 * 1024;
+}
+
+int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count, int kind, int mode)
+{
+  const unsigned int R = b.op[0].rate_cats;
   const bool nt = pllhip_use_nt(c);
+  if (kind >= 1)
+  {
+    // tip row-sum tables of every op of the batch, one launch
+    const size_t per = (size_t)b.op[0].maxstates * R * 20;
+    const size_t need = 2 * per * PLLHIP_BATCH_MAX;
+    if (c->tiptab_elems < need)
+    {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (c->d_tiptab) HIP_TRY(hipFree(c->d_tiptab));
+      c->d_tiptab = nullptr;
+      HIP_TRY(hipMalloc((void **)&c->d_tiptab, need * sizeof(double)));
+      c->tiptab_elems = need;
+    }
+    k_aa_tip_tables<<<dim3(8, count), 256, 0, c->stream>>>(b, c->d_tiptab, b.op[0].maxstates, R,
+                                                           kind == 2 ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      b.op[i].ltab = c->d_tiptab + (size_t)i * 2 * per;
+      b.op[i].rtab = b.op[i].ltab + per;
+    }
+  }
   if (kind == 2)
   {
     switch (R)
     {
-      case 1: return launch_tt<1>(c, a, mode, nt);
-      case 2: return launch_tt<2>(c, a, mode, nt);
-      default: return launch_tt<4>(c, a, mode, nt);
+      case 1: return launch_tt<1>(c, b, count, mode, nt);
+      case 2: return launch_tt<2>(c, b, count, mode, nt);
+      default: return launch_tt<4>(c, b, count, mode, nt);
+    }
+  }
+  if (kind == 1)
+  {
+    switch (R)
+    {
+      case 1: return launch_rc<1, 1>(c, b, count, mode, nt);
+      case 2: return launch_rc<2, 1>(c, b, count, mode, nt);
+      default: return launch_rc<4, 1>(c, b, count, mode, nt);
     }
   }
   switch (R)
   {
-    case 1: return launch_rc<1, 1>(c, a, mode, nt);
-    case 2: return launch_rc<2, 1>(c, a, mode, nt);
-    default: return launch_rc<4, 1>(c, a, mode, nt);
+    case 1: return launch_rc<1, 0>(c, b, count, mode, nt);
+    case 2: return launch_rc<2, 0>(c, b, count, mode, nt);
+    default: return launch_rc<4, 0>(c, b, count, mode, nt);
   }
 }
