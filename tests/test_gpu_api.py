@@ -1,0 +1,153 @@
+"""GPU tests of the library's own additions and of API behaviours a drop-in must
+keep: host mirrors and mirror mode, sumtable slots keyed by the caller's buffer,
+caller-filled sumtables, several partitions side by side, partial traversals
+that reuse CLV slots (buffer-index dependencies inside one op list)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import make_case, build_partition, oracle_run, bits_equal, rel_err
+from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, OPS_DTYPE, SCALE_BUFFER_NONE
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mirror_mode_fills_struct_fields(gpu, orc):
+    """With pll_amd_set_mirror_mode(1) a client may read partition->clv[] /
+    ->scale_buffer[] / ->pmatrix[] directly after each call, as with the reference."""
+    case = make_case(4, "random", 8, 50, seed=3)
+    plan = case["plan"]
+    gpu.lib.pll_amd_set_mirror_mode(1)
+    try:
+        p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+        o = oracle_run(orc, gpu, p, case, ATTRIB_PATTERN_TIP)
+        p.update_partials(plan.ops)
+        o.update_partials()
+        n = 50 * 16
+        for op in plan.ops:
+            node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+            raw = np.ctypeslib.as_array(p.s.clv[node], shape=(n,))       # no sync call
+            assert bits_equal(raw.reshape(50, 4, 4), o.clv[node])
+            assert (np.ctypeslib.as_array(p.s.scale_buffer[sc], shape=(50,)) == o.scalers[sc]).all()
+        m = int(plan.matrix_indices[0])
+        assert bits_equal(np.ctypeslib.as_array(p.s.pmatrix[m], shape=(64,)).reshape(4, 4, 4), o.pmat[m])
+        p.destroy()
+    finally:
+        gpu.lib.pll_amd_set_mirror_mode(0)
+
+
+def test_mirrors_are_null_until_synced(gpu):
+    case = make_case(4, "balanced", 4, 20, seed=1)
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    p.update_partials(case["plan"].ops)
+    node = int(case["plan"].ops[0]["parent_clv_index"])
+    assert not p.s.clv[node]                       # NULL: nothing was copied back
+    clv = p.get_clv(node)                          # pll_amd_sync_clv
+    assert p.s.clv[node] and clv.shape == (20, 4, 4)
+    p.destroy()
+
+
+def test_sumtable_slots_and_caller_filled_tables(gpu, orc):
+    """More host sumtable buffers than device slots (4), and a table the caller
+    computed itself (pll_compute_likelihood_derivatives must upload it)."""
+    case = make_case(4, "random", 10, 200, seed=7)
+    plan = case["plan"]
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    o = oracle_run(orc, gpu, p, case, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    o.update_partials()
+    # edges (parent, child) below each op's parent; tip children give tip-inner tables
+    inner_edges = []
+    for op in plan.ops:
+        for ch in ("child1", "child2"):
+            inner_edges.append((int(op["parent_clv_index"]), int(op["parent_scaler_index"]),
+                                int(op[ch + "_clv_index"]), int(op[ch + "_scaler_index"])))
+    inner_edges = [e for e in inner_edges if e[2] >= plan.tips][:3] + \
+                  [e for e in inner_edges if e[2] < plan.tips][:3]
+    assert len(inner_edges) >= 5
+    tables = []
+    for (pc, ps, cc, cs) in inner_edges:
+        st = p.alloc_sumtable()
+        p.update_sumtable(pc, cc, ps, cs, [0] * 4, st)
+        tables.append(st)
+    # the first table's device slot has been recycled by now: its host copy is stale
+    # (zeros), so fill it the way a caller could -- from the oracle -- and use it
+    pc, ps, cc, cs = inner_edges[0]
+    want = o.sumtable(pc, cc, ps, cs)
+    tables[0][:] = want.reshape(-1)
+    got = p.compute_likelihood_derivatives(ps, cs, 0.3, [0] * 4, tables[0])
+    assert rel_err(got, o.derivatives(want, 0.3)) < 1e-10
+    # the most recent table is still resident
+    pc, ps, cc, cs = inner_edges[-1]
+    want = o.sumtable(pc, cc, ps, cs)
+    got = p.compute_likelihood_derivatives(ps, cs, 0.3, [0] * 4, tables[-1])
+    assert rel_err(got, o.derivatives(want, 0.3)) < 1e-10
+    p.destroy()
+
+
+def test_two_partitions_interleaved(gpu, orc):
+    """Independent partitions (own streams) used alternately, DNA and protein."""
+    ca = make_case(4, "random", 9, 300, seed=21)
+    cb = make_case(20, "balanced", 8, 150, seed=22)
+    cb["rates"], cb["freqs"] = gpu.aa_model("lg")
+    pa = build_partition(gpu, ca, ATTRIB_PATTERN_TIP)
+    pb = build_partition(gpu, cb, 0)
+    oa = oracle_run(orc, gpu, pa, ca, ATTRIB_PATTERN_TIP)
+    ob = oracle_run(orc, gpu, pb, cb, 0)
+    oa.update_partials()
+    ob.update_partials()
+    for _ in range(3):
+        pa.update_partials(ca["plan"].ops)
+        pb.update_partials(cb["plan"].ops)
+        la = pa.compute_edge_loglikelihood(*ca["plan"].root_edge, [0] * 4)
+        lb = pb.compute_edge_loglikelihood(*cb["plan"].root_edge, [0] * 4)
+        assert abs(la - oa.edge_loglikelihood(*ca["plan"].root_edge)) < 1e-11 * abs(la)
+        assert abs(lb - ob.edge_loglikelihood(*cb["plan"].root_edge)) < 1e-11 * abs(lb)
+    pa.destroy()
+    pb.destroy()
+
+
+def test_op_list_with_slot_reuse(gpu, orc):
+    """An op list in which a later op overwrites a CLV an earlier op read, and reads
+    one an earlier op wrote (what re-rooting an unrooted tree produces,
+    test/src/partial-traversal.c): batching must respect buffer-index hazards."""
+    case = make_case(4, "balanced", 8, 333, seed=15)
+    plan = case["plan"]
+    ops = plan.ops.copy()
+    T = plan.tips
+    # after the regular traversal, recompute node T (from tips 0,1) INTO the slot of
+    # node T+1, then combine the new T+1 with T into T+4's slot
+    extra = np.zeros(2, dtype=OPS_DTYPE)
+    extra[0] = (T + 1, 1, 0, 0, SCALE_BUFFER_NONE, 1, 1, SCALE_BUFFER_NONE)
+    extra[1] = (T + 4, 4, T + 1, T + 1, 1, T, T, 0)
+    ops = np.concatenate([ops, extra])
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    o = oracle_run(orc, gpu, p, case, ATTRIB_PATTERN_TIP)
+    p.update_partials(ops)
+    o.update_partials(ops)
+    for node in range(T, 2 * T - 2):
+        assert bits_equal(p.get_clv(node), o.clv[node]), node
+    for sc in range(plan.scale_buffers):
+        assert (p.get_scaler(sc) == o.scalers[sc]).all()
+    p.destroy()
+
+
+def test_root_loglikelihood(gpu, ref):
+    """pll_compute_root_loglikelihood against the genuine reference (rooted use)."""
+    from libpll_amd.pllapi import ATTRIB_ARCH_AVX2
+    for states in (4, 20):
+        case = make_case(states, "random", 7, 140, seed=states)
+        if states == 20:
+            case["rates"], case["freqs"] = gpu.aa_model("jtt")
+        plan = case["plan"]
+        a = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+        r = build_partition(ref, case, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2)
+        a.update_partials(plan.ops)
+        r.update_partials(plan.ops)
+        node, sc = int(plan.ops[-1]["parent_clv_index"]), int(plan.ops[-1]["parent_scaler_index"])
+        la, pa = a.compute_root_loglikelihood(node, sc, [0] * 4, persite=True)
+        lr, pr = r.compute_root_loglikelihood(node, sc, [0] * 4, persite=True)
+        assert rel_err(pa, pr) < 1e-11 and abs(la - lr) < 1e-11 * abs(lr)
+        a.destroy()
+        r.destroy()
