@@ -408,7 +408,6 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   a.prop_invar = c->prop_invar;
   a.pattern_weights = c->pattern_weights;
   a.invariant = c->invariant;
-  a.reduce = pllhip_reduce_out(c);
   a.sites = c->sh.sites;
   a.rate_cats = R;
   a.states = S;
@@ -427,6 +426,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     grid = pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    a.reduce = pllhip_reduce_out(c, grid);
     const bool nt = pllhip_use_nt(c);
 #define DERIV_DNA(RCV)                                                        \
     do {                                                                      \
@@ -446,6 +446,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     grid = pllhip_stream_grid(c, (size_t)a.sites * R, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    a.reduce = pllhip_reduce_out(c, grid);
     switch (R)
     {
       case 1: k_derivatives<1><<<grid, 256, dbytes, c->stream>>>(a); break;
@@ -459,11 +460,15 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     grid = pllhip_stream_grid(c, a.sites, 128);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    a.reduce = pllhip_reduce_out(c, grid);
     k_derivatives_gen<<<grid, 128, 0, c->stream>>>(a);
   }
   HIP_TRY(hipGetLastError());
   prof.stop();
-  (void)grid;
+  {
+    int rc = pllhip_finish_reduce(c, a.reduce, grid, 2);
+    if (rc) return rc;
+  }
   if (c->comm)
   {
     int rc = pllhip_allreduce_result(c, 2);

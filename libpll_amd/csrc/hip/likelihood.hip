@@ -22,14 +22,49 @@
 
 #include "lnl_common.hpp"
 
-ReduceOut pllhip_reduce_out(pllhip_ctx * c)
+#define PLLHIP_FUSE_MAX_GRID 512
+
+ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid)
 {
   ReduceOut r;
   r.partials = c->block_partials;
   r.counter = c->d_counter;
   r.result = c->d_result;
   r.host_result = c->comm ? nullptr : c->h_result_dev;
+  r.fused = grid <= PLLHIP_FUSE_MAX_GRID ? 1 : 0;
   return r;
+}
+
+// adds `nparts` workgroup values of `ncomp` components in a fixed order
+__global__ __launch_bounds__(256) void k_final_sum(ReduceOut ro, unsigned int nparts, unsigned int ncomp)
+{
+  __shared__ double s[256];
+  for (unsigned int comp = 0; comp < ncomp; ++comp)
+  {
+    double v = 0.0;
+    for (unsigned int i = threadIdx.x; i < nparts; i += 256) v += ro.partials[(size_t)comp * nparts + i];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (unsigned int w = 128; w > 0; w >>= 1)
+    {
+      if (threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+      ro.result[comp] = s[0];
+      if (ro.host_result) ro.host_result[comp] = s[0];
+    }
+    __syncthreads();
+  }
+}
+
+int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp)
+{
+  if (ro.fused) return 0;
+  k_final_sum<<<1, 256, 0, c->stream>>>(ro, grid, ncomp);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // Per-(site,rate) kernels.  KIND: EDGE_II / EDGE_TI / ROOT;  S4: 4-state vs 20-state
@@ -438,7 +473,6 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   a.states = S;
   a.maxstates = c->maxstates;
   a.rate_scalers = c->sh.rate_scalers;
-  a.reduce = pllhip_reduce_out(c);
   a.persite = nullptr;
   if (h_persite)
   {
@@ -458,6 +492,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
     grid = s4 ? pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256)
               : pllhip_stream_grid(c, (size_t)a.sites * R, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    a.reduce = pllhip_reduce_out(c, grid);
     size_t lds = 0;
     if (kind == EDGE_II && !s4) lds = (size_t)R * S * S * sizeof(double);
     if (kind == EDGE_TI) lds = (size_t)(s4 ? 16u : c->maxstates) * R * S * sizeof(double);
@@ -469,13 +504,17 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   {
     grid = pllhip_stream_grid(c, a.sites, 128);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    a.reduce = pllhip_reduce_out(c, grid);
     if (kind == EDGE_II) k_lnl_gen<EDGE_II><<<grid, 128, 0, c->stream>>>(a);
     if (kind == EDGE_TI) k_lnl_gen<EDGE_TI><<<grid, 128, 0, c->stream>>>(a);
     if (kind == ROOT) k_lnl_gen<ROOT><<<grid, 128, 0, c->stream>>>(a);
   }
   HIP_TRY(hipGetLastError());
   prof.stop();
-  (void)grid;
+  {
+    int rc = pllhip_finish_reduce(c, a.reduce, grid, 1);
+    if (rc) return rc;
+  }
   if (c->comm)
   {
     // multi-GPU: sum the per-shard values over xGMI, then fetch

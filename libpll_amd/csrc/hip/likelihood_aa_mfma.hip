@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
 }
 
 template <int RC>
-static int launch_lnl_rc(pllhip_ctx * c, const LnlArgs & a, int kind, unsigned int * grid_out)
+static int launch_lnl_rc(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
 {
   using G = aa_geom<RC>;
   const size_t tiles = ((size_t)a.sites + 15) / 16;
@@ -158,6 +158,7 @@ static int launch_lnl_rc(pllhip_ctx * c, const LnlArgs & a, int kind, unsigned i
   if (lds > 80 * 1024) return 1;
   const bool nt = pllhip_use_nt(c);
   const dim3 grid((unsigned int)blocks), block(256);
+  a.reduce = pllhip_reduce_out(c, (unsigned int)blocks);
 #define LNL_ONE(KERNEL)                                                                        \
   do {                                                                                         \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),                       \
@@ -180,7 +181,7 @@ static int launch_lnl_rc(pllhip_ctx * c, const LnlArgs & a, int kind, unsigned i
 }
 
 // returns 1 if not covered (caller falls back to the vector kernels)
-int pllhip_launch_lnl_aa_mfma(pllhip_ctx * c, const LnlArgs & a, int kind, unsigned int * grid_out)
+int pllhip_launch_lnl_aa_mfma(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
 {
   if (kind == EDGE_TI && (a.maxstates == 0 || a.maxstates > 32)) return 1;
   switch (a.rate_cats)

@@ -12,6 +12,9 @@ struct ReduceOut
   unsigned int * counter;  // arrival ticket, zero between launches
   double * result;         // device result [NCOMP] (input of the RCCL all-reduce)
   double * host_result;    // host-mapped copy (nullptr when an all-reduce follows)
+  int fused;               // 1: the last-arriving workgroup finishes the sum in this launch;
+                           // 0: a one-workgroup k_final_sum launch follows (large grids: the
+                           // per-workgroup ticket costs more than a launch there, measured)
 };
 
 struct LnlArgs
@@ -46,8 +49,8 @@ __device__ __forceinline__ double scale_minlh(unsigned int d)
 
 // Sum `v[0..NCOMP)` over the whole grid, reproducibly: lane sums -> wave
 // __shfl_down tree -> LDS -> one value per workgroup in `partials`; the workgroup
-// that arrives LAST (agent-scope release / ticket / acquire, cdna_hip_programming
-// Guideline 16) adds all workgroup values in index order with a fixed tree and
+// that arrives LAST (write-through stores, ticket, acquire + sc1 loads:
+// cdna_hip_programming Guideline 16) adds all workgroup values in index order with a fixed tree and
 // publishes the result -- no second kernel launch, same bits every run.
 template <int NCOMP>
 __device__ __forceinline__ void grid_sum(const double (&v_in)[NCOMP], const ReduceOut & ro)
@@ -72,12 +75,23 @@ __device__ __forceinline__ void grid_sum(const double (&v_in)[NCOMP], const Redu
     {
       double t = 0.0;
       for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) t += s_wave[cidx][w];
-      ro.partials[(size_t)cidx * nparts + blockIdx.x] = t;
+      if (!ro.fused)
+      {
+        ro.partials[(size_t)cidx * nparts + blockIdx.x] = t;
+        continue;
+      }
+      // write-through (sc1) store: visible at device scope without an L2 write-back
+      // fence, which every workgroup would otherwise pay (measured +10 us per launch)
+      __hip_atomic_store(ro.partials + (size_t)cidx * nparts + blockIdx.x, t, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence(); // release: the partial is visible device-wide before the ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int ticket = atomicAdd(ro.counter, 1u);
-    s_last = (ticket == nparts - 1);
+    s_last = false;
+    if (ro.fused)
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores have left before the ticket
+      const unsigned int ticket = atomicAdd(ro.counter, 1u);
+      s_last = (ticket == nparts - 1);
+    }
   }
   __syncthreads();
   if (!s_last) return;
@@ -147,8 +161,10 @@ __device__ __forceinline__ double site_loglk(const LnlArgs & a, double terma, si
 }
 
 
-// fills a ReduceOut from the context (host_result only when no all-reduce follows)
-ReduceOut pllhip_reduce_out(pllhip_ctx * c);
+// fills a ReduceOut from the context (host_result only when no all-reduce follows);
+// pllhip_finish_reduce launches the final pass when the kernel did not fuse it
+ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid);
+int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp);
 
 // 20-state kernels on the matrix cores; returns 1 if the case is not covered
-int pllhip_launch_lnl_aa_mfma(pllhip_ctx * c, const LnlArgs & a, int kind, unsigned int * grid_out);
+int pllhip_launch_lnl_aa_mfma(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out);
