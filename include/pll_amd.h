@@ -140,6 +140,24 @@ typedef struct pll_partition
   int asc_bias_alloc;
 } pll_partition_t;
 
+/* pll.h:183-200: host CPU feature record.  Nothing in this library dispatches on
+ * it (the kernels run on the GPU); kept because clients probe and print it. */
+typedef struct pll_hardware_s
+{
+  int init;
+  int altivec_present;
+  int mmx_present;
+  int sse_present;
+  int sse2_present;
+  int sse3_present;
+  int ssse3_present;
+  int sse41_present;
+  int sse42_present;
+  int popcnt_present;
+  int avx_present;
+  int avx2_present;
+} pll_hardware_t;
+
 /* pll.h:249-259: one pruning step parent <- (child1, child2) */
 typedef struct pll_operation
 {
@@ -252,6 +270,14 @@ PLL_EXPORT int pll_update_invariant_sites(pll_partition_t * partition);
 PLL_EXPORT int pll_update_invariant_sites_proportion(pll_partition_t * partition,
                                                      unsigned int params_index,
                                                      double prop_invar);
+
+/* hardware.c:159-189 */
+PLL_EXPORT extern pll_hardware_t pll_hardware;
+PLL_EXPORT int pll_hardware_probe(void);
+PLL_EXPORT void pll_hardware_dump(void);
+PLL_EXPORT void pll_hardware_ignore(void);
+/* pll.c:1069: always refuses -- partitions here never carry ascertainment sites */
+PLL_EXPORT int pll_set_asc_bias_type(pll_partition_t * partition, int asc_bias_type);
 
 PLL_EXPORT void * pll_aligned_alloc(size_t size, size_t alignment);
 PLL_EXPORT void pll_aligned_free(void * ptr);
