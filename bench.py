@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # (profiles/r1_pmc_hbm_traffic*.csv): FETCH_SIZE x 2 (gfx950 counts 128-B requests
 # at 64 B) + WRITE_SIZE, KB -> bytes, divided by the ops a launch carries.  Valid for
 # the site counts they were taken at; None otherwise.
-TRAFFIC_PER_OP = {4: 396.0e6, 20: 394.4e6}
+TRAFFIC_PER_OP = {4: 396.0e6, 20: 394.2e6}
 TRAFFIC_SITES = {4: 1_000_000, 20: 200_000}
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sites", type=int, default=1_000_000, help="sites per GPU")
+    ap.add_argument("--total-sites", type=int, default=0,
+                    help="fixed total alignment length divided over the GPUs (strong scaling, e.g. "
+                         "BASELINE config 4: --total-sites 8000000 --taxa 128); overrides --sites")
     ap.add_argument("--taxa", type=int, default=64)
     ap.add_argument("--states", type=int, default=4, choices=(4, 20))
     ap.add_argument("--rate-cats", type=int, default=4)
@@ -131,7 +134,8 @@ def main():
             (ATTRIB_RATE_SCALERS if args.rate_scalers else 0)
     plan = {"balanced": W.balanced_tree, "random": W.random_tree,
             "caterpillar": W.caterpillar_tree}[args.tree](T, seed=42)
-    total_sites = args.sites * world
+    strong = args.total_sites > 0
+    total_sites = args.total_sites if strong else args.sites * world
     lo, hi = W.shard_bounds(total_sites, world)[rank:rank + 2]
     ref_path = os.path.join(root, "oracle", "_ref", "libpll_ref.so")
     ref = PllLibrary(ref_path) if os.path.exists(ref_path) else None
@@ -329,13 +333,14 @@ def main():
             "value": round(value, 2), "unit": "M CLV-site-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (%s alignment, seed 42)" % args.alignment,
             "config": {"workload": "%d-state %s, %d Gamma rates, %d sites/GPU, %d-taxon %s "
                                    "tree, %s, %s scalers; step = pll_update_partials(%d ops: %d "
                                    "tip-tip, %d tip-inner, %d inner-inner) + "
                                    "pll_compute_edge_loglikelihood"
-                                   % (S, "GTR" if S == 4 else "LG", R, args.sites, T, args.tree,
+                                   % (S, "GTR" if S == 4 else "LG", R, hi - lo, T, args.tree,
                                       "tip CLVs" if args.tip_clv else "PATTERN_TIP",
                                       "per-rate" if args.rate_scalers else "per-site",
                                       ops_per_eval, tt, ti, ii),

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output directories into the small summaries kept under profiles/.
+
+  kernel trace  (rocprofv3 --kernel-trace --stats --output-format csv -d DIR -- python3 bench.py ...)
+      summarize_rocprof.py stats DIR OUT.csv
+      copies *_kernel_stats.csv (one line per kernel: calls, total, average, min, max)
+
+  PMC passes    (rocprofv3 --pmc FETCH_SIZE -d DIR_F ... ; rocprofv3 --pmc WRITE_SIZE -d DIR_W ...)
+      summarize_rocprof.py hbm DIR_F DIR_W OUT.csv ["command line"]
+      per kernel: mean FETCH_SIZE / WRITE_SIZE (KB) and HBM MB per launch
+          = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024 / 1e6
+      (gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes, WRITE_SIZE is exact:
+      /opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section)
+
+  generic PMC   summarize_rocprof.py pmc DIR OUT.csv ["command line"]
+      per kernel and counter: dispatches, mean, sum
+"""
+import csv
+import glob
+import os
+import sys
+from collections import OrderedDict, defaultdict
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        sys.exit("no *%s under %s" % (suffix, d))
+    return hits
+
+
+def counters(d):
+    """{kernel: {counter: [values per dispatch]}} in first-seen order."""
+    out = OrderedDict()
+    for path in find(d, "_counter_collection.csv"):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                k = out.setdefault(row["Kernel_Name"], defaultdict(list))
+                k[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return out
+
+
+def mean(v):
+    return sum(v) / len(v) if v else 0.0
+
+
+def cmd_stats(d, out):
+    lines, seen_header = [], False
+    for path in find(d, "_kernel_stats.csv"):
+        for line in open(path):
+            if line.startswith('"Name"'):
+                if seen_header:
+                    continue
+                seen_header = True
+            lines.append(line)
+    with open(out, "w") as f:
+        f.writelines(lines)
+
+
+def cmd_hbm(df, dw, out, command=""):
+    fetch, write = counters(df), counters(dw)
+    with open(out, "w") as f:
+        if command:
+            f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: %s\n" % command)
+        f.write("# hbm_MB_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 / 1e6  "
+                "(gfx950: FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md)\n")
+        f.write("# batched launches (blockIdx.y = op) carry several ops per launch\n")
+        f.write("kernel,dispatches,FETCH_SIZE_KB_mean,WRITE_SIZE_KB_mean,hbm_MB_per_launch\n")
+        for k in sorted(set(fetch) | set(write)):
+            fv = fetch.get(k, {}).get("FETCH_SIZE", [])
+            wv = write.get(k, {}).get("WRITE_SIZE", [])
+            fm, wm = mean(fv), mean(wv)
+            f.write('"%s",%d,%.1f,%.1f,%.2f\n' % (k, max(len(fv), len(wv)), fm, wm,
+                                                 (2 * fm + wm) * 1024 / 1e6))
+
+
+def cmd_pmc(d, out, command=""):
+    c = counters(d)
+    with open(out, "w") as f:
+        if command:
+            f.write("# rocprofv3 --pmc ... of: %s\n" % command)
+        f.write("kernel,counter,dispatches,mean,sum\n")
+        for k in sorted(c):
+            for name in sorted(c[k]):
+                v = c[k][name]
+                f.write('"%s",%s,%d,%.3f,%.3f\n' % (k, name, len(v), mean(v), sum(v)))
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    if len(a) >= 3 and a[0] == "stats":
+        cmd_stats(a[1], a[2])
+    elif len(a) >= 4 and a[0] == "hbm":
+        cmd_hbm(a[1], a[2], a[3], a[4] if len(a) > 4 else "")
+    elif len(a) >= 3 and a[0] == "pmc":
+        cmd_pmc(a[1], a[2], a[3] if len(a) > 3 else "")
+    else:
+        sys.exit(__doc__)
