@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--cpu-sites", type=int, default=250_000,
                     help="sample size for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-reps", type=int, default=10)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="diagnostic: take the RCCL path (process group, communicator, lnL all-reduce) "
+                         "even with one rank")
     ap.add_argument("--tree", default="balanced", choices=("balanced", "random", "caterpillar"))
     ap.add_argument("--newton", type=int, default=0,
                     help="also time pll_update_sumtable + N x pll_compute_likelihood_derivatives "
@@ -195,16 +198,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_comm = world > 1 or args.force_comm
+    if use_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     import libpll_amd
     amd = libpll_amd.load()
     amd.lib.pll_amd_set_device(local_rank)
 
     part = W.setup_partition(amd, plan, seqs, S, R, attrs)
-    if world > 1:
+    if use_comm:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             import ctypes
@@ -227,18 +233,18 @@ def main():
     for _ in range(args.warmup):
         lnl = step()
     sync()
-    if world > 1:
+    if use_comm:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lnl = step()
     sync()
-    if world > 1:
+    if use_comm:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_comm:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -350,7 +356,7 @@ def main():
         }
         print(json.dumps(out))
     part.destroy()
-    if world > 1:
+    if use_comm:
         dist.destroy_process_group()
 
 
