@@ -3,7 +3,7 @@ identically to a pll-API library (product or reference) and to the oracle."""
 import numpy as np
 
 from libpll_amd import workload as W
-from libpll_amd.pllapi import ATTRIB_PATTERN_TIP
+from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, OPS_DTYPE, SCALE_BUFFER_NONE
 from oracle_api import OracleRun
 
 TREES = {"balanced": W.balanced_tree, "caterpillar": W.caterpillar_tree, "random": W.random_tree}
@@ -146,3 +146,57 @@ def sumtable_err(a, b):
     entries that are analytically zero (gap columns) carry only rounding noise."""
     scale = np.abs(b).max(axis=2, keepdims=True) + 1e-300
     return float(np.max(np.abs(a - b) / scale))
+
+
+def random_op_sequence(rng, tips, inner, scalers, matrices, length):
+    """A valid-but-arbitrary op sequence over `inner` CLV slots: every op reads
+    tips or slots written earlier and writes any slot other than its children.
+    Produces every kind of dependency between neighbouring ops (read-after-write,
+    write-after-read, write-after-write, shared scaler slots)."""
+    ops = np.zeros(length, dtype=OPS_DTYPE)
+    written = {}                      # inner CLV slot -> scaler slot that goes with it (or NONE)
+    recent = []
+    for i in range(length):
+        pool = list(range(tips)) + sorted(written)
+
+        def child():
+            # mostly recent results, so that deep chains (and scaling events) build up
+            if recent and rng.random() < 0.7:
+                c = int(recent[rng.integers(0, len(recent))])
+            else:
+                c = int(pool[rng.integers(0, len(pool))])
+            return c, (written[c] if c >= tips else SCALE_BUFFER_NONE)
+        (a, sa), (b, sb) = child(), child()
+        free = [s for s in range(tips, tips + inner) if s not in (a, b)]
+        # bias towards a few slots so that reuse is frequent
+        parent = int(free[min(int(rng.exponential(3.0)), len(free) - 1)])
+        psc = int(rng.integers(0, scalers)) if rng.random() < 0.8 else SCALE_BUFFER_NONE
+        # the reference adds child counts into the parent's buffer: a parent sharing its
+        # scaler slot with one of its children would read what it is overwriting
+        if psc in (sa, sb):
+            psc = SCALE_BUFFER_NONE
+        ops[i] = (parent, psc, a, int(rng.integers(0, matrices)), sa, b, int(rng.integers(0, matrices)), sb)
+        # any other CLV that used this scaler slot loses it
+        for k in list(written):
+            if psc != SCALE_BUFFER_NONE and written[k] == psc:
+                written[k] = SCALE_BUFFER_NONE
+        written[parent] = psc
+        recent = ([parent] + [r for r in recent if r != parent])[:3]
+    return ops
+
+
+def random_sequence_case(seed):
+    """(case, attributes, ops, rng) for the random-op-sequence tests: 4- and 20-state
+    data, with and without PATTERN_TIP, per-site and per-rate scalers."""
+    rng = np.random.default_rng(1000 + seed)
+    states = 4 if seed % 3 else 20
+    attrs = (ATTRIB_PATTERN_TIP if seed % 2 else 0) | (ATTRIB_RATE_SCALERS if seed % 4 >= 2 else 0)
+    tips = 12
+    case = make_case(states, "random", tips, 97 + 64 * (seed % 4), seed=seed + 50)
+    plan = case["plan"]
+    ops = random_op_sequence(rng, tips, plan.clv_buffers, plan.scale_buffers, plan.prob_matrices - 1,
+                             120)
+    # every matrix slot gets its own branch length
+    plan.matrix_indices = np.arange(plan.prob_matrices - 1, dtype=np.uint32)
+    plan.branch_lengths = rng.uniform(0.01, 0.5, len(plan.matrix_indices))
+    return case, attrs, ops, rng

@@ -7,8 +7,9 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import make_case, build_partition, oracle_run, bits_equal, rel_err
-from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, OPS_DTYPE, SCALE_BUFFER_NONE
+from helpers import (make_case, build_partition, oracle_run, bits_equal, rel_err,
+                     random_op_sequence, random_sequence_case)
+from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, OPS_DTYPE, SCALE_BUFFER_NONE
 
 pytestmark = pytest.mark.gpu
 
@@ -151,3 +152,75 @@ def test_root_loglikelihood(gpu, ref):
         assert rel_err(pa, pr) < 1e-11 and abs(la - lr) < 1e-11 * abs(lr)
         a.destroy()
         r.destroy()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_op_sequences(gpu, orc, seed, monkeypatch):
+    """Arbitrary op sequences with heavy slot reuse: the level batching may merge
+    only ops that are independent on CLV *and* scale-buffer indices.  Bitwise
+    against the oracle's strictly sequential execution."""
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")
+    case, attrs, ops, rng = random_sequence_case(seed)
+    plan = case["plan"]
+    p = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    p.update_partials(ops)
+    o.update_partials(ops)
+    for node in sorted(set(int(x) for x in ops["parent_clv_index"])):
+        assert bits_equal(p.get_clv(node), o.clv[node]), "CLV slot %d" % node
+    for sc in range(plan.scale_buffers):
+        assert (p.get_scaler(sc) == o.scalers[sc]).all(), "scale buffer %d" % sc
+    # and in pieces: same result whatever the split of the list into calls
+    p2 = build_partition(gpu, case, attrs)
+    cut = sorted(int(x) for x in rng.integers(1, len(ops), size=5))
+    for lo, hi in zip([0] + cut, cut + [len(ops)]):
+        if hi > lo:
+            p2.update_partials(ops[lo:hi])
+    for node in sorted(set(int(x) for x in ops["parent_clv_index"])):
+        assert bits_equal(p2.get_clv(node), p.get_clv(node))
+    p.destroy()
+    p2.destroy()
+
+
+@pytest.mark.parametrize("states,shape", [(4, "random"), (4, "caterpillar"), (20, "random")])
+def test_partial_traversal_after_branch_change(gpu, orc, states, shape, monkeypatch):
+    """Incremental update (test/src/partial-traversal.c's use): after one branch
+    length changes only its P-matrix and the ops on the path to the root edge are
+    redone; CLVs, scalers and lnL must equal a from-scratch evaluation bit for bit."""
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")
+    case = make_case(states, shape, 24, 301, seed=77)
+    plan = case["plan"]
+    R = case["rate_cats"]
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    lnl_before = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    rng = np.random.default_rng(5)
+    for changed in (3, int(plan.ops[2]["parent_clv_index"]), int(plan.ops[len(plan.ops) // 2]["child1_clv_index"])):
+        slot = int(np.nonzero(plan.matrix_indices == changed)[0][0])
+        plan.branch_lengths[slot] = float(rng.uniform(0.3, 0.9))
+        p.update_prob_matrices([0] * R, [changed], [plan.branch_lengths[slot]])
+        # ancestors of the changed node, in list order
+        dirty, node = set(), changed
+        while node in plan.parent_of and plan.parent_of[node] != node:
+            par = plan.parent_of[node]
+            if par in dirty:
+                break
+            dirty.add(par)
+            node = par
+        sub = plan.ops[[int(op["parent_clv_index"]) in dirty for op in plan.ops]]
+        assert 0 < len(sub) < len(plan.ops) or changed in plan.root_edge
+        p.update_partials(sub)
+        lnl_inc = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+        fresh = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+        o = oracle_run(orc, gpu, fresh, case, ATTRIB_PATTERN_TIP)
+        fresh.update_partials(plan.ops)
+        o.update_partials()
+        assert lnl_inc == fresh.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+        assert lnl_inc != lnl_before
+        for op in plan.ops:
+            node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+            assert bits_equal(p.get_clv(node), o.clv[node]), node
+            assert (p.get_scaler(sc) == o.scalers[sc]).all()
+        assert abs(lnl_inc - o.edge_loglikelihood(*plan.root_edge)) <= 1e-12 * abs(lnl_inc)
+        fresh.destroy()
+    p.destroy()

@@ -114,3 +114,24 @@ def test_odd_states_generic_order(ref, orc, states):
     o = oracle_run(orc, ref, p, case, attrs)
     check_against(o, p, case["plan"], 4)
     p.destroy()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_op_sequences(ref, orc, seed):
+    """Arbitrary op sequences with slot reuse, shared scale buffers and CLVs driven
+    down to zero (parents without a scale buffer): pins the oracle's treatment of
+    every pointer-resolution and scaler-inheritance case of partials.c:24-175."""
+    from helpers import random_sequence_case
+    case, attrs, ops, _ = random_sequence_case(seed)
+    p = build_partition(ref, case, attrs | ATTRIB_ARCH_AVX2)
+    o = oracle_run(orc, ref, p, case, attrs)
+    p.update_partials(ops)
+    o.update_partials(ops)
+    fired = 0
+    for node in sorted(set(int(x) for x in ops["parent_clv_index"])):
+        assert bits_equal(p.get_clv(node), o.clv[node]), "CLV slot %d" % node
+    for sc in range(case["plan"].scale_buffers):
+        assert (p.get_scaler(sc) == o.scalers[sc]).all(), "scale buffer %d" % sc
+        fired = max(fired, int(o.scalers[sc].max()))
+    assert fired >= 4, "sequence no longer exercises scaling"
+    p.destroy()
