@@ -69,18 +69,16 @@ __device__ __forceinline__ void tile_matvec(const double * ptab_child, const dou
   for (int k = 0; k < RC; ++k)
   {
     const double * pk = ptab_child + (size_t)k * S20 * S20;
-    double a[5][5];
-#pragma unroll
-    for (int g = 0; g < 5; ++g)
-#pragma unroll
-      for (int c = 0; c < 5; ++c) a[g][c] = pk[(4 * g + i) * S20 + 4 * c + q];
 #pragma unroll
     for (int g = 0; g < 5; ++g)
     {
+      double ag[5];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) ag[c] = pk[(4 * g + i) * S20 + 4 * c + q];
       double acc = 0.0;
 #pragma unroll
       for (int c = 0; c < 5; ++c)
-        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g][c], b[k][c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(ag[c], b[k][c], acc, 0, 0, 0);
       x[k][g] = acc;
     }
   }

@@ -76,6 +76,7 @@ struct pllhip_ctx
   // that every wave makes 2 or 3 grid-stride passes costs 70-72 us.  So the cap
   // is set where it only matters for alignments beyond ~16 M sites per GPU.
   int blocks_per_cu = 256;
+  int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements)
   // 20 states: 1 = bit-exact vector kernels only (env PLLHIP_AA_EXACT=1);
   // 0 = matrix-core kernels where they exist (last-bit differences, see
   // partials_aa_mfma.hip)
@@ -137,6 +138,7 @@ static inline double * pllhip_pmat_ptr(const pllhip_ctx * c, unsigned int idx)
 // one op is still on-die when the next op reads it.
 static inline bool pllhip_use_nt(const pllhip_ctx * c)
 {
+  if (c->nt_override >= 0) return c->nt_override != 0;
   return c->clv_elems * sizeof(double) >= ((size_t)64 << 20);
 }
 

@@ -80,36 +80,122 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
   const bool has_l = a.lscaler != nullptr, has_r = a.rscaler != nullptr;
   double2 * out = reinterpret_cast<double2 *>(a.parent);
 
-  for (size_t tile = (size_t)blockIdx.x * 4 + wave; tile < tiles; tile += nwaves)
+  // One tile = load left, load right, multiply, scale, store.  Its stores are
+  // issued one iteration late -- after the NEXT tile's left operands have been
+  // read out of the image and before that tile's right child is requested -- so
+  // that (a) the next left child is already on its way while this tile is
+  // multiplied, and (b) a wave never sits waiting for its own write
+  // acknowledgements with nothing else in flight (vmcnt counts loads and stores
+  // in one queue).  Measured on the 200 k-site op: 72 -> see DESIGN.md 2.2.
+  const size_t first = (size_t)blockIdx.x * 4 + wave;
+  if (first >= tiles) return; // (no barrier follows)
+  double x[RC][5];            // products of the tile whose stores are pending
+  unsigned int psc[RC];       // its parent scaler count(s), lanes q == 0
+  size_t prev_site0 = 0;
+  bool have_prev = false;
+
+  // write the pending tile: transpose through the (currently free) image,
+  // 16 bytes per lane to HBM
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+#pragma unroll
+      for (int g = 0; g < 5; ++g)
+        *reinterpret_cast<double *>(region + s * ROW_B + k * 160 + (4 * g + q) * 8) = x[k][g];
+    // all LDS reads first, into registers of their own: a store whose data
+    // registers are reloaded for the next store makes the compiler wait for the
+    // store to COMPLETE (vmcnt) before the reload -- 11 serialised round trips
+    double2 v[G::N_IT];
+#pragma unroll
+    for (int it = 0; it < G::N_IT; ++it)
+    {
+      int P = it * 64 + (int)lane;
+      if (P > G::TILE_G - 1) P = G::TILE_G - 1;
+      v[it] = *reinterpret_cast<const double2 *>(region + P * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < G::N_IT; ++it)
+    {
+      const int P = it * 64 + (int)lane;
+      const int site = P / G::ROW_G, col = P - site * G::ROW_G;
+      const size_t ns = prev_site0 + (size_t)site;
+      if (P < G::TILE_G && col < G::ROW_G - 1 && ns < sites)
+        st16<NT>(out + ns * (size_t)(RC * 10) + (size_t)col, v[it].x, v[it].y);
+    }
+    const size_t n = prev_site0 + s;
+    if (MODE == SCALE_SITE && q == 0 && n < sites) a.pscaler[n] = psc[0];
+    if (MODE == SCALE_RATE && q == 0 && n < sites)
+#pragma unroll
+      for (int k = 0; k < RC; ++k) a.pscaler[n * RC + k] = psc[k];
+    // the image is about to be refilled by a DMA: its reads must have left LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // The children's scaler counts of a tile are requested right BEFORE the DMA of
+  // its first operand and consumed right after that DMA has been waited for.
+  // Loads return in order: requested anywhere later they would sit behind a DMA
+  // and their first use would cost that DMA's whole latency.
+  unsigned int lsc_next[RC], rsc_next[RC]; // (kept apart: adding them here would wait for them here)
+  unsigned int code_next = 0;              // tip code of the lane's site (tip-inner)
+  auto load_scalers = [&](size_t site0) {
+    const size_t n = site0 + s;
+    const size_t nc = n < sites ? n : 0;
+    if (KIND == 1) code_next = a.ltip[nc];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+    {
+      const size_t e = (MODE == SCALE_RATE) ? nc * RC + k : nc;
+      const bool used = (MODE == SCALE_RATE) || (MODE == SCALE_SITE && k == 0);
+      lsc_next[k] = (used && KIND == 0) ? ls[has_l ? e : 0] : 0u;
+      rsc_next[k] = used ? rs[has_r ? e : 0] : 0u;
+    }
+  };
+  load_scalers(first * 16);
+  dma_tile<RC, NT>(KIND == 0 ? a.left : a.right, first * 16, sites, region, lane);
+  for (size_t tile = first; tile < tiles; tile += nwaves)
   {
     const size_t site0 = tile * 16;
-    double b[RC][5], x[RC][5], y[RC][5];
+    const size_t next = tile + nwaves;
+    double b[RC][5], xl[RC][5], y[RC][5];
 
+    // ---- first operand tile of this iteration has been requested earlier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    read_b_operands<RC>(region, s, q, b);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the children's scaler counts came in with this tile's first operand
+    unsigned int csc[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+    {
+      csc[k] = lsc_next[k] + rsc_next[k];
+      asm volatile("" : "+v"(csc[k])); // consumed HERE, where nothing is in flight
+    }
+    unsigned int code = code_next;
+    asm volatile("" : "+v"(code));
+    if (have_prev) flush();
     if (KIND == 0)
     {
-      // ---- left child: DMA, fetch B operands, then reuse the image for the right child
-      dma_tile<RC, NT>(a.left, site0, sites, region, lane);
+      dma_tile<RC, NT>(a.right, site0, sites, region, lane);
+      tile_matvec<RC>(ptab, b, lane, xl); // overlaps the right child's DMA and the stores
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       read_b_operands<RC>(region, s, q, b);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      dma_tile<RC, NT>(a.right, site0, sites, region, lane);
-      tile_matvec<RC>(ptab, b, lane, x); // overlaps the right child's DMA
     }
-    else
+    // ---- next tile's first operand: in flight while this tile is finished
+    if (next < tiles)
     {
-      dma_tile<RC, NT>(a.right, site0, sites, region, lane);
+      load_scalers(next * 16);
+      dma_tile<RC, NT>(KIND == 0 ? a.left : a.right, next * 16, sites, region, lane);
+    }
+    if (KIND == 1)
+    {
       // left factor: tip row sums of this column's site, states 4g+q
-      unsigned int code = (site0 + s < sites) ? a.ltip[site0 + s] : 0u;
       if (code >= a.maxstates) code = 0;
 #pragma unroll
       for (int k = 0; k < RC; ++k)
 #pragma unroll
-        for (int g = 0; g < 5; ++g) x[k][g] = ptab[(code * RC + k) * 20 + 4 * g + q];
+        for (int g = 0; g < 5; ++g) xl[k][g] = ptab[(code * RC + k) * 20 + 4 * g + q];
     }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    read_b_operands<RC>(region, s, q, b);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     tile_matvec<RC>(ptab_r, b, lane, y);
 
     // ---- product + scaling (core_partials_avx2.c:752-800)
@@ -122,12 +208,11 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 #pragma unroll
       for (int g = 0; g < 5; ++g)
       {
-        x[k][g] = x[k][g] * y[k][g];
+        x[k][g] = xl[k][g] * y[k][g];
         small_rate[k] = small_rate[k] && (x[k][g] < PLLHIP_SCALE_THRESHOLD);
       }
       small_site = small_site && small_rate[k];
     }
-    const size_t n = site0 + s; // the site of this lane's column
     if (MODE == SCALE_SITE)
     {
       const bool scale = column_all(small_site, s);
@@ -136,8 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
         for (int k = 0; k < RC; ++k)
 #pragma unroll
           for (int g = 0; g < 5; ++g) x[k][g] *= PLLHIP_SCALE_FACTOR;
-      if (q == 0 && n < sites)
-        a.pscaler[n] = (KIND == 0 ? ls[has_l ? n : 0] : 0u) + rs[has_r ? n : 0] + (scale ? 1u : 0u);
+      psc[0] = csc[0] + (scale ? 1u : 0u);
     }
     if (MODE == SCALE_RATE)
     {
@@ -148,33 +232,14 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
         if (scale)
 #pragma unroll
           for (int g = 0; g < 5; ++g) x[k][g] *= PLLHIP_SCALE_FACTOR;
-        if (q == 0 && n < sites)
-          a.pscaler[n * RC + k] = (KIND == 0 ? ls[has_l ? n * RC + k : 0] : 0u) +
-                                  rs[has_r ? n * RC + k : 0] + (scale ? 1u : 0u);
+        psc[k] = csc[k] + (scale ? 1u : 0u);
       }
     }
-
-    // ---- transpose through the LDS image, store 16 bytes per lane
-#pragma unroll
-    for (int k = 0; k < RC; ++k)
-#pragma unroll
-      for (int g = 0; g < 5; ++g)
-        *reinterpret_cast<double *>(region + s * ROW_B + k * 160 + (4 * g + q) * 8) = x[k][g];
-#pragma unroll
-    for (int it = 0; it < G::N_IT; ++it)
-    {
-      const int P = it * 64 + (int)lane;
-      const int site = P / G::ROW_G, col = P - site * G::ROW_G;
-      const size_t ns = site0 + (size_t)site;
-      if (P < G::TILE_G && col < G::ROW_G - 1 && ns < sites)
-      {
-        const double2 v = *reinterpret_cast<const double2 *>(region + P * 16);
-        st16<NT>(out + ns * (size_t)(RC * 10) + (size_t)col, v.x, v.y);
-      }
-    }
-    // the image is refilled by the next tile's DMA: its reads must have left LDS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    prev_site0 = site0;
+    have_prev = true;
   }
+  // ---- the last tile: nothing is in flight into the image any more
+  flush();
 }
 
 // ---- tip tables, built once per op: tab[code][k][i] = sum_{j in tipmap[code]} P[k][i][j]
