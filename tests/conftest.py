@@ -82,3 +82,11 @@ def ref_tree():
     class _L:
         lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
     return _L
+
+
+@pytest.fixture(params=["exact", "mfma"])
+def aa_mode(request, monkeypatch):
+    """20-state kernels: bit-exact vector kernels (PLLHIP_AA_EXACT=1) or the
+    default matrix-core kernels.  Read when a partition is created."""
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1" if request.param == "exact" else "0")
+    return request.param

@@ -224,3 +224,81 @@ def test_partial_traversal_after_branch_change(gpu, orc, states, shape, monkeypa
         assert abs(lnl_inc - o.edge_loglikelihood(*plan.root_edge)) <= 1e-12 * abs(lnl_inc)
         fresh.destroy()
     p.destroy()
+
+
+def _mixture_partition(lib, case, attrs, models, weights, pinvs):
+    """One rate matrix + frequency set per rate category (the LG4X / examples/lg4 use)."""
+    plan, S, R = case["plan"], case["states"], case["rate_cats"]
+    if lib.is_amd:
+        attrs &= ~0xF
+    p = lib.partition_create(plan.tips, plan.clv_buffers, S, case["sites"], R, plan.prob_matrices,
+                             R, plan.scale_buffers, attrs)
+    for k, (rates, freqs) in enumerate(models):
+        p.set_subst_params(k, rates)
+        p.set_frequencies(k, freqs)
+    p.set_category_rates(lib.compute_gamma_cats(case["alpha"], R))
+    p.set_category_weights(weights)
+    cmap = lib.map("nt" if S == 4 else "aa")
+    for i, s in enumerate(case["seqs"]):
+        p.set_tip_states(i, cmap, s)
+    p.set_pattern_weights(case["pw"])
+    for k, pv in enumerate(pinvs):
+        if pv > 0:
+            p.update_invariant_sites_proportion(k, pv)
+    p.update_prob_matrices(list(range(R)), plan.matrix_indices, plan.branch_lengths)
+    return p
+
+
+@pytest.mark.parametrize("states,pinv", [(4, 0.0), (20, 0.0), (4, 0.15), (20, 0.1)])
+def test_one_rate_matrix_per_category(gpu, ref, aa_mode, states, pinv):
+    """params_indices / freqs_indices = {0,1,2,3}: every category has its own
+    eigen-decomposition, frequencies, weight (and +I proportion).  P-matrices, CLVs,
+    lnL, sumtable and derivatives against the genuine reference."""
+    from libpll_amd.pllapi import ATTRIB_ARCH_AVX2
+    if states == 4 and aa_mode == "mfma":
+        pytest.skip("mode only affects 20-state kernels")
+    exact = states == 4 or aa_mode == "exact"
+    rng = np.random.default_rng(states + int(100 * pinv))
+    case = make_case(states, "random", 14, 333, seed=31 + states)
+    R, plan = case["rate_cats"], case["plan"]
+    nr = states * (states - 1) // 2
+    models = [(rng.uniform(0.3, 4.0, nr), rng.dirichlet(np.ones(states) * 6)) for _ in range(R)]
+    weights = rng.dirichlet(np.ones(R) * 4)
+    pinvs = [pinv * (0.5 + 0.25 * k) for k in range(R)]
+    idx = list(range(R))
+    attrs = ATTRIB_PATTERN_TIP
+    g = _mixture_partition(gpu, case, attrs, models, weights, pinvs)
+    r = _mixture_partition(ref, case, attrs | ATTRIB_ARCH_AVX2, models, weights, pinvs)
+    for m in plan.matrix_indices[:6]:
+        assert bits_equal(g.get_pmatrix(int(m)), r.get_pmatrix(int(m)))
+    g.update_partials(plan.ops)
+    r.update_partials(plan.ops)
+    for op in plan.ops:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        if exact:
+            assert bits_equal(g.get_clv(node), r.get_clv(node)), node
+        else:
+            assert rel_err(g.get_clv(node), r.get_clv(node)) < 1e-11
+        assert (g.get_scaler(sc) == r.get_scaler(sc)).all()
+    e = plan.root_edge
+    lg, psg = g.compute_edge_loglikelihood(*e, idx, persite=True)
+    lr, psr = r.compute_edge_loglikelihood(*e, idx, persite=True)
+    assert abs(lg - lr) <= 1e-12 * abs(lr)
+    assert rel_err(psg, psr) < 1e-12
+    # tip-inner edge as well (the root edge of a random tree is inner-inner)
+    op0 = plan.ops[-1]
+    tip_edge = None
+    for op in plan.ops:
+        if int(op["child1_clv_index"]) < plan.tips and int(op["child2_clv_index"]) >= plan.tips:
+            tip_edge = op
+    stg, strf = g.alloc_sumtable(), r.alloc_sumtable()
+    g.update_sumtable(e[0], e[2], e[1], e[3], idx, stg)
+    r.update_sumtable(e[0], e[2], e[1], e[3], idx, strf)
+    from helpers import sumtable_err
+    assert sumtable_err(g.get_sumtable(stg), r.get_sumtable(strf)) < 1e-11
+    for t in (0.02, 0.3, 1.7):
+        dg = g.compute_likelihood_derivatives(e[1], e[3], t, idx, stg)
+        dr = r.compute_likelihood_derivatives(e[1], e[3], t, idx, strf)
+        assert rel_err(np.array(dg), np.array(dr)) < 1e-9, (t, dg, dr)
+    g.destroy()
+    r.destroy()

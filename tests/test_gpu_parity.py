@@ -26,14 +26,6 @@ MFMA_CLV_RTOL = 1e-11
 MFMA_LNL_RTOL = 1e-11
 
 
-@pytest.fixture(params=["exact", "mfma"])
-def aa_mode(request, monkeypatch):
-    """20-state kernels: bit-exact vector kernels (PLLHIP_AA_EXACT=1) or the
-    default matrix-core kernels.  Read when a partition is created."""
-    monkeypatch.setenv("PLLHIP_AA_EXACT", "1" if request.param == "exact" else "0")
-    return request.param
-
-
 def compare(p, o, case, R, exact=True):
     plan = case["plan"]
     clv_tol = 0.0 if exact else MFMA_CLV_RTOL
