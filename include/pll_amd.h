@@ -73,6 +73,17 @@ extern "C" {
 #define PLL_ATTRIB_RATE_SCALERS (1 << 9)
 
 /* error codes shared with the reference (pll.h:137-167) */
+#define PLL_ERROR_FILE_OPEN 100
+#define PLL_ERROR_FILE_SEEK 101
+#define PLL_ERROR_FILE_EOF 102
+#define PLL_ERROR_FASTA_ILLEGALCHAR 103
+#define PLL_ERROR_FASTA_UNPRINTABLECHAR 104
+#define PLL_ERROR_FASTA_INVALIDHEADER 105
+#define PLL_ERROR_PHYLIP_SYNTAX 106
+#define PLL_ERROR_PHYLIP_LONGSEQ 107
+#define PLL_ERROR_PHYLIP_NONALIGNED 108
+#define PLL_ERROR_PHYLIP_ILLEGALCHAR 109
+#define PLL_ERROR_PHYLIP_UNPRINTABLECHAR 110
 #define PLL_ERROR_MEM_ALLOC 112
 #define PLL_ERROR_PARAM_INVALID 113
 #define PLL_ERROR_TIPDATA_ILLEGALSTATE 114
@@ -139,6 +150,44 @@ typedef struct pll_partition
 
   int asc_bias_alloc;
 } pll_partition_t;
+
+/* ---- alignment readers (pll.h:271-308; layouts frozen, fields are public) ---- */
+#define PLL_LINEALLOC 2048
+
+typedef struct pll_msa_s
+{
+  int count;
+  int length;
+  char ** sequence;
+  char ** label;
+} pll_msa_t;
+
+typedef struct pll_fasta
+{
+  FILE * fp;
+  char line[PLL_LINEALLOC];
+  const unsigned int * chrstatus;
+  long no;
+  long filesize;
+  long lineno;
+  long stripped_count;
+  long stripped[256];
+} pll_fasta_t;
+
+typedef struct pll_phylip_s
+{
+  FILE * fp;
+  char * line;
+  size_t line_size;
+  size_t line_maxsize;
+  char buffer[PLL_LINEALLOC];
+  const unsigned int * chrstatus;
+  long no;
+  long filesize;
+  long lineno;
+  long stripped_count;
+  long stripped[256];
+} pll_phylip_t;
 
 /* pll.h:183-200: host CPU feature record.  Nothing in this library dispatches on
  * it (the kernels run on the GPU); kept because clients probe and print it. */
@@ -208,18 +257,54 @@ PLL_EXPORT extern __thread char pll_errmsg[200];
 PLL_EXPORT extern const unsigned int pll_map_bin[256];
 PLL_EXPORT extern const unsigned int pll_map_nt[256];
 PLL_EXPORT extern const unsigned int pll_map_aa[256];
-/* character classes of the (out-of-scope) FASTA / PHYLIP readers, data only */
+/* character classes for the sequence readers below: 0 = stripped and counted,
+ * 1 = data, 2 = fatal, 3 = stripped silently (maps.c of the reference) */
 PLL_EXPORT extern const unsigned int pll_map_fasta[256];
 PLL_EXPORT extern const unsigned int pll_map_phylip[256];
 
-PLL_EXPORT extern const double pll_aa_rates_lg[190];
-PLL_EXPORT extern const double pll_aa_freqs_lg[20];
-PLL_EXPORT extern const double pll_aa_rates_wag[190];
-PLL_EXPORT extern const double pll_aa_freqs_wag[20];
-PLL_EXPORT extern const double pll_aa_rates_jtt[190];
-PLL_EXPORT extern const double pll_aa_freqs_jtt[20];
 PLL_EXPORT extern const double pll_aa_rates_dayhoff[190];
 PLL_EXPORT extern const double pll_aa_freqs_dayhoff[20];
+PLL_EXPORT extern const double pll_aa_rates_lg[190];
+PLL_EXPORT extern const double pll_aa_freqs_lg[20];
+PLL_EXPORT extern const double pll_aa_rates_dcmut[190];
+PLL_EXPORT extern const double pll_aa_freqs_dcmut[20];
+PLL_EXPORT extern const double pll_aa_rates_jtt[190];
+PLL_EXPORT extern const double pll_aa_freqs_jtt[20];
+PLL_EXPORT extern const double pll_aa_rates_mtrev[190];
+PLL_EXPORT extern const double pll_aa_freqs_mtrev[20];
+PLL_EXPORT extern const double pll_aa_rates_wag[190];
+PLL_EXPORT extern const double pll_aa_freqs_wag[20];
+PLL_EXPORT extern const double pll_aa_rates_rtrev[190];
+PLL_EXPORT extern const double pll_aa_freqs_rtrev[20];
+PLL_EXPORT extern const double pll_aa_rates_cprev[190];
+PLL_EXPORT extern const double pll_aa_freqs_cprev[20];
+PLL_EXPORT extern const double pll_aa_rates_vt[190];
+PLL_EXPORT extern const double pll_aa_freqs_vt[20];
+PLL_EXPORT extern const double pll_aa_rates_blosum62[190];
+PLL_EXPORT extern const double pll_aa_freqs_blosum62[20];
+PLL_EXPORT extern const double pll_aa_rates_mtmam[190];
+PLL_EXPORT extern const double pll_aa_freqs_mtmam[20];
+PLL_EXPORT extern const double pll_aa_rates_mtart[190];
+PLL_EXPORT extern const double pll_aa_freqs_mtart[20];
+PLL_EXPORT extern const double pll_aa_rates_mtzoa[190];
+PLL_EXPORT extern const double pll_aa_freqs_mtzoa[20];
+PLL_EXPORT extern const double pll_aa_rates_pmb[190];
+PLL_EXPORT extern const double pll_aa_freqs_pmb[20];
+PLL_EXPORT extern const double pll_aa_rates_hivb[190];
+PLL_EXPORT extern const double pll_aa_freqs_hivb[20];
+PLL_EXPORT extern const double pll_aa_rates_hivw[190];
+PLL_EXPORT extern const double pll_aa_freqs_hivw[20];
+PLL_EXPORT extern const double pll_aa_rates_jttdcmut[190];
+PLL_EXPORT extern const double pll_aa_freqs_jttdcmut[20];
+PLL_EXPORT extern const double pll_aa_rates_flu[190];
+PLL_EXPORT extern const double pll_aa_freqs_flu[20];
+PLL_EXPORT extern const double pll_aa_rates_stmtrev[190];
+PLL_EXPORT extern const double pll_aa_freqs_stmtrev[20];
+/* four-matrix mixtures (pll.h:499-522): one matrix + frequency set per rate category */
+PLL_EXPORT extern const double pll_aa_rates_lg4m[4][190];
+PLL_EXPORT extern const double pll_aa_rates_lg4x[4][190];
+PLL_EXPORT extern const double pll_aa_freqs_lg4m[4][20];
+PLL_EXPORT extern const double pll_aa_freqs_lg4x[4][20];
 
 /* ---- partition container (replaces pll.h:530-555) ---- */
 
@@ -270,6 +355,22 @@ PLL_EXPORT int pll_update_invariant_sites(pll_partition_t * partition);
 PLL_EXPORT int pll_update_invariant_sites_proportion(pll_partition_t * partition,
                                                      unsigned int params_index,
                                                      double prop_invar);
+
+/* fasta.c:40-324: one record per call; *head and *seq are malloc'ed for the caller */
+PLL_EXPORT pll_fasta_t * pll_fasta_open(const char * filename, const unsigned int * map);
+PLL_EXPORT int pll_fasta_getnext(pll_fasta_t * fd, char ** head, long * head_len, char ** seq,
+                                 long * seq_len, long * seqno);
+PLL_EXPORT void pll_fasta_close(pll_fasta_t * fd);
+PLL_EXPORT long pll_fasta_getfilesize(const pll_fasta_t * fd);
+PLL_EXPORT long pll_fasta_getfilepos(pll_fasta_t * fd);
+PLL_EXPORT int pll_fasta_rewind(pll_fasta_t * fd);
+/* phylip.c:282-730: whole alignments, sequential or interleaved layout */
+PLL_EXPORT pll_phylip_t * pll_phylip_open(const char * filename, const unsigned int * map);
+PLL_EXPORT int pll_phylip_rewind(pll_phylip_t * fd);
+PLL_EXPORT void pll_phylip_close(pll_phylip_t * fd);
+PLL_EXPORT pll_msa_t * pll_phylip_parse_interleaved(pll_phylip_t * fd);
+PLL_EXPORT pll_msa_t * pll_phylip_parse_sequential(pll_phylip_t * fd);
+PLL_EXPORT void pll_msa_destroy(pll_msa_t * msa);
 
 /* hardware.c:159-189 */
 PLL_EXPORT extern pll_hardware_t pll_hardware;

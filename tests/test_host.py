@@ -64,11 +64,23 @@ def test_character_maps(amd, ref):
         assert (amd.map(name) == ref.map(name)).all()
 
 
+AA_MODELS = ("dayhoff", "lg", "dcmut", "jtt", "mtrev", "wag", "rtrev", "cprev", "vt", "blosum62",
+             "mtmam", "mtart", "mtzoa", "pmb", "hivb", "hivw", "jttdcmut", "flu", "stmtrev")
+
+
 def test_aa_models_match_reference_data(amd, ref):
-    for name in ("lg", "wag", "jtt", "dayhoff"):
+    import ctypes as C
+    for name in AA_MODELS:
         ra, fa = amd.aa_model(name)
         rr, fr = ref.aa_model(name)
         assert bits_equal(ra, rr) and bits_equal(fa, fr)
+        assert abs(fa.sum() - 1.0) < 1e-5
+    for name in ("lg4m", "lg4x"):
+        for kind, n in (("rates", 190), ("freqs", 20)):
+            sym = "pll_aa_%s_%s" % (kind, name)
+            a = np.ctypeslib.as_array(((C.c_double * n) * 4).in_dll(amd.lib, sym))
+            r = np.ctypeslib.as_array(((C.c_double * n) * 4).in_dll(ref.lib, sym))
+            assert bits_equal(a, r), sym
 
 
 def test_gamma_categories_bit_exact(amd, ref):

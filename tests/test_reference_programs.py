@@ -16,7 +16,7 @@ BIN = os.path.join(ROOT, "oracle", "_ref")
 OUT = os.path.join(ROOT, "tests", "golden", "reference_out")
 TESTS = ["example_unrooted", "00010_NMDU_lkcalc", "00011_NMAU_lkcalc", "00012_NMOU_lkcalc", "00020_NMDR_lkcalc",
          "00021_NMAR_lkcalc", "00022_NMOR_lkcalc", "00030_NMDU_gamma", "00032_NMOU_gamma",
-         "alpha-cats", "derivatives", "derivatives-oddstates", "hky", "pmatrix"]
+         "alpha-cats", "derivatives", "derivatives-oddstates", "hky", "pmatrix", "protein-models"]
 MODES = [[], ["tv"], ["avx2"], ["avx2", "tv"], ["avx"], ["sse", "tv"]]
 
 
