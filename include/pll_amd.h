@@ -377,8 +377,12 @@ PLL_EXPORT extern pll_hardware_t pll_hardware;
 PLL_EXPORT int pll_hardware_probe(void);
 PLL_EXPORT void pll_hardware_dump(void);
 PLL_EXPORT void pll_hardware_ignore(void);
-/* pll.c:1069: always refuses -- partitions here never carry ascertainment sites */
+/* pll.c:1061-1116: ascertainment-bias correction of a partition created with
+ * PLL_ATTRIB_AB_FLAG or one of PLL_ATTRIB_AB_LEWIS / _FELSENSTEIN / _STAMATAKIS.
+ * (With PLL_ATTRIB_PATTERN_TIP only 4-state data is accepted, see DESIGN.md.) */
 PLL_EXPORT int pll_set_asc_bias_type(pll_partition_t * partition, int asc_bias_type);
+PLL_EXPORT void pll_set_asc_state_weights(pll_partition_t * partition,
+                                          const unsigned int * state_weights);
 
 PLL_EXPORT void * pll_aligned_alloc(size_t size, size_t alignment);
 PLL_EXPORT void pll_aligned_free(void * ptr);

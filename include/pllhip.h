@@ -46,6 +46,8 @@ typedef struct pllhip_shape
   unsigned int scale_buffers;
   int pattern_tip;            /* tips are 1-byte codes, not CLVs           */
   int rate_scalers;           /* per-(site,rate) scalers instead of per-site */
+  unsigned int asc_states;    /* how many of `sites` are the trailing one-per-state
+                                 ascertainment-bias sites (pll.c:492-495); 0 = none */
 } pllhip_shape_t;
 
 /* same layout as pll_operation_t (pll.h:249-259) */
@@ -163,9 +165,17 @@ PLLHIP_EXPORT int pllhip_get_sumtable(pllhip_ctx_t * ctx, unsigned int slot,
  * h_diagptable: rate_cats*states*4 doubles built by the host exactly as
  * core_derivatives.c:560-575 does.  Outputs are derivatives of -lnL. */
 PLLHIP_EXPORT int pllhip_likelihood_derivatives(pllhip_ctx_t * ctx, unsigned int slot,
+                                                int parent_scaler, int child_scaler,
                                                 const unsigned int * h_params_indices,
                                                 const double * h_diagptable,
                                                 double * h_d_f, double * h_dd_f);
+
+/* Ascertainment-bias correction (likelihood.c:24-119,170-247,321-414;
+ * core_derivatives.c:654-727): which of PLL_ATTRIB_AB_LEWIS / _FELSENSTEIN /
+ * _STAMATAKIS (the attribute bits, 0 = off) the log-likelihood and derivative
+ * calls apply over the context's asc_states trailing sites, and the sum of the
+ * pattern weights of the ordinary sites (pll_partition_t::pattern_weight_sum). */
+PLLHIP_EXPORT int pllhip_set_asc(pllhip_ctx_t * ctx, int asc_type, unsigned int pattern_weight_sum);
 
 /* ---- multi-GPU: one process per GPU, RCCL sum of the scalar results ---- */
 PLLHIP_EXPORT int pllhip_comm_unique_id(void * id128);

@@ -252,7 +252,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   void * bufs[] = {c->clv_arena, c->tipchars, c->scaler_arena, c->pmatrix, c->eigenvals,
                    c->eigenvecs, c->inv_eigenvecs, c->freqs, c->prop_invar, c->rates,
                    c->rate_weights, c->pattern_weights, c->invariant, c->tipmap,
-                   c->block_partials, c->d_result, c->d_counter, c->d_zero, c->d_sink, c->d_tiptab, c->d_persite, c->d_stage,
+                   c->block_partials, c->d_result, c->d_counter, c->d_zero, c->d_sink, c->d_tiptab, c->d_persite, c->d_stage, c->d_asc,
                    c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3]};
   for (void * p : bufs)
     if (p) (void)hipFree(p);

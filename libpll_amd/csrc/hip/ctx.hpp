@@ -76,6 +76,10 @@ struct pllhip_ctx
   // that every wave makes 2 or 3 grid-stride passes costs 70-72 us.  So the cap
   // is set where it only matters for alignments beyond ~16 M sites per GPU.
   int blocks_per_cu = 256;
+  int asc_type = 0;                      // PLL_ATTRIB_AB_* bits (0 = no correction)
+  unsigned int asc_weight_sum = 0;
+  double * d_asc = nullptr;              // [3] correction terms added by the final sum
+  const double * pending_extra = nullptr; // consumed by the next pllhip_reduce_out
   int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements)
   // 20 states: 1 = bit-exact vector kernels only (env PLLHIP_AA_EXACT=1);
   // 0 = matrix-core kernels where they exist (last-bit differences, see

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(128) void k_derivatives_gen(DerivArgs a)
 }
 
 extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot,
+                                             int parent_scaler, int child_scaler,
                                              const unsigned int * h_params_indices,
                                              const double * h_diagptable, double * h_d_f,
                                              double * h_dd_f)
@@ -408,7 +409,20 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   a.prop_invar = c->prop_invar;
   a.pattern_weights = c->pattern_weights;
   a.invariant = c->invariant;
-  a.sites = c->sh.sites;
+  // ordinary sites; the Stamatakis correction treats the extra per-state sites as
+  // weighted sites of the same loop (core_derivatives.c:536-545), the other two
+  // get an epilogue
+  const size_t ordinary = c->sh.sites - c->sh.asc_states;
+  a.sites = (unsigned int)ordinary;
+  if ((c->asc_type & PLLHIP_AB_MASK) == PLLHIP_AB_STAMATAKIS) a.sites = c->sh.sites;
+  if (parent_scaler >= (int)c->sh.scale_buffers || child_scaler >= (int)c->sh.scale_buffers)
+  {
+    pllhip_set_error("pllhip_likelihood_derivatives: scaler index out of range");
+    return -1;
+  }
+  if (pllhip_asc_derivatives(c, a.sumtable, a.diagp, ordinary, parent_scaler, child_scaler,
+                             &c->pending_extra))
+    return -1;
   a.rate_cats = R;
   a.states = S;
   for (unsigned int k = 0; k < R; ++k)

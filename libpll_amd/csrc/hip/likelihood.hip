@@ -31,6 +31,8 @@ ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid)
   r.counter = c->d_counter;
   r.result = c->d_result;
   r.host_result = c->comm ? nullptr : c->h_result_dev;
+  r.extra = c->pending_extra; // set by the caller for exactly one launch
+  c->pending_extra = nullptr;
   r.fused = grid <= PLLHIP_FUSE_MAX_GRID ? 1 : 0;
   return r;
 }
@@ -52,8 +54,9 @@ __global__ __launch_bounds__(256) void k_final_sum(ReduceOut ro, unsigned int np
     }
     if (threadIdx.x == 0)
     {
-      ro.result[comp] = s[0];
-      if (ro.host_result) ro.host_result[comp] = s[0];
+      const double total = ro.extra ? s[0] + ro.extra[comp] : s[0];
+      ro.result[comp] = total;
+      if (ro.host_result) ro.host_result[comp] = total;
     }
     __syncthreads();
   }
@@ -468,12 +471,13 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   a.invariant = c->invariant;
   a.tipmap = c->tipmap;
   a.zero = c->d_zero;
-  a.sites = c->sh.sites;
+  a.sites = c->sh.sites - c->sh.asc_states; // the ascertainment sites are not part of the sum
   a.rate_cats = R;
   a.states = S;
   a.maxstates = c->maxstates;
   a.rate_scalers = c->sh.rate_scalers;
   a.persite = nullptr;
+  if (pllhip_asc_lnl(c, a, kind, &c->pending_extra)) return -1;
   if (h_persite)
   {
     if (!c->d_persite) HIP_TRY(hipMalloc((void **)&c->d_persite, (size_t)c->sh.sites * sizeof(double)));
@@ -523,7 +527,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   }
   if (h_persite)
-    HIP_TRY(hipMemcpyAsync(h_persite, c->d_persite, (size_t)c->sh.sites * sizeof(double),
+    HIP_TRY(hipMemcpyAsync(h_persite, c->d_persite, (size_t)a.sites * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *h_lnl = c->h_result[0];

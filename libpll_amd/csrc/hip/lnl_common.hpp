@@ -12,6 +12,7 @@ struct ReduceOut
   unsigned int * counter;  // arrival ticket, zero between launches
   double * result;         // device result [NCOMP] (input of the RCCL all-reduce)
   double * host_result;    // host-mapped copy (nullptr when an all-reduce follows)
+  const double * extra;    // [NCOMP] added to the finished sums (asc-bias correction) or nullptr
   int fused;               // 1: the last-arriving workgroup finishes the sum in this launch;
                            // 0: a one-workgroup k_final_sum launch follows (large grids: the
                            // per-workgroup ticket costs more than a launch there, measured)
@@ -38,6 +39,12 @@ struct LnlArgs
   int rate_scalers;
   unsigned int freqs_indices[PLLHIP_MAX_RATE_CATS];
 };
+
+// ascertainment-bias attribute bits (pll.h:120-124)
+#define PLLHIP_AB_LEWIS (1 << 5)
+#define PLLHIP_AB_FELSENSTEIN (2 << 5)
+#define PLLHIP_AB_STAMATAKIS (3 << 5)
+#define PLLHIP_AB_MASK (7 << 5)
 
 enum { EDGE_II = 0, EDGE_TI = 1, ROOT = 2 };
 
@@ -118,8 +125,9 @@ __device__ __forceinline__ void grid_sum(const double (&v_in)[NCOMP], const Redu
 #pragma unroll
     for (int cidx = 0; cidx < NCOMP; ++cidx)
     {
-      ro.result[cidx] = s_tree[cidx][0];
-      if (ro.host_result) ro.host_result[cidx] = s_tree[cidx][0];
+      const double total = ro.extra ? s_tree[cidx][0] + ro.extra[cidx] : s_tree[cidx][0];
+      ro.result[cidx] = total;
+      if (ro.host_result) ro.host_result[cidx] = total;
     }
     *ro.counter = 0u; // ready for the next launch (stream order separates launches)
   }
@@ -165,6 +173,13 @@ __device__ __forceinline__ double site_loglk(const LnlArgs & a, double terma, si
 // pllhip_finish_reduce launches the final pass when the kernel did not fuse it
 ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid);
 int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp);
+
+// asc_bias.hip: launch the correction kernel (if a correction type is set) ahead of the
+// site kernel; *extra = what that kernel's final sum must add
+int pllhip_asc_lnl(pllhip_ctx * c, const LnlArgs & a, int kind, const double ** extra);
+int pllhip_asc_derivatives(pllhip_ctx * c, const double * sumtable, const double * d_diagp,
+                           size_t ordinary_sites, int parent_scaler, int child_scaler,
+                           const double ** extra);
 
 // 20-state kernels on the matrix cores; returns 1 if the case is not covered
 int pllhip_launch_lnl_aa_mfma(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out);

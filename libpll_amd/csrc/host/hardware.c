@@ -57,15 +57,3 @@ void pll_hardware_ignore(void)
   pll_hardware.sse41_present = pll_hardware.sse42_present = pll_hardware.popcnt_present = 1;
   pll_hardware.avx_present = pll_hardware.avx2_present = 1;
 }
-
-/* Ascertainment-bias correction is outside the rebuilt path: partitions are never
- * created with the extra per-state sites, which is exactly the situation in which
- * the reference refuses too (pll.c:1069-1077). */
-int pll_set_asc_bias_type(pll_partition_t * partition, int asc_bias_type)
-{
-  (void)partition;
-  (void)asc_bias_type;
-  pll_amd_set_error(PLL_ERROR_AB_NOSUPPORT,
-                    "Partition was not created with ascertainment bias support");
-  return PLL_FAILURE;
-}

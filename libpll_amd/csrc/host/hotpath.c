@@ -141,9 +141,7 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p, int parent_scaler_in
   unsigned int i, j;
   int slot, rc;
   double * diag;
-  (void)parent_scaler_index; /* scalers only enter through asc-bias terms (core_derivatives.c:683) */
-  (void)child_scaler_index;
-
+  /* (the scaler indices only matter to the asc-bias terms, core_derivatives.c:683-686) */
   if (!pll_amd_flush_model(p)) return PLL_FAILURE;
   slot = slot_of(q, sumtable);
   if (slot < 0)
@@ -176,7 +174,8 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p, int parent_scaler_in
       dp[3] = 0;
     }
   }
-  rc = pllhip_likelihood_derivatives(q->ctx, (unsigned int)slot, params_indices, diag, d_f, dd_f);
+  rc = pllhip_likelihood_derivatives(q->ctx, (unsigned int)slot, parent_scaler_index,
+                                     child_scaler_index, params_indices, diag, d_f, dd_f);
   free(diag);
   if (rc) return pll_amd_fail_hip(rc, "likelihood derivatives");
   return PLL_SUCCESS;

@@ -364,7 +364,14 @@ int pll_update_invariant_sites(pll_partition_t * p)
   unsigned int j;
   int rc;
   unsigned int * acc = (unsigned int *)malloc((size_t)p->sites * sizeof(unsigned int));
-  if (!p->invariant) p->invariant = (int *)malloc((size_t)p->sites * sizeof(int));
+  /* sized for the device upload, which covers the ascertainment sites too (they are never
+     invariant-model sites: -1) */
+  if (!p->invariant)
+  {
+    const size_t n = pll_amd_priv(p)->sites_alloc;
+    p->invariant = (int *)malloc(n * sizeof(int));
+    if (p->invariant) for (size_t t = p->sites; t < n; ++t) p->invariant[t] = -1;
+  }
   if (!acc || !p->invariant)
   {
     free(acc);
@@ -419,6 +426,13 @@ unsigned int pll_count_invariant_sites(pll_partition_t * p, unsigned int * state
 
 int pll_update_invariant_sites_proportion(pll_partition_t * p, unsigned int index, double pinv)
 {
+  /* models.c:407-414 */
+  if (pinv != 0.0 && (p->attributes & PLL_ATTRIB_AB_MASK))
+  {
+    pll_amd_set_error(PLL_ERROR_INVAR_INCOMPAT,
+                      "Invariant sites are not compatible with asc bias correction");
+    return PLL_FAILURE;
+  }
   if (pinv < 0 || pinv >= 1)
   {
     pll_amd_set_error(PLL_ERROR_INVAR_PROPORTION, "Invalid proportion of invariant sites (%f)", pinv);

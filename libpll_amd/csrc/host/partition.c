@@ -150,10 +150,17 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
     pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "Multiple architecture flags specified.");
     return NULL;
   }
-  if (attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG))
+  /* Ascertainment bias: `states` extra sites behind the alignment (pll.c:492-495).
+     With PATTERN_TIP and other than 4 states the reference fills the extra tip
+     characters with ASCII values where charmap codes belong (pll.c:886-901), which
+     makes every extra site impossible; that combination is refused here rather
+     than reproduced. */
+  if ((attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG)) &&
+      (attributes & PLL_ATTRIB_PATTERN_TIP) && states != 4)
   {
-    pll_amd_set_error(PLL_ERROR_AB_NOSUPPORT,
-                      "Ascertainment bias correction is not part of the HIP hot path.");
+    pll_amd_set_error(PLL_ERROR_HIP_UNSUPPORTED,
+                      "Ascertainment bias correction with PLL_ATTRIB_PATTERN_TIP needs 4 states; "
+                      "use tip CLVs for %u-state data.", states);
     return NULL;
   }
   if (!states || !sites || !rate_cats || !rate_matrices || (tips + clv_buffers) == 0)
@@ -191,8 +198,8 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
   p->attributes = attributes;
   p->alignment = PLL_ALIGNMENT_HIP;
   p->states_padded = states;
-  p->asc_bias_alloc = 0;
-  q->sites_alloc = sites;
+  p->asc_bias_alloc = (attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG)) ? 1 : 0;
+  q->sites_alloc = p->asc_bias_alloc ? sites + states : sites;
 
   /* host-side arrays the reference exposes; CLV / scaler mirrors start NULL */
   p->eigen_decomp_valid = (int *)calloc(rate_matrices, sizeof(int));
@@ -208,7 +215,7 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
   p->rates = (double *)calloc(rate_cats, sizeof(double));
   p->rate_weights = (double *)calloc(rate_cats, sizeof(double));
   p->prop_invar = (double *)calloc(rate_matrices, sizeof(double));
-  p->pattern_weights = (unsigned int *)malloc((size_t)sites * sizeof(unsigned int));
+  p->pattern_weights = (unsigned int *)calloc(q->sites_alloc, sizeof(unsigned int));
   q->model_dirty = (int *)calloc(rate_matrices, sizeof(int));
   if (!p->eigen_decomp_valid || !p->clv || !p->scale_buffer || !p->pmatrix || !p->eigenvecs ||
       !p->inv_eigenvecs || !p->eigenvals || !p->subst_params || !p->frequencies || !p->rates ||
@@ -242,6 +249,7 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
   sh.scale_buffers = scale_buffers;
   sh.pattern_tip = (attributes & PLL_ATTRIB_PATTERN_TIP) ? 1 : 0;
   sh.rate_scalers = (attributes & PLL_ATTRIB_RATE_SCALERS) ? 1 : 0;
+  sh.asc_states = p->asc_bias_alloc ? states : 0;
   rc = pllhip_ctx_create(&sh, &q->ctx);
   if (rc)
   {
@@ -250,6 +258,17 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
     q->ctx = NULL;
     pll_partition_destroy(p);
     return NULL;
+  }
+  if (p->asc_bias_alloc)
+  {
+    /* the extra sites start with weight 0 (pll.c:785-786) */
+    if ((rc = pllhip_put_pattern_weights(q->ctx, p->pattern_weights)) ||
+        (rc = pllhip_set_asc(q->ctx, (int)(attributes & PLL_ATTRIB_AB_MASK), p->pattern_weight_sum)))
+    {
+      pll_amd_fail_hip(rc, "ascertainment bias setup");
+      pll_partition_destroy(p);
+      return NULL;
+    }
   }
   return p;
 
@@ -368,6 +387,9 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip_index, const unsign
       /* 4 states: the mask is the code (pll.c:825-845); else the charmap code (pll.c:862-883) */
       codes[i] = (p->states == 4) ? (unsigned char)m : p->charmap[(unsigned char)sequence[i]];
     }
+    /* ascertainment sites: site sites+k shows state k (pll.c:847-855; 4 states only) */
+    if (p->asc_bias_alloc)
+      for (i = 0; i < p->states; ++i) codes[p->sites + i] = (unsigned char)(1u << i);
     if ((rc = pllhip_put_tipchars(q->ctx, tip_index, codes)))
       return pll_amd_fail_hip(rc, "upload of tip characters");
     return PLL_SUCCESS;
@@ -377,7 +399,7 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip_index, const unsign
      device (set_tipclv pll.c:905-939) */
   {
     const unsigned int S = p->states;
-    double * v = (double *)malloc((size_t)p->sites * S * sizeof(double));
+    double * v = (double *)calloc((size_t)q->sites_alloc * S, sizeof(double));
     if (!v)
     {
       pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate tip vector staging.");
@@ -393,6 +415,9 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip_index, const unsign
       }
       for (j = 0; j < S; ++j, m >>= 1) v[(size_t)i * S + j] = (double)(m & 1u);
     }
+    /* ascertainment sites: unit vectors (pll.c:943-961) */
+    if (p->asc_bias_alloc)
+      for (i = 0; i < S; ++i) v[((size_t)p->sites + i) * S + i] = 1.0;
     rc = pllhip_put_tip_clv_persite(q->ctx, tip_index, v, S);
     free(v);
     if (rc) return pll_amd_fail_hip(rc, "upload of tip CLV");
@@ -415,7 +440,25 @@ int pll_set_tip_clv(pll_partition_t * p, unsigned int tip_index, const double * 
     pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "CLV index %u out of range", tip_index);
     return PLL_FAILURE;
   }
-  rc = pllhip_put_tip_clv_persite(pll_amd_priv(p)->ctx, tip_index, clv, p->states);
+  if (p->asc_bias_alloc)
+  {
+    /* the caller's vector covers the alignment; the ascertainment sites get unit
+       vectors (pll.c:1028-1043) */
+    const unsigned int S = p->states;
+    unsigned int i;
+    double * v = (double *)calloc((size_t)pll_amd_priv(p)->sites_alloc * S, sizeof(double));
+    if (!v)
+    {
+      pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate tip vector staging.");
+      return PLL_FAILURE;
+    }
+    memcpy(v, clv, (size_t)p->sites * S * sizeof(double));
+    for (i = 0; i < S; ++i) v[((size_t)p->sites + i) * S + i] = 1.0;
+    rc = pllhip_put_tip_clv_persite(pll_amd_priv(p)->ctx, tip_index, v, S);
+    free(v);
+  }
+  else
+    rc = pllhip_put_tip_clv_persite(pll_amd_priv(p)->ctx, tip_index, clv, p->states);
   if (rc) return pll_amd_fail_hip(rc, "upload of tip CLV");
   return PLL_SUCCESS;
 }
@@ -428,7 +471,56 @@ void pll_set_pattern_weights(pll_partition_t * p, const unsigned int * w)
   p->pattern_weight_sum = 0;
   for (i = 0; i < p->sites; ++i) p->pattern_weight_sum += w[i];
   rc = pllhip_put_pattern_weights(pll_amd_priv(p)->ctx, p->pattern_weights);
+  if (!rc && p->asc_bias_alloc)
+    rc = pllhip_set_asc(pll_amd_priv(p)->ctx, (int)(p->attributes & PLL_ATTRIB_AB_MASK),
+                        p->pattern_weight_sum);
   if (rc) pll_amd_fail_hip(rc, "upload of pattern weights");
+}
+
+/* pll.c:1061-1107 */
+int pll_set_asc_bias_type(pll_partition_t * p, int asc_bias_type)
+{
+  unsigned int i;
+  int rc, pinv = 0;
+  const int bits = asc_bias_type & PLL_ATTRIB_AB_MASK;
+  if (!p->asc_bias_alloc)
+  {
+    pll_amd_set_error(PLL_ERROR_AB_NOSUPPORT,
+                      "Partition was not created with ascertainment bias support");
+    return PLL_FAILURE;
+  }
+  for (i = 0; i < p->rate_matrices; ++i) pinv |= (p->prop_invar[i] > 0);
+  if (asc_bias_type != 0 && pinv)
+  {
+    pll_amd_set_error(PLL_ERROR_INVAR_INCOMPAT,
+                      "Invariant sites are not compatible with asc bias correction");
+    return PLL_FAILURE;
+  }
+  if (bits != asc_bias_type)
+  {
+    pll_amd_set_error(PLL_ERROR_AB_INVALIDMETHOD, "Illegal ascertainment bias algorithm \"%d\"",
+                      asc_bias_type);
+    return PLL_FAILURE;
+  }
+  p->attributes = (p->attributes & ~(unsigned int)PLL_ATTRIB_AB_MASK) | (unsigned int)bits;
+  if ((rc = pllhip_set_asc(pll_amd_priv(p)->ctx, bits, p->pattern_weight_sum)))
+    return pll_amd_fail_hip(rc, "ascertainment bias type");
+  return PLL_SUCCESS;
+}
+
+/* pll.c:1109-1116: how often each state's invariant pattern would have been seen */
+void pll_set_asc_state_weights(pll_partition_t * p, const unsigned int * state_weights)
+{
+  int rc;
+  if (!p->asc_bias_alloc)
+  {
+    pll_amd_set_error(PLL_ERROR_AB_NOSUPPORT,
+                      "Partition was not created with ascertainment bias support");
+    return;
+  }
+  memcpy(p->pattern_weights + p->sites, state_weights, (size_t)p->states * sizeof(unsigned int));
+  rc = pllhip_put_pattern_weights(pll_amd_priv(p)->ctx, p->pattern_weights);
+  if (rc) pll_amd_fail_hip(rc, "upload of state weights");
 }
 
 /* ---- host mirrors -------------------------------------------------------- */

@@ -21,6 +21,10 @@ ATTRIB_ARCH_SSE = 1 << 0
 ATTRIB_ARCH_AVX = 1 << 1
 ATTRIB_ARCH_AVX2 = 1 << 2
 ATTRIB_PATTERN_TIP = 1 << 4
+ATTRIB_AB_LEWIS = 1 << 5
+ATTRIB_AB_FELSENSTEIN = 2 << 5
+ATTRIB_AB_STAMATAKIS = 3 << 5
+ATTRIB_AB_FLAG = 1 << 8
 ATTRIB_RATE_SCALERS = 1 << 9
 GAMMA_RATES_MEAN = 0
 GAMMA_RATES_MEDIAN = 1
@@ -207,9 +211,14 @@ class Partition:
         return self.s.rate_cats * self.s.states_padded
 
     @property
+    def sites_total(self):
+        """alignment sites + the `states` ascertainment sites, if allocated (pll.c:492-495)"""
+        return self.s.sites + (self.s.states if self.s.asc_bias_alloc else 0)
+
+    @property
     def scaler_len(self):
         per = self.s.rate_cats if (self.s.attributes & ATTRIB_RATE_SCALERS) else 1
-        return self.s.sites * per
+        return self.sites_total * per
 
     # -- setters -----------------------------------------------------------------
     def set_tip_states(self, tip, cmap, seq):
@@ -225,6 +234,14 @@ class Partition:
     def set_pattern_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.uint32)
         self.lib.pll_set_pattern_weights(self.ptr, _u(w))
+
+    def set_asc_bias_type(self, asc_type):
+        self._check(self.lib.pll_set_asc_bias_type(self.ptr, asc_type), "pll_set_asc_bias_type")
+
+    def set_asc_state_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.uint32)
+        assert len(w) == self.s.states
+        self.lib.pll_set_asc_state_weights(self.ptr, _u(w))
 
     def set_subst_params(self, idx, params):
         a = np.ascontiguousarray(params, dtype=np.float64)
@@ -282,7 +299,7 @@ class Partition:
 
     def alloc_sumtable(self):
         """A caller-owned, aligned host sumtable like test/src/scaling.c:215-218 allocates."""
-        n = self.s.sites * self.span
+        n = self.sites_total * self.span
         raw = self.lib.pll_aligned_alloc(n * 8, 32)
         arr = np.ctypeslib.as_array(C.cast(raw, _dp), shape=(n,))
         self._keep.append(raw)
@@ -306,9 +323,9 @@ class Partition:
     def get_clv(self, idx):
         if self.o.is_amd:
             self._check(self.lib.pll_amd_sync_clv(self.ptr, idx), "pll_amd_sync_clv")
-        n = self.s.sites * self.span
+        n = self.sites_total * self.span
         return np.ctypeslib.as_array(self.s.clv[idx], shape=(n,)).copy().reshape(
-            self.s.sites, self.s.rate_cats, self.s.states_padded)[:, :, :self.s.states]
+            self.sites_total, self.s.rate_cats, self.s.states_padded)[:, :, :self.s.states]
 
     def get_scaler(self, idx):
         if self.o.is_amd:
@@ -326,7 +343,7 @@ class Partition:
         if self.o.is_amd:
             self._check(self.lib.pll_amd_sync_sumtable(self.ptr, _d(sumtable)),
                         "pll_amd_sync_sumtable")
-        return np.array(sumtable).reshape(self.s.sites, self.s.rate_cats,
+        return np.array(sumtable).reshape(self.sites_total, self.s.rate_cats,
                                           self.s.states_padded)[:, :, :self.s.states]
 
     def get_eigen(self, idx):
