@@ -110,14 +110,17 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   const size_t n_clv = nodes - first;
 
   // CLVs are zeroed like the reference's (pll.c:525-542); scalers calloc'd (pll.c:800-815)
-  if ((rc = dev_alloc(&c->clv_arena, n_clv * c->clv_elems, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->clv_arena, n_clv * c->clv_elems + PLLHIP_TAIL_SITES * c->span, true, c->stream)))
+    goto fail;
   c->clv.assign(nodes, nullptr);
   for (unsigned int i = first; i < nodes; ++i)
     c->clv[i] = c->clv_arena + (size_t)(i - first) * c->clv_elems;
   if (shape->pattern_tip)
-    if ((rc = dev_alloc(&c->tipchars, shape->tips * c->tip_stride, true, c->stream))) goto fail;
-  if ((rc = dev_alloc(&c->scaler_arena, (size_t)shape->scale_buffers * c->scaler_elems,
-                      true, c->stream))) goto fail;
+    if ((rc = dev_alloc(&c->tipchars, shape->tips * c->tip_stride + PLLHIP_TAIL_SITES, true, c->stream)))
+      goto fail;
+  if ((rc = dev_alloc(&c->scaler_arena,
+                      (size_t)shape->scale_buffers * c->scaler_elems + PLLHIP_TAIL_SITES * R, true,
+                      c->stream))) goto fail;
   if ((rc = dev_alloc(&c->pmatrix, (size_t)shape->prob_matrices * c->pmat_elems, true,
                       c->stream))) goto fail;
   if ((rc = dev_alloc(&c->eigenvals, (size_t)shape->rate_matrices * S, true, c->stream))) goto fail;
@@ -128,7 +131,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   c->h_prop_invar.assign(shape->rate_matrices, 0.0);
   if ((rc = dev_alloc(&c->rates, R, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->rate_weights, R, true, c->stream))) goto fail;
-  if ((rc = dev_alloc(&c->pattern_weights, N, false, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->pattern_weights, N + PLLHIP_TAIL_SITES, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->tipmap, (size_t)256, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->block_partials, (size_t)PLLHIP_REDUCE_BLOCKS * 2, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->d_result, (size_t)4, true, c->stream))) goto fail;
@@ -379,7 +382,12 @@ extern "C" int pllhip_put_invariant(pllhip_ctx_t * c, const int * h)
     c->invariant = nullptr;
     return 0;
   }
-  if (!c->invariant) HIP_TRY(hipMalloc((void **)&c->invariant, (size_t)c->sh.sites * sizeof(int)));
+  if (!c->invariant)
+  {
+    const size_t bytes = ((size_t)c->sh.sites + PLLHIP_TAIL_SITES) * sizeof(int);
+    HIP_TRY(hipMalloc((void **)&c->invariant, bytes));
+    HIP_TRY(hipMemsetAsync(c->invariant, 0xff, bytes, c->stream)); // -1 everywhere
+  }
   return h2d(c, c->invariant, h, (size_t)c->sh.sites * sizeof(int));
 }
 

@@ -186,6 +186,11 @@ struct PartialsArgs
 // Several mutually independent ops (one tree level) run in ONE launch:
 // blockIdx.y selects the op.  The op descriptors travel as kernel arguments
 // (24 x 136 B < the 4 KB kernarg segment), so batching needs no staging copy.
+// Every per-site device array carries this many sites of zeroed slack behind its last
+// element, so that a wave working on the last (partial) round of 64 sites may load
+// unconditionally and unclamped; what it computes there is masked out of every result.
+#define PLLHIP_TAIL_SITES 64
+
 #define PLLHIP_BATCH_MAX 24
 struct PartialsBatch
 {

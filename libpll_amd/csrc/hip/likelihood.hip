@@ -280,17 +280,32 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
   const unsigned int grp0 = lane & ~(W - 1);
   const double2 * __restrict__ P2 = reinterpret_cast<const double2 *>(a.parent);
   const double2 * __restrict__ C2 = reinterpret_cast<const double2 *>(a.child);
-  const size_t total = (size_t)a.sites * W;
+  // per-site counts of the lane's own site; in per-rate mode the minimum over the
+  // categories stands in for them and these read the zero word
+  const bool site_ps = has_ps && !per_rate, site_cs = has_cs && !per_rate;
+  const unsigned int * ps_site = site_ps ? a.pscaler : a.zero;
+  const unsigned int * cs_site = site_cs ? a.cscaler : a.zero;
+  const int * inv_site = a.invariant ? a.invariant : reinterpret_cast<const int *>(a.zero);
+  const bool has_inv = a.invariant != nullptr;
   for (size_t r = wave; r < rounds; r += nwaves)
   {
     double my_terma = 1.0;
     unsigned int my_rate_min = 0;
-#pragma unroll
+    // What the lane needs for the ONE site it finishes at the end of the round is
+    // requested first, unconditionally (absent arrays read a zero word): inside the
+    // `if (n < sites)` tail each of these loads was a separate exposed round trip.
+    // (no index clamping anywhere in this kernel: every per-site array has
+    // PLLHIP_TAIL_SITES of slack behind it, and a site past the end is never summed)
+    const size_t n_own = r * 64 + (size_t)(lane & (W - 1)) * SPS + (lane / W);
+    const unsigned int w_own = a.pattern_weights[n_own];
+    const unsigned int ps_own = ps_site[site_ps ? n_own : 0];
+    const unsigned int cs_own = cs_site[site_cs ? n_own : 0];
+    const int inv_raw = inv_site[has_inv ? n_own : 0];
+    const int inv_own = has_inv ? inv_raw : -1;
+#pragma unroll 1
     for (unsigned int j = 0; j < W; ++j)
     {
-      const size_t g = (r * 64 + (size_t)j * SPS) * W + lane;
-      const bool act = g < total;
-      const size_t gc = act ? g : 0;
+      const size_t gc = (r * 64 + (size_t)j * SPS) * W + lane;
       const size_t n = gc / W, e = gc >> 1;
       const double2 p = ld16<NT>(P2 + gc);
       double t0, t1;
@@ -332,6 +347,8 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
         if (rel > PLLHIP_SCALE_RATE_MAXDIFF) rel = PLLHIP_SCALE_RATE_MAXDIFF;
         if (rel > 0) terma_r *= scale_minlh(rel);
       }
+      // invariant-state index of this sub-step's site: held by the lane that owns it
+      const int inv = __shfl(inv_own, (int)(grp0 + j), 64);
       // weighted category term (core_likelihood_avx.c:1225-1240); the 4-state
       // edge kernels skip non-positive terms, the root kernel does not
       double contrib;
@@ -339,7 +356,6 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
         contrib = 0.0;
       else if (pinv > 0.0)
       {
-        const int inv = a.invariant ? a.invariant[n] : -1;
         const double inv_lk = (inv == -1) ? 0.0 : frk[inv];
         contrib = wk * (terma_r * (1.0 - pinv) + inv_lk * pinv);
       }
@@ -355,18 +371,16 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
       }
     }
     // lane l now owns site (l % W) * SPS + l / W of this round
-    const size_t n = r * 64 + (size_t)(lane & (W - 1)) * SPS + (lane / W);
-    if (n < a.sites)
+    if (n_own < a.sites)
     {
-      unsigned int site_scalings = my_rate_min;
-      if (!per_rate)
-      {
-        // per-site counts; the root kernel reads scaler[n] even in per-rate mode
-        // (core_likelihood.c:197-198)
-        if (a.pscaler) site_scalings += a.pscaler[n];
-        if (KIND == EDGE_II && a.cscaler) site_scalings += a.cscaler[n];
-      }
-      acc += site_loglk(a, my_terma, n, site_scalings);
+      // per-site counts (ps_own / cs_own are zero in per-rate mode, where the minimum
+      // over the categories stands in, core_likelihood_avx.c:1136-1154)
+      const unsigned int site_scalings = my_rate_min + ps_own + cs_own;
+      double lk = log(my_terma);
+      if (site_scalings) lk += (double)site_scalings * log(PLLHIP_SCALE_THRESHOLD);
+      lk *= (double)w_own;
+      if (a.persite) a.persite[n_own] = lk;
+      acc += lk;
     }
   }
   block_sum_to_partials(acc, a.reduce);
