@@ -302,16 +302,18 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
     const unsigned int cs_own = cs_site[site_cs ? n_own : 0];
     const int inv_raw = inv_site[has_inv ? n_own : 0];
     const int inv_own = has_inv ? inv_raw : -1;
-#pragma unroll 1
-    for (unsigned int j = 0; j < W; ++j)
-    {
-      const size_t gc = (r * 64 + (size_t)j * SPS) * W + lane;
+    // One sub-step = 64/W sites.  The operands of sub-step j+1 are requested before
+    // sub-step j is evaluated (rolled loop: 96 VGPRs, 5 waves per SIMD; unrolled, the
+    // compiler kept 160 live and still waited for each pair of loads in turn).
+    const size_t g0 = r * 64 * W + lane;
+    double2 p_next = ld16<NT>(P2 + g0), c_next = make_double2(0.0, 0.0);
+    if (KIND == EDGE_II) c_next = ld16<NT>(C2 + g0);
+    auto substep = [&](unsigned int j, const double2 p, const double2 c) {
+      const size_t gc = g0 + (size_t)j * SPS * W;
       const size_t n = gc / W, e = gc >> 1;
-      const double2 p = ld16<NT>(P2 + gc);
       double t0, t1;
       if (KIND == EDGE_II)
       {
-        const double2 c = ld16<NT>(C2 + gc);
         const double2 cp = make_double2(dpp_pair_swap(c.x), dpp_pair_swap(c.y));
         // row dot, x pi, x parent (core_likelihood_avx.c:1175-1213)
         t0 = (fr0 * pm.dot(0, c, cp)) * p.x;
@@ -369,7 +371,17 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
         my_terma = terma;
         my_rate_min = mn;
       }
+    };
+#pragma unroll 1
+    for (unsigned int j = 0; j + 1 < W; ++j)
+    {
+      const double2 p = p_next, c = c_next;
+      const size_t gn = g0 + (size_t)(j + 1) * SPS * W;
+      p_next = ld16<NT>(P2 + gn);
+      if (KIND == EDGE_II) c_next = ld16<NT>(C2 + gn);
+      substep(j, p, c);
     }
+    substep(W - 1, p_next, c_next);
     // lane l now owns site (l % W) * SPS + l / W of this round
     if (n_own < a.sites)
     {
