@@ -444,7 +444,7 @@ extern "C" int pllhip_put_sumtable(pllhip_ctx_t * c, unsigned int slot, const do
 {
   if (slot >= PLLHIP_SUMTABLE_SLOTS) { pllhip_set_error("sumtable slot %u", slot); return -1; }
   HIP_TRY(hipSetDevice(c->sh.device));
-  if (!c->sumtable[slot]) HIP_TRY(hipMalloc((void **)&c->sumtable[slot], c->clv_elems * sizeof(double)));
+  if (!c->sumtable[slot]) HIP_TRY(hipMalloc((void **)&c->sumtable[slot], (c->clv_elems + PLLHIP_TAIL_SITES * c->span) * sizeof(double)));
   return h2d(c, c->sumtable[slot], h, c->clv_elems * sizeof(double));
 }
 

@@ -93,7 +93,7 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
     return -1;
   }
   if (!c->sumtable[slot])
-    HIP_TRY(hipMalloc((void **)&c->sumtable[slot], c->clv_elems * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->sumtable[slot], (c->clv_elems + PLLHIP_TAIL_SITES * c->span) * sizeof(double)));
 
   const unsigned int S = c->sh.states, R = c->sh.rate_cats;
   // the two matrix sets live at the start of the staging buffer's device half
@@ -185,6 +185,9 @@ struct DerivArgs
   ReduceOut reduce;
   unsigned int sites, rate_cats, states;
   unsigned int params_indices[PLLHIP_MAX_RATE_CATS];
+  // 4-state data: the table itself travels as a kernel argument (rate_cats <= 8: 1 KB),
+  // which saves the staging copy -- a third of a derivative call on a small partition
+  double diag_inline[8 * 4 * 4];
 };
 
 __device__ __forceinline__ void block_sum2(double v0, double v1, const ReduceOut & ro)
@@ -265,9 +268,6 @@ template <int RC, bool NT>
 __global__ __launch_bounds__(256) void k_derivatives_dna(DerivArgs a)
 {
   constexpr unsigned int W = 2 * RC, SPS = 64 / W;
-  __shared__ double s_diag[RC * 4 * 4];
-  for (unsigned int t = threadIdx.x; t < RC * 16; t += blockDim.x) s_diag[t] = a.diagp[t];
-  __syncthreads();
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned int h = lane & 1u, k = (lane >> 1) & (RC - 1);
   // diagp[k][j][0..2] for this lane's two states j = 2h, 2h+1
@@ -275,27 +275,38 @@ __global__ __launch_bounds__(256) void k_derivatives_dna(DerivArgs a)
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) dg[jj][t] = s_diag[(k * 4 + 2 * h + jj) * 4 + t];
+    for (int t = 0; t < 3; ++t) dg[jj][t] = a.diag_inline[(k * 4 + 2 * h + jj) * 4 + t];
   const unsigned int pi = a.params_indices[k];
   const double pinv = a.prop_invar[pi];
   const double wk = a.rate_weights[k];
 
   double acc_d = 0.0, acc_dd = 0.0;
-  const size_t sites = a.sites, total = sites * W;
+  const size_t sites = a.sites;
   const size_t rounds = (sites + 63) / 64;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
   const double2 * __restrict__ ST = reinterpret_cast<const double2 *>(a.sumtable);
+  // (absent array: any valid word will do, the value is replaced by -1 below)
+  const int * inv_site = a.invariant ? a.invariant : reinterpret_cast<const int *>(a.pattern_weights);
+  const bool has_inv = a.invariant != nullptr;
   for (size_t r = wave; r < rounds; r += nwaves)
   {
     double m0 = 1.0, m1 = 0.0, m2 = 0.0;
+    // Everything the round needs is requested up front, unclamped (the table, the
+    // weights and the invariant array carry PLLHIP_TAIL_SITES of slack): W KiB of table
+    // plus the weight of the one site the lane finishes.
+    const size_t n_own = r * 64 + (size_t)(lane & (W - 1)) * SPS + lane / W;
+    const unsigned int pw_own = a.pattern_weights[n_own];
+    const int inv_raw = inv_site[has_inv ? n_own : 0];
+    const int inv_own = has_inv ? inv_raw : -1;
+    const unsigned int grp0 = lane & ~(W - 1);
+    double2 sv[W];
+#pragma unroll
+    for (unsigned int j = 0; j < W; ++j) sv[j] = ld16<NT>(ST + (r * 64 + (size_t)j * SPS) * W + lane);
 #pragma unroll
     for (unsigned int j = 0; j < W; ++j)
     {
-      const size_t g = (r * 64 + (size_t)j * SPS) * W + lane;
-      const size_t gc = g < total ? g : 0;
-      const size_t n = gc / W;
-      const double2 s = ld16<NT>(ST + gc);
+      const double2 s = sv[j];
       double c0 = fma(s.y, dg[1][0], s.x * dg[0][0]);
       double c1 = fma(s.y, dg[1][1], s.x * dg[0][1]);
       double c2 = fma(s.y, dg[1][2], s.x * dg[0][2]);
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void k_derivatives_dna(DerivArgs a)
       if (pinv > 0.0)
       {
         // core_derivatives.c:481-491
-        const int inv = a.invariant ? a.invariant[n] : -1;
+        const int inv = __shfl(inv_own, (int)(grp0 + j), 64); // held by the lane that owns the site
         const double inv_lk = (inv == -1) ? 0.0 : a.freqs[(size_t)pi * 4 + inv] * pinv;
         c0 = c0 * (1.0 - pinv) + inv_lk;
         c1 = c1 * (1.0 - pinv);
@@ -322,12 +333,11 @@ __global__ __launch_bounds__(256) void k_derivatives_dna(DerivArgs a)
       }
       if ((lane & (W - 1)) == j) { m0 = c0; m1 = c1; m2 = c2; }
     }
-    const size_t n = r * 64 + (size_t)(lane & (W - 1)) * SPS + lane / W;
-    if (n < sites)
+    if (n_own < sites)
     {
       const double d1 = -m1 / m0;
       const double d2 = d1 * d1 - m2 / m0;
-      const double pw = (double)a.pattern_weights[n];
+      const double pw = (double)pw_own;
       acc_d += pw * d1;
       acc_dd += pw * d2;
     }
@@ -397,11 +407,17 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     pllhip_set_error("pllhip_likelihood_derivatives: diagptable too large");
     return -1;
   }
-  HIP_TRY(hipStreamSynchronize(c->stream)); // staging buffer free?
-  memcpy(c->h_stage, h_diagptable, dbytes);
-  HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, dbytes, hipMemcpyHostToDevice, c->stream));
-
+  const bool dna = (S == 4 && (R == 1 || R == 2 || R == 4 || R == 8));
+  const bool asc_epilogue = c->sh.asc_states && (c->asc_type & PLLHIP_AB_MASK) &&
+                            (c->asc_type & PLLHIP_AB_MASK) != PLLHIP_AB_STAMATAKIS;
   DerivArgs a;
+  if (dna) memcpy(a.diag_inline, h_diagptable, dbytes);
+  if (!dna || asc_epilogue)
+  {
+    HIP_TRY(hipStreamSynchronize(c->stream)); // staging buffer free?
+    memcpy(c->h_stage, h_diagptable, dbytes);
+    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, dbytes, hipMemcpyHostToDevice, c->stream));
+  }
   a.sumtable = c->sumtable[slot];
   a.diagp = (const double *)c->d_stage;
   a.rate_weights = c->rate_weights;
@@ -436,7 +452,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   }
   unsigned int grid;
   pllhip_prof_scope prof(c, PLLHIP_PROF_DERIVATIVES);
-  if (S == 4 && (R == 1 || R == 2 || R == 4 || R == 8))
+  if (dna)
   {
     grid = pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
