@@ -35,6 +35,17 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
       tab[t] = masksum_seq(a.pmat + ((size_t)kk * 20 + j) * 20, a.tipmap[code], 20) *
                a.freqs[(size_t)a.freqs_indices[kk] * 20 + j];
     }
+  // per-category model words the per-site tail needs: in LDS, because a global load
+  // issued while the next tile's DMA is in flight returns only after that DMA
+  __shared__ double s_model[RC][2];  // prop_invar, rate weight
+  __shared__ double s_freqs[RC][20]; // frequencies of the category's rate matrix
+  for (unsigned int t = threadIdx.x; t < RC * 20u; t += blockDim.x)
+    s_freqs[t / 20u][t % 20u] = a.freqs[(size_t)a.freqs_indices[t / 20u] * 20 + t % 20u];
+  if (threadIdx.x < RC)
+  {
+    s_model[threadIdx.x][0] = a.prop_invar[a.freqs_indices[threadIdx.x]];
+    s_model[threadIdx.x][1] = a.rate_weights[threadIdx.x];
+  }
   __syncthreads();
 
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -46,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
 #pragma unroll
   for (int k = 0; k < RC; ++k)
 #pragma unroll
-    for (int g = 0; g < 5; ++g) pi[k][g] = a.freqs[(size_t)a.freqs_indices[k] * 20 + 4 * g + q];
+    for (int g = 0; g < 5; ++g) pi[k][g] = s_freqs[k][4 * g + q];
 
   const size_t sites = a.sites;
   const size_t tiles = (sites + 15) / 16;
@@ -54,14 +65,59 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
   const bool per_rate = a.rate_scalers && KIND != ROOT;
   double acc = 0.0;
 
-  for (size_t tile = (size_t)blockIdx.x * 4 + wave; tile < tiles; tile += nwaves)
+  // Schedule of a tile (one LDS image per wave): its first operand tile -- the child
+  // for EDGE_II, the parent otherwise -- and the per-site words (scaler counts, pattern
+  // weight, invariant-state index, tip code) were requested while the PREVIOUS tile was
+  // being finished; per-site words first, because loads return in order and anything
+  // requested behind a DMA costs that DMA's latency at its first use.  Nothing is
+  // clamped: every per-site array has PLLHIP_TAIL_SITES of slack.
+  const size_t first = (size_t)blockIdx.x * 4 + wave;
+  const bool has_ps = a.pscaler != nullptr, has_cs = (KIND == EDGE_II && a.cscaler != nullptr);
+  const unsigned int * psp = has_ps ? a.pscaler : a.zero;
+  const unsigned int * csp = has_cs ? a.cscaler : a.zero;
+  const int * invp = a.invariant ? a.invariant : reinterpret_cast<const int *>(a.zero);
+  const bool has_inv = a.invariant != nullptr;
+  unsigned int w_next = 0, code_next = 0, ps_next[RC], cs_next[RC];
+  int inv_next = -1;
+  auto request_site_words = [&](size_t site0) {
+    const size_t n = site0 + s;
+    w_next = a.pattern_weights[n];
+    inv_next = invp[has_inv ? n : 0];
+    if (KIND == EDGE_TI) code_next = a.tip[n];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+    {
+      const bool used = per_rate || k == 0;
+      const size_t e = per_rate ? n * RC + k : n;
+      ps_next[k] = used ? psp[has_ps ? e : 0] : 0u;
+      cs_next[k] = used ? csp[has_cs ? e : 0] : 0u;
+    }
+  };
+  if (first < tiles)
+  {
+    request_site_words(first * 16);
+    dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, first * 16, sites, region, lane);
+  }
+  for (size_t tile = first; tile < tiles; tile += nwaves)
   {
     const size_t site0 = tile * 16;
+    const size_t next = tile + nwaves;
     double b[RC][5], x[RC][5];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // this tile's per-site words have landed with the DMA: take them out of the
+    // registers the next request will overwrite
+    unsigned int w_cur = w_next, code = code_next, ps_cur[RC], cs_cur[RC];
+    int inv_cur = has_inv ? inv_next : -1;
+    asm volatile("" : "+v"(w_cur), "+v"(code), "+v"(inv_cur));
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+    {
+      ps_cur[k] = ps_next[k];
+      cs_cur[k] = cs_next[k];
+      asm volatile("" : "+v"(ps_cur[k]), "+v"(cs_cur[k]));
+    }
     if (KIND == EDGE_II)
     {
-      dma_tile<RC, NT>(a.child, site0, sites, region, lane);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       read_b_operands<RC>(region, s, q, b);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       dma_tile<RC, NT>(a.parent, site0, sites, region, lane);
@@ -70,25 +126,24 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
       for (int k = 0; k < RC; ++k)
 #pragma unroll
         for (int g = 0; g < 5; ++g) x[k][g] = x[k][g] * pi[k][g];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     else
     {
-      dma_tile<RC, NT>(a.parent, site0, sites, region, lane);
-      unsigned int code = 0;
-      if (KIND == EDGE_TI)
-      {
-        code = (site0 + s < sites) ? a.tip[site0 + s] : 0u;
-        if (code >= a.maxstates) code = 0;
-      }
+      if (KIND == EDGE_TI && code >= a.maxstates) code = 0;
 #pragma unroll
       for (int k = 0; k < RC; ++k)
 #pragma unroll
         for (int g = 0; g < 5; ++g)
           x[k][g] = (KIND == EDGE_TI) ? tab[(code * RC + k) * 20 + 4 * g + q] : pi[k][g];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     read_b_operands<RC>(region, s, q, b); // parent CLV, states 4g+q
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (next < tiles)
+    {
+      request_site_words(next * 16);
+      dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, next * 16, sites, region, lane);
+    }
 
     double term[RC];
 #pragma unroll
@@ -113,8 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
 #pragma unroll
         for (int k = 0; k < RC; ++k)
         {
-          unsigned int v = a.pscaler ? a.pscaler[n * RC + k] : 0u;
-          if (KIND == EDGE_II && a.cscaler) v += a.cscaler[n * RC + k];
+          const unsigned int v = ps_cur[k] + cs_cur[k];
           rel[k] = v;
           mn = v < mn ? v : mn;
         }
@@ -130,16 +184,31 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
       {
 #pragma unroll
         for (int k = 0; k < RC; ++k) rel[k] = 0;
-        if (a.pscaler) site_scalings += a.pscaler[n];
-        if (KIND == EDGE_II && a.cscaler) site_scalings += a.cscaler[n];
+        site_scalings = ps_cur[0] + cs_cur[0];
       }
       double terma = 0.0;
 #pragma unroll
-      for (int k = 0; k < RC; ++k) terma += category_term<false>(a, term[k], (unsigned int)k, n, rel[k]);
-      acc += site_loglk(a, terma, n, site_scalings);
+      for (int k = 0; k < RC; ++k)
+      {
+        // category term -> weighted contribution (core_likelihood_avx2.c:480-500)
+        double tr = term[k];
+        if (rel[k] > 0) tr *= scale_minlh(rel[k]);
+        const double pinv = s_model[k][0];
+        const double w = s_model[k][1];
+        if (pinv > 0.0)
+        {
+          const double inv_lk = (inv_cur == -1) ? 0.0 : s_freqs[k][inv_cur];
+          terma += w * (tr * (1.0 - pinv) + inv_lk * pinv);
+        }
+        else
+          terma += tr * w;
+      }
+      double lk = log(terma);
+      if (site_scalings) lk += (double)site_scalings * log(PLLHIP_SCALE_THRESHOLD);
+      lk *= (double)w_cur;
+      if (a.persite) a.persite[n] = lk;
+      acc += lk;
     }
-    // the image is refilled by the next tile's DMA
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   block_sum_to_partials(acc, a.reduce);
 }
