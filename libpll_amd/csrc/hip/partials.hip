@@ -24,6 +24,9 @@
 // workgroup itself, so a tip-tip op reads 2 B/site and writes the CLV.
 //
 // Arithmetic order is the reference's: see numerics.hpp.
+#include <algorithm>
+#include <vector>
+
 #include "ctx.hpp"
 #include "numerics.hpp"
 #include <stdlib.h>
@@ -648,70 +651,93 @@ static int resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, 
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)
 {
   HIP_TRY(hipSetDevice(c->sh.device));
-  // Ops execute in list order on one stream.  Unrooted trees reuse CLV slots, so
-  // dependencies follow BUFFER INDICES, not tree shape (partials.c:184-212):
-  // consecutive 4-state ops of the same kind and scaling mode are merged into one
-  // launch as long as none of them touches a CLV or scale buffer another one
-  // writes, and none writes one another reads -- on a balanced tree that is one
-  // launch per level instead of one per node.
+  // Dependencies between the ops of a list follow BUFFER INDICES, not tree shape
+  // (unrooted trees reuse CLV slots, partials.c:184-212).  Each op gets a level:
+  // one more than the highest level among the earlier ops it must not overtake --
+  // the writers of what it reads (RAW), the writer and the readers of what it writes
+  // (WAW, WAR), on CLVs and on scale buffers alike.  Ops of one level are mutually
+  // independent whatever their position in the list, so each level runs as one
+  // launch per (kind, scaling mode) with blockIdx.y selecting the op.  A balanced
+  // tree gives one launch per tree level; a post-order list of a random 200-taxon
+  // tree, where kinds alternate, gives 3 launches per level instead of one per run of
+  // equal kinds (111 -> see DESIGN.md 2.1).
   const char * nb_env = getenv("PLLHIP_NO_BATCH");
   const bool no_batch = nb_env && atoi(nb_env) != 0;
   const bool dna_fast = c->sh.states == 4 && fast_rc(c->sh.rate_cats);
   const bool aa_fast = c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) &&
                        (!c->sh.pattern_tip || pllhip_aa_fast_covers(c, 2));
   const bool batchable = (dna_fast || aa_fast) && !no_batch;
-  PartialsBatch b;
-  unsigned int nb = 0;
-  int bkind = -1, bmode = -1;
-  unsigned int wr_clv[PLLHIP_BATCH_MAX], rd_clv[2 * PLLHIP_BATCH_MAX];
-  int wr_sc[PLLHIP_BATCH_MAX], rd_sc[2 * PLLHIP_BATCH_MAX];
+  if (!batchable)
+  {
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      PartialsArgs a;
+      int kind, mode;
+      int rc = resolve_op(c, ops[i], a, kind, mode);
+      if (rc) return rc;
+      if ((rc = pllhip_launch_partials(c, a, kind, mode, -1))) return rc;
+    }
+    return 0;
+  }
 
-  auto flush = [&]() -> int {
-    if (!nb) return 0;
-    pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II + bkind);
-    int rc = dna_fast ? pllhip_launch_dna_batch(c, b, nb, bkind, bmode)
-                      : pllhip_launch_aa_batch(c, b, nb, bkind, bmode);
-    nb = 0;
-    return rc;
-  };
-
-  for (unsigned int i = 0; i < count; ++i)
+  struct Planned
   {
     PartialsArgs a;
+    unsigned int key; // level << 8 | kind << 4 | mode
+    unsigned int order;
+  };
+  std::vector<Planned> plan(count);
+  // highest level that wrote / has read each buffer since its last write
+  std::vector<unsigned int> clv_w(c->clv.size(), 0u), clv_r(c->clv.size(), 0u);
+  std::vector<unsigned int> sc_w(c->sh.scale_buffers, 0u), sc_r(c->sh.scale_buffers, 0u);
+  auto upto = [](unsigned int & m, unsigned int v) { if (v > m) m = v; };
+  for (unsigned int i = 0; i < count; ++i)
+  {
     int kind, mode;
-    int rc = resolve_op(c, ops[i], a, kind, mode);
+    int rc = resolve_op(c, ops[i], plan[i].a, kind, mode);
     if (rc) return rc;
-    if (!batchable)
-    {
-      if ((rc = pllhip_launch_partials(c, a, kind, mode, -1))) return rc;
-      continue;
-    }
     const pllhip_op_t & op = ops[i];
-    bool conflict = nb == PLLHIP_BATCH_MAX || (nb && (kind != bkind || mode != bmode));
-    for (unsigned int j = 0; j < nb && !conflict; ++j)
+    unsigned int lvl = 0;
+    upto(lvl, clv_w[op.child1_clv]);
+    upto(lvl, clv_w[op.child2_clv]);
+    upto(lvl, clv_w[op.parent_clv]);
+    upto(lvl, clv_r[op.parent_clv]);
+    if (op.child1_scaler >= 0) upto(lvl, sc_w[op.child1_scaler]);
+    if (op.child2_scaler >= 0) upto(lvl, sc_w[op.child2_scaler]);
+    if (op.parent_scaler >= 0)
     {
-      // RAW / WAW / WAR on CLVs
-      conflict = op.child1_clv == wr_clv[j] || op.child2_clv == wr_clv[j] ||
-                 op.parent_clv == wr_clv[j] || op.parent_clv == rd_clv[2 * j] ||
-                 op.parent_clv == rd_clv[2 * j + 1];
-      // ... and on scale buffers
-      if (wr_sc[j] >= 0)
-        conflict = conflict || op.child1_scaler == wr_sc[j] || op.child2_scaler == wr_sc[j] ||
-                   op.parent_scaler == wr_sc[j];
-      if (op.parent_scaler >= 0)
-        conflict = conflict || op.parent_scaler == rd_sc[2 * j] || op.parent_scaler == rd_sc[2 * j + 1];
+      upto(lvl, sc_w[op.parent_scaler]);
+      upto(lvl, sc_r[op.parent_scaler]);
     }
-    if (conflict && (rc = flush())) return rc;
-    b.op[nb] = a;
-    wr_clv[nb] = op.parent_clv;
-    rd_clv[2 * nb] = op.child1_clv;
-    rd_clv[2 * nb + 1] = op.child2_clv;
-    wr_sc[nb] = op.parent_scaler;
-    rd_sc[2 * nb] = op.child1_scaler;
-    rd_sc[2 * nb + 1] = op.child2_scaler;
-    bkind = kind;
-    bmode = mode;
-    ++nb;
+    ++lvl;
+    clv_w[op.parent_clv] = lvl;
+    clv_r[op.parent_clv] = 0;
+    upto(clv_r[op.child1_clv], lvl);
+    upto(clv_r[op.child2_clv], lvl);
+    if (op.parent_scaler >= 0)
+    {
+      sc_w[op.parent_scaler] = lvl;
+      sc_r[op.parent_scaler] = 0;
+    }
+    if (op.child1_scaler >= 0) upto(sc_r[op.child1_scaler], lvl);
+    if (op.child2_scaler >= 0) upto(sc_r[op.child2_scaler], lvl);
+    plan[i].key = (lvl << 8) | ((unsigned int)kind << 4) | (unsigned int)mode;
+    plan[i].order = i;
   }
-  return flush();
+  std::stable_sort(plan.begin(), plan.end(),
+                   [](const Planned & x, const Planned & y) { return x.key < y.key; });
+
+  PartialsBatch b;
+  for (unsigned int i = 0; i < count;)
+  {
+    const unsigned int key = plan[i].key;
+    unsigned int nb = 0;
+    while (i < count && plan[i].key == key && nb < PLLHIP_BATCH_MAX) b.op[nb++] = plan[i++].a;
+    const int kind = (int)((key >> 4) & 15u), mode = (int)(key & 15u);
+    pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II + kind);
+    int rc = dna_fast ? pllhip_launch_dna_batch(c, b, nb, kind, mode)
+                      : pllhip_launch_aa_batch(c, b, nb, kind, mode);
+    if (rc) return rc;
+  }
+  return 0;
 }
