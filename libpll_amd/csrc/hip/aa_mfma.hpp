@@ -24,10 +24,12 @@ struct aa_geom
   static constexpr size_t LDS_BYTES = (size_t)PTAB * 8 + 4 * (size_t)REGION_B;
 };
 
-// copy the 16-site tile starting at site0 of `clv` into the wave's LDS image
-template <int RC, bool NT>
-__device__ __forceinline__ void dma_tile(const double * __restrict__ clv, size_t site0, size_t sites,
-                                         char * region, unsigned int lane)
+// Per-lane byte offsets of the N_IT 16-byte granules a lane moves for a tile, relative
+// to the tile's first byte in HBM: granule P = it*64 + lane of the padded image is
+// (site P / ROW_G, column P % ROW_G); the pad column re-loads the row's last granule.
+// Computed once per kernel: 11 VGPRs instead of 64-bit addresses rebuilt per tile.
+template <int RC>
+__device__ __forceinline__ void tile_offsets(unsigned int lane, unsigned int (&off)[aa_geom<RC>::N_IT])
 {
   using G = aa_geom<RC>;
 #pragma unroll
@@ -37,13 +39,28 @@ __device__ __forceinline__ void dma_tile(const double * __restrict__ clv, size_t
     if (P > G::TILE_G - 1) P = G::TILE_G - 1;
     const int site = P / G::ROW_G;
     int col = P - site * G::ROW_G;
-    if (col > G::ROW_G - 2) col = G::ROW_G - 2; // pad granule: re-load the row's last one
-    size_t n = site0 + (size_t)site;
-    if (n >= sites) n = sites - 1;
-    const double * src = clv + (n * (size_t)(RC * 10) + (size_t)col) * 2;
-    __builtin_amdgcn_global_load_lds((const PLL_AS1 void *)src,
-                                     (PLL_AS3 void *)(region + it * 1024), 16, 0, NT ? 2 : 0);
+    if (col > G::ROW_G - 2) col = G::ROW_G - 2;
+    off[it] = (unsigned int)((site * (RC * 10) + col) * 16);
   }
+}
+
+// copy the 16-site tile starting at site0 (wave-uniform) of `clv` into the wave's LDS
+// image.  Sites past the end of the CLV are read too (every per-site array carries
+// PLLHIP_TAIL_SITES of slack); what is computed from them is never stored.
+template <int RC, bool NT>
+__device__ __forceinline__ void dma_tile(const double * __restrict__ clv, size_t site0,
+                                         const unsigned int (&off)[aa_geom<RC>::N_IT], char * region)
+{
+  using G = aa_geom<RC>;
+  // the tile's base address is the same in every lane: say so, it then lives in SGPRs
+  const unsigned long long b = (unsigned long long)(clv + site0 * (size_t)(RC * 20));
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
+  const char * base = reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+#pragma unroll
+  for (int it = 0; it < G::N_IT; ++it)
+    __builtin_amdgcn_global_load_lds((const PLL_AS1 void *)(base + off[it]),
+                                     (PLL_AS3 void *)(region + it * 1024), 16, 0, NT ? 2 : 0);
 }
 
 // B operands of the whole tile: b[k][c] = state 4c+q of (site s, rate k)
@@ -59,29 +76,33 @@ __device__ __forceinline__ void read_b_operands(const char * region, unsigned in
       b[k][c] = *reinterpret_cast<const double *>(region + s * ROW_B + k * 160 + (4 * c + q) * 8);
 }
 
-// x[k][g] = state 4g+q of  P_k . (column s of the tile), for one child
+// o[g] = state 4g+q of  P . (column s of the tile) for one child and one rate
+// (pk = that rate's 20x20 matrix in LDS, bk = the column's B operands)
+__device__ __forceinline__ void rate_matvec(const double * pk, const double (&bk)[5],
+                                            unsigned int lane, double (&o)[5])
+{
+  const unsigned int i = lane & 3u, q = lane >> 4;
+#pragma unroll
+  for (int g = 0; g < 5; ++g)
+  {
+    double ag[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) ag[c] = pk[(4 * g + i) * S20 + 4 * c + q];
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+      acc = __builtin_amdgcn_mfma_f64_4x4x4f64(ag[c], bk[c], acc, 0, 0, 0);
+    o[g] = acc;
+  }
+}
+
+// x[k][g] for all rates of one child
 template <int RC>
 __device__ __forceinline__ void tile_matvec(const double * ptab_child, const double (&b)[RC][5],
                                             unsigned int lane, double (&x)[RC][5])
 {
-  const unsigned int i = lane & 3u, q = lane >> 4;
 #pragma unroll
-  for (int k = 0; k < RC; ++k)
-  {
-    const double * pk = ptab_child + (size_t)k * S20 * S20;
-#pragma unroll
-    for (int g = 0; g < 5; ++g)
-    {
-      double ag[5];
-#pragma unroll
-      for (int c = 0; c < 5; ++c) ag[c] = pk[(4 * g + i) * S20 + 4 * c + q];
-      double acc = 0.0;
-#pragma unroll
-      for (int c = 0; c < 5; ++c)
-        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(ag[c], b[k][c], acc, 0, 0, 0);
-      x[k][g] = acc;
-    }
-  }
+  for (int k = 0; k < RC; ++k) rate_matvec(ptab_child + (size_t)k * S20 * S20, b[k], lane, x[k]);
 }
 
 // all 4 lanes of this lane's tile column (s, s+16, s+32, s+48) have the flag set

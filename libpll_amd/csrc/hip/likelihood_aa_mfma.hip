@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
 #pragma unroll
     for (int g = 0; g < 5; ++g) pi[k][g] = s_freqs[k][4 * g + q];
 
+  unsigned int toff[G::N_IT];
+  tile_offsets<RC>(lane, toff);
   const size_t sites = a.sites;
   const size_t tiles = (sites + 15) / 16;
   const size_t nwaves = (size_t)gridDim.x * 4;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
   if (first < tiles)
   {
     request_site_words(first * 16);
-    dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, first * 16, sites, region, lane);
+    dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, first * 16, toff, region);
   }
   for (size_t tile = first; tile < tiles; tile += nwaves)
   {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     {
       read_b_operands<RC>(region, s, q, b);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      dma_tile<RC, NT>(a.parent, site0, sites, region, lane);
+      dma_tile<RC, NT>(a.parent, site0, toff, region);
       tile_matvec<RC>(tab, b, lane, x);
 #pragma unroll
       for (int k = 0; k < RC; ++k)
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     if (next < tiles)
     {
       request_site_words(next * 16);
-      dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, next * 16, sites, region, lane);
+      dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, next * 16, toff, region);
     }
 
     double term[RC];

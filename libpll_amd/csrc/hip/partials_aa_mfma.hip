@@ -72,13 +72,22 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
   char * region = reinterpret_cast<char *>(ptab_r + RC * 400) + wave * G::REGION_B;
   constexpr int ROW_B = G::ROW_G * 16;
 
+  unsigned int toff[G::N_IT];
+  tile_offsets<RC>(lane, toff);
+  unsigned int store_mask = 0; // bit it: granule it*64+lane of the image is data (not pad, not past the tile)
+#pragma unroll
+  for (int it = 0; it < G::N_IT; ++it)
+  {
+    const int P = it * 64 + (int)lane;
+    if (P < G::TILE_G && (P % G::ROW_G) < G::ROW_G - 1) store_mask |= 1u << it;
+  }
   const size_t sites = a.sites;
   const size_t tiles = (sites + 15) / 16;
-  const size_t nwaves = (size_t)gridDim.x * 4;
+  const unsigned int wpb = blockDim.x >> 6; // waves per workgroup
+  const size_t nwaves = (size_t)gridDim.x * wpb;
   const unsigned int * ls = a.lscaler ? a.lscaler : a.zero;
   const unsigned int * rs = a.rscaler ? a.rscaler : a.zero;
   const bool has_l = a.lscaler != nullptr, has_r = a.rscaler != nullptr;
-  double2 * out = reinterpret_cast<double2 *>(a.parent);
 
   // One tile = load left, load right, multiply, scale, store.  Its stores are
   // issued one iteration late -- after the NEXT tile's left operands have been
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
   // multiplied, and (b) a wave never sits waiting for its own write
   // acknowledgements with nothing else in flight (vmcnt counts loads and stores
   // in one queue).  Measured on the 200 k-site op: 72 -> see DESIGN.md 2.2.
-  const size_t first = (size_t)blockIdx.x * 4 + wave;
+  const size_t first = (size_t)blockIdx.x * wpb + wave;
   if (first >= tiles) return; // (no barrier follows)
   double x[RC][5];            // products of the tile whose stores are pending
   unsigned int psc[RC];       // its parent scaler count(s), lanes q == 0
@@ -113,14 +122,19 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
       if (P > G::TILE_G - 1) P = G::TILE_G - 1;
       v[it] = *reinterpret_cast<const double2 *>(region + P * 16);
     }
+    // destination = (uniform) start of the tile in the parent CLV + the same per-lane
+    // offsets the DMA uses; pad lanes and sites past the end do not store
+    const unsigned long long ob = (unsigned long long)(a.parent + prev_site0 * (size_t)(RC * 20));
+    const unsigned int olo = __builtin_amdgcn_readfirstlane((unsigned int)ob);
+    const unsigned int ohi = __builtin_amdgcn_readfirstlane((unsigned int)(ob >> 32));
+    char * obase = reinterpret_cast<char *>(((unsigned long long)ohi << 32) | olo);
+    const unsigned int left_sites = (unsigned int)(sites - prev_site0 < 16 ? sites - prev_site0 : 16);
 #pragma unroll
     for (int it = 0; it < G::N_IT; ++it)
     {
-      const int P = it * 64 + (int)lane;
-      const int site = P / G::ROW_G, col = P - site * G::ROW_G;
-      const size_t ns = prev_site0 + (size_t)site;
-      if (P < G::TILE_G && col < G::ROW_G - 1 && ns < sites)
-        st16<NT>(out + ns * (size_t)(RC * 10) + (size_t)col, v[it].x, v[it].y);
+      const unsigned int site = toff[it] / (unsigned int)(RC * 160);
+      if (((store_mask >> it) & 1u) && site < left_sites)
+        st16<NT>(reinterpret_cast<double2 *>(obase + toff[it]), v[it].x, v[it].y);
     }
     const size_t n = prev_site0 + s;
     if (MODE == SCALE_SITE && q == 0 && n < sites) a.pscaler[n] = psc[0];
@@ -151,12 +165,12 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     }
   };
   load_scalers(first * 16);
-  dma_tile<RC, NT>(KIND == 0 ? a.left : a.right, first * 16, sites, region, lane);
+  dma_tile<RC, NT>(KIND == 0 ? a.left : a.right, first * 16, toff, region);
   for (size_t tile = first; tile < tiles; tile += nwaves)
   {
     const size_t site0 = tile * 16;
     const size_t next = tile + nwaves;
-    double b[RC][5], xl[RC][5], y[RC][5];
+    double b[RC][5], xl[RC][5];
 
     // ---- first operand tile of this iteration has been requested earlier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     if (have_prev) flush();
     if (KIND == 0)
     {
-      dma_tile<RC, NT>(a.right, site0, sites, region, lane);
+      dma_tile<RC, NT>(a.right, site0, toff, region);
       tile_matvec<RC>(ptab, b, lane, xl); // overlaps the right child's DMA and the stores
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       read_b_operands<RC>(region, s, q, b);
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     if (next < tiles)
     {
       load_scalers(next * 16);
-      dma_tile<RC, NT>(KIND == 0 ? a.left : a.right, next * 16, sites, region, lane);
+      dma_tile<RC, NT>(KIND == 0 ? a.left : a.right, next * 16, toff, region);
     }
     if (KIND == 1)
     {
@@ -196,19 +210,19 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 #pragma unroll
         for (int g = 0; g < 5; ++g) xl[k][g] = ptab[(code * RC + k) * 20 + 4 * g + q];
     }
-    tile_matvec<RC>(ptab_r, b, lane, y);
-
-    // ---- product + scaling (core_partials_avx2.c:752-800)
+    // ---- right products, product + scaling (core_partials_avx2.c:752-800), a rate at a time
     bool small_site = true;
     bool small_rate[RC];
 #pragma unroll
     for (int k = 0; k < RC; ++k)
     {
+      double yk[5];
+      rate_matvec(ptab_r + (size_t)k * S20 * S20, b[k], lane, yk);
       small_rate[k] = true;
 #pragma unroll
       for (int g = 0; g < 5; ++g)
       {
-        x[k][g] = xl[k][g] * y[k][g];
+        x[k][g] = xl[k][g] * yk[g];
         small_rate[k] = small_rate[k] && (x[k][g] < PLLHIP_SCALE_THRESHOLD);
       }
       small_site = small_site && small_rate[k];
@@ -314,14 +328,19 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   using G = aa_geom<RC>;
   const PartialsArgs & a = b.op[0];
   const size_t tiles = ((size_t)a.sites + 15) / 16;
-  size_t blocks = (tiles + 3) / 4;
-  // two 4-wave workgroups per CU are resident (71 KB of LDS each); the P-matrix
-  // staging per workgroup is amortised over several tiles per wave
+  // Two workgroups per CU share its 160 KB of LDS; each holds the P tables (or the tip
+  // table) once and one 11 KB image per wave.  Four waves per workgroup: a fifth fits
+  // for inner-inner ops (25.6 + 5 x 11 = 80 KB) and was measured -- 69.0 us per op
+  // against 66.7 us: at 8 waves per CU the kernel is no longer short of bytes in flight.
+  const size_t left_elems = (KIND == 0) ? (size_t)RC * 400 : (size_t)a.maxstates * RC * 20;
+  const size_t fixed = (left_elems + (size_t)RC * 400) * sizeof(double);
+  const unsigned int wpb = 4u;
+  size_t blocks = (tiles + wpb - 1) / wpb;
+  // the P-matrix staging per workgroup is amortised over several tiles per wave
   const size_t cap = (size_t)c->num_cus * 2;
   if (blocks > cap) blocks = cap;
-  const dim3 grid((unsigned int)blocks, count), block(256);
-  const size_t left_elems = (KIND == 0) ? (size_t)RC * 400 : (size_t)a.maxstates * RC * 20;
-  const size_t lds = (left_elems + (size_t)RC * 400) * sizeof(double) + 4 * (size_t)G::REGION_B;
+  const dim3 grid((unsigned int)blocks, count), block(64 * wpb);
+  const size_t lds = fixed + wpb * (size_t)G::REGION_B;
   if (lds > 80 * 1024) return 1; // two workgroups per CU must fit
   // more than 64 KB of dynamic LDS has to be requested per kernel
 #define AA_LAUNCH_ONE(KERNEL)                                                                 \
