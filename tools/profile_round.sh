@@ -30,3 +30,5 @@ run c3 --states 20 --sites 200000
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/mfma_c3" -- \
     python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --states 20 --sites 200000 > /dev/null 2> "$out/mfma_c3.err"
 ls "$out"
+# BASELINE config 5's shape (200-taxon random tree, 500 k sites) with the Newton inner loop
+(cd "$root" && python3 bench.py --sites 500000 --taxa 200 --tree random --newton 5 --cpu-sites 0 > "$out/bench_c5shape.json" 2> "$out/bench_c5shape.err")
