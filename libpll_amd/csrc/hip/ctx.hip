@@ -112,6 +112,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   // CLVs are zeroed like the reference's (pll.c:525-542); scalers calloc'd (pll.c:800-815)
   if ((rc = dev_alloc(&c->clv_arena, n_clv * c->clv_elems + PLLHIP_TAIL_SITES * c->span, true, c->stream)))
     goto fail;
+  c->clv_arena_bytes = n_clv * c->clv_elems * sizeof(double);
   c->clv.assign(nodes, nullptr);
   for (unsigned int i = first; i < nodes; ++i)
     c->clv[i] = c->clv_arena + (size_t)(i - first) * c->clv_elems;

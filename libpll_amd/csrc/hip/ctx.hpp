@@ -80,6 +80,7 @@ struct pllhip_ctx
   unsigned int asc_weight_sum = 0;
   double * d_asc = nullptr;              // [3] correction terms added by the final sum
   const double * pending_extra = nullptr; // consumed by the next pllhip_reduce_out
+  size_t clv_arena_bytes = 0;            // all CLVs of the partition
   int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements)
   // 20 states: 1 = bit-exact vector kernels only (env PLLHIP_AA_EXACT=1);
   // 0 = matrix-core kernels where they exist (last-bit differences, see
@@ -136,14 +137,16 @@ static inline double * pllhip_pmat_ptr(const pllhip_ctx * c, unsigned int idx)
   return c->pmatrix + (size_t)idx * c->pmat_elems;
 }
 
-// Streams that cannot be reused from cache before they are evicted (one CLV
-// bigger than a quarter of the 256 MiB Infinity Cache) use non-temporal loads
-// and stores; smaller partitions keep the default policy so a parent written by
-// one op is still on-die when the next op reads it.
+// Cache policy of the streaming kernels.  While all CLVs of the partition together fit
+// the 256 MiB Infinity Cache, the default policy keeps a parent written by one op on die
+// for the op that reads it; beyond that nothing survives until it is needed again and
+// non-temporal loads and stores are faster.  Measured (4 states, 64 taxa, whole
+// evaluation, G site-updates/s, default / non-temporal): 25 k sites (200 MB of CLVs)
+// 15.0 / 13.7; 50 k (400 MB) 17.1 / 17.9; 100 k 17.3 / 18.8; 250 k 18.7 / 20.1.
 static inline bool pllhip_use_nt(const pllhip_ctx * c)
 {
   if (c->nt_override >= 0) return c->nt_override != 0;
-  return c->clv_elems * sizeof(double) >= ((size_t)64 << 20);
+  return c->clv_arena_bytes >= ((size_t)256 << 20);
 }
 
 // Grid size for a streaming kernel over `items` lanes-worth of work: all of it
