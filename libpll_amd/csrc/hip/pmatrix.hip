@@ -11,6 +11,8 @@
 #include "ctx.hpp"
 #include "numerics.hpp"
 
+#define PMAT_INLINE 256
+
 struct PmatArgs
 {
   double * pmatrix;              // [prob_matrices][R][S][S]
@@ -23,6 +25,11 @@ struct PmatArgs
   const double * branch_lengths;       // [count]
   unsigned int states, rate_cats;
   unsigned int params_indices[PLLHIP_MAX_RATE_CATS];
+  // up to PMAT_INLINE branches travel as kernel arguments (used when matrix_indices is
+  // null): no staging copy and, above all, no draining of the stream to reuse the
+  // staging buffer -- a branch-length update in the middle of queued work costs a launch
+  unsigned int mi_inline[PMAT_INLINE];
+  double bl_inline[PMAT_INLINE];
 };
 
 __global__ __launch_bounds__(256) void k_update_pmatrix(PmatArgs a)
@@ -30,8 +37,9 @@ __global__ __launch_bounds__(256) void k_update_pmatrix(PmatArgs a)
   extern __shared__ double s_expd[]; // [R][S]
   const unsigned int S = a.states, R = a.rate_cats;
   const unsigned int b = blockIdx.x;
-  const double t = a.branch_lengths[b];
-  double * const pm = a.pmatrix + (size_t)a.matrix_indices[b] * R * S * S;
+  const bool inl = a.matrix_indices == nullptr;
+  const double t = inl ? a.bl_inline[b] : a.branch_lengths[b];
+  double * const pm = a.pmatrix + (size_t)(inl ? a.mi_inline[b] : a.matrix_indices[b]) * R * S * S;
 
   if (t == 0.0)
   {
@@ -132,9 +140,26 @@ extern "C" int pllhip_update_pmatrices(pllhip_ctx_t * c, const unsigned int * h_
     a.params_indices[n] = h_params_indices[n];
   }
 
-  // The staging buffer is reused by later calls, and the copy below reads it
-  // asynchronously: chunk so one chunk fits, and drain the stream before the
-  // host overwrites it again.
+  const size_t lds_small = (size_t)c->sh.rate_cats * c->sh.states * sizeof(double);
+  if (count <= 4 * PMAT_INLINE)
+  {
+    a.matrix_indices = nullptr;
+    a.branch_lengths = nullptr;
+    for (unsigned int done = 0; done < count;)
+    {
+      const unsigned int n = (count - done < PMAT_INLINE) ? count - done : PMAT_INLINE;
+      memcpy(a.mi_inline, h_matrix_indices + done, n * sizeof(unsigned int));
+      memcpy(a.bl_inline, h_branch_lengths + done, n * sizeof(double));
+      pllhip_prof_scope prof(c, PLLHIP_PROF_PMATRIX);
+      k_update_pmatrix<<<n, 256, lds_small, c->stream>>>(a);
+      HIP_TRY(hipGetLastError());
+      done += n;
+    }
+    return 0;
+  }
+  // Long lists go through the staging buffer.  It is reused by later calls, and the
+  // copy below reads it asynchronously: chunk so one chunk fits, and drain the stream
+  // before the host overwrites it again.
   const size_t per = sizeof(double) + sizeof(unsigned int);
   const unsigned int chunk_max = (unsigned int)(c->stage_bytes / (2 * per));
   for (unsigned int done = 0; done < count;)
