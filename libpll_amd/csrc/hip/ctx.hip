@@ -137,7 +137,6 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if ((rc = dev_alloc(&c->block_partials, (size_t)PLLHIP_REDUCE_BLOCKS * 2, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->d_result, (size_t)4, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->d_zero, (size_t)4, true, c->stream))) goto fail;
-  if ((rc = dev_alloc(&c->d_sink, (size_t)128, true, c->stream))) goto fail;
   HIP_TRY(hipHostMalloc((void **)&c->h_result, 4 * sizeof(double), hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void **)&c->h_result_dev, c->h_result, 0));
   if ((rc = dev_alloc(&c->d_counter, (size_t)4, true, c->stream))) goto fail;
@@ -256,7 +255,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   void * bufs[] = {c->clv_arena, c->tipchars, c->scaler_arena, c->pmatrix, c->eigenvals,
                    c->eigenvecs, c->inv_eigenvecs, c->freqs, c->prop_invar, c->rates,
                    c->rate_weights, c->pattern_weights, c->invariant, c->tipmap,
-                   c->block_partials, c->d_result, c->d_counter, c->d_zero, c->d_sink, c->d_tiptab, c->d_persite, c->d_stage, c->d_asc,
+                   c->block_partials, c->d_result, c->d_counter, c->d_zero, c->d_tiptab, c->d_persite, c->d_stage, c->d_asc,
                    c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3]};
   for (void * p : bufs)
     if (p) (void)hipFree(p);

@@ -52,7 +52,6 @@ struct pllhip_ctx
   double * block_partials = nullptr;   // [PLLHIP_REDUCE_BLOCKS][2]
   double * d_result = nullptr;         // [4]
   unsigned int * d_zero = nullptr;     // [4] zeros
-  double * d_sink = nullptr;           // [128] write-only scratch
   double * d_tiptab = nullptr;         // 20 states: [2][maxstates][rate_cats][20] tip row sums of the current op
   size_t tiptab_elems = 0;
   double * h_result = nullptr;         // pinned, host-mapped [4]
@@ -180,7 +179,6 @@ struct PartialsArgs
   const unsigned int * rscaler;
   const unsigned int * __restrict__ tipmap;
   const unsigned int * zero;             // one device word holding 0 (stand-in for absent scalers)
-  double * sink;                         // 1 KB scratch that masked-off lanes may store to
   const double * ltab;                   // precomputed tip row sums [code][rate][state] (20 states)
   const double * rtab;
   unsigned int sites, rate_cats, states, maxstates;
@@ -188,7 +186,7 @@ struct PartialsArgs
 
 // Several mutually independent ops (one tree level) run in ONE launch:
 // blockIdx.y selects the op.  The op descriptors travel as kernel arguments
-// (24 x 136 B < the 4 KB kernarg segment), so batching needs no staging copy.
+// (24 x 128 B < the 4 KB kernarg segment), so batching needs no staging copy.
 // Every per-site device array carries this many sites of zeroed slack behind its last
 // element, so that a wave working on the last (partial) round of 64 sites may load
 // unconditionally and unclamped; what it computes there is masked out of every result.

@@ -127,7 +127,6 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
   a.parent = c->sumtable[slot];
   a.tipmap = c->tipmap;
   a.zero = c->d_zero;
-  a.sink = c->d_sink;
   a.sites = c->sh.sites;
   a.rate_cats = R;
   a.states = S;

@@ -8,15 +8,19 @@
 //   tip-tip      pll_core_create_lookup + pll_core_update_partial_tt
 //                core_partials.c:725,82; AVX2-flag path core_partials_avx.c:262,146,581,531
 //
-// Mapping: one lane per (site, rate category).  CLVs are [site][rate][state]
-// with state fastest, so lane e reads bytes [e*8*S, (e+1)*8*S): a wave streams
-// 64*8*S contiguous bytes per child with 16-byte loads.  The P-matrices of the
-// lane's rate category sit in VGPRs (4 states: 2 x 16 doubles, loaded once per
-// lane and reused over the grid-stride loop) or in LDS (20+ states).
-// Per-site scaling needs "all rate_cats x states entries < 2^-256": each lane
-// tests its own states, then one __ballot gives every lane the bits of its
-// rate_cats neighbours (rate_cats is a power of two <= 16 in the fast kernels,
-// so a site never straddles a wave).
+// Three families of kernels live here:
+//   4 states            k_dna_partials: one lane per 16 bytes, rounds of 64 sites (below)
+//   20 states, bit-exact k_aa_ii / _ti / _tt: one lane per (site, rate), P in LDS
+//                       (the default 20-state path is partials_aa_mfma.hip)
+//   anything else       k_gen_partials: one lane per site, plain left-to-right sums
+// CLVs are [site][rate][state] with state fastest, so consecutive lanes touch
+// consecutive memory in all three.  Per-site scaling needs "all rate_cats x
+// states entries < 2^-256": each lane tests its own entries, then one __ballot
+// gives every lane the bits of the lanes that share its site (rate_cats is a
+// power of two <= 16 in the fast kernels, so a site never straddles a wave).
+//
+// pllhip_update_partials (bottom of the file) schedules an op list by dependency
+// level and launches one kernel per (level, kind, scaling mode).
 //
 // Roofline: pure HBM stream.  4 states: 396 B and 240 flop per site-update
 // (0.6 flop/B); nothing but the child CLVs, the parent CLV and 12 B of
@@ -598,7 +602,6 @@ static int resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, 
   a.pscaler = pllhip_scaler_ptr(c, op.parent_scaler);
   a.tipmap = c->tipmap;
   a.zero = c->d_zero;
-  a.sink = c->d_sink;
   a.sites = c->sh.sites;
   a.rate_cats = c->sh.rate_cats;
   a.states = c->sh.states;
