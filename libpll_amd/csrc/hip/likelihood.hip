@@ -7,16 +7,21 @@
 // core_likelihood_avx2.c:111) and pll_core_root_loglikelihood
 // (core_likelihood.c:25).
 //
-// Mapping: one lane per (site, rate) like the CLV update; the rate_cats lanes
-// of a site exchange their category terms with __shfl and the lane of category
-// 0 adds them in category order (the reference's order), takes the log, applies
-// scalers and the pattern weight.  HBM traffic per site: two CLVs + two scalers
-// + one weight (268 B for 4x4), nothing written unless persite_lnl is asked for.
+// Kernels: k_lnl_dna (4 states: one lane per 16 bytes, rounds of 64 sites as in
+// partials.hip; after a round every lane owns one site and finishes it -- log,
+// scaler term, pattern weight, optional per-site store -- once), k_lnl_fast
+// (20 states bit-exact: one lane per (site, rate), categories combined with
+// __shfl in category order), k_lnl_gen (any other state count: one lane per
+// site).  The default 20-state path is likelihood_aa_mfma.hip.  HBM traffic per
+// site: two CLVs + two scalers + one weight (268 B for 4x4), nothing written
+// unless persite_lnl is asked for.
 //
 // Site sum: per-lane running sums -> wave __shfl_down tree -> LDS -> one double
-// per workgroup -> a second one-workgroup kernel adds the workgroup values in a
-// fixed order, so the result is reproducible run to run (the reference adds
-// sites sequentially; agreement is ~1e-16*sqrt(sites) relative).
+// per workgroup -> fixed-order final sum, fused into the same launch for grids of
+// up to 512 workgroups (last-arriving workgroup), a one-workgroup k_final_sum
+// launch otherwise (lnl_common.hpp).  Reproducible run to run; the reference adds
+// sites sequentially, agreement is ~1e-16*sqrt(sites) relative.  The final step
+// also adds the ascertainment-bias correction when one is set (asc_bias.hip).
 #include "ctx.hpp"
 #include "numerics.hpp"
 
