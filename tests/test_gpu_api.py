@@ -302,3 +302,39 @@ def test_one_rate_matrix_per_category(gpu, ref, aa_mode, states, pinv):
         assert rel_err(np.array(dg), np.array(dr)) < 1e-9, (t, dg, dr)
     g.destroy()
     r.destroy()
+
+
+def test_two_threads_two_partitions(gpu, orc):
+    """Distinct partitions used concurrently from distinct threads (the reference's
+    threading contract): each thread runs full evaluations on its own
+    partition (own stream); results must equal the single-threaded ones bit for bit."""
+    import threading
+    cases = [make_case(4, "random", 20, 700 + 113 * i, seed=60 + i) for i in range(4)]
+    parts = [build_partition(gpu, c, ATTRIB_PATTERN_TIP) for c in cases]
+    expect = []
+    for p, c in zip(parts, cases):
+        p.update_partials(c["plan"].ops)
+        expect.append(p.compute_edge_loglikelihood(*c["plan"].root_edge, [0] * 4))
+    got = [[] for _ in cases]
+    errors = []
+
+    def worker(i):
+        try:
+            p, plan = parts[i], cases[i]["plan"]
+            for _ in range(40):
+                p.update_prob_matrices([0] * 4, plan.matrix_indices, plan.branch_lengths)
+                p.update_partials(plan.ops)
+                got[i].append(p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4))
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for i in range(len(cases)):
+        assert got[i] == [expect[i]] * 40, i
+    for p in parts:
+        p.destroy()
