@@ -323,13 +323,11 @@ __global__ __launch_bounds__(256) void k_derivatives_dna(DerivArgs a)
         c2 = c2 * (1.0 - pinv);
       }
       c0 *= wk; c1 *= wk; c2 *= wk;
-      // sum the RC categories of the site (lanes 2i of the group hold them)
-      for (unsigned int off = 2; off < W; off <<= 1)
-      {
-        c0 += __shfl_xor(c0, (int)off, 64);
-        c1 += __shfl_xor(c1, (int)off, 64);
-        c2 += __shfl_xor(c2, (int)off, 64);
-      }
+      // sum the RC categories of the site (both lanes of a pair hold the category's
+      // value): DPP butterflies, same association as xor-2 / xor-4 / xor-8 shuffles
+      c0 = dpp_group_sum_pairs<W>(c0);
+      c1 = dpp_group_sum_pairs<W>(c1);
+      c2 = dpp_group_sum_pairs<W>(c2);
       if ((lane & (W - 1)) == j) { m0 = c0; m1 = c1; m2 = c2; }
     }
     if (n_own < sites)

@@ -247,6 +247,29 @@ __device__ __forceinline__ double dpp_pair_swap(double v)
   return __hiloint2double(hi, lo);
 }
 
+// DPP lane exchanges (VALU, no LDS crossbar): CTRL 0x4E = quad_perm [2,3,0,1] (xor 2),
+// 0x141 = row_half_mirror (lane i <-> 7 - i of each 8), 0x140 = row_mirror (i <-> 15 - i)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum of v over the W = 2, 4, 8 or 16 consecutive lanes of a group whose lane pairs
+// (2m, 2m+1) already hold equal values: pairwise tree (v0+v1)+(v2+v3) ..., the same
+// association as xor-2, xor-4, xor-8 butterflies, every lane of the group gets the total.
+template <int W>
+__device__ __forceinline__ double dpp_group_sum_pairs(double v)
+{
+  if (W >= 4) v += dpp_move<0x4E>(v);  // the other pair of the quad
+  if (W >= 8) v += dpp_move<0x141>(v); // the other quad of the 8 (all 4 lanes of a quad are equal)
+  if (W >= 16) v += dpp_move<0x140>(v); // the other 8 of the 16
+  return v;
+}
+
 // matrix rows 2h, 2h+1 of category k, columns split into the lane's own pair
 // (2h, 2h+1) and its partner's: m[r][0..1] own, m[r][2..3] partner
 struct half_rows
