@@ -313,6 +313,50 @@ def test_full_size_properties(gpu):
     q.destroy()
 
 
+def test_full_size_properties_20_states(gpu, monkeypatch):
+    """BASELINE.json configs[2] (20 states, 4 rates, 200,000 sites, 64 taxa) on the
+    matrix-core kernels: reduction complete, halves add up to the whole (per-site
+    values of a half bitwise equal to the whole's -- a tile never mixes sites), run to
+    run reproducible, scaler counts identical to the bit-exact vector kernels' and lnL
+    within the stated tolerance of theirs."""
+    sites, T, R = 200_000, 64, 4
+    plan = W.balanced_tree(T, seed=42)
+    rates, freqs = gpu.aa_model("lg")
+    seqs = W.simulated_alignment(plan, sites, rates, freqs, gpu.compute_gamma_cats(W.GAMMA_ALPHA, R),
+                                 seed=42)
+    fi = [0] * R
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "0")
+    p = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
+    assert np.isfinite(lnl) and lnl < 0
+    assert abs(ps.sum() - lnl) <= 1e-11 * abs(lnl)
+    p.update_partials(plan.ops)
+    lnl2, ps2 = p.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
+    assert lnl2 == lnl and bits_equal(ps, ps2)
+    top_scaler = p.get_scaler(int(plan.ops[-1]["parent_scaler_index"]))
+
+    halves = []
+    for lo, hi in ((0, 99_984), (99_984, sites)):     # a multiple of 16 sites: whole tiles
+        h = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP, site_range=(lo, hi))
+        h.update_partials(plan.ops)
+        v, hps = h.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
+        assert bits_equal(hps, ps[lo:hi])
+        halves.append(v)
+        h.destroy()
+    assert abs(sum(halves) - lnl) <= 1e-12 * abs(lnl)
+    p.destroy()
+
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")
+    n = 50_000
+    e = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP, site_range=(0, n))
+    e.update_partials(plan.ops)
+    _, eps = e.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
+    assert rel_err(ps[:n], eps) < MFMA_LNL_RTOL
+    assert (e.get_scaler(int(plan.ops[-1]["parent_scaler_index"])) == top_scaler[:n]).all()
+    e.destroy()
+
+
 def test_full_size_against_reference_sample(gpu, ref):
     """A 100,000-site slice of the full workload through the genuine reference
     (AVX2 flag) and through the HIP path: scalers and per-site lnL bitwise."""
