@@ -91,6 +91,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e) != 0;
+  if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_BLOCKS_PER_CU"))
     if (atoi(e) > 0) c->blocks_per_cu = atoi(e);
 

@@ -80,6 +80,7 @@ struct pllhip_ctx
   double * d_asc = nullptr;              // [3] correction terms added by the final sum
   const double * pending_extra = nullptr; // consumed by the next pllhip_reduce_out
   size_t clv_arena_bytes = 0;            // all CLVs of the partition
+  bool no_batch = false;                 // PLLHIP_NO_BATCH=1: one launch per op (measurements)
   int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements)
   // 20 states: 1 = bit-exact vector kernels only (env PLLHIP_AA_EXACT=1);
   // 0 = matrix-core kernels where they exist (last-bit differences, see

@@ -664,8 +664,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // tree gives one launch per tree level; a post-order list of a random 200-taxon
   // tree, where kinds alternate, gives 3 launches per level instead of one per run of
   // equal kinds (111 -> see DESIGN.md 2.1).
-  const char * nb_env = getenv("PLLHIP_NO_BATCH");
-  const bool no_batch = nb_env && atoi(nb_env) != 0;
+  const bool no_batch = c->no_batch;
   const bool dna_fast = c->sh.states == 4 && fast_rc(c->sh.rate_cats);
   const bool aa_fast = c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) &&
                        (!c->sh.pattern_tip || pllhip_aa_fast_covers(c, 2));
