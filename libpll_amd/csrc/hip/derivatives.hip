@@ -17,6 +17,7 @@
 //     exactly like core_derivatives.c:560-575, and passed in.
 #include "ctx.hpp"
 #include "numerics.hpp"
+#include "aa_mfma.hpp"
 #include "lnl_common.hpp"
 
 struct SumMatArgs
@@ -259,6 +260,114 @@ __global__ __launch_bounds__(256) void k_derivatives(DerivArgs a)
   block_sum2(acc_d, acc_dd, a.reduce);
 }
 
+// 20 states: the table is walked like a CLV in partials_aa_mfma.hip -- a wave owns 16
+// sites x RC rates, one contiguous block that LDS-DMA copies into a padded per-wave
+// image; lane (s, q) then takes states 4c+q of its site and forms its share of the
+// three dot products per rate, two __shfl_xor add the four q-lanes of a site, and lanes
+// 0..15 finish one site each.  The next tile and its per-site words are requested as
+// soon as the image has been read.  (One lane per (site, rate) reading 160 contiguous
+// bytes of its own -- k_derivatives -- reaches 2.3 TB/s on this layout; this one is
+// bound by the DMA stream.)
+template <int RC, bool NT>
+__global__ __launch_bounds__(256) void k_derivatives_aa_tile(DerivArgs a)
+{
+  using G = aa_geom<RC>;
+  extern __shared__ double smem[]; // [diag RC x 20 x 4][4 images]
+  __shared__ double s_model[RC][2]; // prop_invar, rate weight of the category
+  __shared__ double s_freqs[RC][20];
+  double * s_diag = smem;
+  for (unsigned int t = threadIdx.x; t < RC * 80u; t += blockDim.x) s_diag[t] = a.diagp[t];
+  for (unsigned int t = threadIdx.x; t < RC * 20u; t += blockDim.x)
+    s_freqs[t / 20u][t % 20u] = a.freqs[(size_t)a.params_indices[t / 20u] * 20 + t % 20u];
+  if (threadIdx.x < RC)
+  {
+    s_model[threadIdx.x][0] = a.prop_invar[a.params_indices[threadIdx.x]];
+    s_model[threadIdx.x][1] = a.rate_weights[threadIdx.x];
+  }
+  __syncthreads();
+
+  const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned int s = lane & 15u, q = lane >> 4;
+  char * region = reinterpret_cast<char *>(smem + RC * 80) + wave * G::REGION_B;
+  unsigned int toff[G::N_IT];
+  tile_offsets<RC>(lane, toff);
+
+  const size_t sites = a.sites;
+  const size_t tiles = (sites + 15) / 16;
+  const size_t nwaves = (size_t)gridDim.x * 4;
+  const size_t first = (size_t)blockIdx.x * 4 + wave;
+  // (absent array: any valid word will do, the value is replaced by -1 below)
+  const int * invp = a.invariant ? a.invariant : reinterpret_cast<const int *>(a.pattern_weights);
+  const bool has_inv = a.invariant != nullptr;
+  double acc_d = 0.0, acc_dd = 0.0;
+  unsigned int w_next = 0;
+  int inv_next = -1;
+  if (first < tiles)
+  {
+    w_next = a.pattern_weights[first * 16 + s];
+    inv_next = invp[has_inv ? first * 16 + s : 0];
+    dma_tile<RC, NT>(a.sumtable, first * 16, toff, region);
+  }
+  for (size_t tile = first; tile < tiles; tile += nwaves)
+  {
+    const size_t next = tile + nwaves;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int w_cur = w_next;
+    int inv_cur = has_inv ? inv_next : -1;
+    asm volatile("" : "+v"(w_cur), "+v"(inv_cur));
+    double b[RC][5];
+    read_b_operands<RC>(region, s, q, b);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (next < tiles)
+    {
+      w_next = a.pattern_weights[next * 16 + s];
+      inv_next = invp[has_inv ? next * 16 + s : 0];
+      dma_tile<RC, NT>(a.sumtable, next * 16, toff, region);
+    }
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+    {
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+      {
+        const double * dg = s_diag + (k * 20 + 4 * c + (int)q) * 4;
+        c0 = fma(b[k][c], dg[0], c0);
+        c1 = fma(b[k][c], dg[1], c1);
+        c2 = fma(b[k][c], dg[2], c2);
+      }
+      c0 += __shfl_xor(c0, 16, 64);
+      c1 += __shfl_xor(c1, 16, 64);
+      c2 += __shfl_xor(c2, 16, 64);
+      c0 += __shfl_xor(c0, 32, 64);
+      c1 += __shfl_xor(c1, 32, 64);
+      c2 += __shfl_xor(c2, 32, 64);
+      const double pinv = s_model[k][0], w = s_model[k][1];
+      if (pinv > 0.0)
+      {
+        // core_derivatives.c:481-491
+        const double inv_lk = (inv_cur == -1) ? 0.0 : s_freqs[k][inv_cur] * pinv;
+        c0 = c0 * (1.0 - pinv) + inv_lk;
+        c1 = c1 * (1.0 - pinv);
+        c2 = c2 * (1.0 - pinv);
+      }
+      l0 += c0 * w;
+      l1 += c1 * w;
+      l2 += c2 * w;
+    }
+    if (q == 0 && tile * 16 + s < sites)
+    {
+      const double d1 = -l1 / l0;
+      const double d2 = d1 * d1 - l2 / l0;
+      const double pw = (double)w_cur;
+      acc_d += pw * d1;
+      acc_dd += pw * d2;
+    }
+  }
+  block_sum2(acc_d, acc_dd, a.reduce);
+}
+
 // 4 states: one lane per 16 bytes of the sumtable (two states), 2*RC lanes per
 // site, waves in rounds of 64 sites like the CLV and lnL kernels: every load
 // instruction of a wave is one contiguous KiB and, after a round, each lane
@@ -468,6 +577,29 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
       default: DERIV_DNA(8); break;
     }
 #undef DERIV_DNA
+  }
+  else if (S == 20 && !c->aa_exact && (R == 1 || R == 2 || R == 4))
+  {
+    const size_t tiles = ((size_t)a.sites + 15) / 16;
+    size_t blocks = (tiles + 3) / 4;
+    const size_t cap = (size_t)c->num_cus * 3; // 47 KB of LDS per workgroup
+    if (blocks > cap) blocks = cap;
+    grid = (unsigned int)blocks;
+    a.reduce = pllhip_reduce_out(c, grid);
+    const bool nt = pllhip_use_nt(c);
+#define DERIV_AA(RCV)                                                                               \
+    do {                                                                                            \
+      const size_t lds = (size_t)RCV * 80 * sizeof(double) + 4 * (size_t)aa_geom<RCV>::REGION_B;    \
+      if (nt) k_derivatives_aa_tile<RCV, true><<<grid, 256, lds, c->stream>>>(a);                   \
+      else k_derivatives_aa_tile<RCV, false><<<grid, 256, lds, c->stream>>>(a);                     \
+    } while (0)
+    switch (R)
+    {
+      case 1: DERIV_AA(1); break;
+      case 2: DERIV_AA(2); break;
+      default: DERIV_AA(4); break;
+    }
+#undef DERIV_AA
   }
   else if (R == 1 || R == 2 || R == 4 || R == 8 || R == 16)
   {
