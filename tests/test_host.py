@@ -159,3 +159,25 @@ def test_shard_bounds():
         assert b[0] == 0 and b[-1] == sites and len(b) == n + 1
         assert all(b[i] <= b[i + 1] for i in range(n))
         assert all(x % 256 == 0 for x in b[1:-1] if x != sites)
+
+
+def test_bench_cpu_baseline_leg(ref):
+    """bench.py's cpu_baseline machinery (the reference library on sliced copies of
+    the workload, one process per core) runs here without a GPU and reports a
+    plausible rate; its core count follows the cgroup quota."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cores = bench.usable_cores()
+    assert 1 <= cores <= len(os.sched_getaffinity(0))
+    from libpll_amd import workload as W
+    from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, ATTRIB_ARCH_AVX2
+    plan = W.balanced_tree(16, seed=42)
+    seqs = W.random_alignment(16, 4000, 4, seed=1)
+    ref_path = os.path.join(root, "oracle", "_ref", "libpll_ref.so")
+    rate = bench.cpu_all_cores(ref_path, plan, seqs, 4, 4, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2, 2, 3)
+    assert rate is not None and 1.0 < rate < 1e5      # M site-updates/s on two cores
+    assert set(bench.BYTES_PER_SITE["ii"]) == {4, 20}
