@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--alignment", default="simulated", choices=("simulated", "random"))
     ap.add_argument("--cpu-sites", type=int, default=250_000,
                     help="sample size for the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-reps", type=int, default=10)
+    ap.add_argument("--cpu-reps", type=int, default=0,
+                    help="evaluations per CPU-baseline leg (0 = as many as take about 5 s on one core)")
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: take the RCCL path (process group, communicator, lnL all-reduce) "
                          "even with one rank")
@@ -169,27 +170,31 @@ def main():
         n = min(args.cpu_sites, hi - lo)
         cpu_sample = [s[:n] for s in seqs]
         rp = W.setup_partition(ref, plan, cpu_sample, S, R, attrs | ATTRIB_ARCH_AVX2)
-        rp.update_partials(plan.ops)  # warm-up
         t1 = time.perf_counter()
-        for _ in range(args.cpu_reps):
+        rp.update_partials(plan.ops)  # warm-up, also sizes the sample
+        t_eval = max(time.perf_counter() - t1, 1e-4)
+        reps = args.cpu_reps if args.cpu_reps > 0 else int(min(100, max(3, round(5.0 / t_eval))))
+        t1 = time.perf_counter()
+        for _ in range(reps):
             rp.update_partials(plan.ops)
             cpu_ref_lnl = rp.compute_edge_loglikelihood(*plan.root_edge, fi)
         dt = time.perf_counter() - t1
         rp.destroy()
-        one_core = ops_per_eval * n * args.cpu_reps / dt / 1e6
+        one_core = ops_per_eval * n * reps / dt / 1e6
         cores = usable_cores()
-        # the multi-core leg gets a bigger slice of the same alignment so that every
-        # process still has a few thousand sites
-        n_all = min(hi - lo, max(n, 4000 * cores))
-        all_sample = [s[:n_all] for s in seqs]
+        # the multi-core leg runs the WHOLE per-GPU alignment, sliced over the cores, the
+        # same number of evaluations: about `cores` x 5 s x (sites / sample) / cores of wall
+        # time, 10-30 core-seconds of work in all
+        n_all = hi - lo
+        all_sample = seqs
         all_cores = cpu_all_cores(ref_path, plan, all_sample, S, R, attrs | ATTRIB_ARCH_AVX2, cores,
-                                  args.cpu_reps) if cores > 1 else None
+                                  reps) if cores > 1 else None
         cpu = {"value": round(all_cores if all_cores else one_core, 2),
                "unit": "M CLV-site-updates/s", "cores": cores if all_cores else 1,
                "kind": "reference", "one_core_value": round(one_core, 2),
                "sample": "one core: %d of %d sites; all cores: %d sites sliced over %d processes; "
                          "same tree/ops, %d evaluations each, PLL_ATTRIB_ARCH_AVX2"
-                         % (n, hi - lo, n_all, cores if all_cores else 1, args.cpu_reps)}
+                         % (n, hi - lo, n_all, cores if all_cores else 1, reps)}
 
     # torch first: it carries its own HIP runtime; loading it before our library
     # makes both share one runtime instance in this process.
