@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--rate-cats", type=int, default=4)
     ap.add_argument("--tip-clv", action="store_true", help="tips as CLVs (all ops inner-inner)")
     ap.add_argument("--rate-scalers", action="store_true")
+    ap.add_argument("--site-repeats", action="store_true",
+                    help="PLL_ATTRIB_SITE_REPEATS (an extension: libpll 0.3.2 has none).  The "
+                         "reported rate then counts the site-updates the plain path would do; "
+                         "config.site_repeats says how many rows were really computed")
     ap.add_argument("--alignment", default="simulated", choices=("simulated", "random"))
     ap.add_argument("--cpu-sites", type=int, default=250_000,
                     help="sample size for the CPU baseline (0 = skip)")
@@ -131,7 +135,7 @@ def main():
     sys.path.insert(0, root)
     from libpll_amd import workload as W
     from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_ARCH_AVX2,
-                                   PllLibrary)
+                                   ATTRIB_SITE_REPEATS, PllLibrary)
 
     S, R, T = args.states, args.rate_cats, args.taxa
     attrs = (0 if args.tip_clv else ATTRIB_PATTERN_TIP) | \
@@ -214,7 +218,8 @@ def main():
     amd = libpll_amd.load()
     amd.lib.pll_amd_set_device(local_rank)
 
-    part = W.setup_partition(amd, plan, seqs, S, R, attrs)
+    part = W.setup_partition(amd, plan, seqs, S, R,
+                             attrs | (ATTRIB_SITE_REPEATS if args.site_repeats else 0))
     if use_comm:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -337,6 +342,12 @@ def main():
         lnl_rel_err = abs(g_lnl - cpu_ref_lnl) / abs(cpu_ref_lnl)
         gp.destroy()
 
+    repeats = None
+    if args.site_repeats:
+        rows = [part.repeats_classes(int(op["parent_clv_index"])) or (hi - lo) for op in plan.ops]
+        repeats = {"rows_computed_per_evaluation": int(sum(rows)),
+                   "rows_plain": ops_per_eval * (hi - lo),
+                   "ops_stored_by_class": int(sum(1 for r in rows if r < hi - lo))}
     if rank == 0:
         tt, ti, ii = plan.op_kinds() if not args.tip_clv else (0, 0, ops_per_eval)
         out = {
@@ -355,7 +366,8 @@ def main():
                                       "tip CLVs" if args.tip_clv else "PATTERN_TIP",
                                       "per-rate" if args.rate_scalers else "per-site",
                                       ops_per_eval, tt, ti, ii),
-                       "sites_total": total_sites, "parallelism": "site-sharded x%d" % world},
+                       "sites_total": total_sites, "parallelism": "site-sharded x%d" % world,
+                       "site_repeats": repeats},
             "lnl": lnl, "lnl_rel_err_vs_reference": lnl_rel_err,
             "roofline": roofline, "kernels": per_kernel, "cpu_baseline": cpu, "newton": newton,
         }

@@ -71,6 +71,10 @@ extern "C" {
 #define PLL_ATTRIB_AB_MASK (7 << 5)
 #define PLL_ATTRIB_AB_FLAG (1 << 8)
 #define PLL_ATTRIB_RATE_SCALERS (1 << 9)
+/* Not in libpll 0.3.2 (later versions define this bit): sites that cannot be told
+ * apart below a node share one CLV entry there.  4-state data with
+ * PLL_ATTRIB_PATTERN_TIP only; every result equals the one without the bit. */
+#define PLL_ATTRIB_SITE_REPEATS (1 << 10)
 
 /* error codes shared with the reference (pll.h:137-167) */
 #define PLL_ERROR_FILE_OPEN 100
@@ -377,6 +381,17 @@ PLL_EXPORT extern pll_hardware_t pll_hardware;
 PLL_EXPORT int pll_hardware_probe(void);
 PLL_EXPORT void pll_hardware_dump(void);
 PLL_EXPORT void pll_hardware_ignore(void);
+/* site repeats (PLL_ATTRIB_SITE_REPEATS): number of classes the CLV is stored in, 0 when
+ * it is stored per site; and the identification step itself (distinct pairs of child
+ * classes, numbered by first appearance; returns 0 beyond `max` classes) */
+PLL_EXPORT unsigned int pll_amd_repeats_classes(const pll_partition_t * partition,
+                                                unsigned int clv_index);
+PLL_EXPORT unsigned int pll_amd_identify_repeats(const unsigned int * ida, unsigned int na,
+                                                 const unsigned int * idb, unsigned int nb,
+                                                 unsigned int sites, unsigned int max,
+                                                 unsigned int * site_id, unsigned int * lrow,
+                                                 unsigned int * rrow);
+
 /* pll.c:1061-1116: ascertainment-bias correction of a partition created with
  * PLL_ATTRIB_AB_FLAG or one of PLL_ATTRIB_AB_LEWIS / _FELSENSTEIN / _STAMATAKIS.
  * (With PLL_ATTRIB_PATTERN_TIP only 4-state data is accepted, see DESIGN.md.) */

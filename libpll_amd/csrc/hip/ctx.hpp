@@ -79,6 +79,17 @@ struct pllhip_ctx
   unsigned int asc_weight_sum = 0;
   double * d_asc = nullptr;              // [3] correction terms added by the final sum
   const double * pending_extra = nullptr; // consumed by the next pllhip_reduce_out
+  // site repeats (host/repeats.c): per CLV slot, rows stored (0 = one per site), the
+  // site -> row map, and per row the rows of the two children it is computed from
+  struct node_rows
+  {
+    unsigned int classes = 0;
+    unsigned int * site_id = nullptr; // [sites + slack]
+    unsigned int * lrow = nullptr;    // [classes + slack]
+    unsigned int * rrow = nullptr;
+    size_t row_cap = 0;
+  };
+  std::vector<node_rows> rows;          // empty unless repeats were ever registered
   size_t clv_arena_bytes = 0;            // all CLVs of the partition
   bool no_batch = false;                 // PLLHIP_NO_BATCH=1: one launch per op (measurements)
   int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements)
@@ -183,11 +194,15 @@ struct PartialsArgs
   const double * ltab;                   // precomputed tip row sums [code][rate][state] (20 states)
   const double * rtab;
   unsigned int sites, rate_cats, states, maxstates;
+  // site repeats: for each row of the parent, the row of the left / right child it is
+  // computed from (a tip character when that child is a tip); nullptr = same index
+  const unsigned int * lidx;
+  const unsigned int * ridx;
 };
 
 // Several mutually independent ops (one tree level) run in ONE launch:
 // blockIdx.y selects the op.  The op descriptors travel as kernel arguments
-// (24 x 128 B < the 4 KB kernarg segment), so batching needs no staging copy.
+// (24 x 144 B < the 4 KB kernarg segment), so batching needs no staging copy.
 // Every per-site device array carries this many sites of zeroed slack behind its last
 // element, so that a wave working on the last (partial) round of 64 sites may load
 // unconditionally and unclamped; what it computes there is masked out of every result.

@@ -50,21 +50,25 @@ __global__ void k_build_sumtable_mats(SumMatArgs a)
 __global__ __launch_bounds__(256) void k_sumtable_rescale(double * __restrict__ sum,
                                                           const unsigned int * __restrict__ ps,
                                                           const unsigned int * __restrict__ cs,
+                                                          const unsigned int * __restrict__ pmap,
+                                                          const unsigned int * __restrict__ cmap,
                                                           unsigned int sites, unsigned int R,
                                                           unsigned int S)
 {
   for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < sites;
        n += (size_t)gridDim.x * blockDim.x)
   {
+    // (site repeats: scale buffers stored by class are read through the site -> row maps)
+    const size_t np = pmap ? pmap[n] : n, nc = cmap ? cmap[n] : n;
     unsigned int mn = 0xffffffffu;
     for (unsigned int k = 0; k < R; ++k)
     {
-      unsigned int v = (ps ? ps[n * R + k] : 0) + (cs ? cs[n * R + k] : 0);
+      unsigned int v = (ps ? ps[np * R + k] : 0) + (cs ? cs[nc * R + k] : 0);
       mn = v < mn ? v : mn;
     }
     for (unsigned int k = 0; k < R; ++k)
     {
-      unsigned int d = (ps ? ps[n * R + k] : 0) + (cs ? cs[n * R + k] : 0) - mn;
+      unsigned int d = (ps ? ps[np * R + k] : 0) + (cs ? cs[nc * R + k] : 0) - mn;
       if (!d) continue;
       if (d > PLLHIP_SCALE_RATE_MAXDIFF) d = PLLHIP_SCALE_RATE_MAXDIFF;
       const double f = d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
@@ -162,12 +166,31 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
     pllhip_set_error("pllhip_update_sumtable: CLV missing");
     return -1;
   }
+  // site repeats: the table is per site, a CLV stored by class is read through its
+  // site -> row map (and so is the scale buffer that goes with it)
+  const unsigned int * pmap = nullptr, * cmap = nullptr;
+  if (!c->rows.empty())
+  {
+    if (kind == 0)
+    {
+      if (c->rows[parent_clv].classes) pmap = c->rows[parent_clv].site_id;
+      if (c->rows[child_clv].classes) cmap = c->rows[child_clv].site_id;
+      a.lidx = pmap;
+      a.ridx = cmap;
+    }
+    else
+    {
+      const unsigned int inner = tp ? child_clv : parent_clv;
+      if (c->rows[inner].classes) pmap = c->rows[inner].site_id;
+      a.ridx = pmap; // the inner node is the right operand; its scaler is `ps`
+    }
+  }
   int rc = pllhip_launch_partials(c, a, kind, SCALE_NONE, PLLHIP_PROF_SUMTABLE);
   if (rc) return rc;
   if (c->sh.rate_scalers && (ps || cs))
   {
     k_sumtable_rescale<<<pllhip_stream_grid(c, a.sites, 256), 256, 0, c->stream>>>(
-        c->sumtable[slot], ps, cs, a.sites, R, S);
+        c->sumtable[slot], ps, cs, pmap, cmap, a.sites, R, S);
     HIP_TRY(hipGetLastError());
   }
   return 0;

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_lnl_fast(LnlArgs a)
 // (log, scaler term, weight, optional per-site store) runs once per site
 // instead of once per lane -- f64 VALU ops cost 4 cycles per wave on CDNA4 and
 // a redundant log on all 8 lanes of a site made the kernel VALU-bound.
-template <int RC, int KIND, bool NT>
+template <int RC, int KIND, bool NT, bool GATHER>
 __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
 {
   constexpr unsigned int W = 2 * RC;        // lanes per site
@@ -301,21 +301,36 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
     // `if (n < sites)` tail each of these loads was a separate exposed round trip.
     // (no index clamping anywhere in this kernel: every per-site array has
     // PLLHIP_TAIL_SITES of slack behind it, and a site past the end is never summed)
-    const size_t n_own = r * 64 + (size_t)(lane & (W - 1)) * SPS + (lane / W);
+    const unsigned int own = (lane & (W - 1)) * SPS + (lane / W);
+    const size_t n_own = r * 64 + own;
     const unsigned int w_own = a.pattern_weights[n_own];
-    const unsigned int ps_own = ps_site[site_ps ? n_own : 0];
-    const unsigned int cs_own = cs_site[site_cs ? n_own : 0];
+    // site repeats: the rows of the two CLVs for the 64 sites of this round, one
+    // coalesced load each (the maps carry slack); sub-steps take theirs with a __shfl
+    unsigned int pi_round = (unsigned int)(r * 64 + lane), ci_round = pi_round;
+    if (GATHER && a.pidx) pi_round = a.pidx[r * 64 + lane];
+    if (GATHER && a.cidx) ci_round = a.cidx[r * 64 + lane];
+    const size_t prow_own = GATHER ? (size_t)(unsigned int)__shfl((int)pi_round, (int)own, 64) : n_own;
+    const size_t crow_own = GATHER ? (size_t)(unsigned int)__shfl((int)ci_round, (int)own, 64) : n_own;
+    const unsigned int ps_own = ps_site[site_ps ? prow_own : 0];
+    const unsigned int cs_own = cs_site[site_cs ? crow_own : 0];
     const int inv_raw = inv_site[has_inv ? n_own : 0];
     const int inv_own = has_inv ? inv_raw : -1;
     // One sub-step = 64/W sites.  The operands of sub-step j+1 are requested before
     // sub-step j is evaluated (rolled loop: 96 VGPRs, 5 waves per SIMD; unrolled, the
     // compiler kept 160 live and still waited for each pair of loads in turn).
     const size_t g0 = r * 64 * W + lane;
-    double2 p_next = ld16<NT>(P2 + g0), c_next = make_double2(0.0, 0.0);
-    if (KIND == EDGE_II) c_next = ld16<NT>(C2 + g0);
+    // granule of the parent / child CLV for sub-step j of this lane
+    auto granule = [&](unsigned int j, unsigned int rows_of_round) -> size_t {
+      if (!GATHER) return g0 + (size_t)j * SPS * W;
+      const int src = (int)(j * SPS + lane / W);
+      return (size_t)(unsigned int)__shfl((int)rows_of_round, src, 64) * W + (lane & (W - 1));
+    };
+    double2 p_next = ld16<NT>(P2 + granule(0, pi_round)), c_next = make_double2(0.0, 0.0);
+    if (KIND == EDGE_II) c_next = ld16<NT>(C2 + granule(0, ci_round));
     auto substep = [&](unsigned int j, const double2 p, const double2 c) {
       const size_t gc = g0 + (size_t)j * SPS * W;
-      const size_t n = gc / W, e = gc >> 1;
+      const size_t n = gc / W;
+      const size_t ep = granule(j, pi_round) >> 1, ec = granule(j, ci_round) >> 1;
       double t0, t1;
       if (KIND == EDGE_II)
       {
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
       unsigned int mn = 0;
       if (per_rate)
       {
-        const unsigned int mine = ps_rate[has_ps ? e : 0] + cs_rate[has_cs ? e : 0];
+        const unsigned int mine = ps_rate[has_ps ? ep : 0] + cs_rate[has_cs ? ec : 0];
         mn = mine;
         for (unsigned int off = 2; off < W; off <<= 1)
         {
@@ -381,9 +396,8 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
     for (unsigned int j = 0; j + 1 < W; ++j)
     {
       const double2 p = p_next, c = c_next;
-      const size_t gn = g0 + (size_t)(j + 1) * SPS * W;
-      p_next = ld16<NT>(P2 + gn);
-      if (KIND == EDGE_II) c_next = ld16<NT>(C2 + gn);
+      p_next = ld16<NT>(P2 + granule(j + 1, pi_round));
+      if (KIND == EDGE_II) c_next = ld16<NT>(C2 + granule(j + 1, ci_round));
       substep(j, p, c);
     }
     substep(W - 1, p_next, c_next);
@@ -475,8 +489,9 @@ __global__ __launch_bounds__(128) void k_lnl_gen(LnlArgs a)
 
 #define LAUNCH_LNL(RCV, KINDV)                                                            \
   do {                                                                                    \
-    if (s4 && nt) k_lnl_dna<RCV, KINDV, true><<<grid, 256, lds, c->stream>>>(a);          \
-    else if (s4) k_lnl_dna<RCV, KINDV, false><<<grid, 256, lds, c->stream>>>(a);          \
+    if (s4 && gather) k_lnl_dna<RCV, KINDV, false, true><<<grid, 256, lds, c->stream>>>(a); \
+    else if (s4 && nt) k_lnl_dna<RCV, KINDV, true, false><<<grid, 256, lds, c->stream>>>(a); \
+    else if (s4) k_lnl_dna<RCV, KINDV, false, false><<<grid, 256, lds, c->stream>>>(a);   \
     else k_lnl_fast<RCV, KINDV, false><<<grid, 256, lds, c->stream>>>(a);                 \
   } while (0)
 
@@ -523,6 +538,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   {
     const bool s4 = (S == 4);
     const bool nt = pllhip_use_nt(c);
+    const bool gather = a.pidx || a.cidx;
     // 4 states: a wave consumes 64 sites per round
     grid = s4 ? pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256)
               : pllhip_stream_grid(c, (size_t)a.sites * R, 256);
@@ -610,6 +626,8 @@ extern "C" int pllhip_edge_loglikelihood(pllhip_ctx_t * c, unsigned int parent_c
     a.parent = c->clv[tp ? child_clv : parent_clv];
     a.pscaler = pllhip_scaler_ptr(c, tp ? child_scaler : parent_scaler);
     a.tip = pllhip_tip_ptr(c, tp ? parent_clv : child_clv);
+    if (!c->rows.empty() && c->rows[tp ? child_clv : parent_clv].classes)
+      a.pidx = c->rows[tp ? child_clv : parent_clv].site_id;
     if (c->sh.states != 4 && c->maxstates == 0)
     {
       pllhip_set_error("pllhip_edge_loglikelihood: tipmap not uploaded");
@@ -623,6 +641,11 @@ extern "C" int pllhip_edge_loglikelihood(pllhip_ctx_t * c, unsigned int parent_c
     a.child = c->clv[child_clv];
     a.pscaler = pllhip_scaler_ptr(c, parent_scaler);
     a.cscaler = pllhip_scaler_ptr(c, child_scaler);
+    if (!c->rows.empty())
+    {
+      if (c->rows[parent_clv].classes) a.pidx = c->rows[parent_clv].site_id;
+      if (c->rows[child_clv].classes) a.cidx = c->rows[child_clv].site_id;
+    }
   }
   return run_lnl(c, a, kind, h_persite_lnl, h_lnl);
 }
@@ -642,5 +665,6 @@ extern "C" int pllhip_root_loglikelihood(pllhip_ctx_t * c, unsigned int clv_inde
   if (fill_freqs_indices(c, a, h_freqs_indices)) return -1;
   a.parent = c->clv[clv_index];
   a.pscaler = pllhip_scaler_ptr(c, scaler_index);
+  if (!c->rows.empty() && c->rows[clv_index].classes) a.pidx = c->rows[clv_index].site_id;
   return run_lnl(c, a, ROOT, h_persite_lnl, h_lnl);
 }

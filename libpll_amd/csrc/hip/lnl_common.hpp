@@ -34,6 +34,10 @@ struct LnlArgs
   const unsigned int * __restrict__ tipmap;
   const unsigned int * zero;            // device word holding 0
   double * __restrict__ persite;        // nullable
+  // site repeats: row of the parent / child CLV (and of their scale buffers) that holds
+  // each site; nullptr = the site's own index
+  const unsigned int * pidx;
+  const unsigned int * cidx;
   ReduceOut reduce;
   unsigned int sites, rate_cats, states, maxstates;
   int rate_scalers;

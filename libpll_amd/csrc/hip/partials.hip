@@ -70,14 +70,16 @@ __device__ __forceinline__ void build_tip_table4(double * tab, const double * __
 //
 // W = 2*RC lanes make one site; a wave works in ROUNDS of 64 sites = W sub-steps
 // of 64/W sites.  Per round the per-site data (tip codes, inherited scaler
-// counts, the new scaler count) moves once, one element per lane; inside the
-// round the W sub-steps are unrolled, so a wave has 2*W 16-byte CLV loads in
-// flight before its first use -- a tip-tip update, whose only inputs are two
-// bytes per site, would otherwise wait a full memory round trip per KiB stored.
+// counts, the new scaler count) moves once, one element per lane.
 // Lane l owns site (l % W) * (64/W) + l / W of the round: in sub-step j = l % W
 // its group is exactly that site, so the site's scaling decision is already in
 // the lane when the round ends.
-template <int RC, int MODE, bool NT, int KIND>
+//
+// GATHER (site repeats): "site" then means a row of the parent, and each child is read
+// at the row a.lidx / a.ridx names for it (a tip character when the child is a tip;
+// nullptr = same index as the parent row).  The row indices of a round are one
+// coalesced load per child; every sub-step takes its own with a __shfl.
+template <int RC, int MODE, bool NT, int KIND, bool GATHER>
 __global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
 {
   const PartialsArgs & a = batch.op[blockIdx.y];
@@ -116,10 +118,25 @@ __global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
     const size_t n_own = site0 + own;
     const bool own_ok = n_own < sites;
     unsigned int codes_l = 0, codes_r = 0, base = 0;
-    if (KIND >= 1) codes_l = (site0 + lane < sites) ? a.ltip[site0 + lane] : 0;
-    if (KIND == 2) codes_r = (site0 + lane < sites) ? a.rtip[site0 + lane] : 0;
+    // rows of the two children for the 64 parent rows of this round (the lists carry
+    // zeroed slack, so lanes past the last row gather row 0)
+    unsigned int li_round = (unsigned int)(site0 + lane), ri_round = li_round;
+    if (GATHER && a.lidx) li_round = a.lidx[site0 + lane];
+    if (GATHER && a.ridx) ri_round = a.ridx[site0 + lane];
+    if (KIND >= 1)
+      codes_l = (GATHER && a.lidx) ? li_round : ((site0 + lane < sites) ? a.ltip[site0 + lane] : 0);
+    if (KIND == 2)
+      codes_r = (GATHER && a.ridx) ? ri_round : ((site0 + lane < sites) ? a.rtip[site0 + lane] : 0);
     if (MODE == SCALE_SITE && KIND != 2)
-      base = ls[(has_l && own_ok) ? n_own : 0] + rs[(has_r && own_ok) ? n_own : 0];
+    {
+      size_t nl = n_own, nr = n_own;
+      if (GATHER)
+      {
+        nl = (unsigned int)__shfl((int)li_round, (int)own, 64);
+        nr = (unsigned int)__shfl((int)ri_round, (int)own, 64);
+      }
+      base = ls[(has_l && own_ok) ? nl : 0] + rs[(has_r && own_ok) ? nr : 0];
+    }
     bool own_scaled = false;
 
 #pragma unroll
@@ -129,10 +146,18 @@ __global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
       const bool act = g < total;
       const size_t gc = act ? g : 0;
       const int src = (int)(j * SPS + lane / W); // lane holding this site's per-round data
+      // where the children's (site, rate) elements are: the parent's own granule index,
+      // or row * W + position within the row
+      size_t gl = gc, gr = gc;
+      if (GATHER)
+      {
+        if (KIND == 0) gl = (size_t)(unsigned int)__shfl((int)li_round, src, 64) * W + (lane & (W - 1));
+        if (KIND <= 1) gr = (size_t)(unsigned int)__shfl((int)ri_round, src, 64) * W + (lane & (W - 1));
+      }
       double p0, p1;
       if (KIND == 0)
       {
-        const double2 lo = ld16<NT>(L + gc), ro = ld16<NT>(R + gc);
+        const double2 lo = ld16<NT>(L + gl), ro = ld16<NT>(R + gr);
         const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
         const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
         p0 = pl.dot(0, lo, lp) * pr.dot(0, ro, rp);
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
       }
       else if (KIND == 1)
       {
-        const double2 ro = ld16<NT>(R + gc);
+        const double2 ro = ld16<NT>(R + gr);
         const unsigned int code = (unsigned int)__shfl((int)codes_l, src, 64) & 15u;
         const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
         const double2 tl = *reinterpret_cast<const double2 *>(tabl + (code * RC + k) * 4 + 2 * h);
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
       {
         // one count per (site, rate): 4 bytes per 32 bytes of CLV, kept per sub-step
         const size_t e = gc >> 1;
-        const unsigned int inh = (KIND == 2) ? 0u : ls[has_l ? e : 0] + rs[has_r ? e : 0];
+        const unsigned int inh = (KIND == 2) ? 0u : ls[has_l ? (gl >> 1) : 0] + rs[has_r ? (gr >> 1) : 0];
         if (act && h == 0) a.pscaler[e] = inh + (scale ? 1u : 0u);
       }
       if (MODE == SCALE_SITE && (lane & (W - 1)) == j) own_scaled = scale;
@@ -488,11 +513,17 @@ __global__ __launch_bounds__(256) void k_aa_tt(PartialsArgs a)
     }                                                                             \
   } while (0)
 
-#define LAUNCH_DNA_KIND(RCV, MODEV, NTV)                                                   \
+#define LAUNCH_DNA_GATHER(RCV, MODEV, NTV, KINDV)                                           \
   do {                                                                                     \
-    if (kind == 0) k_dna_partials<RCV, MODEV, NTV, 0><<<grid, 256, 0, s>>>(b);             \
-    else if (kind == 1) k_dna_partials<RCV, MODEV, NTV, 1><<<grid, 256, 0, s>>>(b);        \
-    else k_dna_partials<RCV, MODEV, NTV, 2><<<grid, 256, 0, s>>>(b);                       \
+    if (gather) k_dna_partials<RCV, MODEV, NTV, KINDV, true><<<grid, 256, 0, s>>>(b);      \
+    else k_dna_partials<RCV, MODEV, NTV, KINDV, false><<<grid, 256, 0, s>>>(b);            \
+  } while (0)
+
+#define LAUNCH_DNA_KIND(RCV, MODEV, NTV)                          \
+  do {                                                            \
+    if (kind == 0) LAUNCH_DNA_GATHER(RCV, MODEV, NTV, 0);         \
+    else if (kind == 1) LAUNCH_DNA_GATHER(RCV, MODEV, NTV, 1);    \
+    else LAUNCH_DNA_GATHER(RCV, MODEV, NTV, 2);                   \
   } while (0)
 
 #define LAUNCH_DNA_MODE(RCV, NTV)                                 \
@@ -514,8 +545,17 @@ static int pllhip_launch_dna_batch(pllhip_ctx * c, const PartialsBatch & b, unsi
   const PartialsArgs & a = b.op[0];
   const unsigned int R = a.rate_cats;
   hipStream_t s = c->stream;
-  // a wave consumes 64 sites per round
-  const dim3 grid(pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256), count);
+  // a wave consumes 64 sites per round; with site repeats the ops of a launch differ in
+  // their number of rows: the grid covers the largest, a workgroup past its op's rows
+  // returns at once
+  size_t rows_max = 0;
+  bool gather = false;
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    if (b.op[i].sites > rows_max) rows_max = b.op[i].sites;
+    gather = gather || b.op[i].lidx || b.op[i].ridx;
+  }
+  const dim3 grid(pllhip_stream_grid(c, (rows_max + 63) / 64 * 64, 256), count);
   // the non-temporal variants exist for the common 4-category case only
   const bool nt = (R == 4) && pllhip_use_nt(c);
   switch (R)
@@ -648,6 +688,36 @@ static int resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, 
   }
 
   mode = !a.pscaler ? SCALE_NONE : (c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE);
+
+  // site repeats: the parent may be stored by class (then the host has named, per
+  // class, the row of each child), and an inner child may be (then a parent stored per
+  // site reads it through the child's site -> row map)
+  if (!c->rows.empty())
+  {
+    const pllhip_ctx::node_rows & pr = c->rows[op.parent_clv];
+    const unsigned int * m1, * m2; // row maps for child 1 / child 2
+    if (pr.classes)
+    {
+      a.sites = pr.classes;
+      m1 = pr.lrow;
+      m2 = pr.rrow;
+    }
+    else
+    {
+      m1 = (!t1 && c->rows[op.child1_clv].classes) ? c->rows[op.child1_clv].site_id : nullptr;
+      m2 = (!t2 && c->rows[op.child2_clv].classes) ? c->rows[op.child2_clv].site_id : nullptr;
+    }
+    if (kind == 1 && !t1)
+    {
+      a.lidx = m2; // the tip (child 2) is presented as the left child
+      a.ridx = m1;
+    }
+    else
+    {
+      a.lidx = m1;
+      a.ridx = m2;
+    }
+  }
   return 0;
 }
 

@@ -21,6 +21,7 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops, unsig
   unsigned int i;
   int rc;
   if (!pll_amd_flush_model(p)) return;
+  if (q->rep && !pll_amd_repeats_update(p, ops, count)) return;
   rc = pllhip_update_partials(q->ctx, (const pllhip_op_t *)ops, count);
   if (rc)
   {

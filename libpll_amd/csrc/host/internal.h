@@ -14,6 +14,16 @@
 
 #define PLL_AMD_MAGIC 0x504c4c414d443031ull /* "PLLAMD01" */
 
+/* site repeats (repeats.c): classes of one CLV slot */
+typedef struct pll_amd_node_repeats
+{
+  unsigned int classes;     /* meaningful when site_id != NULL */
+  unsigned int * site_id;   /* [sites] class of each site; NULL = stored per site */
+  unsigned int gen;         /* bumped whenever the classes (or a tip's characters) change */
+  unsigned int sig[4];      /* (child1, its gen, child2, its gen) the classes were built from */
+  int sig_valid;
+} pll_amd_node_repeats_t;
+
 typedef struct pll_amd_partition
 {
   pll_partition_t pub;          /* MUST be first */
@@ -26,6 +36,9 @@ typedef struct pll_amd_partition
   /* device sumtable slots keyed by the caller's host pointer */
   const double * sumtable_key[PLLHIP_SUMTABLE_SLOTS];
   unsigned int sumtable_next;
+  /* PLL_ATTRIB_SITE_REPEATS: per CLV slot, and which CLV each scale buffer belongs to */
+  pll_amd_node_repeats_t * rep;
+  int * scaler_owner;
 } pll_amd_partition_t;
 
 static inline pll_amd_partition_t * pll_amd_priv(const pll_partition_t * p)
@@ -41,5 +54,11 @@ void pll_amd_set_error(int code, const char * fmt, ...);
 int pll_amd_flush_model(pll_partition_t * partition);
 
 extern int pll_amd_mirror_mode;
+
+/* repeats.c */
+int pll_amd_repeats_alloc(pll_amd_partition_t * q);
+void pll_amd_repeats_free(pll_amd_partition_t * q);
+void pll_amd_repeats_tip_changed(pll_amd_partition_t * q, unsigned int tip);
+int pll_amd_repeats_update(pll_partition_t * p, const pll_operation_t * ops, unsigned int count);
 
 #endif

@@ -111,6 +111,7 @@ void pll_partition_destroy(pll_partition_t * p)
   free(p->tipmap);
   free(p->ttlookup);
   free(q->model_dirty);
+  pll_amd_repeats_free(q);
   q->magic = 0;
   free(q);
 }
@@ -161,6 +162,17 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
     pll_amd_set_error(PLL_ERROR_HIP_UNSUPPORTED,
                       "Ascertainment bias correction with PLL_ATTRIB_PATTERN_TIP needs 4 states; "
                       "use tip CLVs for %u-state data.", states);
+    return NULL;
+  }
+  /* site repeats (own extension, host/repeats.c): 4 states, pattern tips, no asc-bias */
+  if ((attributes & PLL_ATTRIB_SITE_REPEATS) &&
+      (states != 4 || !(attributes & PLL_ATTRIB_PATTERN_TIP) ||
+       (attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG)) ||
+       !(rate_cats == 1 || rate_cats == 2 || rate_cats == 4 || rate_cats == 8)))
+  {
+    pll_amd_set_error(PLL_ERROR_HIP_UNSUPPORTED,
+                      "PLL_ATTRIB_SITE_REPEATS needs 4 states, 1/2/4/8 rate categories, "
+                      "PLL_ATTRIB_PATTERN_TIP and no ascertainment-bias attribute.");
     return NULL;
   }
   if (!states || !sites || !rate_cats || !rate_matrices || (tips + clv_buffers) == 0)
@@ -257,6 +269,12 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
                       "Cannot create device context: %s", pllhip_last_error());
     q->ctx = NULL;
     pll_partition_destroy(p);
+    return NULL;
+  }
+  if ((attributes & PLL_ATTRIB_SITE_REPEATS) && !pll_amd_repeats_alloc(q))
+  {
+    pll_partition_destroy(p);
+    pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate site-repeat bookkeeping.");
     return NULL;
   }
   if (p->asc_bias_alloc)
@@ -392,6 +410,7 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip_index, const unsign
       for (i = 0; i < p->states; ++i) codes[p->sites + i] = (unsigned char)(1u << i);
     if ((rc = pllhip_put_tipchars(q->ctx, tip_index, codes)))
       return pll_amd_fail_hip(rc, "upload of tip characters");
+    pll_amd_repeats_tip_changed(q, tip_index);
     return PLL_SUCCESS;
   }
 
@@ -543,6 +562,16 @@ int pll_amd_sync_clv(pll_partition_t * p, unsigned int idx)
     return PLL_FAILURE;
   }
   if ((rc = pllhip_get_clv(q->ctx, idx, p->clv[idx]))) return pll_amd_fail_hip(rc, "CLV download");
+  if (q->rep && q->rep[idx].site_id)
+  {
+    /* stored by class on the device: the mirror shows one row per site.  Rows are
+       expanded back to front -- a site's class index never exceeds the site index */
+    const size_t span = (size_t)p->rate_cats * p->states;
+    const unsigned int * sid = q->rep[idx].site_id;
+    size_t s;
+    for (s = p->sites; s-- > 0;)
+      if (sid[s] != s) memmove(p->clv[idx] + s * span, p->clv[idx] + (size_t)sid[s] * span, span * sizeof(double));
+  }
   return PLL_SUCCESS;
 }
 
@@ -565,6 +594,17 @@ int pll_amd_sync_scaler(pll_partition_t * p, unsigned int idx)
   }
   if ((rc = pllhip_get_scaler(q->ctx, idx, p->scale_buffer[idx])))
     return pll_amd_fail_hip(rc, "scaler download");
+  if (q->rep && q->scaler_owner[idx] >= 0 && q->rep[q->scaler_owner[idx]].site_id)
+  {
+    /* written together with a CLV that is stored by class: same expansion */
+    const size_t per = (p->attributes & PLL_ATTRIB_RATE_SCALERS) ? p->rate_cats : 1;
+    const unsigned int * sid = q->rep[q->scaler_owner[idx]].site_id;
+    size_t s;
+    for (s = p->sites; s-- > 0;)
+      if (sid[s] != s)
+        memmove(p->scale_buffer[idx] + s * per, p->scale_buffer[idx] + (size_t)sid[s] * per,
+                per * sizeof(unsigned int));
+  }
   return PLL_SUCCESS;
 }
 

@@ -26,6 +26,7 @@ ATTRIB_AB_FELSENSTEIN = 2 << 5
 ATTRIB_AB_STAMATAKIS = 3 << 5
 ATTRIB_AB_FLAG = 1 << 8
 ATTRIB_RATE_SCALERS = 1 << 9
+ATTRIB_SITE_REPEATS = 1 << 10   # not in libpll 0.3.2: own extension, see host/repeats.c
 GAMMA_RATES_MEAN = 0
 GAMMA_RATES_MEDIAN = 1
 
@@ -234,6 +235,10 @@ class Partition:
     def set_pattern_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.uint32)
         self.lib.pll_set_pattern_weights(self.ptr, _u(w))
+
+    def repeats_classes(self, clv_index):
+        """rows the CLV is stored in under PLL_ATTRIB_SITE_REPEATS (0 = one per site)"""
+        return int(self.lib.pll_amd_repeats_classes(self.ptr, clv_index))
 
     def set_asc_bias_type(self, asc_type):
         self._check(self.lib.pll_set_asc_bias_type(self.ptr, asc_type), "pll_set_asc_bias_type")

@@ -1,0 +1,128 @@
+"""Site repeats (PLL_ATTRIB_SITE_REPEATS, host/repeats.c -- an extension, the reference
+snapshot has none): every observable result must equal the one obtained without the
+attribute, bit for bit.  CLVs and scale buffers are compared after expansion to one row
+per site (what the host mirrors show), per-site lnL, lnL, sumtable and derivatives
+directly."""
+import numpy as np
+import pytest
+
+from helpers import make_case, build_partition, bits_equal
+from libpll_amd import workload as W
+from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_SITE_REPEATS,
+                               ATTRIB_AB_LEWIS, OPS_DTYPE, SCALE_BUFFER_NONE, PllError)
+
+pytestmark = pytest.mark.gpu
+
+
+def evaluate(p, plan, R):
+    p.update_partials(plan.ops)
+    e = plan.root_edge
+    lnl, ps = p.compute_edge_loglikelihood(*e, [0] * R, persite=True)
+    st = p.alloc_sumtable()
+    p.update_sumtable(e[0], e[2], e[1], e[3], [0] * R, st)
+    d = [p.compute_likelihood_derivatives(e[1], e[3], t, [0] * R, st) for t in (0.05, 0.7)]
+    return lnl, ps, p.get_sumtable(st), d
+
+
+def same_state(p, q, plan):
+    for op in plan.ops:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        assert bits_equal(p.get_clv(node), q.get_clv(node)), "CLV %d" % node
+        if sc >= 0:
+            assert (p.get_scaler(sc) == q.get_scaler(sc)).all(), "scaler %d" % sc
+
+
+@pytest.mark.parametrize("shape,tips,sites,rate_cats,rate_scalers",
+                         [("balanced", 16, 3000, 4, False), ("random", 30, 2111, 4, False),
+                          ("caterpillar", 40, 1500, 4, False), ("random", 24, 1777, 2, True),
+                          ("balanced", 8, 65, 1, False), ("random", 50, 4000, 8, False)])
+def test_repeats_equal_plain(gpu, shape, tips, sites, rate_cats, rate_scalers):
+    case = make_case(4, shape, tips, sites, rate_cats=rate_cats, seed=tips + sites, gap_frac=0.02)
+    # few distinct columns near the tips, like real data: draw sites from a small pool
+    rng = np.random.default_rng(sites)
+    pool = rng.integers(0, sites, size=sites // 6 + 1)
+    pick = pool[rng.integers(0, len(pool), size=sites)]
+    case["seqs"] = [bytes(np.frombuffer(s, dtype=np.uint8)[pick]) for s in case["seqs"]]
+    plan, R = case["plan"], rate_cats
+    attrs = ATTRIB_PATTERN_TIP | (ATTRIB_RATE_SCALERS if rate_scalers else 0)
+    plain = build_partition(gpu, case, attrs)
+    rep = build_partition(gpu, case, attrs | ATTRIB_SITE_REPEATS)
+    a = evaluate(plain, plan, R)
+    b = evaluate(rep, plan, R)
+    compressed = [rep.repeats_classes(int(op["parent_clv_index"])) for op in plan.ops]
+    assert sum(1 for c in compressed if c) >= len(plan.ops) // 2, compressed
+    assert all(c <= sites // 2 for c in compressed)
+    same_state(plain, rep, plan)
+    assert a[0] == b[0] and bits_equal(a[1], b[1])
+    assert bits_equal(a[2], b[2])
+    assert a[3] == b[3]
+    # the root form on a CLV stored by class
+    top = int(plan.ops[-1]["parent_clv_index"])
+    ra = plain.compute_root_loglikelihood(top, int(plan.ops[-1]["parent_scaler_index"]), [0] * R, persite=True)
+    rb = rep.compute_root_loglikelihood(top, int(plan.ops[-1]["parent_scaler_index"]), [0] * R, persite=True)
+    assert ra[0] == rb[0] and bits_equal(ra[1], rb[1])
+    # a second evaluation reuses the classes (nothing changed) and gives the same bits
+    b2 = evaluate(rep, plan, R)
+    assert b2[0] == b[0] and bits_equal(b2[1], b[1])
+    # branch-length change + partial traversal: classes stay, values follow
+    changed = int(plan.ops[0]["parent_clv_index"])
+    slot = int(np.nonzero(plan.matrix_indices == changed)[0][0])
+    plan.branch_lengths[slot] = 0.37
+    for p in (plain, rep):
+        p.update_prob_matrices([0] * R, [changed], [0.37])
+        dirty, node = set(), changed
+        while node in plan.parent_of and plan.parent_of[node] != node and plan.parent_of[node] not in dirty:
+            dirty.add(plan.parent_of[node])
+            node = plan.parent_of[node]
+        p.update_partials(plan.ops[[int(op["parent_clv_index"]) in dirty for op in plan.ops]])
+    same_state(plain, rep, plan)
+    la = plain.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    lb = rep.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    assert la == lb and la != a[0]
+    plain.destroy()
+    rep.destroy()
+
+
+def test_repeats_follow_topology_and_tip_changes(gpu):
+    """Classes are rebuilt when an op pairs different children into a slot, and when a
+    tip's sequence is replaced."""
+    case = make_case(4, "balanced", 8, 900, seed=4, gap_frac=0.0, ambiguity=False)
+    rng = np.random.default_rng(1)
+    pool = rng.integers(0, 900, size=60)
+    pick = pool[rng.integers(0, len(pool), size=900)]
+    case["seqs"] = [bytes(np.frombuffer(s, dtype=np.uint8)[pick]) for s in case["seqs"]]
+    plan, T = case["plan"], 8
+    plain = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    rep = build_partition(gpu, case, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)
+    for p in (plain, rep):
+        p.update_partials(plan.ops)
+    same_state(plain, rep, plan)
+    # re-pair the tips: (0,2) and (1,3) into the slots that held (0,1) and (2,3)
+    ops = plan.ops.copy()
+    ops[0]["child2_clv_index"], ops[1]["child1_clv_index"] = 2, 1
+    ops[0]["child2_matrix_index"], ops[1]["child1_matrix_index"] = 2, 1
+    for p in (plain, rep):
+        p.update_partials(ops)
+    same_state(plain, rep, plan)
+    # new sequence for tip 5
+    new = bytes(np.frombuffer(case["seqs"][3], dtype=np.uint8)[::-1])
+    for p in (plain, rep):
+        p.set_tip_states(5, gpu.map("nt"), new)
+        p.update_partials(ops)
+    same_state(plain, rep, plan)
+    a = plain.compute_edge_loglikelihood(*plan.root_edge, [0] * 4)
+    b = rep.compute_edge_loglikelihood(*plan.root_edge, [0] * 4)
+    assert a == b
+    plain.destroy()
+    rep.destroy()
+
+
+def test_repeats_attribute_contract(gpu):
+    case = make_case(20, "balanced", 8, 50, seed=3)
+    with pytest.raises(PllError):
+        build_partition(gpu, case, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)     # 20 states
+    dna = make_case(4, "balanced", 8, 50, seed=3)
+    with pytest.raises(PllError):
+        build_partition(gpu, dna, ATTRIB_SITE_REPEATS)                           # tip CLVs
+    with pytest.raises(PllError):
+        build_partition(gpu, dna, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS | ATTRIB_AB_LEWIS)

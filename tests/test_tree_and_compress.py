@@ -236,3 +236,32 @@ def test_compress_remaps_wide_state_codes(amd, ref):
     chars = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV-", dtype=np.uint8)
     seqs = [chars[rng.integers(0, len(chars), 300)].tobytes() for _ in range(6)]
     assert compress(amd.lib, seqs, amd.map("aa")) == compress(ref.lib, seqs, ref.map("aa"))
+
+
+def test_identify_repeats(amd):
+    """Class identification of the site-repeats extension (host/repeats.c): distinct
+    pairs numbered by first appearance, both table strategies, and the give-up limit."""
+    import ctypes as C
+    f = amd.lib.pll_amd_identify_repeats
+    f.restype = C.c_uint
+    rng = np.random.default_rng(3)
+    for na, nb, sites in ((16, 16, 5000), (300, 7, 4000), (5000, 3000, 20000), (1, 1, 10)):
+        ida = rng.integers(0, na, sites).astype(np.uint32)
+        idb = rng.integers(0, nb, sites).astype(np.uint32)
+        sid = np.zeros(sites, dtype=np.uint32)
+        lrow = np.zeros(sites, dtype=np.uint32)
+        rrow = np.zeros(sites, dtype=np.uint32)
+        def ptr(a):
+            return a.ctypes.data_as(C.POINTER(C.c_uint))
+        n = f(ptr(ida), na, ptr(idb), nb, sites, sites, ptr(sid), ptr(lrow), ptr(rrow))
+        keys = ida.astype(np.uint64) * nb + idb
+        uniq, first = np.unique(keys, return_index=True)
+        assert n == len(uniq)
+        order = np.argsort(first)                       # classes in order of first appearance
+        rank = np.empty(len(uniq), dtype=np.uint32)
+        rank[order] = np.arange(len(uniq), dtype=np.uint32)
+        assert (sid == rank[np.searchsorted(uniq, keys)]).all()
+        assert (lrow[:n] == ida[np.sort(first)]).all() and (rrow[:n] == idb[np.sort(first)]).all()
+        assert (sid <= np.arange(sites)).all()           # what the in-place expansion relies on
+        if n > 1:
+            assert f(ptr(ida), na, ptr(idb), nb, sites, n - 1, ptr(sid), ptr(lrow), ptr(rrow)) == 0
