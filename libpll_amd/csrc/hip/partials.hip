@@ -556,8 +556,9 @@ static int pllhip_launch_dna_batch(pllhip_ctx * c, const PartialsBatch & b, unsi
     gather = gather || b.op[i].lidx || b.op[i].ridx;
   }
   const dim3 grid(pllhip_stream_grid(c, (rows_max + 63) / 64 * 64, 256), count);
-  // the non-temporal variants exist for the common 4-category case only
-  const bool nt = (R == 4) && pllhip_use_nt(c);
+  // the non-temporal variants exist for the common 4-category case only; rows that are
+  // gathered are re-read by several parent rows and stay on the default policy
+  const bool nt = (R == 4) && pllhip_use_nt(c) && !gather;
   switch (R)
   {
     case 1: LAUNCH_DNA_MODE(1, false); break;
