@@ -14,6 +14,10 @@ per-site scalers.  For N>1 every rank holds its own 1,000,000-site shard of an
 N x 1,000,000-site alignment (weak scaling, no data-path collective; one
 8-byte RCCL all-reduce of lnL per step).
 
+`--site-repeats` (not the default; libpll 0.3.2 has no site repeats) switches on the
+PLL_ATTRIB_SITE_REPEATS extension: same results, CLVs stored by class; the rate then counts
+the site-updates the plain path would do and config.site_repeats the rows really computed.
+
 Inputs are resident in HBM before the timed region starts.  `roofline` is for
 the dominant kernel, the 4-state inner-inner CLV update: 396 algorithmic
 bytes per site-update x sites per launch / the launch's average
