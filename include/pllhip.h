@@ -177,16 +177,20 @@ PLLHIP_EXPORT int pllhip_likelihood_derivatives(pllhip_ctx_t * ctx, unsigned int
  * pattern weights of the ordinary sites (pll_partition_t::pattern_weight_sum). */
 PLLHIP_EXPORT int pllhip_set_asc(pllhip_ctx_t * ctx, int asc_type, unsigned int pattern_weight_sum);
 
-/* Site repeats (host/repeats.c; no counterpart in the reference snapshot).  A CLV slot
- * with `classes` > 0 stores that many rows instead of one per site (and so does the
- * scale buffer written together with it).  h_site_id[sites] maps a site to its row;
- * h_lrow / h_rrow [classes] name, for each row, the row of child 1 / child 2 it is
- * computed from (a tip character when the child is a tip).  classes == 0 returns the
- * slot to per-site storage.  pllhip_update_partials, the log-likelihood calls and
- * pllhip_update_sumtable follow these maps; pllhip_get_clv returns the rows as stored. */
-PLLHIP_EXPORT int pllhip_put_repeats(pllhip_ctx_t * ctx, unsigned int clv_index,
-                                     unsigned int classes, const unsigned int * h_site_id,
-                                     const unsigned int * h_lrow, const unsigned int * h_rrow);
+/* Site repeats (host/repeats.c, hip/repeats.hip; no counterpart in the reference
+ * snapshot).  Finds the classes of CLV slot `parent` when it is computed from `child1`
+ * and `child2`: sites whose rows at both children agree share a row.  If there are at
+ * most max_classes of them the slot is from now on stored by class -- that many rows,
+ * also in the scale buffer written together with it -- and *classes says how many;
+ * otherwise (or when an inner child is itself stored per site) *classes = 0 and the
+ * slot is stored per site.  pllhip_update_partials, the log-likelihood calls and
+ * pllhip_update_sumtable follow the maps; pllhip_get_clv returns the rows as stored,
+ * pllhip_get_site_id the site -> row map to expand them with. */
+PLLHIP_EXPORT int pllhip_identify_repeats(pllhip_ctx_t * ctx, unsigned int parent,
+                                          unsigned int child1, unsigned int child2,
+                                          unsigned int max_classes, unsigned int * classes);
+PLLHIP_EXPORT int pllhip_get_site_id(pllhip_ctx_t * ctx, unsigned int clv_index,
+                                     unsigned int * h_site_id);
 
 /* ---- multi-GPU: one process per GPU, RCCL sum of the scalar results ---- */
 PLLHIP_EXPORT int pllhip_comm_unique_id(void * id128);

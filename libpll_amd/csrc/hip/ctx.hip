@@ -260,6 +260,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
                    c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3]};
   for (void * p : bufs)
     if (p) (void)hipFree(p);
+  pllhip_rep_work_free(c);
   for (pllhip_ctx::node_rows & r : c->rows)
     for (void * p : {(void *)r.site_id, (void *)r.lrow, (void *)r.rrow})
       if (p) (void)hipFree(p);
@@ -270,58 +271,6 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
-}
-
-extern "C" int pllhip_put_repeats(pllhip_ctx_t * c, unsigned int idx, unsigned int classes,
-                                  const unsigned int * h_site_id, const unsigned int * h_lrow,
-                                  const unsigned int * h_rrow)
-{
-  HIP_TRY(hipSetDevice(c->sh.device));
-  if (idx >= c->clv.size() || !c->clv[idx] || classes > c->sh.sites)
-  {
-    pllhip_set_error("pllhip_put_repeats: bad CLV index %u or class count %u", idx, classes);
-    return -1;
-  }
-  if (c->sh.states != 4 || !c->sh.pattern_tip || c->sh.asc_states)
-  {
-    pllhip_set_error("pllhip_put_repeats: site repeats need 4 states, pattern tips, no asc-bias sites");
-    return -1;
-  }
-  if (c->rows.empty()) c->rows.resize(c->clv.size());
-  pllhip_ctx::node_rows & r = c->rows[idx];
-  if (!classes)
-  {
-    r.classes = 0; // (buffers are kept for the next registration)
-    return 0;
-  }
-  const size_t N = c->sh.sites, slack = PLLHIP_TAIL_SITES;
-  if (!r.site_id)
-  {
-    HIP_TRY(hipMalloc((void **)&r.site_id, (N + slack) * sizeof(unsigned int)));
-    HIP_TRY(hipMemsetAsync(r.site_id, 0, (N + slack) * sizeof(unsigned int), c->stream));
-  }
-  if (r.row_cap < classes)
-  {
-    // the maps of earlier launches may still be in use
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (r.lrow) HIP_TRY(hipFree(r.lrow));
-    if (r.rrow) HIP_TRY(hipFree(r.rrow));
-    r.lrow = r.rrow = nullptr;
-    HIP_TRY(hipMalloc((void **)&r.lrow, (classes + slack) * sizeof(unsigned int)));
-    HIP_TRY(hipMalloc((void **)&r.rrow, (classes + slack) * sizeof(unsigned int)));
-    r.row_cap = classes;
-  }
-  // stream-ordered behind every kernel that still reads the old maps; the slack behind
-  // the row lists stays zero so that lanes past the last row gather row 0
-  HIP_TRY(hipMemsetAsync(r.lrow, 0, (r.row_cap + slack) * sizeof(unsigned int), c->stream));
-  HIP_TRY(hipMemsetAsync(r.rrow, 0, (r.row_cap + slack) * sizeof(unsigned int), c->stream));
-  HIP_TRY(hipMemcpyAsync(r.site_id, h_site_id, N * sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(r.lrow, h_lrow, (size_t)classes * sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(r.rrow, h_rrow, (size_t)classes * sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
-  // the host arrays are pageable and reused by the caller: finish the copies now
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  r.classes = classes;
-  return 0;
 }
 
 extern "C" int pllhip_wait(pllhip_ctx_t * c)

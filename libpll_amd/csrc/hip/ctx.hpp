@@ -15,6 +15,8 @@
 
 struct ncclComm;
 
+struct pllhip_rep_work;
+
 struct pllhip_ctx
 {
   pllhip_shape_t sh;
@@ -89,7 +91,8 @@ struct pllhip_ctx
     unsigned int * rrow = nullptr;
     size_t row_cap = 0;
   };
-  std::vector<node_rows> rows;          // empty unless repeats were ever registered
+  std::vector<node_rows> rows;          // empty unless repeats were ever identified
+  struct pllhip_rep_work * rep_work = nullptr; // sort / scan buffers of repeats.hip
   size_t clv_arena_bytes = 0;            // all CLVs of the partition
   bool no_batch = false;                 // PLLHIP_NO_BATCH=1: one launch per op (measurements)
   int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements)
@@ -215,6 +218,8 @@ struct PartialsBatch
 };
 
 enum { SCALE_NONE = 0, SCALE_SITE = 1, SCALE_RATE = 2 };
+
+void pllhip_rep_work_free(pllhip_ctx * c); // repeats.hip
 
 // kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
 int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode,

@@ -17,8 +17,9 @@
 /* site repeats (repeats.c): classes of one CLV slot */
 typedef struct pll_amd_node_repeats
 {
-  unsigned int classes;     /* meaningful when site_id != NULL */
-  unsigned int * site_id;   /* [sites] class of each site; NULL = stored per site */
+  unsigned int classes;     /* rows the CLV is stored in; 0 = one per site */
+  unsigned int * site_id;   /* host copy of the site -> row map, fetched for mirrors only */
+  int site_id_valid;
   unsigned int gen;         /* bumped whenever the classes (or a tip's characters) change */
   unsigned int sig[4];      /* (child1, its gen, child2, its gen) the classes were built from */
   int sig_valid;
@@ -60,5 +61,9 @@ int pll_amd_repeats_alloc(pll_amd_partition_t * q);
 void pll_amd_repeats_free(pll_amd_partition_t * q);
 void pll_amd_repeats_tip_changed(pll_amd_partition_t * q, unsigned int tip);
 int pll_amd_repeats_update(pll_partition_t * p, const pll_operation_t * ops, unsigned int count);
+/* site -> row map of a CLV stored by class (NULL if it is stored per site or on error) */
+const unsigned int * pll_amd_repeats_site_id(pll_partition_t * p, unsigned int clv_index);
+int pll_amd_repeats_expand(void * buf, const unsigned int * site_id, unsigned int classes,
+                           unsigned int sites, size_t row_bytes);
 
 #endif

@@ -562,15 +562,13 @@ int pll_amd_sync_clv(pll_partition_t * p, unsigned int idx)
     return PLL_FAILURE;
   }
   if ((rc = pllhip_get_clv(q->ctx, idx, p->clv[idx]))) return pll_amd_fail_hip(rc, "CLV download");
-  if (q->rep && q->rep[idx].site_id)
+  if (q->rep && q->rep[idx].classes)
   {
-    /* stored by class on the device: the mirror shows one row per site.  Rows are
-       expanded back to front -- a site's class index never exceeds the site index */
-    const size_t span = (size_t)p->rate_cats * p->states;
-    const unsigned int * sid = q->rep[idx].site_id;
-    size_t s;
-    for (s = p->sites; s-- > 0;)
-      if (sid[s] != s) memmove(p->clv[idx] + s * span, p->clv[idx] + (size_t)sid[s] * span, span * sizeof(double));
+    /* stored by class on the device: the mirror shows one row per site */
+    const unsigned int * sid = pll_amd_repeats_site_id(p, idx);
+    if (!sid || !pll_amd_repeats_expand(p->clv[idx], sid, q->rep[idx].classes, p->sites,
+                                        (size_t)p->rate_cats * p->states * sizeof(double)))
+      return PLL_FAILURE;
   }
   return PLL_SUCCESS;
 }
@@ -594,16 +592,15 @@ int pll_amd_sync_scaler(pll_partition_t * p, unsigned int idx)
   }
   if ((rc = pllhip_get_scaler(q->ctx, idx, p->scale_buffer[idx])))
     return pll_amd_fail_hip(rc, "scaler download");
-  if (q->rep && q->scaler_owner[idx] >= 0 && q->rep[q->scaler_owner[idx]].site_id)
+  if (q->rep && q->scaler_owner[idx] >= 0 && q->rep[q->scaler_owner[idx]].classes)
   {
     /* written together with a CLV that is stored by class: same expansion */
+    const unsigned int owner = (unsigned int)q->scaler_owner[idx];
     const size_t per = (p->attributes & PLL_ATTRIB_RATE_SCALERS) ? p->rate_cats : 1;
-    const unsigned int * sid = q->rep[q->scaler_owner[idx]].site_id;
-    size_t s;
-    for (s = p->sites; s-- > 0;)
-      if (sid[s] != s)
-        memmove(p->scale_buffer[idx] + s * per, p->scale_buffer[idx] + (size_t)sid[s] * per,
-                per * sizeof(unsigned int));
+    const unsigned int * sid = pll_amd_repeats_site_id(p, owner);
+    if (!sid || !pll_amd_repeats_expand(p->scale_buffer[idx], sid, q->rep[owner].classes, p->sites,
+                                        per * sizeof(unsigned int)))
+      return PLL_FAILURE;
   }
   return PLL_SUCCESS;
 }

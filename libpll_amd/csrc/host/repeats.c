@@ -10,19 +10,18 @@
  *
  * Two sites belong to the same class at a node iff their classes at both children
  * agree (at a tip: iff the tip shows the same character).  The classes of a parent are
- * therefore the distinct pairs (class at child 1, class at child 2), numbered in order
- * of first appearance.  Per inner node the host keeps
- *      site_id[site]  -> class         (NULL when the node is not compressed)
- * and hands the device, per class, the row of each child it is computed from
- * (lrow / rrow: a class index of that child, a site index if the child is not
- * compressed, a tip character if it is a tip).  A node is compressed when it has at
- * most half as many classes as sites; otherwise it is stored per site as usual, and so
- * is every node above it.
+ * therefore the distinct pairs (class at child 1, class at child 2).  A node is stored
+ * by class when it has at most half as many classes as sites; otherwise it is stored
+ * per site as usual, and so is every node above it.
  *
- * Identification is host work, O(sites) per op, done when an op is seen for the first
- * time with a given pair of children and reused afterwards (branch lengths and model
- * parameters do not change classes): a signature per CLV slot of (child slot,
- * generation of the child's classes) x 2 decides.
+ * This file is the bookkeeping: classes depend on the topology and on the tip sequences
+ * only, so each CLV slot remembers from which (child slot, generation of that child's
+ * classes) pair its classes were built and asks the device to identify them again
+ * (hip/repeats.hip: sort of the pairs, O(sites) per op) only when that signature
+ * changes -- branch lengths and model parameters never do.  It also expands CLVs and
+ * scale buffers stored by class when a host mirror is asked for.
+ * pll_amd_identify_repeats() below is the same identification in plain C; the tests use
+ * it to check the device's classes.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -144,111 +143,88 @@ void pll_amd_repeats_tip_changed(pll_amd_partition_t * q, unsigned int tip)
   if (q->rep) q->rep[tip].gen++;
 }
 
-/* Bring the classes of every parent in `ops` up to date (list order: children first)
- * and tell the device about the ones that changed.  Returns PLL_SUCCESS / PLL_FAILURE. */
+/* Bring the classes of every parent in `ops` up to date (list order: children first).
+ * Returns PLL_SUCCESS / PLL_FAILURE. */
 int pll_amd_repeats_update(pll_partition_t * p, const pll_operation_t * ops, unsigned int count)
 {
   pll_amd_partition_t * q = pll_amd_priv(p);
-  const unsigned int sites = p->sites, tips = p->tips, nodes = p->tips + p->clv_buffers;
-  unsigned int i, n;
-  unsigned int * ida = NULL, * idb = NULL, * lrow = NULL, * rrow = NULL, * sid = NULL;
-  int ok = PLL_SUCCESS;
+  const unsigned int tips = p->tips, nodes = p->tips + p->clv_buffers;
+  unsigned int i;
 
-  for (i = 0; i < count && ok; ++i)
+  for (i = 0; i < count; ++i)
   {
     const pll_operation_t * op = &ops[i];
-    const unsigned int c[2] = {op->child1_clv_index, op->child2_clv_index};
+    const unsigned int c1 = op->child1_clv_index, c2 = op->child2_clv_index;
     pll_amd_node_repeats_t * par;
-    unsigned int sig[4], na[2], classes = 0;
-    int compress = 1, s;
-    if (op->parent_clv_index >= nodes || op->parent_clv_index < tips || c[0] >= nodes || c[1] >= nodes)
+    unsigned int sig[4], classes = 0;
+    int rc;
+    if (op->parent_clv_index >= nodes || op->parent_clv_index < tips || c1 >= nodes || c2 >= nodes)
       continue; /* the device call reports the bad index */
     par = &q->rep[op->parent_clv_index];
     if (op->parent_scaler_index >= 0 && (unsigned int)op->parent_scaler_index < p->scale_buffers)
       q->scaler_owner[op->parent_scaler_index] = (int)op->parent_clv_index;
-    sig[0] = c[0];
-    sig[1] = q->rep[c[0]].gen;
-    sig[2] = c[1];
-    sig[3] = q->rep[c[1]].gen;
+    sig[0] = c1;
+    sig[1] = q->rep[c1].gen;
+    sig[2] = c2;
+    sig[3] = q->rep[c2].gen;
     if (par->sig_valid && !memcmp(sig, par->sig, sizeof(sig))) continue; /* classes still right */
 
-    /* children: a tip shows characters (16 codes), a compressed inner node its classes;
-       an inner node stored per site cannot be the basis of a compression */
-    for (s = 0; s < 2; ++s)
-    {
-      if (c[s] < tips) na[s] = 16;
-      else if (q->rep[c[s]].site_id) na[s] = q->rep[c[s]].classes;
-      else compress = 0;
-    }
-    if (compress)
-    {
-      if (!ida)
-      {
-        ida = (unsigned int *)malloc((size_t)sites * sizeof(unsigned int));
-        idb = (unsigned int *)malloc((size_t)sites * sizeof(unsigned int));
-        lrow = (unsigned int *)malloc((size_t)sites * sizeof(unsigned int));
-        rrow = (unsigned int *)malloc((size_t)sites * sizeof(unsigned int));
-        sid = (unsigned int *)malloc((size_t)sites * sizeof(unsigned int));
-        if (!ida || !idb || !lrow || !rrow || !sid)
-        {
-          pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate site-repeat work arrays.");
-          ok = PLL_FAILURE;
-          break;
-        }
-      }
-      for (s = 0; s < 2; ++s)
-      {
-        unsigned int * dst = s ? idb : ida;
-        if (c[s] < tips)
-        {
-          const unsigned char * codes = p->tipchars[c[s]];
-          for (n = 0; n < sites; ++n) dst[n] = codes[n] & 15u;
-        }
-        else
-          memcpy(dst, q->rep[c[s]].site_id, (size_t)sites * sizeof(unsigned int));
-      }
-      classes = pll_amd_identify_repeats(ida, na[0], idb, na[1], sites, sites / 2, sid, lrow, rrow);
-    }
-
+    if ((rc = pllhip_identify_repeats(q->ctx, op->parent_clv_index, c1, c2, p->sites / 2, &classes)))
+      return pll_amd_fail_hip(rc, "site-repeat identification");
+    par->classes = classes;
+    par->site_id_valid = 0;
     par->gen++;
     memcpy(par->sig, sig, sizeof(sig));
     par->sig_valid = 1;
-    if (classes)
-    {
-      int rc;
-      if (!par->site_id) par->site_id = (unsigned int *)malloc((size_t)sites * sizeof(unsigned int));
-      if (!par->site_id)
-      {
-        pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate site-repeat classes.");
-        ok = PLL_FAILURE;
-        break;
-      }
-      memcpy(par->site_id, sid, (size_t)sites * sizeof(unsigned int));
-      par->classes = classes;
-      if ((rc = pllhip_put_repeats(q->ctx, op->parent_clv_index, classes, sid, lrow, rrow)))
-        ok = pll_amd_fail_hip(rc, "upload of site-repeat classes");
-    }
-    else
-    {
-      int rc;
-      free(par->site_id);
-      par->site_id = NULL;
-      par->classes = 0;
-      if ((rc = pllhip_put_repeats(q->ctx, op->parent_clv_index, 0, NULL, NULL, NULL)))
-        ok = pll_amd_fail_hip(rc, "reset of site-repeat classes");
-    }
   }
-  free(ida);
-  free(idb);
-  free(lrow);
-  free(rrow);
-  free(sid);
-  return ok;
+  return PLL_SUCCESS;
+}
+
+const unsigned int * pll_amd_repeats_site_id(pll_partition_t * p, unsigned int clv_index)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  pll_amd_node_repeats_t * r;
+  int rc;
+  if (!q->rep || clv_index >= p->tips + p->clv_buffers || !q->rep[clv_index].classes) return NULL;
+  r = &q->rep[clv_index];
+  if (r->site_id_valid) return r->site_id;
+  if (!r->site_id) r->site_id = (unsigned int *)malloc((size_t)p->sites * sizeof(unsigned int));
+  if (!r->site_id)
+  {
+    pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate site-repeat map.");
+    return NULL;
+  }
+  if ((rc = pllhip_get_site_id(q->ctx, clv_index, r->site_id)))
+  {
+    pll_amd_fail_hip(rc, "download of site-repeat map");
+    return NULL;
+  }
+  r->site_id_valid = 1;
+  return r->site_id;
+}
+
+/* Expand `rows` stored by class into one row per site, in place: buf holds `classes`
+ * rows of `per` elements of `elem` bytes at its start and has room for `sites` rows. */
+int pll_amd_repeats_expand(void * buf, const unsigned int * site_id, unsigned int classes,
+                           unsigned int sites, size_t row_bytes)
+{
+  char * rows = (char *)malloc((size_t)classes * row_bytes);
+  size_t s;
+  if (!rows)
+  {
+    pll_amd_set_error(PLL_ERROR_MEM_ALLOC, "Cannot allocate site-repeat expansion buffer.");
+    return PLL_FAILURE;
+  }
+  memcpy(rows, buf, (size_t)classes * row_bytes);
+  for (s = 0; s < sites; ++s)
+    memcpy((char *)buf + s * row_bytes, rows + (size_t)site_id[s] * row_bytes, row_bytes);
+  free(rows);
+  return PLL_SUCCESS;
 }
 
 unsigned int pll_amd_repeats_classes(const pll_partition_t * p, unsigned int clv_index)
 {
   const pll_amd_partition_t * q = pll_amd_priv(p);
-  if (!q->rep || clv_index >= p->tips + p->clv_buffers || !q->rep[clv_index].site_id) return 0;
+  if (!q->rep || clv_index >= p->tips + p->clv_buffers) return 0;
   return q->rep[clv_index].classes;
 }
