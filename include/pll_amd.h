@@ -72,8 +72,8 @@ extern "C" {
 #define PLL_ATTRIB_AB_FLAG (1 << 8)
 #define PLL_ATTRIB_RATE_SCALERS (1 << 9)
 /* Not in libpll 0.3.2 (later versions define this bit): sites that cannot be told
- * apart below a node share one CLV entry there.  4-state data with
- * PLL_ATTRIB_PATTERN_TIP only; every result equals the one without the bit. */
+ * apart below a node share one CLV entry there.  4- or 20-state data with
+ * PLL_ATTRIB_PATTERN_TIP; every result equals the one without the bit. */
 #define PLL_ATTRIB_SITE_REPEATS (1 << 10)
 
 /* error codes shared with the reference (pll.h:137-167) */

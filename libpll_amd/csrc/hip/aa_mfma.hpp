@@ -63,6 +63,26 @@ __device__ __forceinline__ void dma_tile(const double * __restrict__ clv, size_t
                                      (PLL_AS3 void *)(region + it * 1024), 16, 0, NT ? 2 : 0);
 }
 
+// Site repeats: the same tile, but site s of it lives in row `rows` (lane s & 15 holds
+// the row of site s) of a CLV stored by class.  A row is 160*RC contiguous bytes, so every
+// lane still moves one 16-byte granule per instruction; only the address differs.
+template <int RC, bool NT>
+__device__ __forceinline__ void dma_tile_rows(const double * __restrict__ clv, unsigned int rows,
+                                              const unsigned int (&off)[aa_geom<RC>::N_IT], char * region)
+{
+  using G = aa_geom<RC>;
+  constexpr unsigned int ROW_BYTES = RC * 160;
+  const char * base = reinterpret_cast<const char *>(clv);
+#pragma unroll
+  for (int it = 0; it < G::N_IT; ++it)
+  {
+    const unsigned int site = off[it] / ROW_BYTES, col = off[it] - site * ROW_BYTES;
+    const size_t row = (unsigned int)__shfl((int)rows, (int)site, 64);
+    __builtin_amdgcn_global_load_lds((const PLL_AS1 void *)(base + row * ROW_BYTES + col),
+                                     (PLL_AS3 void *)(region + it * 1024), 16, 0, NT ? 2 : 0);
+  }
+}
+
 // B operands of the whole tile: b[k][c] = state 4c+q of (site s, rate k)
 template <int RC>
 __device__ __forceinline__ void read_b_operands(const char * region, unsigned int s, unsigned int q,

@@ -17,7 +17,7 @@
 #include "aa_mfma.hpp"
 #include "lnl_common.hpp"
 
-template <int RC, int KIND, bool NT>
+template <int RC, int KIND, bool NT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
 {
   using G = aa_geom<RC>;
@@ -81,8 +81,17 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
   const bool has_inv = a.invariant != nullptr;
   unsigned int w_next = 0, code_next = 0, ps_next[RC], cs_next[RC];
   int inv_next = -1;
-  auto request_site_words = [&](size_t site0) {
-    const size_t n = site0 + s;
+  // Site repeats (GATHER): site n of a CLV stored by class lives in row a.pidx[n] /
+  // a.cidx[n] (nullptr = n), and so do its scaler counts.  The rows of a tile are needed
+  // when its first operand and its per-site words are requested -- one tile ahead -- so
+  // they are fetched two tiles ahead, behind that request.
+  unsigned int prow_next = 0, crow_next = 0, prow_next2 = 0, crow_next2 = 0;
+  auto rows_of = [&](const unsigned int * idx, size_t tile) -> unsigned int {
+    const size_t n = tile * 16 + s;
+    return (GATHER && idx) ? idx[n] : (unsigned int)n; // (the maps carry slack)
+  };
+  auto request_tile = [&](size_t tile, unsigned int prow, unsigned int crow) {
+    const size_t n = tile * 16 + s;
     w_next = a.pattern_weights[n];
     inv_next = invp[has_inv ? n : 0];
     if (KIND == EDGE_TI) code_next = a.tip[n];
@@ -90,15 +99,26 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     for (int k = 0; k < RC; ++k)
     {
       const bool used = per_rate || k == 0;
-      const size_t e = per_rate ? n * RC + k : n;
-      ps_next[k] = used ? psp[has_ps ? e : 0] : 0u;
-      cs_next[k] = used ? csp[has_cs ? e : 0] : 0u;
+      const size_t ep = per_rate ? (size_t)prow * RC + k : (size_t)prow;
+      const size_t ec = per_rate ? (size_t)crow * RC + k : (size_t)crow;
+      ps_next[k] = used ? psp[has_ps ? ep : 0] : 0u;
+      cs_next[k] = used ? csp[has_cs ? ec : 0] : 0u;
     }
+    if (!GATHER) dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, tile * 16, toff, region);
+    else if (KIND == EDGE_II) dma_tile_rows<RC, NT>(a.child, crow, toff, region);
+    else dma_tile_rows<RC, NT>(a.parent, prow, toff, region);
   };
   if (first < tiles)
   {
-    request_site_words(first * 16);
-    dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, first * 16, toff, region);
+    unsigned int p0 = rows_of(a.pidx, first), c0 = rows_of(a.cidx, first);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(p0), "+v"(c0));
+    prow_next = p0;
+    crow_next = c0;
+    const size_t second = first + nwaves < tiles ? first + nwaves : first;
+    prow_next2 = rows_of(a.pidx, second);
+    crow_next2 = rows_of(a.cidx, second);
+    request_tile(first, p0, c0);
   }
   for (size_t tile = first; tile < tiles; tile += nwaves)
   {
@@ -110,7 +130,10 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     // registers the next request will overwrite
     unsigned int w_cur = w_next, code = code_next, ps_cur[RC], cs_cur[RC];
     int inv_cur = has_inv ? inv_next : -1;
-    asm volatile("" : "+v"(w_cur), "+v"(code), "+v"(inv_cur));
+    const unsigned int prow_cur = prow_next; // rows of THIS tile (its second operand is still to come)
+    prow_next = prow_next2;
+    crow_next = crow_next2;
+    asm volatile("" : "+v"(w_cur), "+v"(code), "+v"(inv_cur), "+v"(prow_next), "+v"(crow_next));
 #pragma unroll
     for (int k = 0; k < RC; ++k)
     {
@@ -122,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     {
       read_b_operands<RC>(region, s, q, b);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      dma_tile<RC, NT>(a.parent, site0, toff, region);
+      if (GATHER) dma_tile_rows<RC, NT>(a.parent, prow_cur, toff, region);
+      else dma_tile<RC, NT>(a.parent, site0, toff, region);
       tile_matvec<RC>(tab, b, lane, x);
 #pragma unroll
       for (int k = 0; k < RC; ++k)
@@ -143,8 +167,10 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (next < tiles)
     {
-      request_site_words(next * 16);
-      dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, next * 16, toff, region);
+      request_tile(next, prow_next, crow_next);
+      const size_t after = next + nwaves < tiles ? next + nwaves : next;
+      prow_next2 = rows_of(a.pidx, after);
+      crow_next2 = rows_of(a.cidx, after);
     }
 
     double term[RC];
@@ -228,6 +254,7 @@ static int launch_lnl_rc(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * g
   const size_t lds = head * sizeof(double) + 4 * (size_t)G::REGION_B;
   if (lds > 80 * 1024) return 1;
   const bool nt = pllhip_use_nt(c);
+  const bool gather = a.pidx || a.cidx;
   const dim3 grid((unsigned int)blocks), block(256);
   a.reduce = pllhip_reduce_out(c, (unsigned int)blocks);
 #define LNL_ONE(KERNEL)                                                                        \
@@ -238,8 +265,9 @@ static int launch_lnl_rc(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * g
   } while (0)
 #define LNL_KIND(KINDV)                                                     \
   do {                                                                      \
-    if (nt) LNL_ONE((k_lnl_aa_mfma<RC, KINDV, true>));                      \
-    else LNL_ONE((k_lnl_aa_mfma<RC, KINDV, false>));                        \
+    if (gather) LNL_ONE((k_lnl_aa_mfma<RC, KINDV, false, true>));           \
+    else if (nt) LNL_ONE((k_lnl_aa_mfma<RC, KINDV, true, false>));          \
+    else LNL_ONE((k_lnl_aa_mfma<RC, KINDV, false, false>));                 \
   } while (0)
   if (kind == EDGE_II) LNL_KIND(EDGE_II);
   else if (kind == EDGE_TI) LNL_KIND(EDGE_TI);

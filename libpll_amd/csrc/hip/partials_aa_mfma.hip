@@ -51,7 +51,7 @@
 // KIND 0: inner-inner.  KIND 1: tip-inner -- the left factor is not a mat-vec but
 // a row of the precomputed tip table (a.ltab, [code][rate][state]), which takes
 // the place of the left P-matrix in LDS; the right child goes through the MFMAs.
-template <int RC, int MODE, bool NT, int KIND>
+template <int RC, int MODE, bool NT, int KIND, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 {
   const PartialsArgs & a = batch.op[blockIdx.y];
@@ -145,27 +145,51 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
-  // The children's scaler counts of a tile are requested right BEFORE the DMA of
-  // its first operand and consumed right after that DMA has been waited for.
-  // Loads return in order: requested anywhere later they would sit behind a DMA
-  // and their first use would cost that DMA's whole latency.
-  unsigned int lsc_next[RC], rsc_next[RC]; // (kept apart: adding them here would wait for them here)
-  unsigned int code_next = 0;              // tip code of the lane's site (tip-inner)
-  auto load_scalers = [&](size_t site0) {
-    const size_t n = site0 + s;
-    const size_t nc = n < sites ? n : 0;
-    if (KIND == 1) code_next = a.ltip[nc];
+  // Operand order: the FIRST operand tile of a tile is the left child (inner-inner) or the
+  // inner child (tip-inner), the SECOND the right child (inner-inner only).
+  //
+  // Per-site words are requested ahead of the DMA behind which they would otherwise queue
+  // (loads return in order): the first operand's scaler count and the tip code with the
+  // request of that operand -- one tile ahead --, the second operand's scaler count at the
+  // top of its tile, before the second operand itself.
+  //
+  // Site repeats (GATHER): a parent row takes each child at the row a.lidx / a.ridx name
+  // (nullptr = same index; for a tip the entry IS the tip code).  The row of the first
+  // operand is needed when that operand is requested, so it is fetched two tiles ahead;
+  // the row of the second operand one tile ahead.
+  const double * const first_clv = (KIND == 0) ? a.left : a.right;
+  const unsigned int * const first_idx = (KIND == 0) ? a.lidx : a.ridx;
+  const unsigned int * const first_sc = (KIND == 0) ? ls : rs;
+  const bool has_first = (KIND == 0) ? has_l : has_r;
+  unsigned int fsc_next[RC], code_next = 0; // first operand's scaler count(s), tip code: next tile
+  unsigned int frow_next = 0, frow_next2 = 0, srow_next = 0; // rows: first operand (t+1, t+2), second (t+1)
+  auto row_of = [&](const unsigned int * idx, size_t tile) -> unsigned int {
+    const size_t n = tile * 16 + s;
+    return (GATHER && idx) ? idx[n] : (unsigned int)n; // (lists carry zeroed slack)
+  };
+  auto request_first = [&](size_t tile, unsigned int frow) {
+    // scaler count(s) of the first operand's row, tip code of the parent row, then the tile
+    const size_t n = tile * 16 + s;
+    if (KIND == 1) code_next = (GATHER && a.lidx) ? a.lidx[n] : a.ltip[n < sites ? n : 0];
 #pragma unroll
     for (int k = 0; k < RC; ++k)
     {
-      const size_t e = (MODE == SCALE_RATE) ? nc * RC + k : nc;
+      const size_t e = (MODE == SCALE_RATE) ? (size_t)frow * RC + k : (size_t)frow;
       const bool used = (MODE == SCALE_RATE) || (MODE == SCALE_SITE && k == 0);
-      lsc_next[k] = (used && KIND == 0) ? ls[has_l ? e : 0] : 0u;
-      rsc_next[k] = used ? rs[has_r ? e : 0] : 0u;
+      fsc_next[k] = used ? first_sc[has_first ? e : 0] : 0u;
     }
+    if (GATHER) dma_tile_rows<RC, NT>(first_clv, frow, toff, region);
+    else dma_tile<RC, NT>(first_clv, tile * 16, toff, region);
   };
-  load_scalers(first * 16);
-  dma_tile<RC, NT>(KIND == 0 ? a.left : a.right, first * 16, toff, region);
+  {
+    // prologue: the rows of the first tile have to be here before anything can be requested
+    unsigned int frow0 = row_of(first_idx, first);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(frow0));
+    srow_next = (KIND == 0) ? row_of(a.ridx, first) : 0u;
+    frow_next2 = row_of(first_idx, first + nwaves < tiles ? first + nwaves : first);
+    request_first(first, frow0);
+  }
   for (size_t tile = first; tile < tiles; tile += nwaves)
   {
     const size_t site0 = tile * 16;
@@ -176,30 +200,53 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     read_b_operands<RC>(region, s, q, b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // the children's scaler counts came in with this tile's first operand
-    unsigned int csc[RC];
+    // what came in with it is taken out of the registers the next requests overwrite
+    unsigned int csc[RC], code = code_next, srow = srow_next;
+    frow_next = frow_next2;
+    asm volatile("" : "+v"(code), "+v"(srow), "+v"(frow_next)); // consumed HERE, nothing in flight
 #pragma unroll
     for (int k = 0; k < RC; ++k)
     {
-      csc[k] = lsc_next[k] + rsc_next[k];
-      asm volatile("" : "+v"(csc[k])); // consumed HERE, where nothing is in flight
+      csc[k] = fsc_next[k];
+      asm volatile("" : "+v"(csc[k]));
     }
-    unsigned int code = code_next;
-    asm volatile("" : "+v"(code));
     if (have_prev) flush();
     if (KIND == 0)
     {
-      dma_tile<RC, NT>(a.right, site0, toff, region);
+      // second operand: its scaler count(s) first, then the tile
+      unsigned int ssc[RC];
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+      {
+        const size_t e = (MODE == SCALE_RATE) ? (size_t)srow * RC + k : (size_t)srow;
+        const bool used = (MODE == SCALE_RATE) || (MODE == SCALE_SITE && k == 0);
+        ssc[k] = used ? rs[has_r ? e : 0] : 0u;
+      }
+      if (GATHER) dma_tile_rows<RC, NT>(a.right, srow, toff, region);
+      else dma_tile<RC, NT>(a.right, site0, toff, region);
       tile_matvec<RC>(ptab, b, lane, xl); // overlaps the right child's DMA and the stores
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+      {
+        csc[k] += ssc[k];
+        asm volatile("" : "+v"(csc[k]));
+      }
       read_b_operands<RC>(region, s, q, b);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    // ---- next tile's first operand: in flight while this tile is finished
+    // ---- next tile's first operand: in flight while this tile is finished; behind it the
+    // rows that will be needed one and two tiles from now
     if (next < tiles)
     {
-      load_scalers(next * 16);
-      dma_tile<RC, NT>(KIND == 0 ? a.left : a.right, next * 16, toff, region);
+      request_first(next, frow_next);
+      if (GATHER)
+      {
+        if (KIND == 0) srow_next = row_of(a.ridx, next);
+        frow_next2 = row_of(first_idx, next + nwaves < tiles ? next + nwaves : next);
+      }
+      else
+        srow_next = (unsigned int)(next * 16 + s);
     }
     if (KIND == 1)
     {
@@ -278,7 +325,7 @@ __global__ __launch_bounds__(256) void k_aa_tip_tables(PartialsBatch batch, doub
 // tip-tip: parent = ltab[code_l] (.) rtab[code_r].  One lane per 16 bytes, waves
 // in rounds of 64 sites (codes fetched once per round, one site per lane), the
 // GS = 10*RC store instructions of a round each one contiguous KiB.
-template <int RC, int MODE, bool NT>
+template <int RC, int MODE, bool NT, bool GATHER>
 __global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsBatch batch)
 {
   const PartialsArgs & a = batch.op[blockIdx.y];
@@ -297,8 +344,11 @@ __global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsBatch batch)
   for (size_t r = wave; r < rounds; r += nwaves)
   {
     const size_t site0 = r * 64;
-    unsigned int cl = (site0 + lane < sites) ? a.ltip[site0 + lane] : 0u;
-    unsigned int cr = (site0 + lane < sites) ? a.rtip[site0 + lane] : 0u;
+    // (site repeats: a parent row names the two tip codes it is the product of)
+    unsigned int cl = (GATHER && a.lidx) ? a.lidx[site0 + lane]
+                                         : ((site0 + lane < sites) ? a.ltip[site0 + lane] : 0u);
+    unsigned int cr = (GATHER && a.ridx) ? a.ridx[site0 + lane]
+                                         : ((site0 + lane < sites) ? a.rtip[site0 + lane] : 0u);
     if (cl >= a.maxstates) cl = 0;
     if (cr >= a.maxstates) cr = 0;
     const size_t gbase = site0 * GS, gend = sites * GS;
@@ -327,7 +377,16 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
 {
   using G = aa_geom<RC>;
   const PartialsArgs & a = b.op[0];
-  const size_t tiles = ((size_t)a.sites + 15) / 16;
+  // (site repeats: the ops of a launch differ in their number of rows; the grid covers
+  // the largest, a wave past its op's tiles returns at once)
+  size_t rows_max = 0;
+  bool gather = false;
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    if (b.op[i].sites > rows_max) rows_max = b.op[i].sites;
+    gather = gather || b.op[i].lidx || b.op[i].ridx;
+  }
+  const size_t tiles = (rows_max + 15) / 16;
   // Two workgroups per CU share its 160 KB of LDS; each holds the P tables (or the tip
   // table) once and one 11 KB image per wave.  Four waves per workgroup: a fifth fits
   // for inner-inner ops (25.6 + 5 x 11 = 80 KB) and was measured -- 69.0 us per op
@@ -351,8 +410,9 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   } while (0)
 #define AA_LAUNCH(MODEV)                                                                      \
   do {                                                                                        \
-    if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true, KIND>));                             \
-    else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND>));                               \
+    if (gather) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND, true>));                  \
+    else if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true, KIND, false>));                 \
+    else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND, false>));                        \
   } while (0)
   if (mode == SCALE_NONE) AA_LAUNCH(0);
   else if (mode == SCALE_SITE) AA_LAUNCH(1);
@@ -367,7 +427,14 @@ template <int RC>
 static int launch_tt(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode, bool nt)
 {
   const PartialsArgs & a = b.op[0];
-  const size_t rounds = ((size_t)a.sites + 63) / 64;
+  size_t rows_max = 0;
+  bool gather = false;
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    if (b.op[i].sites > rows_max) rows_max = b.op[i].sites;
+    gather = gather || b.op[i].lidx || b.op[i].ridx;
+  }
+  const size_t rounds = (rows_max + 63) / 64;
   size_t blocks = (rounds + 3) / 4;
   const size_t cap = (size_t)c->num_cus * 8; // 29 KB of table staging per workgroup
   if (blocks > cap) blocks = cap;
@@ -375,8 +442,9 @@ static int launch_tt(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   const dim3 grid((unsigned int)blocks, count), block(256);
 #define TT_LAUNCH(MODEV)                                                                         \
   do {                                                                                           \
-    if (nt) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, true>), grid, block, lds, c->stream, b);  \
-    else hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false>), grid, block, lds, c->stream, b);    \
+    if (gather) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false, true>), grid, block, lds, c->stream, b); \
+    else if (nt) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, true, false>), grid, block, lds, c->stream, b); \
+    else hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false, false>), grid, block, lds, c->stream, b); \
   } while (0)
   if (mode == SCALE_NONE) TT_LAUNCH(0);
   else if (mode == SCALE_SITE) TT_LAUNCH(1);

@@ -30,15 +30,16 @@ __global__ __launch_bounds__(256) void k_rep_keys(const unsigned int * __restric
                                                   const unsigned char * __restrict__ tip1,
                                                   const unsigned int * __restrict__ id2,
                                                   const unsigned char * __restrict__ tip2,
-                                                  unsigned int nb, unsigned int sites,
+                                                  unsigned int nb, unsigned int tip_mask,
+                                                  unsigned int sites,
                                                   unsigned long long * __restrict__ keys,
                                                   unsigned int * __restrict__ vals)
 {
   for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < sites;
        n += (size_t)gridDim.x * blockDim.x)
   {
-    const unsigned int a = tip1 ? (tip1[n] & 15u) : id1[n];
-    const unsigned int b = tip2 ? (tip2[n] & 15u) : id2[n];
+    const unsigned int a = tip1 ? (tip1[n] & tip_mask) : id1[n];
+    const unsigned int b = tip2 ? (tip2[n] & tip_mask) : id2[n];
     keys[n] = (unsigned long long)a * nb + b;
     vals[n] = (unsigned int)n;
   }
@@ -124,21 +125,31 @@ extern "C" int pllhip_identify_repeats(pllhip_ctx_t * c, unsigned int parent, un
     pllhip_set_error("pllhip_identify_repeats: CLV index out of range");
     return -1;
   }
-  if (c->sh.states != 4 || !c->sh.pattern_tip || c->sh.asc_states)
+  if ((c->sh.states != 4 && c->sh.states != 20) || !c->sh.pattern_tip || c->sh.asc_states)
   {
-    pllhip_set_error("pllhip_identify_repeats: site repeats need 4 states, pattern tips, no asc-bias sites");
+    pllhip_set_error("pllhip_identify_repeats: site repeats need 4 or 20 states, pattern tips, no asc-bias sites");
     return -1;
   }
+  // 20 states: only the matrix-core kernels follow row maps; on the bit-exact vector
+  // kernels (PLLHIP_AA_EXACT=1, or a rate_cats / tip alphabet they do not cover) every
+  // CLV simply stays stored per site
+  if (c->sh.states == 20 && !(pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) && c->maxstates <= 32))
+  {
+    if (c->rows.empty()) c->rows.resize(nodes);
+    c->rows[parent].classes = 0;
+    return 0;
+  }
+  const unsigned int tip_rows = (c->sh.states == 4) ? 16u : 32u; // codes a tip can show
   if (c->rows.empty()) c->rows.resize(nodes);
   pllhip_ctx::node_rows & r = c->rows[parent];
   r.classes = 0;
 
-  // rows of the two children: 16 characters at a tip, the class count of an inner node
+  // rows of the two children: 16 (4 states) or 32 (20 states) characters at a tip, the class count of an inner node
   // stored by class; an inner node stored per site cannot carry a compression
   const bool t1 = pllhip_is_tip(c, child1), t2 = pllhip_is_tip(c, child2);
   if ((!t1 && !c->rows[child1].classes) || (!t2 && !c->rows[child2].classes)) return 0;
-  const unsigned int na = t1 ? 16u : c->rows[child1].classes;
-  const unsigned int nb = t2 ? 16u : c->rows[child2].classes;
+  const unsigned int na = t1 ? tip_rows : c->rows[child1].classes;
+  const unsigned int nb = t2 ? tip_rows : c->rows[child2].classes;
   const unsigned int N = c->sh.sites;
   if (max_classes > N) max_classes = N;
 
@@ -148,7 +159,7 @@ extern "C" int pllhip_identify_repeats(pllhip_ctx_t * c, unsigned int parent, un
   k_rep_keys<<<grid, 256, 0, c->stream>>>(t1 ? nullptr : c->rows[child1].site_id,
                                           t1 ? pllhip_tip_ptr(c, child1) : nullptr,
                                           t2 ? nullptr : c->rows[child2].site_id,
-                                          t2 ? pllhip_tip_ptr(c, child2) : nullptr, nb, N,
+                                          t2 ? pllhip_tip_ptr(c, child2) : nullptr, nb, tip_rows - 1u, N,
                                           w->keys_in, w->vals_in);
   HIP_TRY(hipGetLastError());
   // only the bits the key space needs are sorted: a cherry (16 x 16) is one 8-bit pass

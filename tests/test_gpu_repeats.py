@@ -32,12 +32,15 @@ def same_state(p, q, plan):
             assert (p.get_scaler(sc) == q.get_scaler(sc)).all(), "scaler %d" % sc
 
 
-@pytest.mark.parametrize("shape,tips,sites,rate_cats,rate_scalers",
-                         [("balanced", 16, 3000, 4, False), ("random", 30, 2111, 4, False),
-                          ("caterpillar", 40, 1500, 4, False), ("random", 24, 1777, 2, True),
-                          ("balanced", 8, 65, 1, False), ("random", 50, 4000, 8, False)])
-def test_repeats_equal_plain(gpu, shape, tips, sites, rate_cats, rate_scalers):
-    case = make_case(4, shape, tips, sites, rate_cats=rate_cats, seed=tips + sites, gap_frac=0.02)
+@pytest.mark.parametrize("states,shape,tips,sites,rate_cats,rate_scalers",
+                         [(4, "balanced", 16, 3000, 4, False), (4, "random", 30, 2111, 4, False),
+                          (4, "caterpillar", 40, 1500, 4, False), (4, "random", 24, 1777, 2, True),
+                          (4, "balanced", 8, 65, 1, False), (4, "random", 50, 4000, 8, False),
+                          (20, "balanced", 16, 2000, 4, False), (20, "random", 25, 1555, 4, True),
+                          (20, "caterpillar", 20, 777, 2, False), (20, "random", 12, 333, 1, False)])
+def test_repeats_equal_plain(gpu, monkeypatch, states, shape, tips, sites, rate_cats, rate_scalers):
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "0")   # 20 states: the matrix-core kernels follow row maps
+    case = make_case(states, shape, tips, sites, rate_cats=rate_cats, seed=tips + sites, gap_frac=0.02)
     # few distinct columns near the tips, like real data: draw sites from a small pool
     rng = np.random.default_rng(sites)
     pool = rng.integers(0, sites, size=sites // 6 + 1)
@@ -117,10 +120,22 @@ def test_repeats_follow_topology_and_tip_changes(gpu):
     rep.destroy()
 
 
-def test_repeats_attribute_contract(gpu):
-    case = make_case(20, "balanced", 8, 50, seed=3)
+def test_repeats_attribute_contract(gpu, monkeypatch):
+    odd = make_case(4, "balanced", 8, 50, seed=3)
+    odd["states"] = 5
     with pytest.raises(PllError):
-        build_partition(gpu, case, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)     # 20 states
+        gpu.partition_create(8, 6, 5, 50, 1, 14, 4, 6, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)   # 5 states
+    # 20 states on the bit-exact vector kernels: accepted, everything stays stored per site
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")
+    aa = make_case(20, "balanced", 8, 60, seed=3)
+    p = build_partition(gpu, aa, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)
+    q = build_partition(gpu, aa, ATTRIB_PATTERN_TIP)
+    for x in (p, q):
+        x.update_partials(aa["plan"].ops)
+    assert all(p.repeats_classes(int(op["parent_clv_index"])) == 0 for op in aa["plan"].ops)
+    same_state(p, q, aa["plan"])
+    p.destroy()
+    q.destroy()
     dna = make_case(4, "balanced", 8, 50, seed=3)
     with pytest.raises(PllError):
         build_partition(gpu, dna, ATTRIB_SITE_REPEATS)                           # tip CLVs
