@@ -21,9 +21,12 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops, unsig
   unsigned int i;
   int rc;
   if (!pll_amd_flush_model(p)) return;
-  if (q->rep && !pll_amd_repeats_update(p, ops, count)) return;
-  rc = pllhip_update_partials(q->ctx, (const pllhip_op_t *)ops, count);
-  if (rc)
+  if (q->rep)
+  {
+    /* site repeats: identification and execution interleave (repeats.c) */
+    if (!pll_amd_repeats_update(p, ops, count)) return;
+  }
+  else if ((rc = pllhip_update_partials(q->ctx, (const pllhip_op_t *)ops, count)))
   {
     /* void function: errors are reported through pll_errno only, as in the reference */
     pll_amd_fail_hip(rc, "CLV update");
@@ -46,6 +49,9 @@ double pll_compute_edge_loglikelihood(pll_partition_t * p, unsigned int parent_c
   double lnl = -INFINITY;
   int rc;
   if (!pll_amd_flush_model(p)) return -INFINITY;
+  if (!pll_amd_repeats_scaler_ok(p, parent_clv_index, parent_scaler_index) ||
+      !pll_amd_repeats_scaler_ok(p, child_clv_index, child_scaler_index))
+    return -INFINITY;
   rc = pllhip_edge_loglikelihood(pll_amd_priv(p)->ctx, parent_clv_index, parent_scaler_index,
                                  child_clv_index, child_scaler_index, matrix_index,
                                  freqs_indices, persite_lnl, &lnl);
@@ -64,6 +70,7 @@ double pll_compute_root_loglikelihood(pll_partition_t * p, unsigned int clv_inde
   double lnl = -INFINITY;
   int rc;
   if (!pll_amd_flush_model(p)) return -INFINITY;
+  if (!pll_amd_repeats_scaler_ok(p, clv_index, scaler_index)) return -INFINITY;
   rc = pllhip_root_loglikelihood(pll_amd_priv(p)->ctx, clv_index, scaler_index, freqs_indices,
                                  persite_lnl, &lnl);
   if (rc)
@@ -101,6 +108,9 @@ int pll_update_sumtable(pll_partition_t * p, unsigned int parent_clv_index,
     if (!p->eigen_decomp_valid[params_indices[n]])
       if (!pll_update_eigen(p, params_indices[n])) return PLL_FAILURE;
   if (!pll_amd_flush_model(p)) return PLL_FAILURE;
+  if (!pll_amd_repeats_scaler_ok(p, parent_clv_index, parent_scaler_index) ||
+      !pll_amd_repeats_scaler_ok(p, child_clv_index, child_scaler_index))
+    return PLL_FAILURE;
   slot = slot_of(q, sumtable);
   if (slot < 0)
   {

@@ -23,6 +23,7 @@ typedef struct pll_amd_node_repeats
   unsigned int gen;         /* bumped whenever the classes (or a tip's characters) change */
   unsigned int sig[4];      /* (child1, its gen, child2, its gen) the classes were built from */
   int sig_valid;
+  unsigned int touched;     /* rep_epoch of the last op of the current piece that used the slot */
 } pll_amd_node_repeats_t;
 
 typedef struct pll_amd_partition
@@ -40,6 +41,7 @@ typedef struct pll_amd_partition
   /* PLL_ATTRIB_SITE_REPEATS: per CLV slot, and which CLV each scale buffer belongs to */
   pll_amd_node_repeats_t * rep;
   int * scaler_owner;
+  unsigned int rep_epoch;
 } pll_amd_partition_t;
 
 static inline pll_amd_partition_t * pll_amd_priv(const pll_partition_t * p)
@@ -62,6 +64,7 @@ void pll_amd_repeats_free(pll_amd_partition_t * q);
 void pll_amd_repeats_tip_changed(pll_amd_partition_t * q, unsigned int tip);
 int pll_amd_repeats_update(pll_partition_t * p, const pll_operation_t * ops, unsigned int count);
 /* site -> row map of a CLV stored by class (NULL if it is stored per site or on error) */
+int pll_amd_repeats_scaler_ok(pll_partition_t * p, unsigned int clv, int scaler);
 const unsigned int * pll_amd_repeats_site_id(pll_partition_t * p, unsigned int clv_index);
 int pll_amd_repeats_expand(void * buf, const unsigned int * site_id, unsigned int classes,
                            unsigned int sites, size_t row_bytes);

@@ -143,40 +143,73 @@ void pll_amd_repeats_tip_changed(pll_amd_partition_t * q, unsigned int tip)
   if (q->rep) q->rep[tip].gen++;
 }
 
-/* Bring the classes of every parent in `ops` up to date (list order: children first).
+/* pll_update_partials under site repeats: bring the classes of every parent up to date
+ * (list order: children first) and run the ops.  The row maps belong to CLV SLOTS, and a
+ * list may write a slot more than once (re-rooting an unrooted tree does): ops already
+ * accepted that read or write a slot must run with its old maps, so the list is handed
+ * to the device in pieces -- a piece ends where a slot it touches gets new classes.
  * Returns PLL_SUCCESS / PLL_FAILURE. */
 int pll_amd_repeats_update(pll_partition_t * p, const pll_operation_t * ops, unsigned int count)
 {
   pll_amd_partition_t * q = pll_amd_priv(p);
   const unsigned int tips = p->tips, nodes = p->tips + p->clv_buffers;
-  unsigned int i;
+  unsigned int i, start = 0;
+  int rc;
 
+  q->rep_epoch++;
   for (i = 0; i < count; ++i)
   {
     const pll_operation_t * op = &ops[i];
     const unsigned int c1 = op->child1_clv_index, c2 = op->child2_clv_index;
     pll_amd_node_repeats_t * par;
     unsigned int sig[4], classes = 0;
-    int rc;
     if (op->parent_clv_index >= nodes || op->parent_clv_index < tips || c1 >= nodes || c2 >= nodes)
       continue; /* the device call reports the bad index */
     par = &q->rep[op->parent_clv_index];
+    /* A scale buffer is stored the way the CLV it was written with is: a child's counts
+       can only be taken from the buffer that belongs to that child. */
+    {
+      const int cs[2] = {op->child1_scaler_index, op->child2_scaler_index};
+      const unsigned int cc[2] = {c1, c2};
+      int s;
+      for (s = 0; s < 2; ++s)
+        if (cs[s] >= 0 && (unsigned int)cs[s] < p->scale_buffers && q->scaler_owner[cs[s]] != (int)cc[s])
+        {
+          pll_amd_set_error(PLL_ERROR_PARAM_INVALID,
+                            "Site repeats: scale buffer %d was not written together with CLV %u.", cs[s], cc[s]);
+          return PLL_FAILURE;
+        }
+    }
     if (op->parent_scaler_index >= 0 && (unsigned int)op->parent_scaler_index < p->scale_buffers)
       q->scaler_owner[op->parent_scaler_index] = (int)op->parent_clv_index;
     sig[0] = c1;
     sig[1] = q->rep[c1].gen;
     sig[2] = c2;
     sig[3] = q->rep[c2].gen;
-    if (par->sig_valid && !memcmp(sig, par->sig, sizeof(sig))) continue; /* classes still right */
-
-    if ((rc = pllhip_identify_repeats(q->ctx, op->parent_clv_index, c1, c2, p->sites / 2, &classes)))
-      return pll_amd_fail_hip(rc, "site-repeat identification");
-    par->classes = classes;
-    par->site_id_valid = 0;
-    par->gen++;
-    memcpy(par->sig, sig, sizeof(sig));
-    par->sig_valid = 1;
+    if (!par->sig_valid || memcmp(sig, par->sig, sizeof(sig)))
+    {
+      if (par->touched == q->rep_epoch && i > start)
+      {
+        /* earlier ops of this piece use the slot as it is now: run them first */
+        if ((rc = pllhip_update_partials(q->ctx, (const pllhip_op_t *)(ops + start), i - start)))
+          return pll_amd_fail_hip(rc, "CLV update");
+        start = i;
+        q->rep_epoch++;
+      }
+      if ((rc = pllhip_identify_repeats(q->ctx, op->parent_clv_index, c1, c2, p->sites / 2, &classes)))
+        return pll_amd_fail_hip(rc, "site-repeat identification");
+      par->classes = classes;
+      par->site_id_valid = 0;
+      par->gen++;
+      memcpy(par->sig, sig, sizeof(sig));
+      par->sig_valid = 1;
+    }
+    par->touched = q->rep_epoch;
+    q->rep[c1].touched = q->rep_epoch;
+    q->rep[c2].touched = q->rep_epoch;
   }
+  if (count > start && (rc = pllhip_update_partials(q->ctx, (const pllhip_op_t *)(ops + start), count - start)))
+    return pll_amd_fail_hip(rc, "CLV update");
   return PLL_SUCCESS;
 }
 
@@ -220,6 +253,17 @@ int pll_amd_repeats_expand(void * buf, const unsigned int * site_id, unsigned in
     memcpy((char *)buf + s * row_bytes, rows + (size_t)site_id[s] * row_bytes, row_bytes);
   free(rows);
   return PLL_SUCCESS;
+}
+
+/* lnL / sumtable / derivative calls: is `scaler` the buffer written with `clv`? */
+int pll_amd_repeats_scaler_ok(pll_partition_t * p, unsigned int clv, int scaler)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  if (!q->rep || scaler < 0 || (unsigned int)scaler >= p->scale_buffers) return 1;
+  if (q->scaler_owner[scaler] == (int)clv) return 1;
+  pll_amd_set_error(PLL_ERROR_PARAM_INVALID,
+                    "Site repeats: scale buffer %d was not written together with CLV %u.", scaler, clv);
+  return 0;
 }
 
 unsigned int pll_amd_repeats_classes(const pll_partition_t * p, unsigned int clv_index)

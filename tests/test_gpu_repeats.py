@@ -141,3 +141,51 @@ def test_repeats_attribute_contract(gpu, monkeypatch):
         build_partition(gpu, dna, ATTRIB_SITE_REPEATS)                           # tip CLVs
     with pytest.raises(PllError):
         build_partition(gpu, dna, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS | ATTRIB_AB_LEWIS)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_repeats_random_op_sequences(gpu, seed):
+    """The arbitrary op sequences of test_gpu_api (slot reuse, repeated children, scale
+    buffers changing owner) with site repeats on and off: same CLVs and counts."""
+    from helpers import random_sequence_case
+    seed = 3 * seed + 1 if seed % 2 else 3 * seed + 2          # 4-state cases of that generator
+    case, attrs, ops, rng = random_sequence_case(seed)
+    assert case["states"] == 4
+    attrs |= ATTRIB_PATTERN_TIP
+    sites = case["sites"]
+    pool = rng.integers(0, sites, size=sites // 8 + 1)
+    pick = pool[rng.integers(0, len(pool), size=sites)]
+    case["seqs"] = [bytes(np.frombuffer(s, dtype=np.uint8)[pick]) for s in case["seqs"]]
+    plain = build_partition(gpu, case, attrs)
+    rep = build_partition(gpu, case, attrs | ATTRIB_SITE_REPEATS)
+    plain.update_partials(ops)
+    rep.update_partials(ops)
+    written = sorted(set(int(x) for x in ops["parent_clv_index"]))
+    assert any(rep.repeats_classes(n) for n in written)
+    final_scaler = {}
+    for op in ops:                                    # the last op that wrote each CLV owns its scaler
+        final_scaler[int(op["parent_clv_index"])] = int(op["parent_scaler_index"])
+    owner = {}
+    for op in ops:
+        if int(op["parent_scaler_index"]) >= 0:
+            owner[int(op["parent_scaler_index"])] = int(op["parent_clv_index"])
+    for node in written:
+        assert bits_equal(plain.get_clv(node), rep.get_clv(node)), "CLV slot %d" % node
+    for sc, node in owner.items():
+        if final_scaler[node] == sc:
+            assert (plain.get_scaler(sc) == rep.get_scaler(sc)).all(), "scale buffer %d" % sc
+    plain.destroy()
+    rep.destroy()
+
+
+def test_repeats_refuse_foreign_scale_buffer(gpu):
+    """A child's counts must come from the buffer written with that child."""
+    case = make_case(4, "balanced", 8, 400, seed=9)
+    plan = case["plan"]
+    rep = build_partition(gpu, case, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)
+    rep.update_partials(plan.ops)
+    bad = plan.ops[4:5].copy()                        # first inner-inner op: children 8, 9
+    bad[0]["child1_scaler_index"] = int(bad[0]["child2_scaler_index"])
+    rep.update_partials(bad)
+    assert gpu.errno() == 113 and "was not written together" in gpu.errmsg()
+    rep.destroy()
