@@ -154,3 +154,25 @@ def test_asc_bias_api_contract(gpu, ref):
     with pytest.raises(PllError) as ei:
         build(gpu, aa, ATTRIB_PATTERN_TIP | ATTRIB_AB_LEWIS)
     assert "tip CLVs" in str(ei.value)
+
+
+@pytest.mark.parametrize("kind", sorted(TYPES))
+def test_asc_bias_is_additive_over_site_shards(gpu, kind):
+    """What the multi-GPU path relies on: with the per-state extra sites
+    present on every shard, the corrected lnL of the shards adds up to the corrected lnL of
+    the whole alignment (state weights split the same way as the sites)."""
+    case = make_case(4, "random", 10, 512, seed=21)
+    plan, R = case["plan"], case["rate_cats"]
+    sw = np.array([8, 2, 6, 4], dtype=np.uint32)
+    whole = build(gpu, case, TYPES[kind] | ATTRIB_PATTERN_TIP, sw)
+    whole.update_partials(plan.ops)
+    total = whole.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    whole.destroy()
+    parts = 0.0
+    for lo, hi in ((0, 256), (256, 512)):
+        half = dict(case, sites=hi - lo, seqs=[s[lo:hi] for s in case["seqs"]], pw=case["pw"][lo:hi])
+        p = build(gpu, half, TYPES[kind] | ATTRIB_PATTERN_TIP, sw // 2)
+        p.update_partials(plan.ops)
+        parts += p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+        p.destroy()
+    assert abs(parts - total) <= 1e-11 * abs(total), (kind, parts, total)
