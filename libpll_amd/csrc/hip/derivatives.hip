@@ -15,6 +15,10 @@
 //     Streams the table once per Newton iteration: 132 B per site for 4x4.
 //     The (rate_cats x states x 4) diagptable is built by the host with libm exp,
 //     exactly like core_derivatives.c:560-575, and passed in.
+//     Kernels: k_derivatives_dna (4 states, 16 bytes per lane, the table itself a kernel
+//     argument), k_derivatives_aa_tile (20 states, LDS-DMA tiles), k_derivatives (lane per
+//     (site, rate), other cases with power-of-two rate_cats), k_derivatives_gen.
+//     The ascertainment-bias terms come from asc_bias.hip and are added by the final sum.
 #include "ctx.hpp"
 #include "numerics.hpp"
 #include "aa_mfma.hpp"

@@ -25,13 +25,16 @@
 // site rows are padded by one 16-byte granule (pad lanes load a dummy granule),
 // so the B-operand reads of a wave hit 64 different banks.  Left child first;
 // once its operands are in registers the image is refilled with the right child
-// while the left products run.  Both children produce the same accumulator
-// layout, so x*y and the "< 2^-256" test are register-local; the per-site AND
-// over the 4 lanes of a column is one __ballot.  The product tile returns through
-// the same image so the parent CLV is written 16 contiguous bytes per lane.
-// P-matrices sit in LDS ([child][rate][20][20], bank-conflict-free for the A
-// pattern); a category's 50 A operands are fetched right before its MFMAs.
-// Two waves per SIMD overlap one wave's DMA wait with the other's MFMAs.
+// while the left products run, and as soon as the right operands are in registers
+// with the NEXT tile's left child (the schedule is spelled out inside the kernel).
+// Both children produce the same accumulator layout, so x*y and the "< 2^-256" test
+// are register-local; the per-site AND over the 4 lanes of a column is one
+// __ballot.  The product tile returns through the same image, one tile late, so
+// the parent CLV is written 16 contiguous bytes per lane.  P-matrices sit in LDS
+// ([child][rate][20][20], bank-conflict-free for the A pattern); A operands are
+// fetched five at a time right before their MFMAs.  Two waves per SIMD (LDS-bound:
+// two workgroups of four images per CU).  GATHER variants follow site-repeat row
+// maps (host/repeats.c): a tile's 16 site rows are then addressed one by one.
 //
 // Roofline.  1932 B and 6320 flop per site-update: 3.3 flop/B, below
 // the f64 machine balance, so HBM is the bound: 200 MFMAs x 17 cycles per 64
