@@ -189,3 +189,28 @@ def test_repeats_refuse_foreign_scale_buffer(gpu):
     rep.update_partials(bad)
     assert gpu.errno() == 113 and "was not written together" in gpu.errmsg()
     rep.destroy()
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_repeats_with_invariant_sites_and_weights(gpu, monkeypatch, states):
+    """+I model (per-site invariant-state index) and pattern weights are per SITE
+    quantities: unchanged by the way CLVs are stored."""
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "0")
+    case = make_case(states, "random", 18, 1200, seed=states)
+    rng = np.random.default_rng(states)
+    pool = rng.integers(0, 1200, size=150)
+    pick = pool[rng.integers(0, len(pool), size=1200)]
+    case["seqs"] = [bytes(np.frombuffer(s, dtype=np.uint8)[pick]) for s in case["seqs"]]
+    # some constant columns so that the invariant-site term is exercised
+    for col in range(0, 1200, 37):
+        case["seqs"] = [s[:col] + case["seqs"][0][col:col + 1] + s[col + 1:] for s in case["seqs"]]
+    plan, R = case["plan"], case["rate_cats"]
+    res = []
+    for attrs in (ATTRIB_PATTERN_TIP, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS):
+        p = build_partition(gpu, case, attrs, pinv=0.23)
+        res.append(evaluate(p, plan, R))
+        if attrs & ATTRIB_SITE_REPEATS:
+            assert sum(1 for op in plan.ops if p.repeats_classes(int(op["parent_clv_index"]))) >= 8
+        p.destroy()
+    a, b = res
+    assert a[0] == b[0] and bits_equal(a[1], b[1]) and bits_equal(a[2], b[2]) and a[3] == b[3]
