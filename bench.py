@@ -22,6 +22,8 @@ Inputs are resident in HBM before the timed region starts.  `roofline` is for
 the dominant kernel, the 4-state inner-inner CLV update: 396 algorithmic
 bytes per site-update x sites per launch / the launch's average
 duration from HIP events on the partition's own stream, against 8 TB/s.
+`api_calls` times the two API calls of a step on their own (HIP events on the partition's
+stream and wall clock, median and minimum over the steps).
 `cpu_baseline` times the reference's AVX2-flag path (oracle/_ref, built from
 the reference sources in the dev container) on one host core over a bounded
 sample of the same workload.
@@ -309,6 +311,25 @@ def main():
                     "ops_per_launch": round(ops_per_launch, 2),
                     "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": n_launch,
                     "avg_op_us": round(ms / n_ops * 1e3, 2)}
+    # ---- the two API calls of a step on their own: HIP events on the
+    # partition's stream around each call, and wall clock around call + drain
+    def spread(xs):
+        xs = sorted(xs)
+        return {"median": round(xs[len(xs) // 2], 4), "min": round(xs[0], 4)}
+    ev_up, wall_up, wall_lnl = [], [], []
+    for _ in range(max(args.steps, 5)):
+        part.wait()
+        t1 = time.perf_counter()
+        part.timer_start()
+        part.update_partials(plan.ops)
+        ev_up.append(part.timer_stop_ms())
+        wall_up.append((time.perf_counter() - t1) * 1e3)
+        t1 = time.perf_counter()
+        step_lnl = part.compute_edge_loglikelihood(*plan.root_edge, fi)
+        wall_lnl.append((time.perf_counter() - t1) * 1e3)
+    api = {"update_partials_ms_hip_events": spread(ev_up), "update_partials_ms_wall": spread(wall_up),
+           "edge_loglikelihood_ms_wall": spread(wall_lnl)}
+
     # per-class averages with one event pair per launch (diagnostic; each pair
     # adds ~2 us, so these read high)
     part.profile_enable(True)
@@ -379,7 +400,8 @@ def main():
                        "site_repeats": repeats},
             "lnl": lnl, "lnl_rel_err_vs_reference": lnl_rel_err,
             "first_evaluation_ms": round(first_ms, 2),
-            "roofline": roofline, "kernels": per_kernel, "cpu_baseline": cpu, "newton": newton,
+            "roofline": roofline, "api_calls": api, "kernels": per_kernel, "cpu_baseline": cpu,
+            "newton": newton,
         }
         print(json.dumps(out))
     part.destroy()
