@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # (profiles/r1_pmc_hbm_traffic*.csv): FETCH_SIZE x 2 (gfx950 counts 128-B requests
 # at 64 B) + WRITE_SIZE, KB -> bytes, divided by the ops a launch carries.  Valid for
 # the site counts they were taken at; None otherwise.
-TRAFFIC_PER_OP = {4: 396.0e6, 20: 387.9e6}
+TRAFFIC_PER_OP = {4: 396.0e6, 20: 387.6e6}
 TRAFFIC_SITES = {4: 1_000_000, 20: 200_000}
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
