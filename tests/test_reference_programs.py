@@ -33,7 +33,12 @@ def test_reference_program_output(gpu, name, mode):
     run = subprocess.run([exe] + mode, capture_output=True, text=True, timeout=600, env=env)
     assert run.returncode == 0, run.stderr[-2000:]
     got = run.stdout
-    expected = open(os.path.join(OUT, name + ".out")).read()
+    # (protein-models has no stored output in the reference: its expected text is made
+    # from the reference build by oracle/Makefile, next to the binaries)
+    where = os.path.join(BIN, "expected") if name == "protein-models" else OUT
+    if not os.path.exists(os.path.join(where, name + ".out")):
+        pytest.skip("expected output missing (make -C oracle ref)")
+    expected = open(os.path.join(where, name + ".out")).read()
     if got.strip() == "Skip":       # a test may opt out of a mode (test/src/common.c:62-66)
         assert open(os.path.join(OUT, "skip.out")).read().strip() == "Skip"
         return
