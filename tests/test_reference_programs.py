@@ -14,7 +14,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref")
 OUT = os.path.join(ROOT, "tests", "golden", "reference_out")
-TESTS = ["example_unrooted", "00010_NMDU_lkcalc", "00011_NMAU_lkcalc", "00012_NMOU_lkcalc", "00020_NMDR_lkcalc",
+EXAMPLES = ["example_rooted", "example_rooted-tacg", "example_heterotachy", "example_newton"]
+TESTS = ["example_unrooted"] + EXAMPLES + [ "00010_NMDU_lkcalc", "00011_NMAU_lkcalc", "00012_NMOU_lkcalc", "00020_NMDR_lkcalc",
          "00021_NMAR_lkcalc", "00022_NMOR_lkcalc", "00030_NMDU_gamma", "00032_NMOU_gamma",
          "alpha-cats", "derivatives", "derivatives-oddstates", "hky", "pmatrix", "protein-models"]
 MODES = [[], ["tv"], ["avx2"], ["avx2", "tv"], ["avx"], ["sse", "tv"]]
@@ -24,8 +25,8 @@ MODES = [[], ["tv"], ["avx2"], ["avx2", "tv"], ["avx"], ["sse", "tv"]]
 @pytest.mark.parametrize("mode", MODES, ids=lambda m: "+".join(m) or "cpu")
 @pytest.mark.parametrize("name", TESTS)
 def test_reference_program_output(gpu, name, mode):
-    if name == "example_unrooted" and mode:
-        pytest.skip("examples/unrooted takes no attribute arguments")
+    if name.startswith("example_") and mode:
+        pytest.skip("the examples take no attribute arguments")
     exe = os.path.join(BIN, "reftest_" + name)
     if not os.path.exists(exe):
         pytest.skip("prebuilt reference test program missing (make -C oracle reftests)")
@@ -33,9 +34,9 @@ def test_reference_program_output(gpu, name, mode):
     run = subprocess.run([exe] + mode, capture_output=True, text=True, timeout=600, env=env)
     assert run.returncode == 0, run.stderr[-2000:]
     got = run.stdout
-    # (protein-models has no stored output in the reference: its expected text is made
-    # from the reference build by oracle/Makefile, next to the binaries)
-    where = os.path.join(BIN, "expected") if name == "protein-models" else OUT
+    # (protein-models and the extra examples have no stored output in the reference: their
+    # expected text is made from the reference build by oracle/Makefile, next to the binaries)
+    where = os.path.join(BIN, "expected") if (name == "protein-models" or name in EXAMPLES) else OUT
     if not os.path.exists(os.path.join(where, name + ".out")):
         pytest.skip("expected output missing (make -C oracle ref)")
     expected = open(os.path.join(where, name + ".out")).read()
