@@ -212,9 +212,10 @@ struct DerivArgs
   ReduceOut reduce;
   unsigned int sites, rate_cats, states;
   unsigned int params_indices[PLLHIP_MAX_RATE_CATS];
-  // 4-state data: the table itself travels as a kernel argument (rate_cats <= 8: 1 KB),
-  // which saves the staging copy -- a third of a derivative call on a small partition
-  double diag_inline[8 * 4 * 4];
+  // 4-state data (rate_cats <= 8: 1 KB) and 20-state data on the tile kernel (rate_cats
+  // <= 4: 2.5 KB): the table itself travels as a kernel argument, which saves the
+  // staging copy and the stream drain in front of it
+  double diag_inline[4 * 20 * 4];
 };
 
 __device__ __forceinline__ void block_sum2(double v0, double v1, const ReduceOut & ro)
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void k_derivatives_aa_tile(DerivArgs a)
   __shared__ double s_model[RC][2]; // prop_invar, rate weight of the category
   __shared__ double s_freqs[RC][20];
   double * s_diag = smem;
-  for (unsigned int t = threadIdx.x; t < RC * 80u; t += blockDim.x) s_diag[t] = a.diagp[t];
+  for (unsigned int t = threadIdx.x; t < RC * 80u; t += blockDim.x) s_diag[t] = a.diag_inline[t];
   for (unsigned int t = threadIdx.x; t < RC * 20u; t += blockDim.x)
     s_freqs[t / 20u][t % 20u] = a.freqs[(size_t)a.params_indices[t / 20u] * 20 + t % 20u];
   if (threadIdx.x < RC)
@@ -543,9 +544,10 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   const bool dna = (S == 4 && (R == 1 || R == 2 || R == 4 || R == 8));
   const bool asc_epilogue = c->sh.asc_states && (c->asc_type & PLLHIP_AB_MASK) &&
                             (c->asc_type & PLLHIP_AB_MASK) != PLLHIP_AB_STAMATAKIS;
+  const bool aa_tile = (S == 20 && !c->aa_exact && (R == 1 || R == 2 || R == 4));
   DerivArgs a;
-  if (dna) memcpy(a.diag_inline, h_diagptable, dbytes);
-  if (!dna || asc_epilogue)
+  if (dna || aa_tile) memcpy(a.diag_inline, h_diagptable, dbytes);
+  if (!(dna || aa_tile) || asc_epilogue)
   {
     HIP_TRY(hipStreamSynchronize(c->stream)); // staging buffer free?
     memcpy(c->h_stage, h_diagptable, dbytes);
@@ -605,7 +607,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     }
 #undef DERIV_DNA
   }
-  else if (S == 20 && !c->aa_exact && (R == 1 || R == 2 || R == 4))
+  else if (aa_tile)
   {
     const size_t tiles = ((size_t)a.sites + 15) / 16;
     size_t blocks = (tiles + 3) / 4;
