@@ -142,8 +142,10 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   HIP_TRY(hipHostGetDevicePointer((void **)&c->h_result_dev, c->h_result, 0));
   if ((rc = dev_alloc(&c->d_counter, (size_t)4, true, c->stream))) goto fail;
 
+  // (the sumtable's two matrix sets are built in the device half: 2 x one P-matrix set)
   c->stage_bytes = 64 * 1024 + (size_t)shape->prob_matrices * 16 +
-                   (size_t)(shape->tips + shape->clv_buffers) * sizeof(pllhip_op_t);
+                   (size_t)(shape->tips + shape->clv_buffers) * sizeof(pllhip_op_t) +
+                   2 * (size_t)shape->rate_cats * shape->states * shape->states * sizeof(double);
   HIP_TRY(hipHostMalloc(&c->h_stage, c->stage_bytes, hipHostMallocDefault));
   HIP_TRY(hipMalloc(&c->d_stage, c->stage_bytes));
 

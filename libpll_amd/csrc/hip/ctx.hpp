@@ -221,6 +221,10 @@ enum { SCALE_NONE = 0, SCALE_SITE = 1, SCALE_RATE = 2 };
 
 void pllhip_rep_work_free(pllhip_ctx * c); // repeats.hip
 
+// partials_gen_tile.hip: state counts other than 4 and 20
+bool pllhip_gen_tile_covers(const pllhip_ctx * c);
+int pllhip_launch_gen_batch(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int kind, int mode);
+
 // kind: 0 = inner-inner, 1 = tip-inner (tip on the left), 2 = tip-tip
 int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a, int kind, int mode,
                            int prof_kind);

@@ -216,8 +216,9 @@ __global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
 // ------------------------------------------------- any state count (fallback)
 //
 // One lane per SITE, looping over rate categories and states; P-matrices and
-// tip tables are read through L1/L2.  Used for state counts without a
-// dedicated kernel and for rate_cats that are not a power of two <= 16.
+// tip tables are read through L1/L2.  The last resort: 4 or 20 states with a rate_cats
+// the dedicated kernels do not cover, and more than 64 states (every other state count
+// runs on the LDS-tiled kernels of partials_gen_tile.hip).
 // Orders: 4 states pairwise; 20 states the AVX2-flag order (ii fused, ti not);
 // otherwise left-to-right like the plain C kernels.
 
@@ -604,6 +605,13 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, 
     if (kind == 1) LAUNCH_RC_MODE(k_aa_ti, R, mode, grid, 256, mat + tab, s, a);
     if (kind == 2) LAUNCH_RC_MODE(k_aa_tt, R, mode, grid, 256, 2 * tab, s, a);
   }
+  else if (pllhip_gen_tile_covers(c))
+  {
+    // LDS-tiled kernels for any other state count (partials_gen_tile.hip)
+    PartialsBatch b;
+    b.op[0] = a;
+    return pllhip_launch_gen_batch(c, b, 1, kind, mode);
+  }
   else
   {
     const unsigned int grid = pllhip_stream_grid(c, a.sites, 128);
@@ -739,7 +747,8 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   const bool dna_fast = c->sh.states == 4 && fast_rc(c->sh.rate_cats);
   const bool aa_fast = c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) &&
                        (!c->sh.pattern_tip || pllhip_aa_fast_covers(c, 2));
-  const bool batchable = (dna_fast || aa_fast) && !no_batch;
+  const bool gen_fast = pllhip_gen_tile_covers(c);
+  const bool batchable = (dna_fast || aa_fast || gen_fast) && !no_batch;
   if (!batchable)
   {
     for (unsigned int i = 0; i < count; ++i)
@@ -809,7 +818,8 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     const int kind = (int)((key >> 4) & 15u), mode = (int)(key & 15u);
     pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II + kind);
     int rc = dna_fast ? pllhip_launch_dna_batch(c, b, nb, kind, mode)
-                      : pllhip_launch_aa_batch(c, b, nb, kind, mode);
+             : aa_fast ? pllhip_launch_aa_batch(c, b, nb, kind, mode)
+                       : pllhip_launch_gen_batch(c, b, nb, kind, mode);
     if (rc) return rc;
   }
   return 0;

@@ -1,0 +1,378 @@
+// partials_gen_tile.hip -- CLV updates for state counts without a dedicated kernel
+// (2 = binary, 3..19 = morphological / DNA+gap, 21..64 = e.g. 61 codons).
+//
+// Reference: pll_core_update_partial_ii / _ti / _tt, the plain C kernels
+// (core_partials.c:510-662, :354-507, :82-199) -- for these state counts the sums are
+// formed left to right, and so they are here, one multiply and one add per term.
+//
+// Mapping.  A workgroup takes TILES of TS consecutive sites.  Both child tiles are
+// copied to LDS with fully coalesced loads (a tile is one contiguous TS x rate_cats x
+// states block of the CLV), the P-matrices sit in LDS TRANSPOSED ([j][i]), and one lane
+// forms one output entry (site s, rate k, state i):
+//     x = sum_j Pl_k[i][j] * L[s][k][j],   y likewise,   out = x * y
+// Lanes of a wave differ in i fastest: the P reads of one instruction are consecutive
+// LDS words (conflict-free for any state count) and the CLV reads are broadcasts of a
+// few addresses.  The products go to an LDS image of the parent tile; once all rate
+// categories of the tile are there the scaling decision (per site or per rate, from
+// flags raised by entries >= 2^-256) is known, and the tile leaves for HBM as one
+// contiguous, coalesced, possibly rescaled block together with its scaler counts.
+// When all 2 x rate_cats matrices fit in 32 KB they stay resident for the whole kernel;
+// otherwise (61 states: 59.5 KB per pair) the pair of the current category is reloaded
+// per tile from L2.
+//
+// Roofline: 3 x 8 x rate_cats x states B/site of HBM traffic against
+// rate_cats x states x (4 states + 1) flop: HBM-bound up to ~12 states, then bound by
+// the two LDS reads per multiply-add (see DESIGN.md 2.1 for the measured rates).
+#include "ctx.hpp"
+#include "numerics.hpp"
+
+struct GenTileGeom
+{
+  unsigned int ts;       // sites per tile
+  unsigned int resident; // all matrices of the op stay in LDS
+  unsigned int inv_s;    // ceil(2^32 / states): e / states == umulhi(e, inv_s) for e < 2^26
+  unsigned int inv_span; // the same for states * rate_cats
+};
+
+template <int KIND> // 0 = inner-inner, 1 = tip-inner, 2 = tip-tip
+__global__ __launch_bounds__(256) void k_gen_tile(PartialsBatch batch, int mode, GenTileGeom g)
+{
+  const PartialsArgs & a = batch.op[blockIdx.y];
+  extern __shared__ double smem[];
+  const unsigned int S = a.states, R = a.rate_cats, span = S * R, SS = S * S;
+  const unsigned int TS = g.ts, nmat = g.resident ? R : 1u;
+  const unsigned int tid = threadIdx.x;
+
+  double * s_pl = smem;                                // [nmat][j][i]
+  double * s_pr = s_pl + (size_t)nmat * SS;
+  double * s_l = s_pr + (size_t)nmat * SS;             // [TS][R][S], inner child 1 (KIND 0)
+  double * s_r = s_l + (KIND == 0 ? (size_t)TS * span : 0);
+  double * s_out = s_r + (KIND != 2 ? (size_t)TS * span : 0);
+  unsigned int * s_big = (unsigned int *)(s_out + (size_t)TS * span); // [TS][R]: some entry >= threshold
+  unsigned int * s_lmask = s_big + TS * R;             // [TS] state masks of tip child 1 (KIND 1, 2)
+  unsigned int * s_rmask = s_lmask + TS;               // [TS] of tip child 2 (KIND 2)
+
+  auto load_matrices = [&](unsigned int slot, unsigned int k) {
+    for (unsigned int t = tid; t < SS; t += 256u)
+    {
+      const unsigned int i = __umulhi(t, g.inv_s), j = t - i * S;
+      s_pl[slot * SS + j * S + i] = a.lmat[(size_t)k * SS + t];
+      s_pr[slot * SS + j * S + i] = a.rmat[(size_t)k * SS + t];
+    }
+  };
+  if (g.resident)
+    for (unsigned int k = 0; k < R; ++k) load_matrices(k, k);
+
+  const size_t ntiles = ((size_t)a.sites + TS - 1) / TS;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+  {
+    const size_t n0 = tile * TS;
+    const unsigned int ns = (a.sites - n0 < TS) ? (unsigned int)(a.sites - n0) : TS;
+    const unsigned int cnt = ns * span;
+    __syncthreads(); // the previous tile has left s_out / s_big
+    if (KIND == 0)
+      for (unsigned int e = tid; e < cnt; e += 256u) s_l[e] = a.left[n0 * span + e];
+    if (KIND != 2)
+      for (unsigned int e = tid; e < cnt; e += 256u) s_r[e] = a.right[n0 * span + e];
+    if (KIND >= 1)
+      for (unsigned int s = tid; s < ns; s += 256u) s_lmask[s] = a.tipmap[a.ltip[n0 + s]];
+    if (KIND == 2)
+      for (unsigned int s = tid; s < ns; s += 256u) s_rmask[s] = a.tipmap[a.rtip[n0 + s]];
+    for (unsigned int f = tid; f < ns * R; f += 256u) s_big[f] = 0u;
+
+    for (unsigned int k = 0; k < R; ++k)
+    {
+      if (!g.resident)
+      {
+        __syncthreads(); // category k-1 is done with the matrices
+        load_matrices(0, k);
+      }
+      if (k == 0 || !g.resident) __syncthreads();
+      const double * pl = s_pl + (g.resident ? k * SS : 0u);
+      const double * pr = s_pr + (g.resident ? k * SS : 0u);
+      for (unsigned int e = tid; e < ns * S; e += 256u)
+      {
+        const unsigned int s = __umulhi(e, g.inv_s), i = e - s * S;
+        const unsigned int row = s * span + k * S;
+        double x = 0.0, y = 0.0;
+        if (KIND == 0)
+          for (unsigned int j = 0; j < S; ++j) x += pl[j * S + i] * s_l[row + j];
+        else
+        {
+          const unsigned int m = s_lmask[s];
+          for (unsigned int j = 0; j < S; ++j)
+            if ((m >> j) & 1u) x += pl[j * S + i];
+        }
+        if (KIND != 2)
+          for (unsigned int j = 0; j < S; ++j) y += pr[j * S + i] * s_r[row + j];
+        else
+        {
+          const unsigned int m = s_rmask[s];
+          for (unsigned int j = 0; j < S; ++j)
+            if ((m >> j) & 1u) y += pr[j * S + i];
+        }
+        const double p = x * y;
+        s_out[row + i] = p;
+        if (KIND != 2 && !(p < PLLHIP_SCALE_THRESHOLD)) s_big[s * R + k] = 1u;
+      }
+    }
+    __syncthreads();
+
+    // the tile leaves as one contiguous block (tip-tip updates never scale, as in the reference)
+    for (unsigned int e = tid; e < cnt; e += 256u)
+    {
+      double p = s_out[e];
+      if (KIND != 2 && mode != SCALE_NONE)
+      {
+        const unsigned int s = __umulhi(e, g.inv_span);
+        bool big;
+        if (mode == SCALE_RATE)
+          big = s_big[s * R + __umulhi(e - s * span, g.inv_s)] != 0u;
+        else
+        {
+          big = false;
+          for (unsigned int k = 0; k < R; ++k) big = big || (s_big[s * R + k] != 0u);
+        }
+        if (!big) p *= PLLHIP_SCALE_FACTOR;
+      }
+      a.parent[n0 * span + e] = p;
+    }
+    if (mode == SCALE_SITE)
+      for (unsigned int s = tid; s < ns; s += 256u)
+      {
+        unsigned int v = 0u;
+        if (KIND != 2)
+        {
+          if (KIND == 0 && a.lscaler) v += a.lscaler[n0 + s];
+          if (a.rscaler) v += a.rscaler[n0 + s];
+          bool big = false;
+          for (unsigned int k = 0; k < R; ++k) big = big || (s_big[s * R + k] != 0u);
+          v += big ? 0u : 1u;
+        }
+        a.pscaler[n0 + s] = v;
+      }
+    if (mode == SCALE_RATE)
+      for (unsigned int f = tid; f < ns * R; f += 256u)
+      {
+        unsigned int v = 0u;
+        if (KIND != 2)
+        {
+          if (KIND == 0 && a.lscaler) v += a.lscaler[n0 * R + f];
+          if (a.rscaler) v += a.rscaler[n0 * R + f];
+          v += s_big[f] ? 0u : 1u;
+        }
+        a.pscaler[n0 * R + f] = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------ few states: rows in registers
+//
+// Up to 8 states a (site, rate) row of a CLV is at most 64 bytes: one lane takes one row,
+// keeps both child rows and the parent row in registers (state count known at compile
+// time, loops unrolled) and walks the rows of P_l / P_r in LDS -- the lanes of a wave read
+// rate_cats distinct LDS addresses per instruction, matrices padded by two words so that
+// they fall in different banks.  Consecutive lanes own consecutive rows, so a wave's
+// loads and stores cover one contiguous 64 x states x 8 B block.  rate_cats is a power
+// of two here: the lanes of a site are an aligned group of the wave and the per-site
+// scaling decision is one __ballot.
+template <int KIND, int SC>
+__global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
+{
+  const PartialsArgs & a = batch.op[blockIdx.y];
+  extern __shared__ double smem[];
+  const unsigned int R = a.rate_cats, tid = threadIdx.x;
+  constexpr unsigned int MP = SC * SC + 2; // matrix stride in LDS
+  double * s_pl = smem;
+  double * s_pr = smem + R * MP;
+  for (unsigned int t = tid; t < R * SC * SC; t += 256u)
+  {
+    const unsigned int k = t / (SC * SC), ij = t % (SC * SC);
+    s_pl[k * MP + ij] = a.lmat[t];
+    s_pr[k * MP + ij] = a.rmat[t];
+  }
+  __syncthreads();
+
+  const unsigned int rshift = __ffs(R) - 1u;
+  const size_t items = (size_t)a.sites << rshift;
+  const size_t rounds = (items + 255) / 256;
+  for (size_t round = blockIdx.x; round < rounds; round += gridDim.x)
+  {
+    const size_t item = round * 256 + tid;
+    const bool act = item < items;
+    const size_t it = act ? item : 0;
+    const size_t n = it >> rshift;
+    const unsigned int k = (unsigned int)(it & (R - 1u));
+    const double * pl = s_pl + k * MP;
+    const double * pr = s_pr + k * MP;
+    double l[SC], r[SC], out[SC];
+    unsigned int lmask = 0u, rmask = 0u;
+    if (KIND == 0)
+      for (int j = 0; j < SC; ++j) l[j] = a.left[it * SC + j];
+    else
+      lmask = a.tipmap[a.ltip[n]];
+    if (KIND != 2)
+      for (int j = 0; j < SC; ++j) r[j] = a.right[it * SC + j];
+    else
+      rmask = a.tipmap[a.rtip[n]];
+    unsigned int inherited = 0u;
+    if (KIND != 2 && mode != SCALE_NONE)
+    {
+      const size_t w = (mode == SCALE_RATE) ? it : n;
+      if (KIND == 0 && a.lscaler) inherited += a.lscaler[w];
+      if (a.rscaler) inherited += a.rscaler[w];
+    }
+
+    bool small = true;
+#pragma unroll
+    for (int i = 0; i < SC; ++i)
+    {
+      double x = 0.0, y = 0.0;
+#pragma unroll
+      for (int j = 0; j < SC; ++j)
+      {
+        if (KIND == 0) x += pl[i * SC + j] * l[j];
+        else if ((lmask >> j) & 1u) x += pl[i * SC + j];
+        if (KIND != 2) y += pr[i * SC + j] * r[j];
+        else if ((rmask >> j) & 1u) y += pr[i * SC + j];
+      }
+      out[i] = x * y;
+      small = small && (out[i] < PLLHIP_SCALE_THRESHOLD);
+    }
+
+    if (KIND != 2 && mode != SCALE_NONE)
+    {
+      bool scale = small;
+      if (mode == SCALE_SITE)
+      {
+        // all rate_cats lanes of the site (an aligned group of the wave) must agree
+        const unsigned long long b = __ballot(small || !act);
+        const unsigned int lane = tid & 63u;
+        const unsigned long long grp = b >> (lane & ~(R - 1u));
+        const unsigned long long full = (R >= 64u) ? ~0ull : ((1ull << R) - 1ull);
+        scale = (grp & full) == full;
+      }
+      if (scale)
+#pragma unroll
+        for (int i = 0; i < SC; ++i) out[i] *= PLLHIP_SCALE_FACTOR;
+      if (act && (mode == SCALE_RATE || k == 0u))
+        a.pscaler[mode == SCALE_RATE ? it : n] = inherited + (scale ? 1u : 0u);
+    }
+    else if (mode != SCALE_NONE && act && (mode == SCALE_RATE || k == 0u))
+      a.pscaler[mode == SCALE_RATE ? it : n] = 0u;
+    if (act)
+#pragma unroll
+      for (int i = 0; i < SC; ++i) a.parent[it * SC + i] = out[i];
+  }
+}
+
+static bool gen_rows_covers(unsigned int S, unsigned int R)
+{
+  const bool pow2 = R && !(R & (R - 1u)) && R <= 16u;
+  return pow2 && (S == 2 || S == 3 || S == 5 || S == 6 || S == 7 || S == 8);
+}
+
+template <int KIND, int SC>
+static int launch_gen_rows_sc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode)
+{
+  const unsigned int R = c->sh.rate_cats;
+  size_t sites = 0;
+  for (unsigned int i = 0; i < count; ++i)
+    if (b.op[i].sites > sites) sites = b.op[i].sites;
+  if (!sites) return 0;
+  const dim3 grid(pllhip_stream_grid(c, sites * R, 256), count);
+  const size_t lds = 2 * (size_t)R * (SC * SC + 2) * sizeof(double);
+  k_gen_rows<KIND, SC><<<grid, 256, lds, c->stream>>>(b, mode);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <int KIND>
+static int launch_gen_rows(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode)
+{
+  switch (c->sh.states)
+  {
+    case 2: return launch_gen_rows_sc<KIND, 2>(c, b, count, mode);
+    case 3: return launch_gen_rows_sc<KIND, 3>(c, b, count, mode);
+    case 5: return launch_gen_rows_sc<KIND, 5>(c, b, count, mode);
+    case 6: return launch_gen_rows_sc<KIND, 6>(c, b, count, mode);
+    case 7: return launch_gen_rows_sc<KIND, 7>(c, b, count, mode);
+    default: return launch_gen_rows_sc<KIND, 8>(c, b, count, mode);
+  }
+}
+
+static size_t gen_tile_lds(unsigned int S, unsigned int R, int kind, unsigned int ts, bool resident)
+{
+  const size_t span = (size_t)S * R;
+  const size_t images = (kind == 0 ? 3 : kind == 1 ? 2 : 1);
+  return 2 * (size_t)(resident ? R : 1) * S * S * sizeof(double) + images * ts * span * sizeof(double) +
+         (size_t)ts * R * sizeof(unsigned int) + 2 * (size_t)ts * sizeof(unsigned int);
+}
+
+// tile geometry of a partition; ts == 0: the shape is not covered (more than 64 states)
+static GenTileGeom gen_tile_geom(const pllhip_ctx * c, int kind, size_t * lds)
+{
+  const unsigned int S = c->sh.states, R = c->sh.rate_cats;
+  GenTileGeom g = {0u, 0u, 0u, 0u};
+  if (S == 4 || S == 20 || S < 2 || S > 64 || R > 64) return g;
+  g.resident = (2 * (size_t)R * S * S * sizeof(double) <= 32768) ? 1u : 0u;
+  // two workgroups per CU while the matrices are small, one (150 KB) for the large ones
+  const size_t budget = g.resident ? 65536 : 150 * 1024;
+  const size_t fixed = gen_tile_lds(S, R, kind, 0, g.resident);
+  const size_t per_site = gen_tile_lds(S, R, kind, 1, g.resident) - fixed;
+  if (fixed + per_site > budget) return g;
+  size_t ts = (budget - fixed) / per_site;
+  // a tile should give every lane a few outputs per category, not more: smaller tiles
+  // balance better over the workgroups
+  const size_t want = (8 * 256 + S - 1) / S;
+  if (ts > want) ts = want;
+  if (ts > 256) ts = 256;
+  g.ts = (unsigned int)ts;
+  g.inv_s = (unsigned int)((0x100000000ull + S - 1) / S);
+  g.inv_span = (unsigned int)((0x100000000ull + (size_t)S * R - 1) / ((size_t)S * R));
+  *lds = gen_tile_lds(S, R, kind, g.ts, g.resident);
+  return g;
+}
+
+bool pllhip_gen_tile_covers(const pllhip_ctx * c)
+{
+  size_t lds;
+  return gen_tile_geom(c, 0, &lds).ts != 0u;
+}
+
+template <int KIND>
+static int launch_gen_tile(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode)
+{
+  size_t lds = 0;
+  const GenTileGeom g = gen_tile_geom(c, KIND, &lds);
+  size_t tiles = 0;
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    const size_t t = ((size_t)b.op[i].sites + g.ts - 1) / g.ts;
+    if (t > tiles) tiles = t;
+  }
+  if (!tiles) return 0;
+  const size_t per_cu = g.resident ? 2 : 1;
+  const size_t cap = (size_t)c->num_cus * per_cu * 2; // two tiles in flight per resident workgroup slot
+  if (lds > 65536)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_tile<KIND>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((unsigned int)(tiles < cap ? tiles : cap), count);
+  k_gen_tile<KIND><<<grid, 256, lds, c->stream>>>(b, mode, g);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ops of one kind and scaling mode, mutually independent, in one launch
+int pllhip_launch_gen_batch(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int kind, int mode)
+{
+  if (gen_rows_covers(c->sh.states, c->sh.rate_cats))
+  {
+    if (kind == 0) return launch_gen_rows<0>(c, b, count, mode);
+    if (kind == 1) return launch_gen_rows<1>(c, b, count, mode);
+    return launch_gen_rows<2>(c, b, count, mode);
+  }
+  if (kind == 0) return launch_gen_tile<0>(c, b, count, mode);
+  if (kind == 1) return launch_gen_tile<1>(c, b, count, mode);
+  return launch_gen_tile<2>(c, b, count, mode);
+}

@@ -34,11 +34,15 @@ def make_case(states=4, shape="balanced", tips=16, sites=200, rate_cats=4, seed=
                 alpha=alpha, pw=pw, rates=rates, freqs=freqs, seed=seed, tips=tips, cmap=None)
 
 
-def odd_state_case(states, tips=9, sites=30, seed=3):
-    """5- or 7-state data over the alphabet A.. with a hand-made character map."""
-    case = make_case(states, "random", tips, sites, seed=seed)
+ALPHABET = b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789"
+
+
+def odd_state_case(states, tips=9, sites=30, seed=3, shape="random", **kw):
+    """Data with 2..32 states (other than 4 and 20) over the alphabet A.. with a
+    hand-made character map."""
+    case = make_case(states, shape, tips, sites, seed=seed, **kw)
     rng = np.random.default_rng(seed)
-    alphabet = b"ABCDEFGHIJ"[:states]
+    alphabet = ALPHABET[:states]
     chars = np.frombuffer(alphabet, dtype=np.uint8)
     case["seqs"] = [chars[rng.integers(0, states, sites)].tobytes() for _ in range(tips)]
     cmap = np.zeros(256, dtype=np.uint32)
@@ -51,6 +55,24 @@ def odd_state_case(states, tips=9, sites=30, seed=3):
         case["seqs"][s] = bytes(b)
     case["cmap"] = cmap
     return case
+
+
+def many_state_case(states, tips=9, sites=30, seed=3, shape="random", **kw):
+    """More than 32 states (61 = codons): the character maps of the API are 32-bit masks,
+    so such data enters as tip CLVs; case["tip_index"][tip][site] = state, -1 = gap."""
+    case = make_case(states, shape, tips, sites, seed=seed, **kw)
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, states, size=(tips, sites))
+    idx[rng.random((tips, sites)) < 0.03] = -1
+    case["tip_index"] = idx
+    return case
+
+
+def index_tip_clvs(case):
+    S, R = case["states"], case["rate_cats"]
+    idx = case["tip_index"]
+    out = (idx[:, :, None] == np.arange(S)[None, None, :]) | (idx[:, :, None] < 0)
+    return np.repeat(out[:, :, None, :].astype(np.float64), R, axis=2)
 
 
 def case_map(lib, case):
@@ -69,9 +91,13 @@ def build_partition(lib, case, attrs, pinv=0.0):
     p.set_frequencies(0, case["freqs"])
     p.set_subst_params(0, case["rates"])
     p.set_category_rates(lib.compute_gamma_cats(case["alpha"], R))
-    cmap = case_map(lib, case)
-    for i, s in enumerate(case["seqs"]):
-        p.set_tip_states(i, cmap, s)
+    if case.get("tip_index") is not None:
+        for i, clv in enumerate(index_tip_clvs(case)):
+            p.set_tip_clv(i, clv[:, 0, :].reshape(-1))   # [sites][states]; the call replicates over rates
+    else:
+        cmap = case_map(lib, case)
+        for i, s in enumerate(case["seqs"]):
+            p.set_tip_states(i, cmap, s)
     if case["pw"] is not None:
         p.set_pattern_weights(case["pw"])
     if pinv > 0:
@@ -124,6 +150,9 @@ def oracle_run(orc, lib, part, case, attrs, pinv=0.0):
     if attrs & ATTRIB_PATTERN_TIP:
         codes, tipmap = encode_tips(part)
         return OracleRun(orc, model, case["plan"], attrs, tipcodes=codes, tipmap=tipmap,
+                         pattern_weights=case["pw"], invariant=inv)
+    if case.get("tip_index") is not None:
+        return OracleRun(orc, model, case["plan"], attrs, tipclvs=index_tip_clvs(case),
                          pattern_weights=case["pw"], invariant=inv)
     return OracleRun(orc, model, case["plan"], attrs, tipclvs=tip_clvs(case, case_map(lib, case)),
                      pattern_weights=case["pw"], invariant=inv)

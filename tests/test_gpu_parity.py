@@ -9,7 +9,7 @@ within 1e-12 relative (GPU adds sites in a tree, the reference sequentially).
 import numpy as np
 import pytest
 
-from helpers import (make_case, odd_state_case, build_partition, oracle_run, bits_equal, rel_err,
+from helpers import (make_case, odd_state_case, many_state_case, build_partition, oracle_run, bits_equal, rel_err,
                      sumtable_err)
 from libpll_amd import workload as W
 from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, SCALE_BUFFER_NONE,
@@ -138,6 +138,57 @@ def test_odd_state_counts(gpu, orc, states, pattern_tip):
     o = oracle_run(orc, gpu, p, case, pattern_tip)
     compare(p, o, case, 4)
     p.destroy()
+
+
+# state counts without a dedicated kernel: rows-in-registers kernels (2, 3, 5..8 states with
+# a power-of-two rate_cats) and the LDS-tiled kernels (everything else up to 64 states;
+# 61 states reload the matrices per category), partials_gen_tile.hip
+GENERIC_SHAPES = [(2, 4), (3, 4), (5, 4), (6, 2), (7, 1), (8, 8), (5, 3), (9, 4), (13, 4), (11, 16),
+                  (32, 4), (61, 4), (64, 2)]
+
+
+@pytest.mark.parametrize("states,rate_cats", GENERIC_SHAPES)
+@pytest.mark.parametrize("pattern_tip", [0, ATTRIB_PATTERN_TIP])
+@pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
+def test_generic_state_kernels(gpu, orc, states, rate_cats, pattern_tip, rate_scalers):
+    """Several tiles / rounds per op, all three op kinds, both scaling modes; bit-exact
+    against the plain-C order of the reference."""
+    attrs = pattern_tip | rate_scalers
+    if states > 32:
+        if pattern_tip:
+            pytest.skip("tip characters are 32-bit state masks")
+        case = many_state_case(states, tips=7, sites=75, seed=states, rate_cats=rate_cats)
+    else:
+        case = odd_state_case(states, tips=10, sites=333, seed=states + rate_cats, rate_cats=rate_cats)
+    p = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    compare(p, o, case, rate_cats)
+    e = case["plan"].root_edge
+    st = p.alloc_sumtable()
+    p.update_sumtable(e[0], e[2], e[1], e[3], [0] * rate_cats, st)
+    so = o.sumtable(e[0], e[2], e[1], e[3])
+    assert sumtable_err(p.get_sumtable(st), so) < 1e-12
+    assert rel_err(p.compute_likelihood_derivatives(e[1], e[3], 0.13, [0] * rate_cats, st),
+                   o.derivatives(so, 0.13)) < DERIV_RTOL
+    p.destroy()
+
+
+@pytest.mark.parametrize("states,rate_cats,tips", [(2, 4, 900), (5, 4, 500), (5, 3, 500), (13, 4, 400), (61, 4, 300)])
+@pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
+def test_generic_state_deep_scaling(gpu, orc, states, rate_cats, tips, rate_scalers):
+    """Caterpillars deep enough for several scaling events per site, tips as CLVs (all
+    ops inner-inner) and as characters (tip-inner all the way down)."""
+    for pattern_tip in ((0,) if states > 32 else (0, ATTRIB_PATTERN_TIP)):
+        attrs = pattern_tip | rate_scalers
+        kw = dict(tips=tips, sites=9, seed=5, shape="caterpillar", rate_cats=rate_cats, alpha=0.5,
+                  branch=0.5, weights=False, gap_frac=0.0)
+        case = many_state_case(states, **kw) if states > 32 else odd_state_case(states, **kw)
+        p = build_partition(gpu, case, attrs)
+        o = oracle_run(orc, gpu, p, case, attrs)
+        compare(p, o, case, rate_cats)
+        last = int(case["plan"].ops[-1]["parent_scaler_index"])
+        assert p.get_scaler(last).min() >= 2
+        p.destroy()
 
 
 @pytest.mark.parametrize("sites", [1, 2, 15, 16, 17, 63, 64, 65, 255, 257])
