@@ -259,7 +259,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
                    c->eigenvecs, c->inv_eigenvecs, c->freqs, c->prop_invar, c->rates,
                    c->rate_weights, c->pattern_weights, c->invariant, c->tipmap,
                    c->block_partials, c->d_result, c->d_counter, c->d_zero, c->d_tiptab, c->d_persite, c->d_stage, c->d_asc,
-                   c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3]};
+                   c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3], c->lnl_scratch};
   for (void * p : bufs)
     if (p) (void)hipFree(p);
   pllhip_rep_work_free(c);

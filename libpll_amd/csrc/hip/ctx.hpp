@@ -49,6 +49,7 @@ struct pllhip_ctx
   unsigned int * tipmap = nullptr;     // [256]
   unsigned int maxstates = 0;
   double * sumtable[PLLHIP_SUMTABLE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  double * lnl_scratch = nullptr; // CLV-sized: per-state lnL terms of the two-pass kernels (likelihood.hip)
 
   // reductions: per-block partial sums, then a fixed-order final pass
   double * block_partials = nullptr;   // [PLLHIP_REDUCE_BLOCKS][2]

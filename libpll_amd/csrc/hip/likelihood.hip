@@ -487,6 +487,316 @@ __global__ __launch_bounds__(128) void k_lnl_gen(LnlArgs a)
   block_sum_to_partials(acc, a.reduce);
 }
 
+// ---- any other state count up to 64: two passes over fast kernels
+//
+// The per-state terms of an edge likelihood, (p_i pi_i) * sum_j P[i][j] c_j
+// (core_likelihood.c:955), are exactly what a CLV update WITHOUT scaling computes when
+// the parent-side "P-matrix" is diag(pi): its row sum 0 + ... + pi_i p_i + ... + 0 is
+// exact, and (pi_i p_i) * termb_i is the reference's product.  So the terms are produced
+// by the CLV-update kernels of partials_gen_tile.hip (rows-in-registers, LDS-tiled or
+// wave-per-row, whichever covers the shape) into a scratch CLV, and k_lnl_rowsum adds
+// them per (site, rate) in state order, then forms the site's category sum, logarithm
+// and scaler term exactly like k_lnl_gen.  The root likelihood needs no first pass:
+// the row sum multiplies by pi itself (core_likelihood.c:80-93).
+struct DiagArgs
+{
+  double * out; // [R][S][S]
+  const double * freqs;
+  unsigned int states, rate_cats;
+  unsigned int freqs_indices[PLLHIP_MAX_RATE_CATS];
+};
+
+__global__ void k_diag_freqs(DiagArgs d)
+{
+  const unsigned int S = d.states, total = d.rate_cats * S * S;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x)
+  {
+    const unsigned int k = t / (S * S), i = (t / S) % S, j = t % S;
+    d.out[t] = (i == j) ? d.freqs[(size_t)d.freqs_indices[k] * S + i] : 0.0;
+  }
+}
+
+struct RowsumGeom
+{
+  unsigned int ts;    // sites per tile
+  unsigned int pad;   // LDS row stride in doubles (odd: conflict-free for lane-per-row reads)
+  unsigned int inv_s; // ceil(2^32 / states)
+};
+
+template <bool ROOTK> // true: a.parent is a CLV and the terms are p_i * pi_i; false: a.parent holds the terms
+__global__ __launch_bounds__(256) void k_lnl_rowsum(LnlArgs a, RowsumGeom g)
+{
+  extern __shared__ double smem[];
+  const unsigned int S = a.states, R = a.rate_cats, span = S * R, tid = threadIdx.x;
+  double * s_tile = smem;                              // [ts * R][pad]
+  double * s_term = smem + (size_t)g.ts * R * g.pad;   // [ts * R]
+  double acc = 0.0;
+  const size_t ntiles = ((size_t)a.sites + g.ts - 1) / g.ts;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+  {
+    const size_t n0 = tile * g.ts;
+    const unsigned int ns = (a.sites - n0 < g.ts) ? (unsigned int)(a.sites - n0) : g.ts;
+    __syncthreads();
+    for (unsigned int e = tid; e < ns * span; e += 256u)
+    {
+      const unsigned int row = __umulhi(e, g.inv_s);
+      s_tile[row * g.pad + (e - row * S)] = a.parent[n0 * span + e];
+    }
+    __syncthreads();
+    for (unsigned int row = tid; row < ns * R; row += 256u)
+    {
+      const double * v = s_tile + row * g.pad;
+      double t = 0.0;
+      if (ROOTK)
+      {
+        const double * fr = a.freqs + (size_t)a.freqs_indices[row % R] * S;
+        for (unsigned int j = 0; j < S; ++j) t += v[j] * fr[j];
+      }
+      else
+        for (unsigned int j = 0; j < S; ++j) t += v[j];
+      s_term[row] = t;
+    }
+    __syncthreads();
+    for (unsigned int s = tid; s < ns; s += 256u)
+    {
+      const size_t n = n0 + s;
+      unsigned int rs[PLLHIP_MAX_RATE_CATS];
+      unsigned int site_scalings = 0;
+      if (a.rate_scalers && !ROOTK)
+      {
+        unsigned int mn = 0xffffffffu;
+        for (unsigned int k = 0; k < R; ++k)
+        {
+          unsigned int v = a.pscaler ? a.pscaler[n * R + k] : 0;
+          if (a.cscaler) v += a.cscaler[n * R + k];
+          rs[k] = v;
+          mn = v < mn ? v : mn;
+        }
+        site_scalings = mn;
+        for (unsigned int k = 0; k < R; ++k)
+        {
+          const unsigned int d = rs[k] - mn;
+          rs[k] = d > PLLHIP_SCALE_RATE_MAXDIFF ? PLLHIP_SCALE_RATE_MAXDIFF : d;
+        }
+      }
+      else
+      {
+        for (unsigned int k = 0; k < R; ++k) rs[k] = 0;
+        if (a.pscaler) site_scalings += a.pscaler[n];
+        if (!ROOTK && a.cscaler) site_scalings += a.cscaler[n];
+      }
+      double terma = 0.0;
+      for (unsigned int k = 0; k < R; ++k) terma += category_term<false>(a, s_term[s * R + k], k, n, rs[k]);
+      acc += site_loglk(a, terma, n, site_scalings);
+    }
+  }
+  block_sum_to_partials(acc, a.reduce);
+}
+
+// ---- 2, 3, 5..8 states with a power-of-two rate_cats: one pass, rows in registers
+//
+// The mapping of k_gen_rows (partials_gen_tile.hip): one lane per (site, rate) row, both
+// rows in registers, P in LDS, loops unrolled over the compile-time state count; the
+// category sum and the per-rate scaler minimum travel over the R adjacent lanes of a site
+// with __shfl.  Sums in the plain-C order (core_likelihood.c:80-93, :600-640, :940-960).
+template <int KIND, int SC>
+__global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
+{
+  extern __shared__ double smem[];
+  const unsigned int R = a.rate_cats, tid = threadIdx.x;
+  constexpr unsigned int MP = SC * SC + 2;
+  if (KIND != ROOT)
+  {
+    for (unsigned int t = tid; t < R * SC * SC; t += 256u)
+      smem[(t / (SC * SC)) * MP + t % (SC * SC)] = a.pmat[t];
+    __syncthreads();
+  }
+  const unsigned int rshift = __ffs(R) - 1u;
+  const size_t total = (size_t)a.sites << rshift;
+  const unsigned int lane = tid & 63u, grp0 = lane & ~(R - 1u);
+  // A wave takes 64 sites at a time, in R rounds of 64 rows (64 / R sites each); after
+  // round r the lanes [r * 64/R, (r+1) * 64/R) keep the category sums of that round's
+  // sites, so that in the end every lane owns ONE site and the logarithm (a hundred
+  // 4-cycle f64 instructions) runs once per site instead of once per row.
+  const unsigned int spr_shift = 6u - rshift, spr_mask = (64u >> rshift) - 1u;
+  const size_t sites_up = ((size_t)a.sites + 63) & ~(size_t)63;
+  double acc = 0.0;
+  for (size_t sbase = ((size_t)blockIdx.x * 4u + (tid >> 6)) * 64u; sbase < sites_up;
+       sbase += (size_t)gridDim.x * 256u)
+  {
+   double own_terma = 1.0;
+   unsigned int own_scalings = 0u;
+   for (unsigned int round = 0; round < R; ++round)
+   {
+    const size_t e = (sbase << rshift) + round * 64u + lane;
+    const bool act = e < total;
+    const size_t ec = act ? e : 0;
+    const size_t n = ec >> rshift;
+    const unsigned int k = (unsigned int)(ec & (R - 1u));
+    const double * fr = a.freqs + (size_t)a.freqs_indices[k] * SC;
+    const double * m = smem + k * MP;
+    double p[SC], c[SC];
+#pragma unroll
+    for (int j = 0; j < SC; ++j) p[j] = a.parent[ec * SC + j];
+    unsigned int mask = 0u;
+    if (KIND == EDGE_II)
+#pragma unroll
+      for (int j = 0; j < SC; ++j) c[j] = a.child[ec * SC + j];
+    if (KIND == EDGE_TI) mask = a.tipmap[a.tip[n]];
+    double terma_r = 0.0;
+#pragma unroll
+    for (int i = 0; i < SC; ++i)
+    {
+      if (KIND == ROOT)
+        terma_r += p[i] * fr[i];
+      else
+      {
+        double termb = 0.0;
+#pragma unroll
+        for (int j = 0; j < SC; ++j)
+        {
+          if (KIND == EDGE_II) termb += m[i * SC + j] * c[j];
+          else if ((mask >> j) & 1u) termb += m[i * SC + j];
+        }
+        terma_r += p[i] * fr[i] * termb;
+      }
+    }
+    unsigned int site_scalings = 0, rel = 0;
+    if (a.rate_scalers && KIND != ROOT)
+    {
+      unsigned int mine = 0;
+      if (a.pscaler) mine += a.pscaler[ec];
+      if (KIND == EDGE_II && a.cscaler) mine += a.cscaler[ec];
+      unsigned int mn = mine;
+      for (unsigned int off = 1; off < R; off <<= 1)
+      {
+        const unsigned int o = (unsigned int)__shfl_xor((int)mn, (int)off, 64);
+        mn = o < mn ? o : mn;
+      }
+      site_scalings = mn;
+      rel = mine - mn;
+      if (rel > PLLHIP_SCALE_RATE_MAXDIFF) rel = PLLHIP_SCALE_RATE_MAXDIFF;
+    }
+    else
+    {
+      if (a.pscaler) site_scalings += a.pscaler[n];
+      if (KIND == EDGE_II && a.cscaler) site_scalings += a.cscaler[n];
+    }
+    const double contrib = category_term<false>(a, terma_r, k, n, rel);
+    double terma = 0.0;
+    for (unsigned int i = 0; i < R; ++i) terma += __shfl(contrib, (int)(grp0 + i), 64);
+    const int src = (int)((lane & spr_mask) << rshift);
+    const double t_own = __shfl(terma, src, 64);
+    const unsigned int s_own = (unsigned int)__shfl((int)site_scalings, src, 64);
+    if ((lane >> spr_shift) == round)
+    {
+      own_terma = t_own;
+      own_scalings = s_own;
+    }
+   }
+   if (sbase + lane < a.sites) acc += site_loglk(a, own_terma, sbase + lane, own_scalings);
+  }
+  block_sum_to_partials(acc, a.reduce);
+}
+
+template <int SC>
+static void launch_lnl_rows_sc(pllhip_ctx * c, const LnlArgs & a, int kind, unsigned int grid)
+{
+  const size_t lds = (kind == ROOT) ? 0 : (size_t)a.rate_cats * (SC * SC + 2) * sizeof(double);
+  if (kind == EDGE_II) k_lnl_rows<EDGE_II, SC><<<grid, 256, lds, c->stream>>>(a);
+  if (kind == EDGE_TI) k_lnl_rows<EDGE_TI, SC><<<grid, 256, lds, c->stream>>>(a);
+  if (kind == ROOT) k_lnl_rows<ROOT, SC><<<grid, 256, lds, c->stream>>>(a);
+}
+
+// returns 1 if the shape is not covered
+static int launch_lnl_rows(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
+{
+  const unsigned int S = c->sh.states, R = c->sh.rate_cats;
+  const bool pow2 = R && !(R & (R - 1u)) && R <= 16u;
+  if (!pow2 || !(S == 2 || S == 3 || (S >= 5 && S <= 8))) return 1;
+  // a workgroup takes 256 sites per trip
+  unsigned int grid = pllhip_stream_grid(c, (size_t)a.sites, 256);
+  if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+  a.reduce = pllhip_reduce_out(c, grid);
+  switch (S)
+  {
+    case 2: launch_lnl_rows_sc<2>(c, a, kind, grid); break;
+    case 3: launch_lnl_rows_sc<3>(c, a, kind, grid); break;
+    case 5: launch_lnl_rows_sc<5>(c, a, kind, grid); break;
+    case 6: launch_lnl_rows_sc<6>(c, a, kind, grid); break;
+    case 7: launch_lnl_rows_sc<7>(c, a, kind, grid); break;
+    default: launch_lnl_rows_sc<8>(c, a, kind, grid); break;
+  }
+  *grid_out = grid;
+  return 0;
+}
+
+// kind as in run_lnl; returns 1 if the shape is not covered
+static int launch_lnl_two_pass(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
+{
+  if (!pllhip_gen_tile_covers(c)) return 1;
+  const unsigned int S = c->sh.states, R = c->sh.rate_cats;
+  LnlArgs b = a; // what the row-sum pass sees
+  if (kind != ROOT)
+  {
+    if (!c->lnl_scratch)
+      HIP_TRY(hipMalloc((void **)&c->lnl_scratch, (c->clv_elems + PLLHIP_TAIL_SITES * c->span) * sizeof(double)));
+    DiagArgs d;
+    d.out = (double *)c->d_stage;
+    d.freqs = c->freqs;
+    d.states = S;
+    d.rate_cats = R;
+    for (unsigned int k = 0; k < R; ++k) d.freqs_indices[k] = a.freqs_indices[k];
+    k_diag_freqs<<<(R * S * S + 255) / 256, 256, 0, c->stream>>>(d);
+    HIP_TRY(hipGetLastError());
+    PartialsArgs p;
+    memset(&p, 0, sizeof(p));
+    p.parent = c->lnl_scratch;
+    p.tipmap = c->tipmap;
+    p.zero = c->d_zero;
+    p.sites = a.sites;
+    p.rate_cats = R;
+    p.states = S;
+    p.maxstates = c->maxstates;
+    if (kind == EDGE_II)
+    {
+      p.left = a.parent;
+      p.lmat = d.out;
+      p.right = a.child;
+      p.rmat = a.pmat;
+    }
+    else
+    {
+      p.ltip = a.tip;
+      p.lmat = a.pmat;
+      p.right = a.parent;
+      p.rmat = d.out;
+    }
+    int rc = pllhip_launch_partials(c, p, kind == EDGE_II ? 0 : 1, SCALE_NONE, PLLHIP_PROF_LNL);
+    if (rc) return rc;
+    b.parent = c->lnl_scratch;
+    if (kind == EDGE_TI) b.cscaler = nullptr;
+  }
+  RowsumGeom g;
+  g.pad = S | 1u;
+  g.inv_s = (unsigned int)((0x100000000ull + S - 1) / S);
+  const size_t per_site = (size_t)R * (g.pad + 1) * sizeof(double);
+  size_t ts = 49152 / per_site;
+  if (ts > 256) ts = 256;
+  if (ts < 1) return 1;
+  g.ts = (unsigned int)ts;
+  const size_t tiles = ((size_t)a.sites + ts - 1) / ts;
+  unsigned int grid = (unsigned int)(tiles < (size_t)c->num_cus * 4 ? tiles : (size_t)c->num_cus * 4);
+  if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+  if (grid < 1) grid = 1;
+  b.reduce = a.reduce = pllhip_reduce_out(c, grid);
+  const size_t lds = ts * per_site;
+  if (kind == ROOT) k_lnl_rowsum<true><<<grid, 256, lds, c->stream>>>(b, g);
+  else k_lnl_rowsum<false><<<grid, 256, lds, c->stream>>>(b, g);
+  *grid_out = grid;
+  return 0;
+}
+
 #define LAUNCH_LNL(RCV, KINDV)                                                            \
   do {                                                                                    \
     if (s4 && gather) k_lnl_dna<RCV, KINDV, false, true><<<grid, 256, lds, c->stream>>>(a); \
@@ -531,6 +841,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   }
 
   unsigned int grid = 0;
+  bool two_pass = false;
   pllhip_prof_scope prof(c, PLLHIP_PROF_LNL);
   const bool mfma = (S == 20 && !c->aa_exact && pllhip_launch_lnl_aa_mfma(c, a, kind, &grid) == 0);
   const bool fast = !mfma && (S == 4 || S == 20) && (R == 1 || R == 2 || R == 4 || R == 8);
@@ -550,6 +861,10 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
     if (kind == EDGE_II) LAUNCH_LNL_RC(EDGE_II);
     if (kind == EDGE_TI) LAUNCH_LNL_RC(EDGE_TI);
     if (kind == ROOT) LAUNCH_LNL_RC(ROOT);
+  }
+  else if (!mfma && (two_pass = (launch_lnl_rows(c, a, kind, &grid) == 0 ||
+                                 launch_lnl_two_pass(c, a, kind, &grid) == 0)))
+  {
   }
   else if (!mfma)
   {

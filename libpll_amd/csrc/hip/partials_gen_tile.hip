@@ -95,21 +95,16 @@ __global__ __launch_bounds__(256) void k_gen_tile(PartialsBatch batch, int mode,
         const unsigned int s = __umulhi(e, g.inv_s), i = e - s * S;
         const unsigned int row = s * span + k * S;
         double x = 0.0, y = 0.0;
-        if (KIND == 0)
-          for (unsigned int j = 0; j < S; ++j) x += pl[j * S + i] * s_l[row + j];
-        else
+        const unsigned int lm = (KIND >= 1) ? s_lmask[s] : 0u, rm = (KIND == 2) ? s_rmask[s] : 0u;
+        // both sums advance together, four terms per trip, so that eight (sixteen) LDS reads
+        // are in flight instead of one
+#pragma unroll 4
+        for (unsigned int j = 0; j < S; ++j)
         {
-          const unsigned int m = s_lmask[s];
-          for (unsigned int j = 0; j < S; ++j)
-            if ((m >> j) & 1u) x += pl[j * S + i];
-        }
-        if (KIND != 2)
-          for (unsigned int j = 0; j < S; ++j) y += pr[j * S + i] * s_r[row + j];
-        else
-        {
-          const unsigned int m = s_rmask[s];
-          for (unsigned int j = 0; j < S; ++j)
-            if ((m >> j) & 1u) y += pr[j * S + i];
+          if (KIND == 0) x += pl[j * S + i] * s_l[row + j];
+          else if ((lm >> j) & 1u) x += pl[j * S + i];
+          if (KIND != 2) y += pr[j * S + i] * s_r[row + j];
+          else if ((rm >> j) & 1u) y += pr[j * S + i];
         }
         const double p = x * y;
         s_out[row + i] = p;
@@ -301,6 +296,158 @@ static int launch_gen_rows(pllhip_ctx * c, const PartialsBatch & b, unsigned int
   }
 }
 
+// ------------------------------------------------------- many states (codons): one wave per row
+//
+// From ~40 states on the update is arithmetic-bound (61 states: 10 flop per byte), and
+// the LDS-tiled kernel above spends two LDS reads per multiply-add with little occupancy.
+// Here one LANE owns one output state i and keeps row i of the current P-matrix in
+// registers (states padded to SP, a multiple of 8, with zeros); the child rows of a GROUP
+// of WT consecutive sites are copied into a wave-private LDS block (one coalesced
+// 8 x states byte load per row) and read back as broadcasts, two columns per ds_read_b128:
+//     x_i = sum_j P[i][j] (VGPR) * l[j] (same LDS address for all lanes)
+// so a multiply-add costs half an LDS instruction and no address arithmetic.  Per rate
+// category the wave loads its row of P_l, forms x for the WT sites, loads its row of P_r,
+// forms y and stores x * y (a coalesced row per site and category).  Waves never
+// synchronise with each other.  Whether a site (or a (site, rate) row) must be rescaled is
+// known only after all its entries exist; that is rare (once every 10-20 tree levels),
+// so the products are stored unscaled and the few rows concerned are multiplied by 2^256
+// in place afterwards by the lanes that wrote them.
+// The LDS columns beyond the last state stay zero and so do the P columns: the padded
+// terms add +0.0, which leaves every sum bit-exact.
+#define GEN_WIDE_WT 16
+
+template <int SP> // states rounded up to a multiple of 8
+__global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
+{
+  const PartialsArgs & a = batch.op[blockIdx.y];
+  extern __shared__ double smem[];
+  const unsigned int S = a.states, R = a.rate_cats;
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool lane_on = lane < S;
+  const unsigned int i = lane_on ? lane : S - 1u; // idle lanes shadow the last state
+  constexpr int WT = GEN_WIDE_WT;
+  double * s_l = smem + (size_t)wave * (2 * WT * SP); // [WT][SP] rows of child 1
+  double * s_r = s_l + WT * SP;                       // and of child 2
+  for (unsigned int t = lane; t < 2u * WT * SP; t += 64u) s_l[t] = 0.0;
+  const size_t groups = ((size_t)a.sites + WT - 1) / WT;
+
+  for (size_t grp = (size_t)blockIdx.x * 4u + wave; grp < groups; grp += (size_t)gridDim.x * 4u)
+  {
+    const size_t n0 = grp * WT;
+    unsigned int site_small = ~0u; // bit t: every entry of site n0 + t below the threshold so far
+    for (unsigned int k = 0; k < R; ++k)
+    {
+      double P[SP];
+      {
+        // the rows of both children for this category: 2 x WT loads in flight, then LDS
+        // (sites past the end read the zeroed slack behind the CLV)
+        double lv[WT], rv[WT];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) lv[t] = a.left[((n0 + t) * R + k) * S + i];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) rv[t] = a.right[((n0 + t) * R + k) * S + i];
+        if (lane_on)
+        {
+#pragma unroll
+          for (int t = 0; t < WT; ++t) s_l[t * SP + lane] = lv[t];
+#pragma unroll
+          for (int t = 0; t < WT; ++t) s_r[t * SP + lane] = rv[t];
+        }
+      }
+      // row i of a P-matrix, zero beyond the last state (only the last chunk of 8 can be partial)
+      auto load_p_row = [&](const double * prow) {
+#pragma unroll
+        for (int j = 0; j < SP - 8; ++j) P[j] = prow[j];
+#pragma unroll
+        for (int j = SP - 8; j < SP; ++j)
+        {
+          const double v = prow[(unsigned int)j < S ? (unsigned int)j : S - 1u]; // unconditional load
+          P[j] = ((unsigned int)j < S) ? v : 0.0;
+        }
+      };
+      load_p_row(a.lmat + ((size_t)k * S + i) * S);
+      // (the site loops stay rolled: one row's 64 broadcast reads are enough to keep in
+      // flight, and x goes back into the row it was computed from -- every lane is done
+      // with that row, LDS executes a wave's accesses in order)
+#pragma unroll 1
+      for (int t = 0; t < WT; ++t)
+      {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < SP; ++j) acc += P[j] * s_l[t * SP + j];
+        if (lane_on) s_l[t * SP + lane] = acc;
+      }
+      load_p_row(a.rmat + ((size_t)k * S + i) * S);
+      unsigned int rate_small = 0u;
+#pragma unroll 1
+      for (int t = 0; t < WT; ++t)
+      {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < SP; ++j) acc += P[j] * s_r[t * SP + j];
+        const double p = s_l[t * SP + i] * acc;
+        if (lane_on && n0 + t < a.sites) a.parent[((n0 + t) * R + k) * S + i] = p;
+        if (__ballot(p < PLLHIP_SCALE_THRESHOLD || !lane_on) == ~0ull) rate_small |= 1u << t;
+      }
+      site_small &= rate_small;
+      if (mode == SCALE_RATE)
+      {
+        for (unsigned int m = rate_small; m; m &= m - 1u)
+        {
+          const unsigned int t = __ffs(m) - 1u;
+          if (lane_on && n0 + t < a.sites) a.parent[((n0 + t) * R + k) * S + i] *= PLLHIP_SCALE_FACTOR;
+        }
+        if (lane < (unsigned int)WT && n0 + lane < a.sites)
+        {
+          const size_t w = (n0 + lane) * R + k;
+          a.pscaler[w] = (a.lscaler ? a.lscaler[w] : 0u) + (a.rscaler ? a.rscaler[w] : 0u) +
+                         ((rate_small >> lane) & 1u);
+        }
+      }
+    }
+    if (mode == SCALE_SITE)
+    {
+      for (unsigned int m = site_small; m; m &= m - 1u)
+      {
+        const unsigned int t = __ffs(m) - 1u;
+        if (lane_on && n0 + t < a.sites)
+          for (unsigned int k = 0; k < R; ++k) a.parent[((n0 + t) * R + k) * S + i] *= PLLHIP_SCALE_FACTOR;
+      }
+      if (lane < (unsigned int)WT && n0 + lane < a.sites)
+        a.pscaler[n0 + lane] = (a.lscaler ? a.lscaler[n0 + lane] : 0u) +
+                               (a.rscaler ? a.rscaler[n0 + lane] : 0u) + ((site_small >> lane) & 1u);
+    }
+  }
+}
+
+static bool gen_wide_covers(unsigned int S, int kind)
+{
+  return kind == 0 && S >= 40 && S <= 64;
+}
+
+static int launch_gen_wide(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode)
+{
+  size_t sites = 0;
+  for (unsigned int i = 0; i < count; ++i)
+    if (b.op[i].sites > sites) sites = b.op[i].sites;
+  if (!sites) return 0;
+  const size_t groups = (sites + GEN_WIDE_WT - 1) / GEN_WIDE_WT;
+  const size_t cap = (size_t)c->num_cus * 2; // 2 workgroups of 4 waves per CU
+  const size_t need = (groups + 3) / 4;
+  const dim3 grid((unsigned int)(need < cap ? need : cap), count);
+  const unsigned int S = c->sh.states;
+#define LAUNCH_WIDE(SPV) \
+  k_gen_wide<SPV><<<grid, 256, 4 * 2 * GEN_WIDE_WT * SPV * sizeof(double), c->stream>>>(b, mode)
+  if (S <= 40) LAUNCH_WIDE(40);
+  else if (S <= 48) LAUNCH_WIDE(48);
+  else if (S <= 56) LAUNCH_WIDE(56);
+  else LAUNCH_WIDE(64);
+#undef LAUNCH_WIDE
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static size_t gen_tile_lds(unsigned int S, unsigned int R, int kind, unsigned int ts, bool resident)
 {
   const size_t span = (size_t)S * R;
@@ -372,6 +519,7 @@ int pllhip_launch_gen_batch(pllhip_ctx * c, const PartialsBatch & b, unsigned in
     if (kind == 1) return launch_gen_rows<1>(c, b, count, mode);
     return launch_gen_rows<2>(c, b, count, mode);
   }
+  if (gen_wide_covers(c->sh.states, kind)) return launch_gen_wide(c, b, count, mode);
   if (kind == 0) return launch_gen_tile<0>(c, b, count, mode);
   if (kind == 1) return launch_gen_tile<1>(c, b, count, mode);
   return launch_gen_tile<2>(c, b, count, mode);

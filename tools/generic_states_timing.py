@@ -8,7 +8,7 @@ import libpll_amd
 from libpll_amd import workload as W
 amd = libpll_amd.load()
 taxa, rc = 16, 4
-for states, sites in ((2, 1_000_000), (5, 1_000_000), (7, 500_000), (61, 60_000)):
+for states, sites in ((2, 1_000_000), (5, 1_000_000), (7, 500_000), (13, 300_000), (32, 100_000), (61, 60_000)):
     plan = W.balanced_tree(taxa, seed=42)
     rng = np.random.default_rng(7)
     p = amd.partition_create(taxa, taxa - 2, states, sites, 1, 2 * taxa - 3, rc, taxa - 2, 0)
@@ -33,4 +33,19 @@ for states, sites in ((2, 1_000_000), (5, 1_000_000), (7, 500_000), (61, 60_000)
     print("states %2d sites %8d: %.1f us/op, %.2f TB/s algorithmic, %.2f TFLOP/s f64, lnL %.4f"
           % (states, sites, dt / nops * 1e6, bytes_op / (dt / nops) / 1e12, flop_op / (dt / nops) / 1e12,
              p.compute_edge_loglikelihood(*plan.root_edge, [0] * rc)))
+    e = plan.root_edge
+    t0 = time.perf_counter()
+    for _ in range(reps): p.compute_edge_loglikelihood(*e, [0] * rc)
+    t_lnl = (time.perf_counter() - t0) / reps
+    st = p.alloc_sumtable()
+    t0 = time.perf_counter()
+    for _ in range(reps): p.update_sumtable(e[0], e[2], e[1], e[3], [0] * rc, st)
+    p.wait()
+    t_sum = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps): p.compute_likelihood_derivatives(e[1], e[3], 0.1, [0] * rc, st)
+    t_der = (time.perf_counter() - t0) / reps
+    print("          lnL call %.1f us (%.2f TB/s), sumtable %.1f us, derivative call %.1f us (%.2f TB/s)"
+          % (t_lnl * 1e6, sites * 2 * rc * states * 8 / t_lnl / 1e12, t_sum * 1e6, t_der * 1e6,
+             sites * rc * states * 8 / t_der / 1e12))
     p.destroy()
