@@ -713,7 +713,7 @@ static int launch_lnl_rows(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int *
 {
   const unsigned int S = c->sh.states, R = c->sh.rate_cats;
   const bool pow2 = R && !(R & (R - 1u)) && R <= 16u;
-  if (!pow2 || !(S == 2 || S == 3 || (S >= 5 && S <= 8))) return 1;
+  if (!pow2 || S < 2 || S > 16 || S == 4) return 1;
   // a workgroup takes 256 sites per trip
   unsigned int grid = pllhip_stream_grid(c, (size_t)a.sites, 256);
   if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
@@ -725,7 +725,15 @@ static int launch_lnl_rows(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int *
     case 5: launch_lnl_rows_sc<5>(c, a, kind, grid); break;
     case 6: launch_lnl_rows_sc<6>(c, a, kind, grid); break;
     case 7: launch_lnl_rows_sc<7>(c, a, kind, grid); break;
-    default: launch_lnl_rows_sc<8>(c, a, kind, grid); break;
+    case 8: launch_lnl_rows_sc<8>(c, a, kind, grid); break;
+    case 9: launch_lnl_rows_sc<9>(c, a, kind, grid); break;
+    case 10: launch_lnl_rows_sc<10>(c, a, kind, grid); break;
+    case 11: launch_lnl_rows_sc<11>(c, a, kind, grid); break;
+    case 12: launch_lnl_rows_sc<12>(c, a, kind, grid); break;
+    case 13: launch_lnl_rows_sc<13>(c, a, kind, grid); break;
+    case 14: launch_lnl_rows_sc<14>(c, a, kind, grid); break;
+    case 15: launch_lnl_rows_sc<15>(c, a, kind, grid); break;
+    default: launch_lnl_rows_sc<16>(c, a, kind, grid); break;
   }
   *grid_out = grid;
   return 0;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
 static bool gen_rows_covers(unsigned int S, unsigned int R)
 {
   const bool pow2 = R && !(R & (R - 1u)) && R <= 16u;
-  return pow2 && (S == 2 || S == 3 || S == 5 || S == 6 || S == 7 || S == 8);
+  return pow2 && S >= 2 && S <= 16 && S != 4;
 }
 
 template <int KIND, int SC>
@@ -292,67 +292,100 @@ static int launch_gen_rows(pllhip_ctx * c, const PartialsBatch & b, unsigned int
     case 5: return launch_gen_rows_sc<KIND, 5>(c, b, count, mode);
     case 6: return launch_gen_rows_sc<KIND, 6>(c, b, count, mode);
     case 7: return launch_gen_rows_sc<KIND, 7>(c, b, count, mode);
-    default: return launch_gen_rows_sc<KIND, 8>(c, b, count, mode);
+    case 8: return launch_gen_rows_sc<KIND, 8>(c, b, count, mode);
+    case 9: return launch_gen_rows_sc<KIND, 9>(c, b, count, mode);
+    case 10: return launch_gen_rows_sc<KIND, 10>(c, b, count, mode);
+    case 11: return launch_gen_rows_sc<KIND, 11>(c, b, count, mode);
+    case 12: return launch_gen_rows_sc<KIND, 12>(c, b, count, mode);
+    case 13: return launch_gen_rows_sc<KIND, 13>(c, b, count, mode);
+    case 14: return launch_gen_rows_sc<KIND, 14>(c, b, count, mode);
+    case 15: return launch_gen_rows_sc<KIND, 15>(c, b, count, mode);
+    default: return launch_gen_rows_sc<KIND, 16>(c, b, count, mode);
   }
 }
 
-// ------------------------------------------------------- many states (codons): one wave per row
+// ------------------------------------------------ 9 to 64 states: P rows in registers
 //
-// From ~40 states on the update is arithmetic-bound (61 states: 10 flop per byte), and
-// the LDS-tiled kernel above spends two LDS reads per multiply-add with little occupancy.
-// Here one LANE owns one output state i and keeps row i of the current P-matrix in
-// registers (states padded to SP, a multiple of 8, with zeros); the child rows of a GROUP
-// of WT consecutive sites are copied into a wave-private LDS block (one coalesced
-// 8 x states byte load per row) and read back as broadcasts, two columns per ds_read_b128:
-//     x_i = sum_j P[i][j] (VGPR) * l[j] (same LDS address for all lanes)
+// From ~10 states on the update is bound by arithmetic and operand delivery, not by HBM
+// (61 states: 10 flop per byte), and the LDS-tiled kernel above spends two LDS reads per
+// multiply-add with little occupancy.  Here one LANE owns one output state i of one site
+// and keeps row i of the current P-matrix in registers (states padded to SP, a multiple
+// of 8, with zeros).  LPS = 16, 32 or 64 lanes make one site, so a wave works on
+// Q = 64 / LPS sites at once; the child rows of a GROUP of WT x Q consecutive sites are
+// copied into a wave-private LDS block (coalesced 8 x states byte rows) and read back as
+// broadcasts within each site's lanes, two columns per 16-byte read:
+//     x_i = sum_j P[i][j] (VGPR) * l[j] (one LDS address per site)
 // so a multiply-add costs half an LDS instruction and no address arithmetic.  Per rate
-// category the wave loads its row of P_l, forms x for the WT sites, loads its row of P_r,
-// forms y and stores x * y (a coalesced row per site and category).  Waves never
-// synchronise with each other.  Whether a site (or a (site, rate) row) must be rescaled is
-// known only after all its entries exist; that is rare (once every 10-20 tree levels),
-// so the products are stored unscaled and the few rows concerned are multiplied by 2^256
-// in place afterwards by the lanes that wrote them.
+// category the wave loads its rows of P_l, forms x for the group (x goes back into the
+// LDS row it was computed from), loads its rows of P_r, forms y and stores x * y.
+// Waves never synchronise with each other.  A tip child contributes the sum of the P
+// entries its state mask selects, ascending (core_partials.c:113-127), written as
+// "+ (bit ? P[j] : +0.0)", which is bit-identical because the running sum is never -0.0.
+// Whether a site (or a (site, rate) row) must be rescaled is known only after all its
+// entries exist; that is rare (once every 10-20 tree levels), so the products are
+// stored unscaled and the few rows concerned are multiplied by 2^256 in place
+// afterwards by the lanes that wrote them.
 // The LDS columns beyond the last state stay zero and so do the P columns: the padded
 // terms add +0.0, which leaves every sum bit-exact.
-#define GEN_WIDE_WT 16
+// steps per group: as many as keep a workgroup's four LDS blocks within 64 KB (two workgroups per CU)
+__host__ __device__ constexpr int gen_wide_wt(int SP, int LPS)
+{
+  return LPS == 64 ? 16 : LPS == 32 ? (SP == 32 ? 14 : 16) : 12;
+}
 
-template <int SP> // states rounded up to a multiple of 8
+template <int KIND, int SP, int LPS> // SP: states rounded up to a multiple of 8; LPS: lanes per site
 __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
 {
   const PartialsArgs & a = batch.op[blockIdx.y];
   extern __shared__ double smem[];
+  constexpr int WT = gen_wide_wt(SP, LPS), Q = 64 / LPS, ROWS = WT * Q;
+  constexpr int SPL = (Q == 1) ? SP : SP + 2; // LDS row stride: the Q rows read together fall in different banks
   const unsigned int S = a.states, R = a.rate_cats;
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool lane_on = lane < S;
-  const unsigned int i = lane_on ? lane : S - 1u; // idle lanes shadow the last state
-  constexpr int WT = GEN_WIDE_WT;
-  double * s_l = smem + (size_t)wave * (2 * WT * SP); // [WT][SP] rows of child 1
-  double * s_r = s_l + WT * SP;                       // and of child 2
-  for (unsigned int t = lane; t < 2u * WT * SP; t += 64u) s_l[t] = 0.0;
-  const size_t groups = ((size_t)a.sites + WT - 1) / WT;
+  const unsigned int q = lane / LPS, li = lane % LPS;
+  const bool lane_on = li < S;
+  const unsigned int i = lane_on ? li : S - 1u; // idle lanes shadow the last state
+  double * s_l = smem + (size_t)wave * (2 * ROWS * SPL); // [ROWS][SPL] rows of child 1, then x
+  double * s_r = s_l + ROWS * SPL;                       // rows of child 2
+  for (unsigned int t = lane; t < 2u * ROWS * SPL; t += 64u) s_l[t] = 0.0;
+  const size_t groups = ((size_t)a.sites + ROWS - 1) / ROWS;
+  constexpr unsigned long long SLOT_FULL = (LPS == 64) ? ~0ull : ((1ull << (LPS % 64)) - 1ull);
 
   for (size_t grp = (size_t)blockIdx.x * 4u + wave; grp < groups; grp += (size_t)gridDim.x * 4u)
   {
-    const size_t n0 = grp * WT;
-    unsigned int site_small = ~0u; // bit t: every entry of site n0 + t below the threshold so far
+    const size_t n0 = grp * ROWS;
+    unsigned long long site_small = ~0ull; // bit r: every entry of site n0 + r below the threshold so far
+    // state masks of the tip children for the sites this lane's slot meets (row t * Q + q)
+    unsigned int lmask[KIND >= 1 ? WT : 1], rmask[KIND == 2 ? WT : 1];
+    if (KIND >= 1)
+#pragma unroll
+      for (int t = 0; t < WT; ++t) lmask[t] = a.tipmap[a.ltip[n0 + t * Q + q]];
+    if (KIND == 2)
+#pragma unroll
+      for (int t = 0; t < WT; ++t) rmask[t] = a.tipmap[a.rtip[n0 + t * Q + q]];
+
     for (unsigned int k = 0; k < R; ++k)
     {
       double P[SP];
       {
-        // the rows of both children for this category: 2 x WT loads in flight, then LDS
+        // the rows of the inner children for this category: up to 2 x WT loads in flight, then LDS
         // (sites past the end read the zeroed slack behind the CLV)
-        double lv[WT], rv[WT];
+        double lv[KIND == 0 ? WT : 1], rv[KIND != 2 ? WT : 1];
+        if (KIND == 0)
 #pragma unroll
-        for (int t = 0; t < WT; ++t) lv[t] = a.left[((n0 + t) * R + k) * S + i];
+          for (int t = 0; t < WT; ++t) lv[t] = a.left[((n0 + t * Q + q) * R + k) * S + i];
+        if (KIND != 2)
 #pragma unroll
-        for (int t = 0; t < WT; ++t) rv[t] = a.right[((n0 + t) * R + k) * S + i];
+          for (int t = 0; t < WT; ++t) rv[t] = a.right[((n0 + t * Q + q) * R + k) * S + i];
         if (lane_on)
         {
+          if (KIND == 0)
 #pragma unroll
-          for (int t = 0; t < WT; ++t) s_l[t * SP + lane] = lv[t];
+            for (int t = 0; t < WT; ++t) s_l[(t * Q + q) * SPL + li] = lv[t];
+          if (KIND != 2)
 #pragma unroll
-          for (int t = 0; t < WT; ++t) s_r[t * SP + lane] = rv[t];
+            for (int t = 0; t < WT; ++t) s_r[(t * Q + q) * SPL + li] = rv[t];
         }
       }
       // row i of a P-matrix, zero beyond the last state (only the last chunk of 8 can be partial)
@@ -367,85 +400,140 @@ __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
         }
       };
       load_p_row(a.lmat + ((size_t)k * S + i) * S);
-      // (the site loops stay rolled: one row's 64 broadcast reads are enough to keep in
-      // flight, and x goes back into the row it was computed from -- every lane is done
-      // with that row, LDS executes a wave's accesses in order)
+      // (the site loops stay rolled: one step's broadcast reads are enough to keep in
+      // flight, and x goes back into the row it was computed from -- every lane of the
+      // site is done with that row, LDS executes a wave's accesses in order)
 #pragma unroll 1
       for (int t = 0; t < WT; ++t)
       {
+        const double * row = s_l + (t * Q + q) * SPL;
         double acc = 0.0;
+        if (KIND == 0)
+        {
 #pragma unroll
-        for (int j = 0; j < SP; ++j) acc += P[j] * s_l[t * SP + j];
-        if (lane_on) s_l[t * SP + lane] = acc;
+          for (int j = 0; j < SP; ++j) acc += P[j] * row[j];
+        }
+        else
+        {
+          const unsigned int m = lmask[t];
+#pragma unroll
+          for (int j = 0; j < SP; ++j) acc += ((m >> j) & 1u) ? P[j] : 0.0;
+        }
+        if (lane_on) s_l[(t * Q + q) * SPL + li] = acc;
       }
       load_p_row(a.rmat + ((size_t)k * S + i) * S);
-      unsigned int rate_small = 0u;
+      unsigned long long rate_small = 0ull;
 #pragma unroll 1
       for (int t = 0; t < WT; ++t)
       {
+        const double * row = s_r + (t * Q + q) * SPL;
         double acc = 0.0;
+        if (KIND != 2)
+        {
 #pragma unroll
-        for (int j = 0; j < SP; ++j) acc += P[j] * s_r[t * SP + j];
-        const double p = s_l[t * SP + i] * acc;
-        if (lane_on && n0 + t < a.sites) a.parent[((n0 + t) * R + k) * S + i] = p;
-        if (__ballot(p < PLLHIP_SCALE_THRESHOLD || !lane_on) == ~0ull) rate_small |= 1u << t;
+          for (int j = 0; j < SP; ++j) acc += P[j] * row[j];
+        }
+        else
+        {
+          const unsigned int m = rmask[t];
+#pragma unroll
+          for (int j = 0; j < SP; ++j) acc += ((m >> j) & 1u) ? P[j] : 0.0;
+        }
+        const size_t n = n0 + t * Q + q;
+        const double p = s_l[(t * Q + q) * SPL + i] * acc;
+        if (lane_on && n < a.sites) a.parent[(n * R + k) * S + i] = p;
+        if (KIND != 2)
+        {
+          const unsigned long long b = __ballot(p < PLLHIP_SCALE_THRESHOLD || !lane_on);
+#pragma unroll
+          for (int qq = 0; qq < Q; ++qq)
+            if (((b >> (qq * LPS)) & SLOT_FULL) == SLOT_FULL) rate_small |= 1ull << (t * Q + qq);
+        }
       }
       site_small &= rate_small;
       if (mode == SCALE_RATE)
       {
-        for (unsigned int m = rate_small; m; m &= m - 1u)
-        {
-          const unsigned int t = __ffs(m) - 1u;
-          if (lane_on && n0 + t < a.sites) a.parent[((n0 + t) * R + k) * S + i] *= PLLHIP_SCALE_FACTOR;
-        }
-        if (lane < (unsigned int)WT && n0 + lane < a.sites)
+        if (rate_small)
+#pragma unroll 1
+          for (int t = 0; t < WT; ++t)
+          {
+            const size_t n = n0 + t * Q + q;
+            if (((rate_small >> (t * Q + q)) & 1ull) && lane_on && n < a.sites)
+              a.parent[(n * R + k) * S + i] *= PLLHIP_SCALE_FACTOR;
+          }
+        if (lane < (unsigned int)ROWS && n0 + lane < a.sites)
         {
           const size_t w = (n0 + lane) * R + k;
-          a.pscaler[w] = (a.lscaler ? a.lscaler[w] : 0u) + (a.rscaler ? a.rscaler[w] : 0u) +
-                         ((rate_small >> lane) & 1u);
+          a.pscaler[w] = (KIND == 2) ? 0u
+                                     : ((KIND == 0 && a.lscaler) ? a.lscaler[w] : 0u) +
+                                           (a.rscaler ? a.rscaler[w] : 0u) +
+                                           (unsigned int)((rate_small >> lane) & 1ull);
         }
       }
     }
     if (mode == SCALE_SITE)
     {
-      for (unsigned int m = site_small; m; m &= m - 1u)
-      {
-        const unsigned int t = __ffs(m) - 1u;
-        if (lane_on && n0 + t < a.sites)
-          for (unsigned int k = 0; k < R; ++k) a.parent[((n0 + t) * R + k) * S + i] *= PLLHIP_SCALE_FACTOR;
-      }
-      if (lane < (unsigned int)WT && n0 + lane < a.sites)
-        a.pscaler[n0 + lane] = (a.lscaler ? a.lscaler[n0 + lane] : 0u) +
-                               (a.rscaler ? a.rscaler[n0 + lane] : 0u) + ((site_small >> lane) & 1u);
+      if (KIND != 2 && site_small)
+#pragma unroll 1
+        for (int t = 0; t < WT; ++t)
+        {
+          const size_t n = n0 + t * Q + q;
+          if (((site_small >> (t * Q + q)) & 1ull) && lane_on && n < a.sites)
+            for (unsigned int k = 0; k < R; ++k) a.parent[(n * R + k) * S + i] *= PLLHIP_SCALE_FACTOR;
+        }
+      if (lane < (unsigned int)ROWS && n0 + lane < a.sites)
+        a.pscaler[n0 + lane] = (KIND == 2) ? 0u
+                                           : ((KIND == 0 && a.lscaler) ? a.lscaler[n0 + lane] : 0u) +
+                                                 (a.rscaler ? a.rscaler[n0 + lane] : 0u) +
+                                                 (unsigned int)((site_small >> lane) & 1ull);
     }
   }
 }
 
 static bool gen_wide_covers(unsigned int S, int kind)
 {
-  return kind == 0 && S >= 40 && S <= 64;
+  // tip children are 32-bit state masks: tip kinds exist up to 32 states only
+  return S >= 9 && S <= 64 && S != 20 && (kind == 0 || S <= 32);
 }
 
+template <int KIND, int SP, int LPS>
+static int launch_gen_wide_shape(pllhip_ctx * c, const PartialsBatch & b, const dim3 & grid, int mode)
+{
+  const size_t lds = 4 * 2 * (size_t)(gen_wide_wt(SP, LPS) * (64 / LPS)) * (LPS == 64 ? SP : SP + 2) * sizeof(double);
+  if (lds > 65536)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_wide<KIND, SP, LPS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_gen_wide<KIND, SP, LPS><<<grid, 256, lds, c->stream>>>(b, mode);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <int KIND>
 static int launch_gen_wide(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode)
 {
   size_t sites = 0;
   for (unsigned int i = 0; i < count; ++i)
     if (b.op[i].sites > sites) sites = b.op[i].sites;
   if (!sites) return 0;
-  const size_t groups = (sites + GEN_WIDE_WT - 1) / GEN_WIDE_WT;
+  const unsigned int S = c->sh.states;
+  const size_t rows = S <= 16 ? gen_wide_wt(16, 16) * 4 : S <= 24 ? gen_wide_wt(24, 32) * 2
+                      : S <= 32 ? gen_wide_wt(32, 32) * 2 : gen_wide_wt(64, 64);
+  const size_t groups = (sites + rows - 1) / rows;
   const size_t cap = (size_t)c->num_cus * 2; // 2 workgroups of 4 waves per CU
   const size_t need = (groups + 3) / 4;
   const dim3 grid((unsigned int)(need < cap ? need : cap), count);
-  const unsigned int S = c->sh.states;
-#define LAUNCH_WIDE(SPV) \
-  k_gen_wide<SPV><<<grid, 256, 4 * 2 * GEN_WIDE_WT * SPV * sizeof(double), c->stream>>>(b, mode)
-  if (S <= 40) LAUNCH_WIDE(40);
-  else if (S <= 48) LAUNCH_WIDE(48);
-  else if (S <= 56) LAUNCH_WIDE(56);
-  else LAUNCH_WIDE(64);
-#undef LAUNCH_WIDE
-  HIP_TRY(hipGetLastError());
-  return 0;
+  if (S <= 16) return launch_gen_wide_shape<KIND, 16, 16>(c, b, grid, mode);
+  if (S <= 24) return launch_gen_wide_shape<KIND, 24, 32>(c, b, grid, mode);
+  if (S <= 32) return launch_gen_wide_shape<KIND, 32, 32>(c, b, grid, mode);
+  if (KIND == 0)
+  {
+    if (S <= 40) return launch_gen_wide_shape<0, 40, 64>(c, b, grid, mode);
+    if (S <= 48) return launch_gen_wide_shape<0, 48, 64>(c, b, grid, mode);
+    if (S <= 56) return launch_gen_wide_shape<0, 56, 64>(c, b, grid, mode);
+    return launch_gen_wide_shape<0, 64, 64>(c, b, grid, mode);
+  }
+  pllhip_set_error("tip-state kernels cover at most 32 states");
+  return -1;
 }
 
 static size_t gen_tile_lds(unsigned int S, unsigned int R, int kind, unsigned int ts, bool resident)
@@ -519,7 +607,12 @@ int pllhip_launch_gen_batch(pllhip_ctx * c, const PartialsBatch & b, unsigned in
     if (kind == 1) return launch_gen_rows<1>(c, b, count, mode);
     return launch_gen_rows<2>(c, b, count, mode);
   }
-  if (gen_wide_covers(c->sh.states, kind)) return launch_gen_wide(c, b, count, mode);
+  if (gen_wide_covers(c->sh.states, kind))
+  {
+    if (kind == 0) return launch_gen_wide<0>(c, b, count, mode);
+    if (kind == 1) return launch_gen_wide<1>(c, b, count, mode);
+    return launch_gen_wide<2>(c, b, count, mode);
+  }
   if (kind == 0) return launch_gen_tile<0>(c, b, count, mode);
   if (kind == 1) return launch_gen_tile<1>(c, b, count, mode);
   return launch_gen_tile<2>(c, b, count, mode);

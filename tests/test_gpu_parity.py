@@ -140,11 +140,11 @@ def test_odd_state_counts(gpu, orc, states, pattern_tip):
     p.destroy()
 
 
-# state counts without a dedicated kernel: rows-in-registers kernels (2, 3, 5..8 states with
-# a power-of-two rate_cats) and the LDS-tiled kernels (everything else up to 64 states;
-# 61 states reload the matrices per category), partials_gen_tile.hip
-GENERIC_SHAPES = [(2, 4), (3, 4), (5, 4), (6, 2), (7, 1), (8, 8), (5, 3), (9, 4), (13, 4), (11, 16),
-                  (32, 4), (61, 4), (64, 2)]
+# state counts without a dedicated kernel (partials_gen_tile.hip): rows-in-registers kernels
+# (up to 16 states with a power-of-two rate_cats), P-rows-in-registers kernels (9..64 states,
+# 16 / 32 / 64 lanes per site) and the LDS-tiled kernels (up to 8 states with any other rate_cats)
+GENERIC_SHAPES = [(2, 4), (3, 4), (5, 4), (6, 2), (7, 1), (8, 8), (5, 3), (9, 4), (13, 4), (11, 16), (16, 2),
+                  (13, 3), (17, 3), (21, 4), (32, 4), (40, 1), (50, 2), (61, 4), (64, 2)]
 
 
 @pytest.mark.parametrize("states,rate_cats", GENERIC_SHAPES)
@@ -173,7 +173,8 @@ def test_generic_state_kernels(gpu, orc, states, rate_cats, pattern_tip, rate_sc
     p.destroy()
 
 
-@pytest.mark.parametrize("states,rate_cats,tips", [(2, 4, 900), (5, 4, 500), (5, 3, 500), (13, 4, 400), (61, 4, 300)])
+@pytest.mark.parametrize("states,rate_cats,tips", [(2, 4, 900), (5, 4, 500), (5, 3, 500), (13, 4, 400), (13, 3, 400),
+                                                   (24, 2, 350), (61, 4, 300)])
 @pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
 def test_generic_state_deep_scaling(gpu, orc, states, rate_cats, tips, rate_scalers):
     """Caterpillars deep enough for several scaling events per site, tips as CLVs (all
