@@ -214,14 +214,22 @@ def random_op_sequence(rng, tips, inner, scalers, matrices, length):
     return ops
 
 
-def random_sequence_case(seed):
+def random_sequence_case(seed, states=None, rate_cats=4):
     """(case, attributes, ops, rng) for the random-op-sequence tests: 4- and 20-state
-    data, with and without PATTERN_TIP, per-site and per-rate scalers."""
+    data (or the state count given), with and without PATTERN_TIP, per-site and per-rate
+    scalers."""
     rng = np.random.default_rng(1000 + seed)
-    states = 4 if seed % 3 else 20
     attrs = (ATTRIB_PATTERN_TIP if seed % 2 else 0) | (ATTRIB_RATE_SCALERS if seed % 4 >= 2 else 0)
     tips = 12
-    case = make_case(states, "random", tips, 97 + 64 * (seed % 4), seed=seed + 50)
+    sites = 97 + 64 * (seed % 4)
+    if states is None:
+        states = 4 if seed % 3 else 20
+        case = make_case(states, "random", tips, sites, seed=seed + 50)
+    elif states > 32:
+        attrs &= ~ATTRIB_PATTERN_TIP
+        case = many_state_case(states, tips=tips, sites=sites, seed=seed + 50, rate_cats=rate_cats)
+    else:
+        case = odd_state_case(states, tips=tips, sites=sites, seed=seed + 50, rate_cats=rate_cats)
     plan = case["plan"]
     ops = random_op_sequence(rng, tips, plan.clv_buffers, plan.scale_buffers, plan.prob_matrices - 1,
                              120)

@@ -182,6 +182,24 @@ def test_random_op_sequences(gpu, orc, seed, monkeypatch):
     p2.destroy()
 
 
+@pytest.mark.parametrize("states,rate_cats", [(2, 4), (5, 4), (5, 3), (13, 2), (13, 3), (24, 4), (61, 2)])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_op_sequences_other_state_counts(gpu, orc, states, rate_cats, seed):
+    """The same for the kernels of partials_gen_tile.hip (rows, P-rows and LDS-tiled
+    mappings), which are level-batched like the 4- and 20-state ones."""
+    case, attrs, ops, rng = random_sequence_case(seed, states, rate_cats)
+    plan = case["plan"]
+    p = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    p.update_partials(ops)
+    o.update_partials(ops)
+    for node in sorted(set(int(x) for x in ops["parent_clv_index"])):
+        assert bits_equal(p.get_clv(node), o.clv[node]), "CLV slot %d" % node
+    for sc in range(plan.scale_buffers):
+        assert (p.get_scaler(sc) == o.scalers[sc]).all(), "scale buffer %d" % sc
+    p.destroy()
+
+
 @pytest.mark.parametrize("states,shape", [(4, "random"), (4, "caterpillar"), (20, "random")])
 def test_partial_traversal_after_branch_change(gpu, orc, states, shape, monkeypatch):
     """Incremental update (test/src/partial-traversal.c's use): after one branch
