@@ -299,14 +299,17 @@ def main():
         n_ops = len(ii_ops) * args.steps
         avg_launch_s = ms / n_launch / 1e3
         ops_per_launch = len(ii_ops) / launches_per_pass
-        algo_bytes = BYTES_PER_SITE["ii"][S] * (hi - lo) * ops_per_launch   # per launch
+        # three CLV rows of 8 * states * rate_cats bytes + three per-site scaler words
+        # (396 / 1932 B at the 4 rate categories the configs name)
+        ii_bytes = 3 * 8 * S * R + 12
+        algo_bytes = ii_bytes * (hi - lo) * ops_per_launch   # per launch
         achieved = algo_bytes / avg_launch_s / 1e9
-        traffic = TRAFFIC_PER_OP.get(S) if (hi - lo) == TRAFFIC_SITES.get(S) else None
+        traffic = TRAFFIC_PER_OP.get(S) if (hi - lo) == TRAFFIC_SITES.get(S) and R == 4 else None
         roofline = {"bound": "hbm", "kernel": "pll_core_update_partial_ii (%d states)" % S,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic * ops_per_launch if traffic else None,
-                    "bytes_per_site_update": BYTES_PER_SITE["ii"][S],
+                    "bytes_per_site_update": ii_bytes,
                     "site_updates_per_launch": (hi - lo) * ops_per_launch,
                     "ops_per_launch": round(ops_per_launch, 2),
                     "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": n_launch,

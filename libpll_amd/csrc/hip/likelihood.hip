@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_lnl_rowsum(LnlArgs a, RowsumGeom g)
   block_sum_to_partials(acc, a.reduce);
 }
 
-// ---- 2, 3, 5..8 states with a power-of-two rate_cats: one pass, rows in registers
+// ---- up to 16 states (4 only with an unusual rate_cats): one pass, rows in registers
 //
 // The mapping of k_gen_rows (partials_gen_tile.hip): one lane per (site, rate) row, both
 // rows in registers, P in LDS, loops unrolled over the compile-time state count; the
@@ -611,14 +611,18 @@ __global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
       smem[(t / (SC * SC)) * MP + t % (SC * SC)] = a.pmat[t];
     __syncthreads();
   }
-  const unsigned int rshift = __ffs(R) - 1u;
-  const size_t total = (size_t)a.sites << rshift;
-  const unsigned int lane = tid & 63u, grp0 = lane & ~(R - 1u);
-  // A wave takes 64 sites at a time, in R rounds of 64 rows (64 / R sites each); after
-  // round r the lanes [r * 64/R, (r+1) * 64/R) keep the category sums of that round's
+  // A wave takes 64 sites at a time, in rounds of spr = 64 / R whole sites (lane = g * R + k
+  // is row k of the round's g-th site; all 64 lanes when R is a power of two); after
+  // round r the lanes [r * spr, (r+1) * spr) keep the category sums of that round's
   // sites, so that in the end every lane owns ONE site and the logarithm (a hundred
   // 4-cycle f64 instructions) runs once per site instead of once per row.
-  const unsigned int spr_shift = 6u - rshift, spr_mask = (64u >> rshift) - 1u;
+  const unsigned int lane = tid & 63u;
+  const unsigned int spr = 64u / R, nrounds = (64u + spr - 1u) / spr;
+  const unsigned int g = lane / R, k = lane - g * R, grp0 = g * R;
+  const unsigned int own_round = lane / spr;
+  const int own_src = (int)((lane - own_round * spr) * R);
+  const double * fr = a.freqs + (size_t)a.freqs_indices[k] * SC;
+  const double * m = smem + k * MP;
   const size_t sites_up = ((size_t)a.sites + 63) & ~(size_t)63;
   double acc = 0.0;
   for (size_t sbase = ((size_t)blockIdx.x * 4u + (tid >> 6)) * 64u; sbase < sites_up;
@@ -626,15 +630,12 @@ __global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
   {
    double own_terma = 1.0;
    unsigned int own_scalings = 0u;
-   for (unsigned int round = 0; round < R; ++round)
+   for (unsigned int round = 0; round < nrounds; ++round)
    {
-    const size_t e = (sbase << rshift) + round * 64u + lane;
-    const bool act = e < total;
-    const size_t ec = act ? e : 0;
-    const size_t n = ec >> rshift;
-    const unsigned int k = (unsigned int)(ec & (R - 1u));
-    const double * fr = a.freqs + (size_t)a.freqs_indices[k] * SC;
-    const double * m = smem + k * MP;
+    const unsigned int pos = round * spr + g; // the site's place among the wave's 64
+    const bool act = g < spr && pos < 64u && sbase + pos < a.sites;
+    const size_t n = act ? sbase + pos : 0;
+    const size_t ec = act ? n * R + k : 0;
     double p[SC], c[SC];
 #pragma unroll
     for (int j = 0; j < SC; ++j) p[j] = a.parent[ec * SC + j];
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
     if (KIND == EDGE_II)
 #pragma unroll
       for (int j = 0; j < SC; ++j) c[j] = a.child[ec * SC + j];
-    if (KIND == EDGE_TI) mask = a.tipmap[a.tip[n]];
+    if (KIND == EDGE_TI) mask = (SC == 4) ? a.tip[n] : a.tipmap[a.tip[n]];
     double terma_r = 0.0;
 #pragma unroll
     for (int i = 0; i < SC; ++i)
@@ -668,9 +669,9 @@ __global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
       if (a.pscaler) mine += a.pscaler[ec];
       if (KIND == EDGE_II && a.cscaler) mine += a.cscaler[ec];
       unsigned int mn = mine;
-      for (unsigned int off = 1; off < R; off <<= 1)
+      for (unsigned int i = 0; i < R; ++i)
       {
-        const unsigned int o = (unsigned int)__shfl_xor((int)mn, (int)off, 64);
+        const unsigned int o = (unsigned int)__shfl((int)mine, (int)(grp0 + i), 64);
         mn = o < mn ? o : mn;
       }
       site_scalings = mn;
@@ -685,10 +686,9 @@ __global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
     const double contrib = category_term<false>(a, terma_r, k, n, rel);
     double terma = 0.0;
     for (unsigned int i = 0; i < R; ++i) terma += __shfl(contrib, (int)(grp0 + i), 64);
-    const int src = (int)((lane & spr_mask) << rshift);
-    const double t_own = __shfl(terma, src, 64);
-    const unsigned int s_own = (unsigned int)__shfl((int)site_scalings, src, 64);
-    if ((lane >> spr_shift) == round)
+    const double t_own = __shfl(terma, own_src, 64);
+    const unsigned int s_own = (unsigned int)__shfl((int)site_scalings, own_src, 64);
+    if (own_round == round)
     {
       own_terma = t_own;
       own_scalings = s_own;
@@ -712,8 +712,8 @@ static void launch_lnl_rows_sc(pllhip_ctx * c, const LnlArgs & a, int kind, unsi
 static int launch_lnl_rows(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
 {
   const unsigned int S = c->sh.states, R = c->sh.rate_cats;
-  const bool pow2 = R && !(R & (R - 1u)) && R <= 16u;
-  if (!pow2 || S < 2 || S > 16 || S == 4) return 1;
+  // (4 states arrive here only with a rate_cats the dedicated kernels do not cover)
+  if (R < 1 || R > 64 || S < 2 || S > 16 || (size_t)R * (S * S + 2) * sizeof(double) > 65536) return 1;
   // a workgroup takes 256 sites per trip
   unsigned int grid = pllhip_stream_grid(c, (size_t)a.sites, 256);
   if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
@@ -722,6 +722,7 @@ static int launch_lnl_rows(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int *
   {
     case 2: launch_lnl_rows_sc<2>(c, a, kind, grid); break;
     case 3: launch_lnl_rows_sc<3>(c, a, kind, grid); break;
+    case 4: launch_lnl_rows_sc<4>(c, a, kind, grid); break;
     case 5: launch_lnl_rows_sc<5>(c, a, kind, grid); break;
     case 6: launch_lnl_rows_sc<6>(c, a, kind, grid); break;
     case 7: launch_lnl_rows_sc<7>(c, a, kind, grid); break;

@@ -163,14 +163,16 @@ __global__ __launch_bounds__(256) void k_gen_tile(PartialsBatch batch, int mode,
 
 // ------------------------------------------------------------ few states: rows in registers
 //
-// Up to 8 states a (site, rate) row of a CLV is at most 64 bytes: one lane takes one row,
+// Up to 16 states a (site, rate) row of a CLV is at most 128 bytes: one lane takes one row,
 // keeps both child rows and the parent row in registers (state count known at compile
 // time, loops unrolled) and walks the rows of P_l / P_r in LDS -- the lanes of a wave read
 // rate_cats distinct LDS addresses per instruction, matrices padded by two words so that
 // they fall in different banks.  Consecutive lanes own consecutive rows, so a wave's
-// loads and stores cover one contiguous 64 x states x 8 B block.  rate_cats is a power
-// of two here: the lanes of a site are an aligned group of the wave and the per-site
-// scaling decision is one __ballot.
+// loads and stores cover one contiguous block of up to 64 x states x 8 B.  A wave holds
+// 64 / rate_cats whole sites (any rate_cats up to 64; a few lanes idle when it is not a
+// power of two), so the per-site scaling decision is one __ballot.  This is also where
+// 4-state data with an unusual rate_cats (3, 5, 6, 10 ...) runs, in the pairwise order of
+// the reference's 4x4 kernels.
 template <int KIND, int SC>
 __global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
 {
@@ -188,28 +190,29 @@ __global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
   }
   __syncthreads();
 
-  const unsigned int rshift = __ffs(R) - 1u;
-  const size_t items = (size_t)a.sites << rshift;
-  const size_t rounds = (items + 255) / 256;
-  for (size_t round = blockIdx.x; round < rounds; round += gridDim.x)
+  // a wave takes 64 / R whole sites per trip (all 64 lanes when R is a power of two):
+  // lane = g * R + k is row k of the wave's g-th site, consecutive lanes own consecutive rows
+  const unsigned int lane = tid & 63u;
+  const unsigned int spw = 64u / R;
+  const unsigned int g = lane / R, k = lane - g * R;
+  const double * pl = s_pl + k * MP;
+  const double * pr = s_pr + k * MP;
+  const size_t trips = ((size_t)a.sites + spw - 1) / spw;
+  for (size_t trip = (size_t)blockIdx.x * 4u + (tid >> 6); trip < trips; trip += (size_t)gridDim.x * 4u)
   {
-    const size_t item = round * 256 + tid;
-    const bool act = item < items;
-    const size_t it = act ? item : 0;
-    const size_t n = it >> rshift;
-    const unsigned int k = (unsigned int)(it & (R - 1u));
-    const double * pl = s_pl + k * MP;
-    const double * pr = s_pr + k * MP;
+    const bool act = g < spw && trip * spw + g < a.sites;
+    const size_t n = act ? trip * spw + g : 0;
+    const size_t it = act ? n * R + k : 0;
     double l[SC], r[SC], out[SC];
     unsigned int lmask = 0u, rmask = 0u;
     if (KIND == 0)
       for (int j = 0; j < SC; ++j) l[j] = a.left[it * SC + j];
     else
-      lmask = a.tipmap[a.ltip[n]];
+      lmask = (SC == 4) ? a.ltip[n] : a.tipmap[a.ltip[n]]; // 4 states: the tip code is the mask
     if (KIND != 2)
       for (int j = 0; j < SC; ++j) r[j] = a.right[it * SC + j];
     else
-      rmask = a.tipmap[a.rtip[n]];
+      rmask = (SC == 4) ? a.rtip[n] : a.tipmap[a.rtip[n]];
     unsigned int inherited = 0u;
     if (KIND != 2 && mode != SCALE_NONE)
     {
@@ -223,13 +226,22 @@ __global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
     for (int i = 0; i < SC; ++i)
     {
       double x = 0.0, y = 0.0;
-#pragma unroll
-      for (int j = 0; j < SC; ++j)
+      if (SC == 4)
       {
-        if (KIND == 0) x += pl[i * SC + j] * l[j];
-        else if ((lmask >> j) & 1u) x += pl[i * SC + j];
-        if (KIND != 2) y += pr[i * SC + j] * r[j];
-        else if ((rmask >> j) & 1u) y += pr[i * SC + j];
+        // 4 states keep the pairwise order of the reference's 4x4 kernels (numerics.hpp)
+        x = (KIND == 0) ? dot4(pl + i * 4, l[0], l[1], l[2], l[3]) : masksum4(pl + i * 4, lmask);
+        y = (KIND != 2) ? dot4(pr + i * 4, r[0], r[1], r[2], r[3]) : masksum4(pr + i * 4, rmask);
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < SC; ++j)
+        {
+          if (KIND == 0) x += pl[i * SC + j] * l[j];
+          else if ((lmask >> j) & 1u) x += pl[i * SC + j];
+          if (KIND != 2) y += pr[i * SC + j] * r[j];
+          else if ((rmask >> j) & 1u) y += pr[i * SC + j];
+        }
       }
       out[i] = x * y;
       small = small && (out[i] < PLLHIP_SCALE_THRESHOLD);
@@ -240,10 +252,9 @@ __global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
       bool scale = small;
       if (mode == SCALE_SITE)
       {
-        // all rate_cats lanes of the site (an aligned group of the wave) must agree
+        // all rate_cats lanes of the site must agree
         const unsigned long long b = __ballot(small || !act);
-        const unsigned int lane = tid & 63u;
-        const unsigned long long grp = b >> (lane & ~(R - 1u));
+        const unsigned long long grp = b >> (g * R);
         const unsigned long long full = (R >= 64u) ? ~0ull : ((1ull << R) - 1ull);
         scale = (grp & full) == full;
       }
@@ -261,10 +272,10 @@ __global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
   }
 }
 
+// 4 states come here only with a rate_cats the dedicated kernels of partials.hip do not cover
 static bool gen_rows_covers(unsigned int S, unsigned int R)
 {
-  const bool pow2 = R && !(R & (R - 1u)) && R <= 16u;
-  return pow2 && S >= 2 && S <= 16 && S != 4;
+  return R >= 1 && R <= 64 && S >= 2 && S <= 16 && 2 * (size_t)R * (S * S + 2) * sizeof(double) <= 65536;
 }
 
 template <int KIND, int SC>
@@ -275,7 +286,9 @@ static int launch_gen_rows_sc(pllhip_ctx * c, const PartialsBatch & b, unsigned 
   for (unsigned int i = 0; i < count; ++i)
     if (b.op[i].sites > sites) sites = b.op[i].sites;
   if (!sites) return 0;
-  const dim3 grid(pllhip_stream_grid(c, sites * R, 256), count);
+  // a workgroup's four waves take 64 / R sites each per trip
+  const size_t trips = (sites + 64 / R - 1) / (64 / R);
+  const dim3 grid(pllhip_stream_grid(c, trips * 64, 256), count);
   const size_t lds = 2 * (size_t)R * (SC * SC + 2) * sizeof(double);
   k_gen_rows<KIND, SC><<<grid, 256, lds, c->stream>>>(b, mode);
   HIP_TRY(hipGetLastError());
@@ -289,6 +302,7 @@ static int launch_gen_rows(pllhip_ctx * c, const PartialsBatch & b, unsigned int
   {
     case 2: return launch_gen_rows_sc<KIND, 2>(c, b, count, mode);
     case 3: return launch_gen_rows_sc<KIND, 3>(c, b, count, mode);
+    case 4: return launch_gen_rows_sc<KIND, 4>(c, b, count, mode);
     case 5: return launch_gen_rows_sc<KIND, 5>(c, b, count, mode);
     case 6: return launch_gen_rows_sc<KIND, 6>(c, b, count, mode);
     case 7: return launch_gen_rows_sc<KIND, 7>(c, b, count, mode);
@@ -569,9 +583,13 @@ static GenTileGeom gen_tile_geom(const pllhip_ctx * c, int kind, size_t * lds)
   return g;
 }
 
+// does one of the kernels of this file cover the partition's shape?  (4 states are asked
+// only after the dedicated kernels declined, i.e. for unusual rate_cats; 20 states never)
 bool pllhip_gen_tile_covers(const pllhip_ctx * c)
 {
   size_t lds;
+  if (c->sh.states == 20) return false;
+  if (gen_rows_covers(c->sh.states, c->sh.rate_cats)) return true;
   return gen_tile_geom(c, 0, &lds).ts != 0u;
 }
 
