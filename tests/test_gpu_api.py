@@ -182,7 +182,7 @@ def test_random_op_sequences(gpu, orc, seed, monkeypatch):
     p2.destroy()
 
 
-@pytest.mark.parametrize("states,rate_cats", [(2, 4), (5, 4), (5, 3), (13, 2), (13, 3), (24, 4), (61, 2)])
+@pytest.mark.parametrize("states,rate_cats", [(2, 4), (5, 4), (5, 3), (13, 2), (13, 3), (24, 4), (61, 2), (7, 64)])
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_random_op_sequences_other_state_counts(gpu, orc, states, rate_cats, seed):
     """The same for the kernels of partials_gen_tile.hip (rows, P-rows and LDS-tiled

@@ -144,7 +144,8 @@ def test_odd_state_counts(gpu, orc, states, pattern_tip):
 # (up to 16 states with a power-of-two rate_cats), P-rows-in-registers kernels (9..64 states,
 # 16 / 32 / 64 lanes per site) and the LDS-tiled kernels (up to 8 states with any other rate_cats)
 GENERIC_SHAPES = [(2, 4), (3, 4), (5, 4), (6, 2), (7, 1), (8, 8), (5, 3), (9, 4), (13, 4), (11, 16), (16, 2),
-                  (13, 3), (17, 3), (21, 4), (32, 4), (40, 1), (50, 2), (61, 4), (64, 2)]
+                  (13, 3), (17, 3), (21, 4), (32, 4), (40, 1), (50, 2), (61, 4), (64, 2),
+                  (7, 64), (12, 40)]  # P tables too large for the rows kernel: LDS-tiled / P-row kernels
 
 
 @pytest.mark.parametrize("states,rate_cats", GENERIC_SHAPES)
