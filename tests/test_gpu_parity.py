@@ -174,6 +174,19 @@ def test_generic_state_kernels(gpu, orc, states, rate_cats, pattern_tip, rate_sc
     p.destroy()
 
 
+@pytest.mark.parametrize("states,rate_cats", [(5, 4), (5, 3), (13, 3), (24, 2), (61, 1), (7, 64)])
+def test_generic_state_ragged_site_counts(gpu, orc, states, rate_cats):
+    """Site counts around the group sizes of the kernels (a wave's 64 / rate_cats sites, 16..64-site groups)."""
+    for sites in (1, 2, 15, 17, 47, 48, 49, 63, 64, 65, 130):
+        for attrs in ((0, ATTRIB_RATE_SCALERS) if states > 32 else (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS)):
+            kw = dict(tips=6, sites=sites, seed=sites + states, rate_cats=rate_cats)
+            case = many_state_case(states, **kw) if states > 32 else odd_state_case(states, **kw)
+            p = build_partition(gpu, case, attrs)
+            o = oracle_run(orc, gpu, p, case, attrs)
+            compare(p, o, case, rate_cats)
+            p.destroy()
+
+
 @pytest.mark.parametrize("states,rate_cats,tips", [(2, 4, 900), (5, 4, 500), (5, 3, 500), (13, 4, 400), (13, 3, 400),
                                                    (24, 2, 350), (61, 4, 300)])
 @pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
