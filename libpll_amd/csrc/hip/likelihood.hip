@@ -743,7 +743,8 @@ static int launch_lnl_rows(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int *
 // kind as in run_lnl; returns 1 if the shape is not covered
 static int launch_lnl_two_pass(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
 {
-  if (!pllhip_gen_tile_covers(c)) return 1;
+  // (4 and 20 states keep their own summation orders: not here)
+  if (c->sh.states == 4 || c->sh.states == 20 || !pllhip_gen_tile_covers(c)) return 1;
   const unsigned int S = c->sh.states, R = c->sh.rate_cats;
   LnlArgs b = a; // what the row-sum pass sees
   if (kind != ROOT)

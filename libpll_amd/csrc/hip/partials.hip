@@ -8,16 +8,15 @@
 //   tip-tip      pll_core_create_lookup + pll_core_update_partial_tt
 //                core_partials.c:725,82; AVX2-flag path core_partials_avx.c:262,146,581,531
 //
-// Three families of kernels live here:
-//   4 states            k_dna_partials: one lane per 16 bytes, rounds of 64 sites (below)
-//   20 states, bit-exact k_aa_ii / _ti / _tt: one lane per (site, rate), P in LDS
-//                       (the default 20-state path is partials_aa_mfma.hip)
-//   anything else       k_gen_partials: one lane per site, plain left-to-right sums
-// CLVs are [site][rate][state] with state fastest, so consecutive lanes touch
-// consecutive memory in all three.  Per-site scaling needs "all rate_cats x
+// Kernels:
+//   4 states, rate_cats 1/2/4/8/16   k_dna_partials: one lane per 16 bytes, rounds of 64 sites (below)
+//   20 states, rate_cats 1/2/4       partials_aa_mfma.hip (matrix cores)
+//   every other shape up to 64 states (and 20 states bit-exact, PLLHIP_AA_EXACT=1)
+//                                    partials_gen_tile.hip
+//   more than 64 states              k_gen_partials: one lane per site (below)
+// CLVs are [site][rate][state] with state fastest.  Per-site scaling needs "all rate_cats x
 // states entries < 2^-256": each lane tests its own entries, then one __ballot
-// gives every lane the bits of the lanes that share its site (rate_cats is a
-// power of two <= 16 in the fast kernels, so a site never straddles a wave).
+// gives every lane the bits of the lanes that share its site.
 //
 // pllhip_update_partials (bottom of the file) schedules an op list by dependency
 // level and launches one kernel per (level, kind, scaling mode).
@@ -216,9 +215,8 @@ __global__ __launch_bounds__(256) void k_dna_partials(PartialsBatch batch)
 // ------------------------------------------------- any state count (fallback)
 //
 // One lane per SITE, looping over rate categories and states; P-matrices and
-// tip tables are read through L1/L2.  The last resort: 4 or 20 states with a rate_cats
-// the dedicated kernels do not cover, and more than 64 states (every other state count
-// runs on the LDS-tiled kernels of partials_gen_tile.hip).
+// tip tables are read through L1/L2.  The last resort: more than 64 states (everything
+// else runs on the kernels of partials_gen_tile.hip).
 // Orders: 4 states pairwise; 20 states the AVX2-flag order (ii fused, ti not);
 // otherwise left-to-right like the plain C kernels.
 
@@ -304,215 +302,7 @@ __global__ __launch_bounds__(128) void k_gen_partials(PartialsArgs a, int mode)
   }
 }
 
-// ---------------------------------------------------------------- 20 states
-//
-// Vector (non-MFMA) kernels that reproduce the AVX2-flag arithmetic exactly:
-// one lane per (site, rate); the lane keeps both child vectors in registers
-// and walks the 20 rows of P_l / P_r, which sit in LDS ([R][20][20] each,
-// 25.6 KB for 4 categories).  Lanes of one wave read at most RC distinct LDS
-// addresses per instruction (one per rate), rows padded so the RC addresses
-// fall in different banks.
-
-#define AA_S 20
-#define AA_ROWPAD 20 /* row stride in doubles */
-#define AA_MATPAD (AA_S * AA_ROWPAD + 2) /* matrix stride: +2 doubles skews banks between rates */
-
-template <int RC>
-__device__ __forceinline__ void aa_stage_matrix(double * dst, const double * __restrict__ src)
-{
-  for (unsigned int t = threadIdx.x; t < RC * AA_S * AA_S; t += blockDim.x)
-  {
-    const unsigned int k = t / (AA_S * AA_S), ij = t % (AA_S * AA_S);
-    dst[k * AA_MATPAD + ij] = src[t];
-  }
-}
-
-struct reg20
-{
-  double v[AA_S];
-  __device__ __forceinline__ double operator[](unsigned int j) const { return v[j]; }
-};
-
-__device__ __forceinline__ void aa_load(reg20 & r, const double * __restrict__ p)
-{
-  const double2 * q = reinterpret_cast<const double2 *>(p);
-#pragma unroll
-  for (int j = 0; j < AA_S / 2; ++j)
-  {
-    const double2 t = q[j];
-    r.v[2 * j] = t.x;
-    r.v[2 * j + 1] = t.y;
-  }
-}
-
-template <int MODE, int RC>
-__device__ __forceinline__ void aa_finish(const PartialsArgs & a, size_t e, bool act,
-                                          unsigned int k, reg20 & p, bool small,
-                                          unsigned int base_scale)
-{
-  bool scale = false;
-  if (MODE == SCALE_RATE) scale = small;
-  if (MODE == SCALE_SITE) scale = site_all<RC>(small || !act);
-  if (!act) return;
-  double2 * out = reinterpret_cast<double2 *>(a.parent + (size_t)AA_S * e);
-#pragma unroll
-  for (int j = 0; j < AA_S / 2; ++j)
-  {
-    double x = p.v[2 * j], y = p.v[2 * j + 1];
-    if (scale) { x *= PLLHIP_SCALE_FACTOR; y *= PLLHIP_SCALE_FACTOR; }
-    out[j] = make_double2(x, y);
-  }
-  if (MODE == SCALE_RATE) a.pscaler[e] = base_scale + (scale ? 1u : 0u);
-  if (MODE == SCALE_SITE && k == 0) a.pscaler[e / RC] = base_scale + (scale ? 1u : 0u);
-}
-
-template <int RC, int MODE>
-__global__ __launch_bounds__(256) void k_aa_ii(PartialsArgs a)
-{
-  extern __shared__ double smem[];
-  double * sl = smem;
-  double * sr = smem + RC * AA_MATPAD;
-  aa_stage_matrix<RC>(sl, a.lmat);
-  aa_stage_matrix<RC>(sr, a.rmat);
-  __syncthreads();
-  const unsigned int k = threadIdx.x & (RC - 1);
-  const double * ml = sl + k * AA_MATPAD;
-  const double * mr = sr + k * AA_MATPAD;
-
-  const size_t total = (size_t)a.sites * RC;
-  const size_t total_up = (total + 63) & ~(size_t)63;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
-  {
-    const bool act = e < total;
-    const size_t ec = act ? e : 0;
-    reg20 L, R, P;
-    aa_load(L, a.left + (size_t)AA_S * ec);
-    aa_load(R, a.right + (size_t)AA_S * ec);
-    unsigned int base = 0;
-    if (MODE != SCALE_NONE)
-    {
-      const size_t si = (MODE == SCALE_RATE) ? ec : ec / RC;
-      if (a.lscaler) base += a.lscaler[si];
-      if (a.rscaler) base += a.rscaler[si];
-    }
-    bool small = true;
-#pragma unroll
-    for (int i = 0; i < AA_S; ++i)
-    {
-      const double x = dot_strided4<true>(ml + i * AA_ROWPAD, L, AA_S);
-      const double y = dot_strided4<true>(mr + i * AA_ROWPAD, R, AA_S);
-      P.v[i] = x * y;
-      small = small && (P.v[i] < PLLHIP_SCALE_THRESHOLD);
-    }
-    aa_finish<MODE, RC>(a, e, act, k, P, small, base);
-  }
-}
-
-// tip row sums for every code of the tipmap: tab[(code*RC + k)*20 + i]
-template <int RC>
-__device__ __forceinline__ void aa_build_tip_table(double * tab, const double * __restrict__ mat,
-                                                   const unsigned int * __restrict__ tipmap,
-                                                   unsigned int maxstates)
-{
-  for (unsigned int t = threadIdx.x; t < maxstates * RC * AA_S; t += blockDim.x)
-  {
-    const unsigned int code = t / (RC * AA_S), ki = t % (RC * AA_S);
-    tab[t] = masksum_seq(mat + (size_t)ki * AA_S, tipmap[code], AA_S);
-  }
-}
-
-template <int RC, int MODE>
-__global__ __launch_bounds__(256) void k_aa_ti(PartialsArgs a)
-{
-  extern __shared__ double smem[];
-  double * sr = smem;                       // [RC] padded matrices
-  double * tab = smem + RC * AA_MATPAD;     // [maxstates][RC][20]
-  aa_stage_matrix<RC>(sr, a.rmat);
-  aa_build_tip_table<RC>(tab, a.lmat, a.tipmap, a.maxstates);
-  __syncthreads();
-  const unsigned int k = threadIdx.x & (RC - 1);
-  const double * mr = sr + k * AA_MATPAD;
-
-  const size_t total = (size_t)a.sites * RC;
-  const size_t total_up = (total + 63) & ~(size_t)63;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
-  {
-    const bool act = e < total;
-    const size_t ec = act ? e : 0;
-    reg20 R, P;
-    aa_load(R, a.right + (size_t)AA_S * ec);
-    unsigned int code = a.ltip[ec / RC];
-    if (code >= a.maxstates) code = 0;
-    const double * tl = tab + ((size_t)code * RC + k) * AA_S;
-    unsigned int base = 0;
-    if (MODE != SCALE_NONE && a.rscaler) base = a.rscaler[(MODE == SCALE_RATE) ? ec : ec / RC];
-    bool small = true;
-#pragma unroll
-    for (int i = 0; i < AA_S; ++i)
-    {
-      // the AVX2 flag runs the AVX (mul, add) tip-inner kernel: core_partials.c:428-443
-      const double y = dot_strided4<false>(mr + i * AA_ROWPAD, R, AA_S);
-      P.v[i] = tl[i] * y;
-      small = small && (P.v[i] < PLLHIP_SCALE_THRESHOLD);
-    }
-    aa_finish<MODE, RC>(a, e, act, k, P, small, base);
-  }
-}
-
-template <int RC, int MODE>
-__global__ __launch_bounds__(256) void k_aa_tt(PartialsArgs a)
-{
-  extern __shared__ double smem[];
-  double * tabl = smem;
-  double * tabr = smem + (size_t)a.maxstates * RC * AA_S;
-  aa_build_tip_table<RC>(tabl, a.lmat, a.tipmap, a.maxstates);
-  aa_build_tip_table<RC>(tabr, a.rmat, a.tipmap, a.maxstates);
-  __syncthreads();
-  const unsigned int k = threadIdx.x & (RC - 1);
-  const size_t total = (size_t)a.sites * RC;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += stride)
-  {
-    const size_t n = e / RC;
-    unsigned int cl = a.ltip[n], cr = a.rtip[n];
-    if (cl >= a.maxstates) cl = 0;
-    if (cr >= a.maxstates) cr = 0;
-    const double * tl = tabl + ((size_t)cl * RC + k) * AA_S;
-    const double * tr = tabr + ((size_t)cr * RC + k) * AA_S;
-    double2 * out = reinterpret_cast<double2 *>(a.parent + (size_t)AA_S * e);
-#pragma unroll
-    for (int j = 0; j < AA_S / 2; ++j)
-      out[j] = make_double2(tl[2 * j] * tr[2 * j], tl[2 * j + 1] * tr[2 * j + 1]);
-    if (MODE == SCALE_RATE) a.pscaler[e] = 0u;
-    if (MODE == SCALE_SITE && k == 0) a.pscaler[n] = 0u;
-  }
-}
-
 // ---------------------------------------------------------------- dispatch
-
-#define LAUNCH_RC_MODE(KERNEL, rc, mode, grid, block, lds, stream, args)          \
-  do {                                                                            \
-    switch ((rc) * 4 + (mode)) {                                                  \
-      case 1 * 4 + 0: KERNEL<1, 0><<<grid, block, lds, stream>>>(args); break;    \
-      case 1 * 4 + 1: KERNEL<1, 1><<<grid, block, lds, stream>>>(args); break;    \
-      case 1 * 4 + 2: KERNEL<1, 2><<<grid, block, lds, stream>>>(args); break;    \
-      case 2 * 4 + 0: KERNEL<2, 0><<<grid, block, lds, stream>>>(args); break;    \
-      case 2 * 4 + 1: KERNEL<2, 1><<<grid, block, lds, stream>>>(args); break;    \
-      case 2 * 4 + 2: KERNEL<2, 2><<<grid, block, lds, stream>>>(args); break;    \
-      case 4 * 4 + 0: KERNEL<4, 0><<<grid, block, lds, stream>>>(args); break;    \
-      case 4 * 4 + 1: KERNEL<4, 1><<<grid, block, lds, stream>>>(args); break;    \
-      case 4 * 4 + 2: KERNEL<4, 2><<<grid, block, lds, stream>>>(args); break;    \
-      case 8 * 4 + 0: KERNEL<8, 0><<<grid, block, lds, stream>>>(args); break;    \
-      case 8 * 4 + 1: KERNEL<8, 1><<<grid, block, lds, stream>>>(args); break;    \
-      case 8 * 4 + 2: KERNEL<8, 2><<<grid, block, lds, stream>>>(args); break;    \
-      case 16 * 4 + 0: KERNEL<16, 0><<<grid, block, lds, stream>>>(args); break;  \
-      case 16 * 4 + 1: KERNEL<16, 1><<<grid, block, lds, stream>>>(args); break;  \
-      case 16 * 4 + 2: KERNEL<16, 2><<<grid, block, lds, stream>>>(args); break;  \
-      default: break;                                                             \
-    }                                                                             \
-  } while (0)
 
 #define LAUNCH_DNA_GATHER(RCV, MODEV, NTV, KINDV)                                           \
   do {                                                                                     \
@@ -578,7 +368,6 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, 
 {
   PartialsArgs a = a_in;
   const unsigned int R = a.rate_cats;
-  const size_t items = (size_t)a.sites * R;
   hipStream_t s = c->stream;
   pllhip_prof_scope prof(c, prof_kind >= 0 ? prof_kind : PLLHIP_PROF_PARTIALS_II + kind);
 
@@ -595,15 +384,6 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, 
     PartialsBatch b;
     b.op[0] = a;
     return pllhip_launch_aa_batch(c, b, 1, kind, mode);
-  }
-  else if (a.states == 20 && fast_rc(R) && R <= 8)
-  {
-    const unsigned int grid = pllhip_stream_grid(c, items, 256);
-    const size_t mat = (size_t)R * AA_MATPAD * sizeof(double);
-    const size_t tab = (size_t)c->maxstates * R * AA_S * sizeof(double);
-    if (kind == 0) LAUNCH_RC_MODE(k_aa_ii, R, mode, grid, 256, 2 * mat, s, a);
-    if (kind == 1) LAUNCH_RC_MODE(k_aa_ti, R, mode, grid, 256, mat + tab, s, a);
-    if (kind == 2) LAUNCH_RC_MODE(k_aa_tt, R, mode, grid, 256, 2 * tab, s, a);
   }
   else if (pllhip_gen_tile_covers(c))
   {
@@ -747,7 +527,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   const bool dna_fast = c->sh.states == 4 && fast_rc(c->sh.rate_cats);
   const bool aa_fast = c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) &&
                        (!c->sh.pattern_tip || pllhip_aa_fast_covers(c, 2));
-  const bool gen_fast = pllhip_gen_tile_covers(c);
+  const bool gen_fast = !dna_fast && !aa_fast && pllhip_gen_tile_covers(c);
   const bool batchable = (dna_fast || aa_fast || gen_fast) && !no_batch;
   if (!batchable)
   {

@@ -44,7 +44,7 @@
 // fused multiply-adds in state order; the reference's AVX2 kernel uses four
 // interleaved chains and a pairwise tree.  Results agree to ~2e-16 relative but
 // not bitwise, so this kernel is used unless PLLHIP_AA_EXACT=1 asks for the
-// bit-exact vector kernel (partials.hip, k_aa_ii).  Scaler counts still match
+// bit-exact kernel (partials_gen_tile.hip, k_gen_wide in the AVX2-flag order).  Scaler counts still match
 // exactly unless a CLV entry lies within an ulp of 2^-256.
 #include "ctx.hpp"
 #include "numerics.hpp"

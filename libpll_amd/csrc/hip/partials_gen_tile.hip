@@ -347,7 +347,27 @@ __host__ __device__ constexpr int gen_wide_wt(int SP, int LPS)
   return LPS == 64 ? 16 : LPS == 32 ? (SP == 32 ? 14 : 16) : 12;
 }
 
-template <int KIND, int SP, int LPS> // SP: states rounded up to a multiple of 8; LPS: lanes per site
+// ORD 1 = 20 states in the order of the reference's AVX2-flag kernels (numerics.hpp): inner
+// children four accumulators strided by j mod 4 and a pairwise tree, fused for inner-inner
+// updates (core_partials_avx2.c:671-750), multiply-then-add for the inner side of tip-inner
+// updates (core_partials_avx.c:1237-1262); tip sums ascending as everywhere.  This is what
+// runs 20-state data when the matrix-core kernels do not apply (PLLHIP_AA_EXACT=1, rate_cats
+// other than 1, 2, 4).
+template <int ORD, bool FUSED>
+__device__ __forceinline__ void wide_term(double (&acc)[4], int j, double p, double v)
+{
+  if (ORD == 0) acc[0] += p * v;
+  else if (FUSED) acc[j & 3] = fma(p, v, acc[j & 3]);
+  else acc[j & 3] = acc[j & 3] + p * v;
+}
+
+template <int ORD>
+__device__ __forceinline__ double wide_sum(const double (&acc)[4])
+{
+  return ORD == 0 ? acc[0] : pairsum4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+template <int KIND, int SP, int LPS, int ORD = 0> // SP: states rounded up to a multiple of 8; LPS: lanes per site
 __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
 {
   const PartialsArgs & a = batch.op[blockIdx.y];
@@ -424,8 +444,10 @@ __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
         double acc = 0.0;
         if (KIND == 0)
         {
+          double a4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int j = 0; j < SP; ++j) acc += P[j] * row[j];
+          for (int j = 0; j < SP; ++j) wide_term<ORD, true>(a4, j, P[j], row[j]);
+          acc = wide_sum<ORD>(a4);
         }
         else
         {
@@ -444,8 +466,10 @@ __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
         double acc = 0.0;
         if (KIND != 2)
         {
+          double a4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int j = 0; j < SP; ++j) acc += P[j] * row[j];
+          for (int j = 0; j < SP; ++j) wide_term<ORD, KIND == 0>(a4, j, P[j], row[j]);
+          acc = wide_sum<ORD>(a4);
         }
         else
         {
@@ -507,17 +531,17 @@ __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
 static bool gen_wide_covers(unsigned int S, int kind)
 {
   // tip children are 32-bit state masks: tip kinds exist up to 32 states only
-  return S >= 9 && S <= 64 && S != 20 && (kind == 0 || S <= 32);
+  return S >= 9 && S <= 64 && (kind == 0 || S <= 32);
 }
 
-template <int KIND, int SP, int LPS>
+template <int KIND, int SP, int LPS, int ORD = 0>
 static int launch_gen_wide_shape(pllhip_ctx * c, const PartialsBatch & b, const dim3 & grid, int mode)
 {
   const size_t lds = 4 * 2 * (size_t)(gen_wide_wt(SP, LPS) * (64 / LPS)) * (LPS == 64 ? SP : SP + 2) * sizeof(double);
   if (lds > 65536)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_wide<KIND, SP, LPS>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_wide<KIND, SP, LPS, ORD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_gen_wide<KIND, SP, LPS><<<grid, 256, lds, c->stream>>>(b, mode);
+  k_gen_wide<KIND, SP, LPS, ORD><<<grid, 256, lds, c->stream>>>(b, mode);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -536,6 +560,7 @@ static int launch_gen_wide(pllhip_ctx * c, const PartialsBatch & b, unsigned int
   const size_t cap = (size_t)c->num_cus * 2; // 2 workgroups of 4 waves per CU
   const size_t need = (groups + 3) / 4;
   const dim3 grid((unsigned int)(need < cap ? need : cap), count);
+  if (S == 20) return launch_gen_wide_shape<KIND, 24, 32, 1>(c, b, grid, mode);
   if (S <= 16) return launch_gen_wide_shape<KIND, 16, 16>(c, b, grid, mode);
   if (S <= 24) return launch_gen_wide_shape<KIND, 24, 32>(c, b, grid, mode);
   if (S <= 32) return launch_gen_wide_shape<KIND, 32, 32>(c, b, grid, mode);
@@ -583,12 +608,12 @@ static GenTileGeom gen_tile_geom(const pllhip_ctx * c, int kind, size_t * lds)
   return g;
 }
 
-// does one of the kernels of this file cover the partition's shape?  (4 states are asked
-// only after the dedicated kernels declined, i.e. for unusual rate_cats; 20 states never)
+// does one of the kernels of this file cover the partition's shape?  (4 and 20 states are
+// asked only after their dedicated kernels declined)
 bool pllhip_gen_tile_covers(const pllhip_ctx * c)
 {
   size_t lds;
-  if (c->sh.states == 20) return false;
+  if (c->sh.states == 20) return true; // the P-row kernels in the AVX2-flag order
   if (gen_rows_covers(c->sh.states, c->sh.rate_cats)) return true;
   return gen_tile_geom(c, 0, &lds).ts != 0u;
 }
@@ -619,7 +644,7 @@ static int launch_gen_tile(pllhip_ctx * c, const PartialsBatch & b, unsigned int
 // ops of one kind and scaling mode, mutually independent, in one launch
 int pllhip_launch_gen_batch(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int kind, int mode)
 {
-  if (gen_rows_covers(c->sh.states, c->sh.rate_cats))
+  if (c->sh.states != 20 && gen_rows_covers(c->sh.states, c->sh.rate_cats))
   {
     if (kind == 0) return launch_gen_rows<0>(c, b, count, mode);
     if (kind == 1) return launch_gen_rows<1>(c, b, count, mode);
