@@ -743,8 +743,11 @@ static int launch_lnl_rows(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int *
 // kind as in run_lnl; returns 1 if the shape is not covered
 static int launch_lnl_two_pass(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
 {
-  // (4 and 20 states keep their own summation orders: not here)
-  if (c->sh.states == 4 || c->sh.states == 20 || !pllhip_gen_tile_covers(c)) return 1;
+  // (4 states have their own kernels for every rate_cats.  20 states come here only with a
+  // rate_cats no 20-state lnL kernel covers: the first pass then forms the matrix-vector
+  // terms in the AVX2-flag order, the products and the state sum associate differently
+  // from core_likelihood_avx2.c:432-502 -- last-bit differences, as with k_lnl_gen before.)
+  if (c->sh.states == 4 || !pllhip_gen_tile_covers(c)) return 1;
   const unsigned int S = c->sh.states, R = c->sh.rate_cats;
   LnlArgs b = a; // what the row-sum pass sees
   if (kind != ROOT)

@@ -333,8 +333,9 @@ static int launch_gen_rows(pllhip_ctx * c, const PartialsBatch & b, unsigned int
 // category the wave loads its rows of P_l, forms x for the group (x goes back into the
 // LDS row it was computed from), loads its rows of P_r, forms y and stores x * y.
 // Waves never synchronise with each other.  A tip child contributes the sum of the P
-// entries its state mask selects, ascending (core_partials.c:113-127), written as
-// "+ (bit ? P[j] : +0.0)", which is bit-identical because the running sum is never -0.0.
+// entries its state mask selects, ascending (core_partials.c:113-127): a row of a per-op
+// table [character][rate][state] built by k_gen_tip_tables, so a tip-tip update is two
+// table rows multiplied and a tip-inner update needs one P-row pass instead of two.
 // Whether a site (or a (site, rate) row) must be rescaled is known only after all its
 // entries exist; that is rare (once every 10-20 tree levels), so the products are
 // stored unscaled and the few rows concerned are multiplied by 2^256 in place
@@ -390,14 +391,24 @@ __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
   {
     const size_t n0 = grp * ROWS;
     unsigned long long site_small = ~0ull; // bit r: every entry of site n0 + r below the threshold so far
-    // state masks of the tip children for the sites this lane's slot meets (row t * Q + q)
-    unsigned int lmask[KIND >= 1 ? WT : 1], rmask[KIND == 2 ? WT : 1];
+    // characters of the tip children for the sites this lane's slot meets (row t * Q + q);
+    // a tip's factor is a row of its per-op table ltab / rtab[code][rate][state] (the sum
+    // of the P entries the character's state mask selects, k_gen_tip_tables)
+    unsigned int lcode[KIND >= 1 ? WT : 1], rcode[KIND == 2 ? WT : 1];
     if (KIND >= 1)
 #pragma unroll
-      for (int t = 0; t < WT; ++t) lmask[t] = a.tipmap[a.ltip[n0 + t * Q + q]];
+      for (int t = 0; t < WT; ++t)
+      {
+        const unsigned int ch = a.ltip[n0 + t * Q + q];
+        lcode[t] = ch < a.maxstates ? ch : 0u;
+      }
     if (KIND == 2)
 #pragma unroll
-      for (int t = 0; t < WT; ++t) rmask[t] = a.tipmap[a.rtip[n0 + t * Q + q]];
+      for (int t = 0; t < WT; ++t)
+      {
+        const unsigned int ch = a.rtip[n0 + t * Q + q];
+        rcode[t] = ch < a.maxstates ? ch : 0u;
+      }
 
     for (unsigned int k = 0; k < R; ++k)
     {
@@ -433,37 +444,30 @@ __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
           P[j] = ((unsigned int)j < S) ? v : 0.0;
         }
       };
-      load_p_row(a.lmat + ((size_t)k * S + i) * S);
       // (the site loops stay rolled: one step's broadcast reads are enough to keep in
       // flight, and x goes back into the row it was computed from -- every lane of the
       // site is done with that row, LDS executes a wave's accesses in order)
-#pragma unroll 1
-      for (int t = 0; t < WT; ++t)
+      if (KIND == 0)
       {
-        const double * row = s_l + (t * Q + q) * SPL;
-        double acc = 0.0;
-        if (KIND == 0)
+        load_p_row(a.lmat + ((size_t)k * S + i) * S);
+#pragma unroll 1
+        for (int t = 0; t < WT; ++t)
         {
+          const double * row = s_l + (t * Q + q) * SPL;
           double a4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int j = 0; j < SP; ++j) wide_term<ORD, true>(a4, j, P[j], row[j]);
-          acc = wide_sum<ORD>(a4);
+          const double acc = wide_sum<ORD>(a4);
+          if (lane_on) s_l[(t * Q + q) * SPL + li] = acc;
         }
-        else
-        {
-          const unsigned int m = lmask[t];
-#pragma unroll
-          for (int j = 0; j < SP; ++j) acc += ((m >> j) & 1u) ? P[j] : 0.0;
-        }
-        if (lane_on) s_l[(t * Q + q) * SPL + li] = acc;
       }
-      load_p_row(a.rmat + ((size_t)k * S + i) * S);
+      if (KIND != 2) load_p_row(a.rmat + ((size_t)k * S + i) * S);
       unsigned long long rate_small = 0ull;
 #pragma unroll 1
       for (int t = 0; t < WT; ++t)
       {
         const double * row = s_r + (t * Q + q) * SPL;
-        double acc = 0.0;
+        double acc;
         if (KIND != 2)
         {
           double a4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -472,13 +476,10 @@ __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
           acc = wide_sum<ORD>(a4);
         }
         else
-        {
-          const unsigned int m = rmask[t];
-#pragma unroll
-          for (int j = 0; j < SP; ++j) acc += ((m >> j) & 1u) ? P[j] : 0.0;
-        }
+          acc = a.rtab[((size_t)rcode[t] * R + k) * S + i];
         const size_t n = n0 + t * Q + q;
-        const double p = s_l[(t * Q + q) * SPL + i] * acc;
+        const double x = (KIND == 0) ? s_l[(t * Q + q) * SPL + i] : a.ltab[((size_t)lcode[t] * R + k) * S + i];
+        const double p = x * acc;
         if (lane_on && n < a.sites) a.parent[(n * R + k) * S + i] = p;
         if (KIND != 2)
         {
@@ -528,6 +529,25 @@ __global__ __launch_bounds__(256) void k_gen_wide(PartialsBatch batch, int mode)
   }
 }
 
+// tip tables of the ops of a batch: tab[op][side][code][k][i] = sum of P_k[i][j] over the
+// states j of tipmap[code], ascending (core_partials.c:725-770 builds the same sums as its
+// tip-tip lookup)
+__global__ __launch_bounds__(256) void k_gen_tip_tables(PartialsBatch batch, double * __restrict__ tab,
+                                                        unsigned int maxstates, int both)
+{
+  const PartialsArgs & a = batch.op[blockIdx.y];
+  const unsigned int S = a.states, RS = a.rate_cats * S;
+  const unsigned int per = maxstates * RS;
+  const unsigned int total = both ? 2 * per : per;
+  double * out = tab + (size_t)blockIdx.y * 2 * per;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x)
+  {
+    const unsigned int side = t / per, u = t % per;
+    const unsigned int code = u / RS, ki = u % RS;
+    out[t] = masksum_seq((side ? a.rmat : a.lmat) + (size_t)ki * S, a.tipmap[code], S);
+  }
+}
+
 static bool gen_wide_covers(unsigned int S, int kind)
 {
   // tip children are 32-bit state masks: tip kinds exist up to 32 states only
@@ -547,13 +567,42 @@ static int launch_gen_wide_shape(pllhip_ctx * c, const PartialsBatch & b, const 
 }
 
 template <int KIND>
-static int launch_gen_wide(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode)
+static int launch_gen_wide(pllhip_ctx * c, const PartialsBatch & b_in, unsigned int count, int mode)
 {
   size_t sites = 0;
   for (unsigned int i = 0; i < count; ++i)
-    if (b.op[i].sites > sites) sites = b.op[i].sites;
+    if (b_in.op[i].sites > sites) sites = b_in.op[i].sites;
   if (!sites) return 0;
   const unsigned int S = c->sh.states;
+  PartialsBatch b = b_in;
+  if (KIND >= 1)
+  {
+    // tip row-sum tables of every op of the batch, one launch (the buffer is reused by
+    // the next batch: same stream, so that launch waits for this batch's kernel)
+    if (!c->maxstates)
+    {
+      pllhip_set_error("tip-state update: tipmap not uploaded");
+      return -1;
+    }
+    const size_t per = (size_t)c->maxstates * c->sh.rate_cats * S;
+    const size_t need = 2 * per * PLLHIP_BATCH_MAX;
+    if (c->tiptab_elems < need)
+    {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (c->d_tiptab) HIP_TRY(hipFree(c->d_tiptab));
+      c->d_tiptab = nullptr;
+      HIP_TRY(hipMalloc((void **)&c->d_tiptab, need * sizeof(double)));
+      c->tiptab_elems = need;
+    }
+    k_gen_tip_tables<<<dim3(8, count), 256, 0, c->stream>>>(b, c->d_tiptab, c->maxstates, KIND == 2 ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      b.op[i].ltab = c->d_tiptab + (size_t)i * 2 * per;
+      b.op[i].rtab = b.op[i].ltab + per;
+      b.op[i].maxstates = c->maxstates;
+    }
+  }
   const size_t rows = S <= 16 ? gen_wide_wt(16, 16) * 4 : S <= 24 ? gen_wide_wt(24, 32) * 2
                       : S <= 32 ? gen_wide_wt(32, 32) * 2 : gen_wide_wt(64, 64);
   const size_t groups = (sites + rows - 1) / rows;
