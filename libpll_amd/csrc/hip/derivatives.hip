@@ -16,8 +16,8 @@
 //     The (rate_cats x states x 4) diagptable is built by the host with libm exp,
 //     exactly like core_derivatives.c:560-575, and passed in.
 //     Kernels: k_derivatives_dna (4 states, 16 bytes per lane, the table itself a kernel
-//     argument), k_derivatives_aa_tile (20 states, LDS-DMA tiles), k_derivatives (lane per
-//     (site, rate), other cases with power-of-two rate_cats), k_derivatives_gen.
+//     argument), k_derivatives_aa_tile (20 states, LDS-DMA tiles), k_derivatives_rows (lane per
+//     (site, rate) row, every other shape), k_derivatives_gen (tables beyond 64 KB of LDS).
 //     The ascertainment-bias terms come from asc_bias.hip and are added by the final sum.
 #include "ctx.hpp"
 #include "numerics.hpp"
@@ -224,63 +224,97 @@ __device__ __forceinline__ void block_sum2(double v0, double v1, const ReduceOut
   grid_sum<2>(two, ro);
 }
 
-// one lane per (site, rate); RC lanes of a site combine with __shfl
-template <int RC>
-__global__ __launch_bounds__(256) void k_derivatives(DerivArgs a)
+// Any state count (SC = compile-time count up to 16, 0 = run-time count) and any rate_cats
+// up to 64: one lane per (site, rate) row of the table, a wave takes 64 sites at a time
+// in rounds of 64 / R whole sites; after round r the lanes [r * 64/R, (r+1) * 64/R) keep
+// that round's site sums, so that the two divisions of the site tail run once per site,
+// on all lanes (the mapping of k_lnl_rows, likelihood.hip).
+template <int SC>
+__global__ __launch_bounds__(256) void k_derivatives_rows(DerivArgs a)
 {
-  extern __shared__ double s_diag[]; // [RC][S][4]
-  const unsigned int S = a.states;
-  for (unsigned int t = threadIdx.x; t < RC * S * 4; t += blockDim.x) s_diag[t] = a.diagp[t];
+  extern __shared__ double s_diag[]; // [R][S * 4 + 2]: the two extra words skew the banks between rates
+  const unsigned int S = SC ? (unsigned int)SC : a.states, R = a.rate_cats, tid = threadIdx.x;
+  const unsigned int DP = S * 4u + 2u;
+  for (unsigned int t = tid; t < R * S * 4u; t += 256u) s_diag[(t / (S * 4u)) * DP + t % (S * 4u)] = a.diagp[t];
   __syncthreads();
-  const unsigned int k = threadIdx.x & (RC - 1);
-  const double * dg = s_diag + k * S * 4;
+  const unsigned int lane = tid & 63u;
+  const unsigned int spr = 64u / R, nrounds = (64u + spr - 1u) / spr;
+  const unsigned int g = lane / R, k = lane - g * R, grp0 = g * R;
+  const unsigned int own_round = lane / spr;
+  const int own_src = (int)((lane - own_round * spr) * R);
   const unsigned int pi = a.params_indices[k];
   const double pinv = a.prop_invar[pi];
   const double w = a.rate_weights[k];
-  const unsigned int lane = threadIdx.x & 63u;
-  const unsigned int grp0 = lane & ~(unsigned int)(RC - 1);
-
+  const size_t sites_up = ((size_t)a.sites + 63) & ~(size_t)63;
   double acc_d = 0.0, acc_dd = 0.0;
-  const size_t total = (size_t)a.sites * RC;
-  const size_t total_up = (total + 63) & ~(size_t)63;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total_up; e += stride)
+  for (size_t sbase = ((size_t)blockIdx.x * 4u + (tid >> 6)) * 64u; sbase < sites_up;
+       sbase += (size_t)gridDim.x * 256u)
   {
-    const bool act = e < total;
-    const size_t ec = act ? e : 0;
-    const size_t n = ec / RC;
-    const double * sm = a.sumtable + ec * S;
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-    for (unsigned int j = 0; j < S; ++j)
+    double o0 = 1.0, o1 = 0.0, o2 = 0.0;
+    for (unsigned int round = 0; round < nrounds; ++round)
     {
-      const double s = sm[j];
-      c0 = fma(s, dg[j * 4 + 0], c0);
-      c1 = fma(s, dg[j * 4 + 1], c1);
-      c2 = fma(s, dg[j * 4 + 2], c2);
-    }
-    if (pinv > 0.0)
-    {
-      // core_derivatives.c:481-491
-      const int inv = a.invariant ? a.invariant[n] : -1;
-      const double inv_lk = (inv == -1) ? 0.0 : a.freqs[(size_t)pi * S + inv] * pinv;
-      c0 = c0 * (1.0 - pinv) + inv_lk;
-      c1 = c1 * (1.0 - pinv);
-      c2 = c2 * (1.0 - pinv);
-    }
-    c0 *= w; c1 *= w; c2 *= w;
-    double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+      unsigned int koff = k * DP; // pinned: the table reads are loop-invariant and would be hoisted
+      asm volatile("" : "+v"(koff));
+      const double * dg = s_diag + koff;
+      const unsigned int pos = round * spr + g;
+      const bool act = g < spr && pos < 64u && sbase + pos < a.sites;
+      const size_t n = act ? sbase + pos : 0;
+      const double * sm = a.sumtable + (n * R + k) * S;
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+      if (SC)
+      {
+        double v[SC ? SC : 1];
 #pragma unroll
-    for (int i = 0; i < RC; ++i)
-    {
-      l0 += __shfl(c0, (int)(grp0 + i), 64);
-      l1 += __shfl(c1, (int)(grp0 + i), 64);
-      l2 += __shfl(c2, (int)(grp0 + i), 64);
+        for (int j = 0; j < SC; ++j) v[j] = sm[j];
+#pragma unroll
+        for (int j = 0; j < SC; ++j)
+        {
+          c0 = fma(v[j], dg[j * 4 + 0], c0);
+          c1 = fma(v[j], dg[j * 4 + 1], c1);
+          c2 = fma(v[j], dg[j * 4 + 2], c2);
+        }
+      }
+      else
+      {
+#pragma unroll 4
+        for (unsigned int j = 0; j < S; ++j)
+        {
+          const double v = sm[j];
+          c0 = fma(v, dg[j * 4 + 0], c0);
+          c1 = fma(v, dg[j * 4 + 1], c1);
+          c2 = fma(v, dg[j * 4 + 2], c2);
+        }
+      }
+      if (pinv > 0.0)
+      {
+        // core_derivatives.c:481-491
+        const int inv = a.invariant ? a.invariant[n] : -1;
+        const double inv_lk = (inv == -1) ? 0.0 : a.freqs[(size_t)pi * S + inv] * pinv;
+        c0 = c0 * (1.0 - pinv) + inv_lk;
+        c1 = c1 * (1.0 - pinv);
+        c2 = c2 * (1.0 - pinv);
+      }
+      c0 *= w; c1 *= w; c2 *= w;
+      double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+      for (unsigned int i = 0; i < R; ++i)
+      {
+        l0 += __shfl(c0, (int)(grp0 + i), 64);
+        l1 += __shfl(c1, (int)(grp0 + i), 64);
+        l2 += __shfl(c2, (int)(grp0 + i), 64);
+      }
+      const double t0 = __shfl(l0, own_src, 64), t1 = __shfl(l1, own_src, 64), t2 = __shfl(l2, own_src, 64);
+      if (own_round == round)
+      {
+        o0 = t0;
+        o1 = t1;
+        o2 = t2;
+      }
     }
-    if (act && k == 0)
+    if (sbase + lane < a.sites)
     {
-      const double d1 = -l1 / l0;
-      const double d2 = d1 * d1 - l2 / l0;
-      const double pw = (double)a.pattern_weights[n];
+      const double d1 = -o1 / o0;
+      const double d2 = d1 * d1 - o2 / o0;
+      const double pw = (double)a.pattern_weights[sbase + lane];
       acc_d += pw * d1;
       acc_dd += pw * d2;
     }
@@ -294,7 +328,7 @@ __global__ __launch_bounds__(256) void k_derivatives(DerivArgs a)
 // three dot products per rate, two __shfl_xor add the four q-lanes of a site, and lanes
 // 0..15 finish one site each.  The next tile and its per-site words are requested as
 // soon as the image has been read.  (One lane per (site, rate) reading 160 contiguous
-// bytes of its own -- k_derivatives -- reaches 2.3 TB/s on this layout; this one is
+// bytes of its own reached 2.3 TB/s on this layout; this one is
 // bound by the DMA stream.)
 template <int RC, bool NT>
 __global__ __launch_bounds__(256) void k_derivatives_aa_tile(DerivArgs a)
@@ -630,18 +664,20 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     }
 #undef DERIV_AA
   }
-  else if (R == 1 || R == 2 || R == 4 || R == 8 || R == 16)
+  else if (R <= 64 && (size_t)R * (S * 4 + 2) * sizeof(double) <= 65536)
   {
-    grid = pllhip_stream_grid(c, (size_t)a.sites * R, 256);
+    grid = pllhip_stream_grid(c, (size_t)a.sites, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
     a.reduce = pllhip_reduce_out(c, grid);
-    switch (R)
+    const size_t lds = (size_t)R * (S * 4 + 2) * sizeof(double);
+    switch (S <= 16 ? S : 0u)
     {
-      case 1: k_derivatives<1><<<grid, 256, dbytes, c->stream>>>(a); break;
-      case 2: k_derivatives<2><<<grid, 256, dbytes, c->stream>>>(a); break;
-      case 4: k_derivatives<4><<<grid, 256, dbytes, c->stream>>>(a); break;
-      case 8: k_derivatives<8><<<grid, 256, dbytes, c->stream>>>(a); break;
-      default: k_derivatives<16><<<grid, 256, dbytes, c->stream>>>(a); break;
+#define DERIV_ROWS(SCV) case SCV: k_derivatives_rows<SCV><<<grid, 256, lds, c->stream>>>(a); break
+      DERIV_ROWS(1); DERIV_ROWS(2); DERIV_ROWS(3); DERIV_ROWS(4); DERIV_ROWS(5); DERIV_ROWS(6);
+      DERIV_ROWS(7); DERIV_ROWS(8); DERIV_ROWS(9); DERIV_ROWS(10); DERIV_ROWS(11); DERIV_ROWS(12);
+      DERIV_ROWS(13); DERIV_ROWS(14); DERIV_ROWS(15); DERIV_ROWS(16);
+#undef DERIV_ROWS
+      default: k_derivatives_rows<0><<<grid, 256, lds, c->stream>>>(a); break;
     }
   }
   else

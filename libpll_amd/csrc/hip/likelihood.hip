@@ -622,7 +622,6 @@ __global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
   const unsigned int own_round = lane / spr;
   const int own_src = (int)((lane - own_round * spr) * R);
   const double * fr = a.freqs + (size_t)a.freqs_indices[k] * SC;
-  const double * m = smem + k * MP;
   const size_t sites_up = ((size_t)a.sites + 63) & ~(size_t)63;
   double acc = 0.0;
   for (size_t sbase = ((size_t)blockIdx.x * 4u + (tid >> 6)) * 64u; sbase < sites_up;
@@ -632,6 +631,7 @@ __global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
    unsigned int own_scalings = 0u;
    for (unsigned int round = 0; round < nrounds; ++round)
    {
+    unsigned int koff = k * MP;
     const unsigned int pos = round * spr + g; // the site's place among the wave's 64
     const bool act = g < spr && pos < 64u && sbase + pos < a.sites;
     const size_t n = act ? sbase + pos : 0;
@@ -652,6 +652,9 @@ __global__ __launch_bounds__(256) void k_lnl_rows(LnlArgs a)
         terma_r += p[i] * fr[i];
       else
       {
+        // (pinned per matrix row: otherwise all S x S reads are issued up front and spilled)
+        asm volatile("" : "+v"(koff));
+        const double * m = smem + koff;
         double termb = 0.0;
 #pragma unroll
         for (int j = 0; j < SC; ++j)

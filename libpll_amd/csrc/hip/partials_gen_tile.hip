@@ -195,11 +195,12 @@ __global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
   const unsigned int lane = tid & 63u;
   const unsigned int spw = 64u / R;
   const unsigned int g = lane / R, k = lane - g * R;
-  const double * pl = s_pl + k * MP;
-  const double * pr = s_pr + k * MP;
   const size_t trips = ((size_t)a.sites + spw - 1) / spw;
   for (size_t trip = (size_t)blockIdx.x * 4u + (tid >> 6); trip < trips; trip += (size_t)gridDim.x * 4u)
   {
+    // (the lane's matrices are the same in every trip: without this the compiler hoists
+    // all 2 x S x S LDS reads out of the loop and spills them)
+    unsigned int koff = k * MP;
     const bool act = g < spw && trip * spw + g < a.sites;
     const size_t n = act ? trip * spw + g : 0;
     const size_t it = act ? n * R + k : 0;
@@ -225,6 +226,9 @@ __global__ __launch_bounds__(256) void k_gen_rows(PartialsBatch batch, int mode)
 #pragma unroll
     for (int i = 0; i < SC; ++i)
     {
+      asm volatile("" : "+v"(koff)); // per matrix row: keeps one row's reads in flight, not S x S
+      const double * pl = s_pl + koff;
+      const double * pr = s_pr + koff;
       double x = 0.0, y = 0.0;
       if (SC == 4)
       {
