@@ -92,6 +92,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
+  if (const char * e = getenv("PLLHIP_FUSED")) c->no_fused = atoi(e) == 0;
   if (const char * e = getenv("PLLHIP_BLOCKS_PER_CU"))
     if (atoi(e) > 0) c->blocks_per_cu = atoi(e);
 
@@ -137,7 +138,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if ((rc = dev_alloc(&c->tipmap, (size_t)256, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->block_partials, (size_t)PLLHIP_REDUCE_BLOCKS * 2, true, c->stream))) goto fail;
   if ((rc = dev_alloc(&c->d_result, (size_t)4, true, c->stream))) goto fail;
-  if ((rc = dev_alloc(&c->d_zero, (size_t)4, true, c->stream))) goto fail;
+  if ((rc = dev_alloc(&c->d_zero, (size_t)64, true, c->stream))) goto fail; // a zero word; 16-byte dummy loads read it too
   HIP_TRY(hipHostMalloc((void **)&c->h_result, 4 * sizeof(double), hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void **)&c->h_result_dev, c->h_result, 0));
   if ((rc = dev_alloc(&c->d_counter, (size_t)4, true, c->stream))) goto fail;
@@ -262,6 +263,13 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
                    c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3], c->lnl_scratch};
   for (void * p : bufs)
     if (p) (void)hipFree(p);
+  if (c->d_plan) (void)hipFree(c->d_plan);
+  if (c->d_sink) (void)hipFree(c->d_sink);
+  for (int b = 0; b < 2; ++b)
+  {
+    if (c->h_plan[b]) (void)hipHostFree(c->h_plan[b]);
+    if (c->plan_done[b]) (void)hipEventDestroy(c->plan_done[b]);
+  }
   pllhip_rep_work_free(c);
   for (pllhip_ctx::node_rows & r : c->rows)
     for (void * p : {(void *)r.site_id, (void *)r.lrow, (void *)r.rrow})

@@ -50,6 +50,15 @@ struct pllhip_ctx
   unsigned int maxstates = 0;
   double * sumtable[PLLHIP_SUMTABLE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   double * lnl_scratch = nullptr; // CLV-sized: per-state lnL terms of the two-pass kernels (likelihood.hip)
+  // whole-list kernel (partials_fused.hip): the plan's device copy and two pinned staging buffers
+  void * d_plan = nullptr;
+  void * d_sink = nullptr; // 1 KB that the stores of lanes past the last site go to
+  void * h_plan[2] = {nullptr, nullptr};
+  hipEvent_t plan_done[2] = {nullptr, nullptr};
+  bool plan_pending[2] = {false, false};
+  size_t plan_cap = 0;
+  int plan_next = 0;
+  bool no_fused = false; // env PLLHIP_FUSED=0: one launch per dependency level instead
 
   // reductions: per-block partial sums, then a fixed-order final pass
   double * block_partials = nullptr;   // [PLLHIP_REDUCE_BLOCKS][2]

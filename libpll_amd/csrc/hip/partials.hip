@@ -32,6 +32,7 @@
 
 #include "ctx.hpp"
 #include "numerics.hpp"
+#include "partials_fused.hpp"
 #include <stdlib.h>
 
 
@@ -540,6 +541,30 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       if ((rc = pllhip_launch_partials(c, a, kind, mode, -1))) return rc;
     }
     return 0;
+  }
+
+  // 4 states, more than one op, no site repeats: the whole list in one site-blocked
+  // launch (partials_fused.hip)
+  if (dna_fast && c->sh.rate_cats <= 8 && !c->no_fused && c->rows.empty() && count >= 2)
+  {
+    std::vector<PartialsArgs> args(count);
+    std::vector<int> kinds(count), modes(count);
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      int rc = resolve_op(c, ops[i], args[i], kinds[i], modes[i]);
+      if (rc) return rc;
+    }
+    std::vector<FusedOp> fplan;
+    bool ext = false;
+    const unsigned int nslots = pllhip_fused_slots(c);
+    int rc = pllhip_fused_plan(c, ops, args.data(), kinds.data(), modes.data(), count, nslots, fplan, &ext);
+    if (rc < 0) return rc;
+    if (rc == 0)
+    {
+      pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
+      return pllhip_launch_fused(c, fplan, nslots, ext);
+    }
+    // (a list shape the kernel does not take: per-level launches below)
   }
 
   struct Planned

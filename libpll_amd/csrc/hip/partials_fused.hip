@@ -1,0 +1,630 @@
+// partials_fused.hip -- a whole op list of 4-state CLV updates in ONE kernel, site-blocked.
+//
+// Replaces the per-level launches of partials.hip for pll_update_partials
+// (partials.c:214-278 -> core_partials.c) when the list has more than one op.
+//
+// Observation.  A CLV update at site n needs the children's entries of site n only, so
+// the order "all sites of op 1, all sites of op 2, ..." of the reference is a choice, not
+// a dependency: a wave may just as well take a TILE of sites through the whole list.
+// What it wrote for a child a moment ago is then still on chip -- and in the lane mapping
+// of k_dna_partials (one lane per 16 bytes = two states of a (site, rate) element, lane
+// pairs joined by DPP) every lane needs exactly the 16 bytes IT wrote for that child.
+// So a parent's tile is stored to HBM (every CLV remains a result of the call) and kept
+// in a wave-private LDS slot together with its scaler counts, from which the op that
+// consumes it reads it back; no synchronisation of any kind.  HBM traffic per site-update
+// drops from 396 B (read two children, write the parent) to 132 B + tip characters: the
+// list becomes a WRITE stream.
+//
+//   tile      J sub-steps of 64 lanes x 16 B (J x 64 / (2 rate_cats) sites)
+//   slots     tiles per wave in LDS (6 x 2.5 KB for 4 rate categories); the host assigns
+//             them: a value keeps its slot until its last reader in the list has run; a
+//             value that loses its slot is read from HBM by its later readers
+//   op order  any order that respects the list's read/write hazards on CLV and scale
+//             buffer indices is equivalent; the host re-orders the list depth-first,
+//             heavier subtree first (Sethi-Ullman), which bounds the number of live
+//             values by the tree's Strahler number (5 for a balanced 64-taxon tree, not
+//             the 32 of a level-by-level list)
+//   look-ahead  vector-memory loads and stores retire in ONE in-order queue, so a load
+//             issued after a store cannot be consumed before that store is acknowledged.
+//             Everything an op needs from memory (its two P-matrices, tip characters, and
+//             -- EXT variant -- operands that live in HBM) is therefore requested at the
+//             top of the PREVIOUS op, ahead of that op's stores, with unconditional loads
+//             (absent operands read a zero block); the op itself contains LDS traffic and
+//             stores only.
+//
+// The arithmetic per site is that of k_dna_partials, statement for statement (dot4 /
+// masksum4 order, scaling rule of core_partials_avx.c:486-527), so results are
+// bit-identical to the per-level path; tests/test_gpu_parity.py and the random-op-sequence
+// tests run through this kernel.
+//
+// Roofline: HBM writes.  132 B per site-update (128 B CLV + 4 B scaler count) + 1 B per
+// tip character read; operands without a slot add 128 B each.
+#include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "ctx.hpp"
+#include "numerics.hpp"
+#include "partials_fused.hpp"
+
+// what a lane requests for an op one op ahead of its use
+template <int PL, int J, bool EXT>
+struct FusedFetch
+{
+  double2 pm[PL];                   // its 16 bytes of the two P-matrices (a coalesced block per wave)
+  unsigned int codes_l[J], codes_r[J]; // tip characters of the lane's own site in each sub-step
+  double2 kl[EXT ? J : 1], kr[EXT ? J : 1];     // EXT: operands from HBM
+  unsigned int cl[EXT ? J : 1], cr[EXT ? J : 1]; //      and inherited scaler counts from HBM
+};
+
+template <int RC, int J, int MODE, bool NT, bool EXT>
+__global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ plan_g, unsigned int nops,
+                                                   unsigned int sites, unsigned int nslots,
+                                                   const unsigned int * __restrict__ zero, double2 * sink)
+{
+  constexpr unsigned int W = 2 * RC, SPS = 64 / W, TS = J * SPS;
+  constexpr unsigned int MG = RC * 8;                   // 16-byte granules of one P-matrix
+  constexpr int PL = (2 * MG + 63) / 64;                // granules of [P_l | P_r] per lane
+  extern __shared__ double2 lds_fused[];
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int h = lane & 1u;
+  const unsigned int k = (lane >> 1) & (RC - 1);
+  const unsigned int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // per wave: [nslots][J][64] CLV granules | 2 x [2 * MG] matrix granules | [nslots][J][64] counts
+  const size_t wave_g = (size_t)nslots * J * 64 + 4 * MG + (size_t)nslots * J * 16;
+  double2 * clv = lds_fused + wave_in_wg * wave_g;
+  double2 * pst = clv + (size_t)nslots * J * 64;
+  unsigned int * cnt = reinterpret_cast<unsigned int *>(pst + 4 * MG);
+  // the plan is the same for every lane: read it through the scalar path.  It carries one
+  // entry more than there are ops (a copy of the last), so that "the next op" always exists.
+  typedef const FusedOp __attribute__((address_space(4))) * plan_ptr;
+  const plan_ptr plan = (plan_ptr)(unsigned long long)plan_g;
+  const double2 * zero16 = reinterpret_cast<const double2 *>(zero);
+  const unsigned char * zero8 = reinterpret_cast<const unsigned char *>(zero);
+
+  const size_t total = (size_t)sites * W; // 16-byte granules of a CLV
+  const size_t tiles = ((size_t)sites + TS - 1) / TS;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+
+  for (size_t tile = wave; tile < tiles; tile += nwaves)
+  {
+    const size_t site0 = tile * TS;
+
+    // every load is unconditional (absent operands read the zero block): a load inside a
+    // branch makes the compiler wait for everything in flight
+    auto request = [&](FusedFetch<PL, J, EXT> & f, unsigned int i) {
+      const double2 * lm = reinterpret_cast<const double2 *>(plan[i].lmat);
+      const double2 * rm = reinterpret_cast<const double2 *>(plan[i].rmat);
+      const unsigned char * ltip = plan[i].ltip;
+      const unsigned char * rtip = plan[i].rtip;
+      asm volatile("" ::"s"(lm), "s"(rm), "s"(ltip), "s"(rtip)); // (all four in one round trip)
+#pragma unroll
+      for (int t = 0; t < PL; ++t)
+      {
+        const unsigned int q = lane + 64u * t;
+        const double2 * src = (q < MG) ? lm + q : (q < 2 * MG) ? rm + (q - MG) : zero16;
+        f.pm[t] = *src;
+      }
+#pragma unroll
+      for (unsigned int j = 0; j < J; ++j)
+      {
+        const size_t n = site0 + (size_t)j * SPS + lane / W;
+        const size_t nc = n < sites ? n : 0;
+        f.codes_l[j] = (ltip ? ltip : zero8)[ltip ? nc : 0];
+        f.codes_r[j] = (rtip ? rtip : zero8)[rtip ? nc : 0];
+      }
+      if (EXT)
+      {
+        const double2 * L = reinterpret_cast<const double2 *>(plan[i].left_hbm);
+        const double2 * R = reinterpret_cast<const double2 *>(plan[i].right_hbm);
+        const unsigned int * ls = plan[i].lsc_hbm;
+        const unsigned int * rs = plan[i].rsc_hbm;
+#pragma unroll
+        for (unsigned int j = 0; j < J; ++j)
+        {
+          const size_t g = (site0 + (size_t)j * SPS) * W + lane;
+          const size_t gc = g < total ? g : 0;
+          const size_t e = (MODE == SCALE_RATE) ? (gc >> 1) : gc / W; // (site, rate) or site
+          f.kl[j] = ld16<NT>(L ? L + gc : zero16);
+          f.kr[j] = ld16<NT>(R ? R + gc : zero16);
+          f.cl[j] = (ls ? ls : zero)[ls ? e : 0];
+          f.cr[j] = (rs ? rs : zero)[rs ? e : 0];
+        }
+      }
+    };
+
+    // the op's matrices: the wave's coalesced block goes through LDS (two buffers in turn),
+    // each lane takes rows 2h, 2h+1 of category k (own column pair first, then the partner's)
+    auto stage_rows = [&](const FusedFetch<PL, J, EXT> & f, unsigned int buf, half_rows & pl, half_rows & pr) {
+      double2 * p = pst + buf * 2 * MG;
+#pragma unroll
+      for (int t = 0; t < PL; ++t)
+        if (lane + 64u * t < 2 * MG) p[lane + 64u * t] = f.pm[t];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+      {
+        const unsigned int row = k * 8 + (2 * h + r) * 2;
+        const double2 lo = p[row + h], lp = p[row + 1 - h];
+        const double2 ro = p[MG + row + h], rp = p[MG + row + 1 - h];
+        pl.m[r][0] = lo.x; pl.m[r][1] = lo.y; pl.m[r][2] = lp.x; pl.m[r][3] = lp.y;
+        pr.m[r][0] = ro.x; pr.m[r][1] = ro.y; pr.m[r][2] = rp.x; pr.m[r][3] = rp.y;
+      }
+    };
+
+    // Two ops of look-ahead: at the top of op i the block of op i+2 is requested, the block
+    // of op i+1 (requested one op ago) goes through LDS into the registers op i+1 will use,
+    // and op i runs on registers filled one op ago.
+    FusedFetch<PL, J, EXT> cur, fa;
+    half_rows pl, pr;
+    request(cur, 0u);
+    request(fa, 1u);
+    // The compiler counts the memory operations issued after a load to know how many may
+    // stay in flight when the load is consumed, and takes the minimum over all paths into
+    // the loop.  On the path through the loop an op's stores follow the look-ahead loads;
+    // these stores to the sink give the entry path the same shape, so that the wait at the
+    // top of an op leaves the previous op's stores in flight.
+#pragma unroll
+    for (unsigned int j = 0; j < J; ++j)
+    {
+      st16<NT>(sink + lane, 0.0, 0.0);
+      if (MODE != SCALE_NONE) reinterpret_cast<unsigned int *>(sink)[lane] = 0u;
+    }
+    stage_rows(cur, 0u, pl, pr);
+    for (unsigned int i = 0; i < nops; ++i)
+    {
+      // All scalar (plan) loads of the op happen HERE, before any LDS traffic of the op:
+      // scalar loads return out of order, so consuming one means waiting for every
+      // outstanding scalar AND LDS operation (they share a counter) -- a plan field fetched
+      // in the middle of the op would drain the LDS reads in flight.  The empty asm makes
+      // each value live at this point.
+      const int kind = plan[i].kind;
+      const int lslot = plan[i].lslot, rslot = plan[i].rslot, pslot = plan[i].pslot;
+      const int lsc_slot = plan[i].lsc_slot, rsc_slot = plan[i].rsc_slot;
+      double2 * out = reinterpret_cast<double2 *>(plan[i].parent);
+      unsigned int * pscaler = plan[i].pscaler;
+      asm volatile("" ::"s"(kind), "s"(lslot), "s"(rslot), "s"(pslot), "s"(lsc_slot), "s"(rsc_slot), "s"(out), "s"(pscaler));
+      const bool scaling = MODE != SCALE_NONE && pscaler != nullptr;
+      FusedFetch<PL, J, EXT> fb;
+      request(fb, i + 2u);
+      half_rows nl, nr;
+      stage_rows(fa, (i + 1u) & 1u, nl, nr);
+
+#pragma unroll
+      for (unsigned int j = 0; j < J; ++j)
+      {
+        const size_t g = (site0 + (size_t)j * SPS) * W + lane;
+        const bool act = g < total;
+        const size_t gc = act ? g : 0;
+        // operands and inherited counts: LDS slot (slot 0 is read when there is none), or
+        // what the look-ahead fetched from HBM
+        double2 lo = clv[((lslot >= 0 ? lslot : 0) * J + j) * 64 + lane];
+        double2 ro = clv[((rslot >= 0 ? rslot : 0) * J + j) * 64 + lane];
+        unsigned int lc = cnt[((lsc_slot >= 0 ? lsc_slot : 0) * J + j) * 64 + lane];
+        unsigned int rc = cnt[((rsc_slot >= 0 ? rsc_slot : 0) * J + j) * 64 + lane];
+        if (EXT)
+        {
+          if (lslot < 0) lo = cur.kl[j];
+          if (rslot < 0) ro = cur.kr[j];
+          if (lsc_slot < 0) lc = cur.cl[j];
+          if (rsc_slot < 0) rc = cur.cr[j];
+        }
+        else
+        {
+          if (lsc_slot < 0) lc = 0u;
+          if (rsc_slot < 0) rc = 0u;
+        }
+        double x0, x1, y0, y1;
+        if (kind == 0)
+        {
+          const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
+          x0 = pl.dot(0, lo, lp);
+          x1 = pl.dot(1, lo, lp);
+        }
+        else
+        {
+          // tip: the entries of rows 2h, 2h+1 that the character's state mask selects, in
+          // the pairwise order of masksum4 (own pair + partner pair; commutative)
+          const unsigned int code = cur.codes_l[j] & 15u;
+          const unsigned int b0 = (code >> (2 * h)) & 1u, b1 = (code >> (2 * h + 1)) & 1u;
+          const unsigned int b2 = (code >> (2 - 2 * h)) & 1u, b3 = (code >> (3 - 2 * h)) & 1u;
+          x0 = ((b0 ? pl.m[0][0] : 0.0) + (b1 ? pl.m[0][1] : 0.0)) + ((b2 ? pl.m[0][2] : 0.0) + (b3 ? pl.m[0][3] : 0.0));
+          x1 = ((b0 ? pl.m[1][0] : 0.0) + (b1 ? pl.m[1][1] : 0.0)) + ((b2 ? pl.m[1][2] : 0.0) + (b3 ? pl.m[1][3] : 0.0));
+          lc = 0u;
+        }
+        if (kind != 2)
+        {
+          const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
+          y0 = pr.dot(0, ro, rp);
+          y1 = pr.dot(1, ro, rp);
+        }
+        else
+        {
+          const unsigned int code = cur.codes_r[j] & 15u;
+          const unsigned int b0 = (code >> (2 * h)) & 1u, b1 = (code >> (2 * h + 1)) & 1u;
+          const unsigned int b2 = (code >> (2 - 2 * h)) & 1u, b3 = (code >> (3 - 2 * h)) & 1u;
+          y0 = ((b0 ? pr.m[0][0] : 0.0) + (b1 ? pr.m[0][1] : 0.0)) + ((b2 ? pr.m[0][2] : 0.0) + (b3 ? pr.m[0][3] : 0.0));
+          y1 = ((b0 ? pr.m[1][0] : 0.0) + (b1 ? pr.m[1][1] : 0.0)) + ((b2 ? pr.m[1][2] : 0.0) + (b3 ? pr.m[1][3] : 0.0));
+          rc = 0u;
+        }
+        double p0 = x0 * y0, p1 = x1 * y1;
+
+        // scaling rule of core_partials_avx.c:486-527; tip-tip never scales and clears
+        // its scaler (core_partials_avx.c:598-599)
+        bool scale = false;
+        if (scaling && kind != 2)
+        {
+          const bool small = (p0 < PLLHIP_SCALE_THRESHOLD) & (p1 < PLLHIP_SCALE_THRESHOLD);
+          scale = (MODE == SCALE_RATE) ? group_all<2>(small || !act) : group_all<W>(small || !act);
+          if (scale)
+          {
+            p0 *= PLLHIP_SCALE_FACTOR;
+            p1 *= PLLHIP_SCALE_FACTOR;
+          }
+        }
+        const unsigned int count = lc + rc + (scale ? 1u : 0u);
+        // Stores are unconditional too -- lanes past the last site (and the counts of an op
+        // without a scale buffer) go to a sink -- so that their NUMBER per op is known to
+        // the compiler: it can then wait for the look-ahead loads by count and leave this
+        // op's stores in flight (a store under a branch forces a full drain instead).
+        st16<NT>(act ? out + g : sink + lane, p0, p1);
+        if (pslot >= 0)
+        {
+          clv[(pslot * J + j) * 64 + lane] = make_double2(p0, p1);
+          cnt[(pslot * J + j) * 64 + lane] = scaling ? count : 0u;
+        }
+        if (MODE != SCALE_NONE)
+        {
+          // one count per site (all W lanes of the site write the same word) or per (site, rate)
+          unsigned int * dst = reinterpret_cast<unsigned int *>(sink) + lane;
+          if (scaling && act) dst = pscaler + (MODE == SCALE_SITE ? gc / W : gc >> 1);
+          *dst = count;
+        }
+      }
+      cur = fa;
+      fa = fb;
+      pl = nl;
+      pr = nr;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host: order, slots, launch
+
+namespace
+{
+struct Node
+{
+  std::vector<unsigned int> hard; // WAW / WAR predecessors (and scaler hazards): must run before
+  int raw[2] = {-1, -1};          // producers of the two children within the list (-1: outside)
+  int sraw[2] = {-1, -1};         // writers of the two child scale buffers within the list
+  unsigned int need = 1;          // Sethi-Ullman number of the subtree rooted here
+};
+}
+
+unsigned int pllhip_fused_slots(const pllhip_ctx * c)
+{
+  // 64 KB per workgroup of four waves: 16 KB per wave minus the matrix block
+  const unsigned int R = c->sh.rate_cats;
+  const size_t per_slot = (size_t)PLLHIP_FUSED_J * 64 * (16 + 4);
+  const size_t pmat = 4 * (size_t)R * 16 * sizeof(double); // two buffers of [P_l | P_r]
+  const size_t budget = PLLHIP_FUSED_J == 1 ? 8448 : 16384; // J = 1: four workgroups per CU
+  return (unsigned int)((budget - pmat) / per_slot);
+}
+
+int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArgs * args,
+                      const int * kinds, const int * modes, unsigned int count, unsigned int nslots,
+                      std::vector<FusedOp> & plan, bool * ext_out)
+{
+  (void)modes;
+  std::vector<Node> node(count);
+  const size_t nclv = c->clv.size(), nsc = c->sh.scale_buffers;
+  // last writer and readers-since of every CLV / scale buffer, in list order
+  std::vector<int> clv_w(nclv, -1), sc_w(nsc, -1);
+  std::vector<std::vector<unsigned int>> clv_r(nclv), sc_r(nsc);
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    const pllhip_op_t & op = ops[i];
+    Node & nd = node[i];
+    auto hard = [&](int p) { if (p >= 0 && (unsigned int)p != i) nd.hard.push_back((unsigned int)p); };
+    nd.raw[0] = clv_w[op.child1_clv];
+    nd.raw[1] = clv_w[op.child2_clv];
+    nd.sraw[0] = op.child1_scaler >= 0 ? sc_w[op.child1_scaler] : -1;
+    nd.sraw[1] = op.child2_scaler >= 0 ? sc_w[op.child2_scaler] : -1;
+    hard(clv_w[op.parent_clv]);
+    for (unsigned int r : clv_r[op.parent_clv]) hard((int)r);
+    hard(nd.sraw[0]);
+    hard(nd.sraw[1]);
+    if (op.parent_scaler >= 0)
+    {
+      hard(sc_w[op.parent_scaler]);
+      for (unsigned int r : sc_r[op.parent_scaler]) hard((int)r);
+    }
+    clv_w[op.parent_clv] = (int)i;
+    clv_r[op.parent_clv].clear();
+    clv_r[op.child1_clv].push_back(i);
+    clv_r[op.child2_clv].push_back(i);
+    if (op.parent_scaler >= 0)
+    {
+      sc_w[op.parent_scaler] = (int)i;
+      sc_r[op.parent_scaler].clear();
+    }
+    if (op.child1_scaler >= 0) sc_r[op.child1_scaler].push_back(i);
+    if (op.child2_scaler >= 0) sc_r[op.child2_scaler].push_back(i);
+    const unsigned int a = nd.raw[0] >= 0 ? node[nd.raw[0]].need : 0;
+    const unsigned int b = nd.raw[1] >= 0 ? node[nd.raw[1]].need : 0;
+    nd.need = std::max(1u, a == b ? a + (a ? 1u : 0u) : std::max(a, b));
+  }
+
+  // depth-first order from the end of the list: hazards first, then the heavier child
+  std::vector<unsigned int> order;
+  order.reserve(count);
+  {
+    std::vector<unsigned char> state(count, 0); // 0 new, 1 open, 2 emitted
+    std::vector<std::pair<unsigned int, unsigned int>> stack; // (op, next predecessor to look at)
+    std::vector<std::vector<unsigned int>> preds(count);
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      preds[i] = node[i].hard;
+      int r0 = node[i].raw[0], r1 = node[i].raw[1];
+      if (r0 >= 0 && r1 >= 0 && node[r1].need > node[r0].need) std::swap(r0, r1);
+      if (r0 >= 0) preds[i].push_back((unsigned int)r0);
+      if (r1 >= 0 && r1 != r0) preds[i].push_back((unsigned int)r1);
+    }
+    for (unsigned int root = count; root-- > 0;)
+    {
+      if (state[root]) continue;
+      stack.push_back({root, 0});
+      state[root] = 1;
+      while (!stack.empty())
+      {
+        auto & top = stack.back();
+        if (top.second < preds[top.first].size())
+        {
+          const unsigned int p = preds[top.first][top.second++];
+          if (!state[p])
+          {
+            state[p] = 1;
+            stack.push_back({p, 0});
+          }
+        }
+        else
+        {
+          state[top.first] = 2;
+          order.push_back(top.first);
+          stack.pop_back();
+        }
+      }
+    }
+  }
+  std::vector<unsigned int> pos_of(count);
+  for (unsigned int pos = 0; pos < count; ++pos) pos_of[order[pos]] = pos;
+
+  // which list op produced each inner operand of op i, as the kernel sees them (a tip is
+  // always presented as the LEFT child of a tip-inner op, resolve_op)
+  auto operands = [&](unsigned int i, int & wl, int & wr, int & swl, int & swr) {
+    wl = wr = swl = swr = -1;
+    if (kinds[i] == 0)
+    {
+      wl = node[i].raw[0]; wr = node[i].raw[1];
+      swl = node[i].sraw[0]; swr = node[i].sraw[1];
+    }
+    else if (kinds[i] == 1)
+    {
+      const int inner = pllhip_is_tip(c, ops[i].child1_clv) ? 1 : 0;
+      wr = node[i].raw[inner];
+      swr = node[i].sraw[inner];
+    }
+  };
+  // positions (in the new order) at which each value is read
+  std::vector<std::vector<unsigned int>> uses(count);
+  for (unsigned int pos = 0; pos < count; ++pos)
+  {
+    int wl, wr, swl, swr;
+    operands(order[pos], wl, wr, swl, swr);
+    if (wl >= 0) uses[wl].push_back(pos);
+    if (wr >= 0 && wr != wl) uses[wr].push_back(pos);
+  }
+  std::vector<unsigned int> next_use(count, 0); // index into uses[]
+
+  // slots: a value keeps one from the op that writes it to its last reader; when there is
+  // none left the live value whose next reader is farthest away gives its slot up (its
+  // later readers fetch it from HBM, one op ahead) -- a value read by the very next op
+  // always has one, because that read would be issued before the value is stored
+  std::vector<int> slot_of(count, -1);
+  std::vector<int> free_slots;
+  for (int s = (int)nslots - 1; s >= 0; --s) free_slots.push_back(s);
+  std::vector<unsigned int> live; // values that hold a slot
+  bool ext = false;
+  plan.resize(count);
+  for (unsigned int pos = 0; pos < count; ++pos)
+  {
+    const unsigned int i = order[pos];
+    const PartialsArgs & a = args[i];
+    FusedOp & f = plan[pos];
+    memset(&f, 0, sizeof(f));
+    f.parent = a.parent;
+    f.ltip = a.ltip;
+    f.rtip = a.rtip;
+    f.lmat = a.lmat;
+    f.rmat = a.rmat;
+    f.pscaler = a.pscaler;
+    f.kind = kinds[i];
+    int wl, wr, swl, swr;
+    operands(i, wl, wr, swl, swr);
+    f.lslot = wl >= 0 ? slot_of[wl] : -1;
+    f.rslot = wr >= 0 ? slot_of[wr] : -1;
+    // an operand without a slot comes from HBM, requested two ops ahead: its producer must
+    // have stored it before that
+    auto hbm_ok = [&](int w) { return w < 0 || pos_of[w] + 2 < pos; };
+    if (f.kind == 0 && f.lslot < 0)
+    {
+      if (!hbm_ok(wl)) return 1;
+      f.left_hbm = a.left;
+      ext = true;
+    }
+    if (f.kind != 2 && f.rslot < 0)
+    {
+      if (!hbm_ok(wr)) return 1;
+      f.right_hbm = a.right;
+      ext = true;
+    }
+    // inherited counts: from the slot of the operand they were written with, else from HBM
+    f.lsc_slot = f.rsc_slot = -1;
+    if (a.lscaler)
+    {
+      if (swl >= 0 && swl == wl && f.lslot >= 0) f.lsc_slot = f.lslot;
+      else if (!hbm_ok(swl)) return 1;
+      else { f.lsc_hbm = a.lscaler; ext = true; }
+    }
+    if (a.rscaler)
+    {
+      if (swr >= 0 && swr == wr && f.rslot >= 0) f.rsc_slot = f.rslot;
+      else if (!hbm_ok(swr)) return 1;
+      else { f.rsc_hbm = a.rscaler; ext = true; }
+    }
+    // operands read for the last time give their slots back
+    for (int w : {wl, (wr != wl ? wr : -1)})
+      if (w >= 0)
+      {
+        if (next_use[w] < uses[w].size() && uses[w][next_use[w]] == pos) next_use[w]++;
+        if (next_use[w] >= uses[w].size() && slot_of[w] >= 0)
+        {
+          free_slots.push_back(slot_of[w]);
+          slot_of[w] = -1;
+          live.erase(std::find(live.begin(), live.end(), (unsigned int)w));
+        }
+      }
+    f.pslot = -1;
+    if (!uses[i].empty())
+    {
+      if (free_slots.empty())
+      {
+        // farthest next reader among the live values and the new one
+        unsigned int victim = i, far = uses[i][0];
+        for (unsigned int v : live)
+          if (uses[v][next_use[v]] > far)
+          {
+            far = uses[v][next_use[v]];
+            victim = v;
+          }
+        if (victim == i && uses[i][0] <= pos + 2)
+        {
+          // one of the next two ops reads the new value: take the slot of the farthest other one
+          far = 0;
+          for (unsigned int v : live)
+            if (uses[v][next_use[v]] >= far)
+            {
+              far = uses[v][next_use[v]];
+              victim = v;
+            }
+        }
+        if (victim != i)
+        {
+          if (uses[victim][next_use[victim]] <= pos + 2) return 1; // (cannot happen with >= 5 slots)
+          free_slots.push_back(slot_of[victim]);
+          slot_of[victim] = -1;
+          live.erase(std::find(live.begin(), live.end(), victim));
+        }
+      }
+      if (!free_slots.empty())
+      {
+        f.pslot = free_slots.back();
+        free_slots.pop_back();
+        slot_of[i] = f.pslot;
+        live.push_back(i);
+      }
+    }
+  }
+  if (getenv("PLLHIP_FUSED_DEBUG"))
+  {
+    unsigned int hbm = 0, slotted = 0;
+    for (const FusedOp & f : plan)
+    {
+      hbm += (f.left_hbm != nullptr) + (f.right_hbm != nullptr);
+      slotted += (f.lslot >= 0) + (f.rslot >= 0);
+    }
+    fprintf(stderr, "pllhip fused plan: %u ops, %u slots, operands from LDS %u, from HBM %u, ext %d\n", count,
+            nslots, slotted, hbm, (int)ext);
+  }
+  plan.push_back(plan.back()); // "the ops after the last": what the kernel's look-ahead requests
+  plan.push_back(plan.back());
+  *ext_out = ext;
+  return 0;
+}
+
+template <int RC>
+static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int count, unsigned int nslots,
+                           int mode, bool ext)
+{
+  constexpr int J = PLLHIP_FUSED_J;
+  const unsigned int sites = c->sh.sites;
+  const size_t tile_sites = (size_t)J * (64 / (2 * RC));
+  const size_t tiles = (sites + tile_sites - 1) / tile_sites;
+  const size_t lds = 4 * ((size_t)nslots * J * 64 * (16 + 4) + 4 * (size_t)RC * 16 * sizeof(double));
+  // two workgroups (8 waves) per CU, each wave walking its share of the tiles
+  size_t grid = (tiles + 3) / 4;
+  const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : 2);
+  if (grid > cap) grid = cap;
+  const bool nt = pllhip_use_nt(c);
+#define LAUNCH_FUSED(MODEV, NTV, EXTV) \
+  k_dna_fused<RC, J, MODEV, NTV, EXTV><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites, nslots, c->d_zero, (double2 *)c->d_sink)
+#define LAUNCH_FUSED_MODE(NTV, EXTV)                         \
+  do {                                                        \
+    if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV, EXTV);       \
+    else if (mode == SCALE_SITE) LAUNCH_FUSED(1, NTV, EXTV);  \
+    else LAUNCH_FUSED(2, NTV, EXTV);                          \
+  } while (0)
+  if (nt && ext) LAUNCH_FUSED_MODE(true, true);
+  else if (nt) LAUNCH_FUSED_MODE(true, false);
+  else if (ext) LAUNCH_FUSED_MODE(false, true);
+  else LAUNCH_FUSED_MODE(false, false);
+#undef LAUNCH_FUSED_MODE
+#undef LAUNCH_FUSED
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots, bool ext)
+{
+  const unsigned int count = (unsigned int)plan.size() - 2; // the last two entries are look-ahead sentinels
+  // every op with a parent scaler scales the partition's way
+  int mode = SCALE_NONE;
+  for (const FusedOp & f : plan)
+    if (f.pscaler) mode = c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE;
+  const size_t bytes = plan.size() * sizeof(FusedOp);
+  if (c->plan_cap < bytes)
+  {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < 2; ++b)
+    {
+      if (c->h_plan[b]) HIP_TRY(hipHostFree(c->h_plan[b]));
+      c->h_plan[b] = nullptr;
+      HIP_TRY(hipHostMalloc(&c->h_plan[b], bytes * 2, hipHostMallocDefault));
+      if (!c->plan_done[b]) HIP_TRY(hipEventCreateWithFlags(&c->plan_done[b], hipEventDisableTiming));
+      c->plan_pending[b] = false;
+    }
+    if (c->d_plan) HIP_TRY(hipFree(c->d_plan));
+    c->d_plan = nullptr;
+    HIP_TRY(hipMalloc(&c->d_plan, bytes * 2));
+    c->plan_cap = bytes * 2;
+  }
+  // two pinned staging buffers in turn: the copy of the call before last has long finished
+  const int b = c->plan_next;
+  c->plan_next ^= 1;
+  if (c->plan_pending[b]) HIP_TRY(hipEventSynchronize(c->plan_done[b]));
+  memcpy(c->h_plan[b], plan.data(), bytes);
+  HIP_TRY(hipMemcpyAsync(c->d_plan, c->h_plan[b], bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
+  c->plan_pending[b] = true;
+  if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, 64 * sizeof(double2)));
+  const FusedOp * d_plan = (const FusedOp *)c->d_plan;
+  switch (c->sh.rate_cats)
+  {
+    case 1: return launch_fused_rc<1>(c, d_plan, count, nslots, mode, ext);
+    case 2: return launch_fused_rc<2>(c, d_plan, count, nslots, mode, ext);
+    case 4: return launch_fused_rc<4>(c, d_plan, count, nslots, mode, ext);
+    default: return launch_fused_rc<8>(c, d_plan, count, nslots, mode, ext);
+  }
+}
