@@ -43,6 +43,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # the site counts they were taken at; None otherwise.
 TRAFFIC_PER_OP = {4: 396.0e6, 20: 387.6e6}
 TRAFFIC_SITES = {4: 1_000_000, 20: 200_000}
+# the same for the whole-list launch of 4-state data, keyed by (rate_cats, sites, taxa, tree,
+# tip CLVs, per-rate scalers): bytes per launch
+TRAFFIC_FUSED = {}
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
 
@@ -282,7 +285,44 @@ def main():
     c2 = plan.ops["child2_clv_index"] >= T
     ii_ops = plan.ops if args.tip_clv else plan.ops[c1 & c2]
     roofline = None
-    if len(ii_ops):
+    # 4 states: the library runs the WHOLE op list as one site-blocked launch (children are
+    # read back from on-chip slots, partials_fused.hip); that launch is then the dominant
+    # kernel.  `achieved` stays what the contract defines -- SURVEY 8(d)'s algorithmic bytes
+    # of the ops (396 / 265 / 134 B per inner-inner / tip-inner / tip-tip site-update) over
+    # the launch time -- and `traffic` / `moved_bytes_expected` say how much of that the
+    # kernel still has to move through HBM.
+    part.profile_enable(True)
+    part.update_partials(plan.ops)
+    prof_full = part.profile_read()
+    part.profile_enable(False)
+    full_launches = sum(v[0] for k, v in prof_full.items() if k.startswith("partials"))
+    if S == 4 and full_launches == 1 and len(plan.ops) > 1:
+        n_ii = int((c1 & c2).sum()) if not args.tip_clv else len(plan.ops)
+        n_tt = 0 if args.tip_clv else int((~c1 & ~c2).sum())
+        n_ti = len(plan.ops) - n_ii - n_tt
+        B = 8 * S * R
+        sc = 4 if not args.rate_scalers else 4 * R
+        per_site = n_ii * (3 * B + 3 * sc) + n_ti * (1 + 2 * B + 2 * sc) + n_tt * (2 + B + sc)
+        moved = len(plan.ops) * (B + sc) + (0 if args.tip_clv else n_ti + 2 * n_tt) + \
+            (2 * B * T // 2 if args.tip_clv else 0)
+        part.wait()
+        part.timer_start()
+        for _ in range(args.steps):
+            part.update_partials(plan.ops)
+        ms = part.timer_stop_ms()
+        launch_s = ms / args.steps / 1e3
+        achieved = per_site * (hi - lo) / launch_s / 1e9
+        traffic = TRAFFIC_FUSED.get((R, hi - lo, T, args.tree, bool(args.tip_clv), bool(args.rate_scalers)))
+        roofline = {"bound": "hbm", "kernel": "k_dna_fused: pll_update_partials, %d ops in one launch "
+                                              "(%d inner-inner, %d tip-inner, %d tip-tip)" % (len(plan.ops), n_ii, n_ti, n_tt),
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_site": per_site, "moved_bytes_expected_per_site": moved,
+                    "moved_GBs": round(moved * (hi - lo) / launch_s / 1e9, 1),
+                    "site_updates_per_launch": (hi - lo) * len(plan.ops), "ops_per_launch": len(plan.ops),
+                    "avg_launch_us": round(launch_s * 1e6, 2), "launches": args.steps,
+                    "avg_op_us": round(launch_s * 1e6 / len(plan.ops), 2)}
+    elif len(ii_ops):
         # how many kernel launches the library makes for this op list (independent
         # ops of one tree level are batched into one launch, blockIdx.y = op)
         part.profile_enable(True)

@@ -105,6 +105,8 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   c->clv_elems = N * c->span;
   c->scaler_elems = shape->rate_scalers ? N * R : N;
   c->tip_stride = (N + 255) & ~(size_t)255;
+  c->clv_stride = c->clv_elems + (size_t)PLLHIP_TAIL_SITES * c->span;
+  c->scaler_stride = c->scaler_elems + (size_t)PLLHIP_TAIL_SITES * (shape->rate_scalers ? R : 1);
   c->pmat_elems = R * S * S;
 
   const unsigned int nodes = shape->tips + shape->clv_buffers;
@@ -112,17 +114,17 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   const size_t n_clv = nodes - first;
 
   // CLVs are zeroed like the reference's (pll.c:525-542); scalers calloc'd (pll.c:800-815)
-  if ((rc = dev_alloc(&c->clv_arena, n_clv * c->clv_elems + PLLHIP_TAIL_SITES * c->span, true, c->stream)))
+  if ((rc = dev_alloc(&c->clv_arena, n_clv * c->clv_stride, true, c->stream)))
     goto fail;
   c->clv_arena_bytes = n_clv * c->clv_elems * sizeof(double);
   c->clv.assign(nodes, nullptr);
   for (unsigned int i = first; i < nodes; ++i)
-    c->clv[i] = c->clv_arena + (size_t)(i - first) * c->clv_elems;
+    c->clv[i] = c->clv_arena + (size_t)(i - first) * c->clv_stride;
   if (shape->pattern_tip)
     if ((rc = dev_alloc(&c->tipchars, shape->tips * c->tip_stride + PLLHIP_TAIL_SITES, true, c->stream)))
       goto fail;
   if ((rc = dev_alloc(&c->scaler_arena,
-                      (size_t)shape->scale_buffers * c->scaler_elems + PLLHIP_TAIL_SITES * R, true,
+                      (size_t)shape->scale_buffers * c->scaler_stride + PLLHIP_TAIL_SITES * R, true,
                       c->stream))) goto fail;
   if ((rc = dev_alloc(&c->pmatrix, (size_t)shape->prob_matrices * c->pmat_elems, true,
                       c->stream))) goto fail;

@@ -25,6 +25,9 @@ struct pllhip_ctx
   size_t span = 0;         // states * rate_cats doubles per site
   size_t clv_elems = 0;    // sites * span
   size_t scaler_elems = 0; // sites (per-site mode) or sites * rate_cats
+  // distance between two CLVs / scale buffers in their arenas: the elements plus
+  // PLLHIP_TAIL_SITES sites of slack EACH, so that a kernel may also STORE a whole last tile
+  size_t clv_stride = 0, scaler_stride = 0;
   size_t tip_stride = 0;   // bytes between two tips' code rows
   size_t pmat_elems = 0;   // rate_cats * states * states
 
@@ -148,7 +151,7 @@ static inline bool pllhip_is_tip(const pllhip_ctx * c, unsigned int clv_index)
 
 static inline unsigned int * pllhip_scaler_ptr(const pllhip_ctx * c, int idx)
 {
-  return idx < 0 ? nullptr : c->scaler_arena + (size_t)idx * c->scaler_elems;
+  return idx < 0 ? nullptr : c->scaler_arena + (size_t)idx * c->scaler_stride;
 }
 
 static inline const unsigned char * pllhip_tip_ptr(const pllhip_ctx * c, unsigned int tip)

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
   const unsigned int k = (lane >> 1) & (RC - 1);
   const unsigned int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // per wave: [nslots][J][64] CLV granules | 2 x [2 * MG] matrix granules | [nslots][J][64] counts
-  const size_t wave_g = (size_t)nslots * J * 64 + 4 * MG + (size_t)nslots * J * 16;
+  // (counts: one word per site, or per (site, rate) with per-rate scalers, of a sub-step)
+  constexpr unsigned int CW = (MODE == SCALE_RATE) ? 32u : (SPS < 4u ? 4u : SPS); // words per sub-step, 16-byte multiple
+  const size_t wave_g = (size_t)nslots * J * 64 + 4 * MG + (size_t)nslots * J * CW / 4;
   double2 * clv = lds_fused + wave_in_wg * wave_g;
   double2 * pst = clv + (size_t)nslots * J * 64;
   unsigned int * cnt = reinterpret_cast<unsigned int *>(pst + 4 * MG);
@@ -94,12 +96,10 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
 
     // every load is unconditional (absent operands read the zero block): a load inside a
     // branch makes the compiler wait for everything in flight
-    auto request = [&](FusedFetch<PL, J, EXT> & f, unsigned int i) {
-      const double2 * lm = reinterpret_cast<const double2 *>(plan[i].lmat);
-      const double2 * rm = reinterpret_cast<const double2 *>(plan[i].rmat);
-      const unsigned char * ltip = plan[i].ltip;
-      const unsigned char * rtip = plan[i].rtip;
-      asm volatile("" ::"s"(lm), "s"(rm), "s"(ltip), "s"(rtip)); // (all four in one round trip)
+    auto request = [&](FusedFetch<PL, J, EXT> & f, unsigned int i, const double * lmat, const double * rmat,
+                       const unsigned char * ltip, const unsigned char * rtip) {
+      const double2 * lm = reinterpret_cast<const double2 *>(lmat);
+      const double2 * rm = reinterpret_cast<const double2 *>(rmat);
 #pragma unroll
       for (int t = 0; t < PL; ++t)
       {
@@ -121,16 +121,21 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
         const double2 * R = reinterpret_cast<const double2 *>(plan[i].right_hbm);
         const unsigned int * ls = plan[i].lsc_hbm;
         const unsigned int * rs = plan[i].rsc_hbm;
-#pragma unroll
-        for (unsigned int j = 0; j < J; ++j)
+        // (only the few ops that have such an operand issue these loads: a wave-uniform
+        // branch; their destination registers are written nowhere else)
+        if (L || R || ls || rs)
         {
-          const size_t g = (site0 + (size_t)j * SPS) * W + lane;
-          const size_t gc = g < total ? g : 0;
-          const size_t e = (MODE == SCALE_RATE) ? (gc >> 1) : gc / W; // (site, rate) or site
-          f.kl[j] = ld16<NT>(L ? L + gc : zero16);
-          f.kr[j] = ld16<NT>(R ? R + gc : zero16);
-          f.cl[j] = (ls ? ls : zero)[ls ? e : 0];
-          f.cr[j] = (rs ? rs : zero)[rs ? e : 0];
+#pragma unroll
+          for (unsigned int j = 0; j < J; ++j)
+          {
+            const size_t g = (site0 + (size_t)j * SPS) * W + lane;
+            const size_t gc = g < total ? g : 0;
+            const size_t e = (MODE == SCALE_RATE) ? (gc >> 1) : gc / W; // (site, rate) or site
+            f.kl[j] = ld16<NT>(L ? L + gc : zero16);
+            f.kr[j] = ld16<NT>(R ? R + gc : zero16);
+            f.cl[j] = (ls ? ls : zero)[ls ? e : 0];
+            f.cr[j] = (rs ? rs : zero)[rs ? e : 0];
+          }
         }
       }
     };
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
     // and op i runs on registers filled one op ago.
     FusedFetch<PL, J, EXT> cur, fa;
     half_rows pl, pr;
-    request(cur, 0u);
-    request(fa, 1u);
+    request(cur, 0u, plan[0].lmat, plan[0].rmat, plan[0].ltip, plan[0].rtip);
+    request(fa, 1u, plan[1].lmat, plan[1].rmat, plan[1].ltip, plan[1].rtip);
     // The compiler counts the memory operations issued after a load to know how many may
     // stay in flight when the load is consumed, and takes the minimum over all paths into
     // the loop.  On the path through the loop an op's stores follow the look-ahead loads;
@@ -172,24 +177,35 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
       if (MODE != SCALE_NONE) reinterpret_cast<unsigned int *>(sink)[lane] = 0u;
     }
     stage_rows(cur, 0u, pl, pr);
+    // The scalar (plan) fields are fetched one op ahead as well: what op i computes with and
+    // what it requests (for op i+2) was loaded during op i-1.  Scalar loads return out of
+    // order and share a counter with LDS, so a plan field consumed in the middle of an op
+    // would drain the LDS reads in flight; and the plan of a large tree (22 KB for 200 taxa)
+    // does not stay in the scalar cache, so a field consumed right after its load would
+    // expose an L2 round trip per op.
+    int n_kind = plan[0].kind, n_lslot = plan[0].lslot, n_rslot = plan[0].rslot, n_pslot = plan[0].pslot;
+    int n_lsc = plan[0].lsc_slot, n_rsc = plan[0].rsc_slot, n_flags = plan[0].hbm_flags;
+    double * n_out = plan[0].parent;
+    unsigned int * n_psc = plan[0].pscaler;
+    const double * q_lmat = plan[2].lmat, * q_rmat = plan[2].rmat;
+    const unsigned char * q_ltip = plan[2].ltip, * q_rtip = plan[2].rtip;
     for (unsigned int i = 0; i < nops; ++i)
     {
-      // All scalar (plan) loads of the op happen HERE, before any LDS traffic of the op:
-      // scalar loads return out of order, so consuming one means waiting for every
-      // outstanding scalar AND LDS operation (they share a counter) -- a plan field fetched
-      // in the middle of the op would drain the LDS reads in flight.  The empty asm makes
-      // each value live at this point.
-      const int kind = plan[i].kind;
-      const int lslot = plan[i].lslot, rslot = plan[i].rslot, pslot = plan[i].pslot;
-      const int lsc_slot = plan[i].lsc_slot, rsc_slot = plan[i].rsc_slot;
-      double2 * out = reinterpret_cast<double2 *>(plan[i].parent);
-      unsigned int * pscaler = plan[i].pscaler;
-      asm volatile("" ::"s"(kind), "s"(lslot), "s"(rslot), "s"(pslot), "s"(lsc_slot), "s"(rsc_slot), "s"(out), "s"(pscaler));
+      const int kind = n_kind, lslot = n_lslot, rslot = n_rslot, pslot = n_pslot;
+      const int lsc_slot = n_lsc, rsc_slot = n_rsc, hbm_flags = n_flags;
+      double2 * out = reinterpret_cast<double2 *>(n_out);
+      unsigned int * pscaler = n_psc;
+      const double * r_lmat = q_lmat, * r_rmat = q_rmat;
+      const unsigned char * r_ltip = q_ltip, * r_rtip = q_rtip;
+      asm volatile("" ::"s"(kind), "s"(lslot), "s"(rslot), "s"(pslot), "s"(lsc_slot), "s"(rsc_slot), "s"(out),
+                   "s"(pscaler), "s"(hbm_flags), "s"(r_lmat), "s"(r_rmat), "s"(r_ltip), "s"(r_rtip));
+      n_kind = plan[i + 1].kind; n_lslot = plan[i + 1].lslot; n_rslot = plan[i + 1].rslot; n_pslot = plan[i + 1].pslot;
+      n_lsc = plan[i + 1].lsc_slot; n_rsc = plan[i + 1].rsc_slot; n_flags = plan[i + 1].hbm_flags;
+      n_out = plan[i + 1].parent; n_psc = plan[i + 1].pscaler;
+      q_lmat = plan[i + 3].lmat; q_rmat = plan[i + 3].rmat; q_ltip = plan[i + 3].ltip; q_rtip = plan[i + 3].rtip;
       const bool scaling = MODE != SCALE_NONE && pscaler != nullptr;
       FusedFetch<PL, J, EXT> fb;
-      request(fb, i + 2u);
-      half_rows nl, nr;
-      stage_rows(fa, (i + 1u) & 1u, nl, nr);
+      request(fb, i + 2u, r_lmat, r_rmat, r_ltip, r_rtip);
 
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
@@ -201,14 +217,15 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
         // what the look-ahead fetched from HBM
         double2 lo = clv[((lslot >= 0 ? lslot : 0) * J + j) * 64 + lane];
         double2 ro = clv[((rslot >= 0 ? rslot : 0) * J + j) * 64 + lane];
-        unsigned int lc = cnt[((lsc_slot >= 0 ? lsc_slot : 0) * J + j) * 64 + lane];
-        unsigned int rc = cnt[((rsc_slot >= 0 ? rsc_slot : 0) * J + j) * 64 + lane];
+        const unsigned int cw = (MODE == SCALE_RATE) ? lane >> 1 : lane / W; // this lane's count within a sub-step
+        unsigned int lc = cnt[((lsc_slot >= 0 ? lsc_slot : 0) * J + j) * CW + cw];
+        unsigned int rc = cnt[((rsc_slot >= 0 ? rsc_slot : 0) * J + j) * CW + cw];
         if (EXT)
         {
           if (lslot < 0) lo = cur.kl[j];
           if (rslot < 0) ro = cur.kr[j];
-          if (lsc_slot < 0) lc = cur.cl[j];
-          if (rsc_slot < 0) rc = cur.cr[j];
+          if (lsc_slot < 0) lc = (hbm_flags & 1) ? cur.cl[j] : 0u;
+          if (rsc_slot < 0) rc = (hbm_flags & 2) ? cur.cr[j] : 0u;
         }
         else
         {
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
         if (pslot >= 0)
         {
           clv[(pslot * J + j) * 64 + lane] = make_double2(p0, p1);
-          cnt[(pslot * J + j) * 64 + lane] = scaling ? count : 0u;
+          cnt[(pslot * J + j) * CW + cw] = scaling ? count : 0u;
         }
         if (MODE != SCALE_NONE)
         {
@@ -282,10 +299,11 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
           *dst = count;
         }
       }
+      // the next op's matrix rows replace this op's in the same registers: the block was
+      // requested an op ago, the LDS round trip overlaps the next op's scalar phase
+      stage_rows(fa, (i + 1u) & 1u, pl, pr);
       cur = fa;
       fa = fb;
-      pl = nl;
-      pr = nr;
     }
   }
 }
@@ -307,7 +325,9 @@ unsigned int pllhip_fused_slots(const pllhip_ctx * c)
 {
   // 64 KB per workgroup of four waves: 16 KB per wave minus the matrix block
   const unsigned int R = c->sh.rate_cats;
-  const size_t per_slot = (size_t)PLLHIP_FUSED_J * 64 * (16 + 4);
+  const unsigned int sps = 64 / (2 * R);
+  const size_t cw = c->sh.rate_scalers ? 32 : (sps < 4 ? 4 : sps);
+  const size_t per_slot = (size_t)PLLHIP_FUSED_J * (64 * 16 + cw * 4);
   const size_t pmat = 4 * (size_t)R * 16 * sizeof(double); // two buffers of [P_l | P_r]
   const size_t budget = PLLHIP_FUSED_J == 1 ? 8448 : 16384; // J = 1: four workgroups per CU
   return (unsigned int)((budget - pmat) / per_slot);
@@ -476,13 +496,13 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
     {
       if (swl >= 0 && swl == wl && f.lslot >= 0) f.lsc_slot = f.lslot;
       else if (!hbm_ok(swl)) return 1;
-      else { f.lsc_hbm = a.lscaler; ext = true; }
+      else { f.lsc_hbm = a.lscaler; f.hbm_flags |= 1; ext = true; }
     }
     if (a.rscaler)
     {
       if (swr >= 0 && swr == wr && f.rslot >= 0) f.rsc_slot = f.rslot;
       else if (!hbm_ok(swr)) return 1;
-      else { f.rsc_hbm = a.rscaler; ext = true; }
+      else { f.rsc_hbm = a.rscaler; f.hbm_flags |= 2; ext = true; }
     }
     // operands read for the last time give their slots back
     for (int w : {wl, (wr != wl ? wr : -1)})
@@ -550,6 +570,7 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
   }
   plan.push_back(plan.back()); // "the ops after the last": what the kernel's look-ahead requests
   plan.push_back(plan.back());
+  plan.push_back(plan.back());
   *ext_out = ext;
   return 0;
 }
@@ -562,7 +583,8 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
   const unsigned int sites = c->sh.sites;
   const size_t tile_sites = (size_t)J * (64 / (2 * RC));
   const size_t tiles = (sites + tile_sites - 1) / tile_sites;
-  const size_t lds = 4 * ((size_t)nslots * J * 64 * (16 + 4) + 4 * (size_t)RC * 16 * sizeof(double));
+  const size_t cw = c->sh.rate_scalers ? 32 : ((64 / (2 * RC)) < 4 ? 4 : (64 / (2 * RC)));
+  const size_t lds = 4 * ((size_t)nslots * J * (64 * 16 + cw * 4) + 4 * (size_t)RC * 16 * sizeof(double));
   // two workgroups (8 waves) per CU, each wave walking its share of the tiles
   size_t grid = (tiles + 3) / 4;
   const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : 2);
@@ -588,7 +610,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
 
 int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots, bool ext)
 {
-  const unsigned int count = (unsigned int)plan.size() - 2; // the last two entries are look-ahead sentinels
+  const unsigned int count = (unsigned int)plan.size() - 3; // the last three entries are look-ahead sentinels
   // every op with a parent scaler scales the partition's way
   int mode = SCALE_NONE;
   for (const FusedOp & f : plan)

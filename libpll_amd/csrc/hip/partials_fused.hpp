@@ -25,7 +25,8 @@ struct FusedOp
   int lslot, rslot, pslot;         // LDS slots of the two inner children / the parent; -1 = none
   int lsc_slot, rsc_slot;          // LDS slots the inherited counts are taken from; -1 = none / HBM
   int kind;                        // 0 inner-inner, 1 tip-inner, 2 tip-tip
-  int pad[2];
+  int hbm_flags;                   // bit 0 / 1: lsc_hbm / rsc_hbm present
+  int pad;
 };
 
 // Order the list, assign slots.  args/kinds/modes are resolve_op's results per op.
