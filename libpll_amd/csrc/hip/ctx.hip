@@ -92,7 +92,11 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
-  if (const char * e = getenv("PLLHIP_FUSED")) c->no_fused = atoi(e) == 0;
+  if (const char * e = getenv("PLLHIP_FUSED"))
+  {
+    c->no_fused = atoi(e) == 0;
+    c->force_fused = atoi(e) == 2;
+  }
   if (const char * e = getenv("PLLHIP_BLOCKS_PER_CU"))
     if (atoi(e) > 0) c->blocks_per_cu = atoi(e);
 

@@ -62,6 +62,7 @@ struct pllhip_ctx
   size_t plan_cap = 0;
   int plan_next = 0;
   bool no_fused = false; // env PLLHIP_FUSED=0: one launch per dependency level instead
+  bool force_fused = false; // env PLLHIP_FUSED=2: also for partitions too small for it to pay (tests)
 
   // reductions: per-block partial sums, then a fixed-order final pass
   double * block_partials = nullptr;   // [PLLHIP_REDUCE_BLOCKS][2]

@@ -545,7 +545,12 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
 
   // 4 states, more than one op, no site repeats: the whole list in one site-blocked
   // launch (partials_fused.hip)
-  if (dna_fast && c->sh.rate_cats <= 8 && !c->no_fused && c->rows.empty() && count >= 2)
+  // (a wave takes the list op by op, ~1.5 us each: with fewer tiles than about 1.5 per
+  // resident wave -- 49 k sites at 4 rate categories -- the per-level launches are faster;
+  // measured crossover for 64 taxa: 50 k sites)
+  const size_t fused_tile_sites = (size_t)PLLHIP_FUSED_J * 64 / (2 * c->sh.rate_cats);
+  const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 8 * 3 / 2 || c->force_fused;
+  if (dna_fast && c->sh.rate_cats <= 8 && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
   {
     std::vector<PartialsArgs> args(count);
     std::vector<int> kinds(count), modes(count);

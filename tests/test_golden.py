@@ -111,7 +111,7 @@ def test_oracle_matches_golden(orc, amd, path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", FIXTURES, ids=IDS)
-def test_hip_matches_golden(gpu, path, monkeypatch):
+def test_hip_matches_golden(gpu, path, monkeypatch, dna_path):
     """The product, driven exactly like a reference client, reproduces the
     reference's stored outputs."""
     g = load(path)

@@ -11,7 +11,7 @@ from helpers import (make_case, build_partition, oracle_run, bits_equal, rel_err
                      random_op_sequence, random_sequence_case)
 from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, OPS_DTYPE, SCALE_BUFFER_NONE
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("dna_path")]
 
 
 def test_mirror_mode_fills_struct_fields(gpu, orc):

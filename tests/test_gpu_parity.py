@@ -15,7 +15,7 @@ from libpll_amd import workload as W
 from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, SCALE_BUFFER_NONE,
                                PllError)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("dna_path")]
 
 LNL_RTOL = 1e-12      # lnL (sum over sites), relative
 PERSITE_RTOL = 1e-13  # per-site lnL, relative (in practice bit-identical)
