@@ -12,7 +12,7 @@ from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_A
                                ATTRIB_AB_LEWIS, ATTRIB_AB_FELSENSTEIN, ATTRIB_AB_STAMATAKIS,
                                ATTRIB_AB_FLAG, PllError)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("dna_path")]
 
 TYPES = {"lewis": ATTRIB_AB_LEWIS, "felsenstein": ATTRIB_AB_FELSENSTEIN,
          "stamatakis": ATTRIB_AB_STAMATAKIS}
