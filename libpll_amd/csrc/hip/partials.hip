@@ -559,10 +559,18 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       int rc = resolve_op(c, ops[i], args[i], kinds[i], modes[i]);
       if (rc) return rc;
     }
+    // three workgroups per CU (12 waves) hide the per-op latencies better than two, but
+    // leave one LDS slot less per wave: taken when the list fits without giving a slot up
     std::vector<FusedOp> fplan;
     bool ext = false;
-    const unsigned int nslots = pllhip_fused_slots(c);
-    int rc = pllhip_fused_plan(c, ops, args.data(), kinds.data(), modes.data(), count, nslots, fplan, &ext);
+    unsigned int evictions = 0;
+    unsigned int nslots = pllhip_fused_slots(c, 3);
+    int rc = pllhip_fused_plan(c, ops, args.data(), kinds.data(), modes.data(), count, nslots, fplan, &ext, &evictions);
+    if (rc > 0 || (rc == 0 && evictions))
+    {
+      nslots = pllhip_fused_slots(c, 2);
+      rc = pllhip_fused_plan(c, ops, args.data(), kinds.data(), modes.data(), count, nslots, fplan, &ext, &evictions);
+    }
     if (rc < 0) return rc;
     if (rc == 0)
     {

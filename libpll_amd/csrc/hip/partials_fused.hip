@@ -321,7 +321,9 @@ struct Node
 };
 }
 
-unsigned int pllhip_fused_slots(const pllhip_ctx * c)
+// slots per wave when `wgs` workgroups of four waves share a CU's LDS: 64 KB per workgroup
+// for two (8 waves per CU), 52 KB for three (12 waves: better latency hiding, one slot less)
+unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int wgs)
 {
   // 64 KB per workgroup of four waves: 16 KB per wave minus the matrix block
   const unsigned int R = c->sh.rate_cats;
@@ -329,14 +331,15 @@ unsigned int pllhip_fused_slots(const pllhip_ctx * c)
   const size_t cw = c->sh.rate_scalers ? 32 : (sps < 4 ? 4 : sps);
   const size_t per_slot = (size_t)PLLHIP_FUSED_J * (64 * 16 + cw * 4);
   const size_t pmat = 4 * (size_t)R * 16 * sizeof(double); // two buffers of [P_l | P_r]
-  const size_t budget = PLLHIP_FUSED_J == 1 ? 8448 : 16384; // J = 1: four workgroups per CU
+  const size_t budget = PLLHIP_FUSED_J == 1 ? 8448 : (wgs >= 3 ? 13312 : 16384); // J = 1: four workgroups per CU
   return (unsigned int)((budget - pmat) / per_slot);
 }
 
 int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArgs * args,
                       const int * kinds, const int * modes, unsigned int count, unsigned int nslots,
-                      std::vector<FusedOp> & plan, bool * ext_out)
+                      std::vector<FusedOp> & plan, bool * ext_out, unsigned int * evictions_out)
 {
+  unsigned int evictions = 0;
   (void)modes;
   std::vector<Node> node(count);
   const size_t nclv = c->clv.size(), nsc = c->sh.scale_buffers;
@@ -547,6 +550,7 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
           slot_of[victim] = -1;
           live.erase(std::find(live.begin(), live.end(), victim));
         }
+        ++evictions; // (a value that has readers goes without a slot, or another loses its own)
       }
       if (!free_slots.empty())
       {
@@ -565,13 +569,14 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
       hbm += (f.left_hbm != nullptr) + (f.right_hbm != nullptr);
       slotted += (f.lslot >= 0) + (f.rslot >= 0);
     }
-    fprintf(stderr, "pllhip fused plan: %u ops, %u slots, operands from LDS %u, from HBM %u, ext %d\n", count,
-            nslots, slotted, hbm, (int)ext);
+    fprintf(stderr, "pllhip fused plan: %u ops, %u slots, operands from LDS %u, from HBM %u, ext %d, evictions %u\n",
+            count, nslots, slotted, hbm, (int)ext, evictions);
   }
   plan.push_back(plan.back()); // "the ops after the last": what the kernel's look-ahead requests
   plan.push_back(plan.back());
   plan.push_back(plan.back());
   *ext_out = ext;
+  *evictions_out = evictions;
   return 0;
 }
 
@@ -587,7 +592,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
   const size_t lds = 4 * ((size_t)nslots * J * (64 * 16 + cw * 4) + 4 * (size_t)RC * 16 * sizeof(double));
   // two workgroups (8 waves) per CU, each wave walking its share of the tiles
   size_t grid = (tiles + 3) / 4;
-  const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : 2);
+  const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
 #define LAUNCH_FUSED(MODEV, NTV, EXTV) \

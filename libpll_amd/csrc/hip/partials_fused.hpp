@@ -35,8 +35,8 @@ struct FusedOp
 // then launches per level), < 0 on error.
 int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArgs * args,
                       const int * kinds, const int * modes, unsigned int count, unsigned int nslots,
-                      std::vector<FusedOp> & plan, bool * ext);
-unsigned int pllhip_fused_slots(const pllhip_ctx * c);
+                      std::vector<FusedOp> & plan, bool * ext, unsigned int * evictions);
+unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int workgroups_per_cu);
 int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots, bool ext);
 
 #endif
