@@ -71,13 +71,13 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
   const unsigned int h = lane & 1u;
   const unsigned int k = (lane >> 1) & (RC - 1);
   const unsigned int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // per wave: [nslots][J][64] CLV granules | 2 x [2 * MG] matrix granules | [nslots][J][64] counts
+  // per wave: [nslots][J][64] CLV granules | [2 * MG] matrix granules | counts
   // (counts: one word per site, or per (site, rate) with per-rate scalers, of a sub-step)
   constexpr unsigned int CW = (MODE == SCALE_RATE) ? 32u : (SPS < 4u ? 4u : SPS); // words per sub-step, 16-byte multiple
-  const size_t wave_g = (size_t)nslots * J * 64 + 4 * MG + (size_t)nslots * J * CW / 4;
+  const size_t wave_g = (size_t)nslots * J * 64 + 2 * MG + (size_t)nslots * J * CW / 4;
   double2 * clv = lds_fused + wave_in_wg * wave_g;
   double2 * pst = clv + (size_t)nslots * J * 64;
-  unsigned int * cnt = reinterpret_cast<unsigned int *>(pst + 4 * MG);
+  unsigned int * cnt = reinterpret_cast<unsigned int *>(pst + 2 * MG);
   // the plan is the same for every lane: read it through the scalar path.  It carries one
   // entry more than there are ops (a copy of the last), so that "the next op" always exists.
   typedef const FusedOp __attribute__((address_space(4))) * plan_ptr;
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
       }
     };
 
-    // the op's matrices: the wave's coalesced block goes through LDS (two buffers in turn),
+    // the op's matrices: the wave's coalesced block goes through LDS (the previous op's rows are in registers by then),
     // each lane takes rows 2h, 2h+1 of category k (own column pair first, then the partner's)
-    auto stage_rows = [&](const FusedFetch<PL, J, EXT> & f, unsigned int buf, half_rows & pl, half_rows & pr) {
-      double2 * p = pst + buf * 2 * MG;
+    auto stage_rows = [&](const FusedFetch<PL, J, EXT> & f, half_rows & pl, half_rows & pr) {
+      double2 * p = pst;
 #pragma unroll
       for (int t = 0; t < PL; ++t)
         if (lane + 64u * t < 2 * MG) p[lane + 64u * t] = f.pm[t];
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
       st16<NT>(sink + lane, 0.0, 0.0);
       if (MODE != SCALE_NONE) reinterpret_cast<unsigned int *>(sink)[lane] = 0u;
     }
-    stage_rows(cur, 0u, pl, pr);
+    stage_rows(cur, pl, pr);
     // The scalar (plan) fields are fetched one op ahead as well: what op i computes with and
     // what it requests (for op i+2) was loaded during op i-1.  Scalar loads return out of
     // order and share a counter with LDS, so a plan field consumed in the middle of an op
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
       }
       // the next op's matrix rows replace this op's in the same registers: the block was
       // requested an op ago, the LDS round trip overlaps the next op's scalar phase
-      stage_rows(fa, (i + 1u) & 1u, pl, pr);
+      stage_rows(fa, pl, pr);
       cur = fa;
       fa = fb;
     }
@@ -330,7 +330,7 @@ unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int wgs)
   const unsigned int sps = 64 / (2 * R);
   const size_t cw = c->sh.rate_scalers ? 32 : (sps < 4 ? 4 : sps);
   const size_t per_slot = (size_t)PLLHIP_FUSED_J * (64 * 16 + cw * 4);
-  const size_t pmat = 4 * (size_t)R * 16 * sizeof(double); // two buffers of [P_l | P_r]
+  const size_t pmat = 2 * (size_t)R * 16 * sizeof(double); // [P_l | P_r]
   const size_t budget = PLLHIP_FUSED_J == 1 ? 8448 : (wgs >= 3 ? 13312 : 16384); // J = 1: four workgroups per CU
   return (unsigned int)((budget - pmat) / per_slot);
 }
@@ -589,7 +589,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
   const size_t tile_sites = (size_t)J * (64 / (2 * RC));
   const size_t tiles = (sites + tile_sites - 1) / tile_sites;
   const size_t cw = c->sh.rate_scalers ? 32 : ((64 / (2 * RC)) < 4 ? 4 : (64 / (2 * RC)));
-  const size_t lds = 4 * ((size_t)nslots * J * (64 * 16 + cw * 4) + 4 * (size_t)RC * 16 * sizeof(double));
+  const size_t lds = 4 * ((size_t)nslots * J * (64 * 16 + cw * 4) + 2 * (size_t)RC * 16 * sizeof(double));
   // two workgroups (8 waves) per CU, each wave walking its share of the tiles
   size_t grid = (tiles + 3) / 4;
   const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
