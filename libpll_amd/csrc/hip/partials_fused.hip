@@ -85,10 +85,13 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
   const double2 * zero16 = reinterpret_cast<const double2 *>(zero);
   const unsigned char * zero8 = reinterpret_cast<const unsigned char *>(zero);
 
-  const size_t total = (size_t)sites * W; // 16-byte granules of a CLV
+  // Every CLV, scale buffer and tip row has PLLHIP_TAIL_SITES sites of slack of its own
+  // behind its last site (ctx.hip), so the last tile is loaded and STORED whole: no lane
+  // predicates, and every address is a wave-uniform tile base plus a lane offset that
+  // never changes.
   const size_t tiles = ((size_t)sites + TS - 1) / TS;
-  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const size_t wave = (size_t)blockIdx.x * 4u + wave_in_wg;
+  const size_t nwaves = (size_t)gridDim.x * 4u;
 
   for (size_t tile = wave; tile < tiles; tile += nwaves)
   {
@@ -107,13 +110,13 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
         const double2 * src = (q < MG) ? lm + q : (q < 2 * MG) ? rm + (q - MG) : zero16;
         f.pm[t] = *src;
       }
+      const unsigned char * lt = ltip ? ltip + site0 : zero8; // (uniform: tile base or the zero block)
+      const unsigned char * rt = rtip ? rtip + site0 : zero8;
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
-        const size_t n = site0 + (size_t)j * SPS + lane / W;
-        const size_t nc = n < sites ? n : 0;
-        f.codes_l[j] = (ltip ? ltip : zero8)[ltip ? nc : 0];
-        f.codes_r[j] = (rtip ? rtip : zero8)[rtip ? nc : 0];
+        f.codes_l[j] = lt[ltip ? j * SPS + lane / W : 0u];
+        f.codes_r[j] = rt[rtip ? j * SPS + lane / W : 0u];
       }
       if (EXT)
       {
@@ -128,13 +131,13 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
 #pragma unroll
           for (unsigned int j = 0; j < J; ++j)
           {
-            const size_t g = (site0 + (size_t)j * SPS) * W + lane;
-            const size_t gc = g < total ? g : 0;
-            const size_t e = (MODE == SCALE_RATE) ? (gc >> 1) : gc / W; // (site, rate) or site
-            f.kl[j] = ld16<NT>(L ? L + gc : zero16);
-            f.kr[j] = ld16<NT>(R ? R + gc : zero16);
-            f.cl[j] = (ls ? ls : zero)[ls ? e : 0];
-            f.cr[j] = (rs ? rs : zero)[rs ? e : 0];
+            const unsigned int g = j * 64u + lane;                              // granule within the tile
+            const unsigned int e = (MODE == SCALE_RATE) ? (g >> 1) : g / W;     // count within the tile
+            const size_t e0 = (MODE == SCALE_RATE) ? site0 * RC : site0;        // first count of the tile
+            f.kl[j] = ld16<NT>(L ? L + site0 * W + g : zero16);
+            f.kr[j] = ld16<NT>(R ? R + site0 * W + g : zero16);
+            f.cl[j] = (ls ? ls + e0 : zero)[ls ? e : 0u];
+            f.cr[j] = (rs ? rs + e0 : zero)[rs ? e : 0u];
           }
         }
       }
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
 #pragma unroll
     for (unsigned int j = 0; j < J; ++j)
     {
-      st16<NT>(sink + lane, 0.0, 0.0);
+      st16<NT>(sink + 64 + lane, 0.0, 0.0);
       if (MODE != SCALE_NONE) reinterpret_cast<unsigned int *>(sink)[lane] = 0u;
     }
     stage_rows(cur, pl, pr);
@@ -207,12 +210,15 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
       FusedFetch<PL, J, EXT> fb;
       request(fb, i + 2u, r_lmat, r_rmat, r_ltip, r_rtip);
 
+      double2 * out_tile = out + site0 * W;
+      // (the counts of an op without a scale buffer go to a sink, so that every op issues the
+      // same number of stores, see below)
+      unsigned int * cnt_tile = scaling ? pscaler + ((MODE == SCALE_RATE) ? site0 * RC : site0)
+                                        : reinterpret_cast<unsigned int *>(sink);
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
-        const size_t g = (site0 + (size_t)j * SPS) * W + lane;
-        const bool act = g < total;
-        const size_t gc = act ? g : 0;
+        const unsigned int g = j * 64u + lane; // granule within the tile
         // operands and inherited counts: LDS slot (slot 0 is read when there is none), or
         // what the look-ahead fetched from HBM
         double2 lo = clv[((lslot >= 0 ? lslot : 0) * J + j) * 64 + lane];
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
         if (scaling && kind != 2)
         {
           const bool small = (p0 < PLLHIP_SCALE_THRESHOLD) & (p1 < PLLHIP_SCALE_THRESHOLD);
-          scale = (MODE == SCALE_RATE) ? group_all<2>(small || !act) : group_all<W>(small || !act);
+          scale = (MODE == SCALE_RATE) ? group_all<2>(small) : group_all<W>(small);
           if (scale)
           {
             p0 *= PLLHIP_SCALE_FACTOR;
@@ -281,11 +287,10 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
           }
         }
         const unsigned int count = lc + rc + (scale ? 1u : 0u);
-        // Stores are unconditional too -- lanes past the last site (and the counts of an op
-        // without a scale buffer) go to a sink -- so that their NUMBER per op is known to
-        // the compiler: it can then wait for the look-ahead loads by count and leave this
-        // op's stores in flight (a store under a branch forces a full drain instead).
-        st16<NT>(act ? out + g : sink + lane, p0, p1);
+        // The NUMBER of stores per op is fixed (a store under a branch forces a full drain
+        // of the memory queue): the compiler can then wait for the look-ahead loads by count
+        // and leave this op's stores in flight.
+        st16<NT>(out_tile + g, p0, p1);
         if (pslot >= 0)
         {
           clv[(pslot * J + j) * 64 + lane] = make_double2(p0, p1);
@@ -294,9 +299,8 @@ __global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ 
         if (MODE != SCALE_NONE)
         {
           // one count per site (all W lanes of the site write the same word) or per (site, rate)
-          unsigned int * dst = reinterpret_cast<unsigned int *>(sink) + lane;
-          if (scaling && act) dst = pscaler + (MODE == SCALE_SITE ? gc / W : gc >> 1);
-          *dst = count;
+          const unsigned int e = (MODE == SCALE_SITE) ? g / W : g >> 1;
+          cnt_tile[scaling ? e : lane] = count;
         }
       }
       // the next op's matrix rows replace this op's in the same registers: the block was
@@ -645,7 +649,7 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   HIP_TRY(hipMemcpyAsync(c->d_plan, c->h_plan[b], bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
-  if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, 64 * sizeof(double2)));
+  if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, 128 * sizeof(double2)));
   const FusedOp * d_plan = (const FusedOp *)c->d_plan;
   switch (c->sh.rate_cats)
   {
