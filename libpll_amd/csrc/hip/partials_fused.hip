@@ -58,8 +58,9 @@ struct FusedFetch
   unsigned int cl[EXT ? J : 1], cr[EXT ? J : 1]; //      and inherited scaler counts from HBM
 };
 
-template <int RC, int J, int MODE, bool NT, bool EXT>
-__global__ __launch_bounds__(256) void k_dna_fused(const FusedOp * __restrict__ plan_g, unsigned int nops,
+// WPS: waves per SIMD the register budget is sized for (3 = 168 VGPRs: twelve waves per CU)
+template <int RC, int J, int MODE, bool NT, bool EXT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restrict__ plan_g, unsigned int nops,
                                                    unsigned int sites, unsigned int nslots,
                                                    const unsigned int * __restrict__ zero, double2 * sink)
 {
@@ -599,8 +600,20 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
   const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
-#define LAUNCH_FUSED(MODEV, NTV, EXTV) \
-  k_dna_fused<RC, J, MODEV, NTV, EXTV><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites, nslots, c->d_zero, (double2 *)c->d_sink)
+  // (the EXT variant needs 212 registers to stay out of scratch: two waves per SIMD; it is
+  // squeezed into three only for the 12-wave configuration)
+  const bool three = nslots <= pllhip_fused_slots(c, 3);
+#define LAUNCH_FUSED(MODEV, NTV, EXTV)                                                                              \
+  do {                                                                                                               \
+    if (EXTV && !three)                                                                                              \
+      k_dna_fused<RC, J, MODEV, NTV, EXTV, 2><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites,    \
+                                                                                            nslots, c->d_zero,      \
+                                                                                            (double2 *)c->d_sink);   \
+    else                                                                                                             \
+      k_dna_fused<RC, J, MODEV, NTV, EXTV, 3><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites,    \
+                                                                                            nslots, c->d_zero,      \
+                                                                                            (double2 *)c->d_sink);   \
+  } while (0)
 #define LAUNCH_FUSED_MODE(NTV, EXTV)                         \
   do {                                                        \
     if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV, EXTV);       \
