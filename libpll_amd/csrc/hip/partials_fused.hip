@@ -336,7 +336,7 @@ unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int wgs)
   const size_t cw = c->sh.rate_scalers ? 32 : (sps < 4 ? 4 : sps);
   const size_t per_slot = (size_t)PLLHIP_FUSED_J * (64 * 16 + cw * 4);
   const size_t pmat = 2 * (size_t)R * 16 * sizeof(double); // [P_l | P_r]
-  const size_t budget = PLLHIP_FUSED_J == 1 ? 8448 : (wgs >= 3 ? 13312 : 16384); // J = 1: four workgroups per CU
+  const size_t budget = PLLHIP_FUSED_J == 1 ? 9472 : (wgs >= 3 ? 13312 : 16384); // J = 1: four workgroups per CU
   return (unsigned int)((budget - pmat) / per_slot);
 }
 
@@ -610,7 +610,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
                                                                                             nslots, c->d_zero,      \
                                                                                             (double2 *)c->d_sink);   \
     else                                                                                                             \
-      k_dna_fused<RC, J, MODEV, NTV, EXTV, 3><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites,    \
+      k_dna_fused<RC, J, MODEV, NTV, EXTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites,    \
                                                                                             nslots, c->d_zero,      \
                                                                                             (double2 *)c->d_sink);   \
   } while (0)
