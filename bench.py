@@ -19,9 +19,13 @@ PLL_ATTRIB_SITE_REPEATS extension: same results, CLVs stored by class; the rate 
 the site-updates the plain path would do and config.site_repeats the rows really computed.
 
 Inputs are resident in HBM before the timed region starts.  `roofline` is for
-the dominant kernel, the 4-state inner-inner CLV update: 396 algorithmic
-bytes per site-update x sites per launch / the launch's average
-duration from HIP events on the partition's own stream, against 8 TB/s.
+the dominant kernel.  4 states: the launch that runs the WHOLE op list site-blocked
+(k_dna_fused): SURVEY.md 8(d)'s algorithmic bytes of its ops (396 / 265 /
+134 B per inner-inner / tip-inner / tip-tip site-update) x sites / the launch's average
+duration from HIP events on the partition's own stream, against 8 TB/s; `traffic`
+(rocprofv3 PMC) and `moved_bytes_expected_per_site` say what the launch really moves
+(children stay on chip: about half).  20 states, and 4 states with PLLHIP_FUSED=0: the
+inner-inner CLV update of one tree level, 1932 / 396 B per site-update x sites x ops per launch.
 `api_calls` times the two API calls of a step on their own (HIP events on the partition's
 stream and wall clock, median and minimum over the steps).
 `cpu_baseline` times the reference's AVX2-flag path (oracle/_ref, built from
