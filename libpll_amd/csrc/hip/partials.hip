@@ -550,7 +550,9 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // measured crossover for 64 taxa: 50 k sites)
   const size_t fused_tile_sites = (size_t)PLLHIP_FUSED_J * 64 / (2 * c->sh.rate_cats);
   const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 8 * 3 / 2 || c->force_fused;
-  if (dna_fast && c->sh.rate_cats <= 8 && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
+  // (8 rate categories: a tile is 8 sites only and the variant spills -- 5.6 against 10.2 G/s
+  // for the per-level launches at 500 k sites; not used)
+  if (dna_fast && c->sh.rate_cats <= 4 && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
   {
     std::vector<PartialsArgs> args(count);
     std::vector<int> kinds(count), modes(count);
