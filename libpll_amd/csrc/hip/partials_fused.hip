@@ -56,6 +56,26 @@ struct FusedFetch
   unsigned int codes_l[J], codes_r[J]; // tip characters of the lane's own site in each sub-step
   double2 kl[EXT ? J : 1], kr[EXT ? J : 1];     // EXT: operands from HBM
   unsigned int cl[EXT ? J : 1], cr[EXT ? J : 1]; //      and inherited scaler counts from HBM
+  // element by element: a plain struct assignment of the arrays goes through scratch memory
+  __device__ __forceinline__ void take(const FusedFetch & o)
+  {
+#pragma unroll
+    for (int t = 0; t < PL; ++t) pm[t] = o.pm[t];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+    {
+      codes_l[j] = o.codes_l[j];
+      codes_r[j] = o.codes_r[j];
+    }
+#pragma unroll
+    for (int j = 0; j < (EXT ? J : 1); ++j)
+    {
+      kl[j] = o.kl[j];
+      kr[j] = o.kr[j];
+      cl[j] = o.cl[j];
+      cr[j] = o.cr[j];
+    }
+  }
 };
 
 // WPS: waves per SIMD the register budget is sized for (3 = 168 VGPRs: twelve waves per CU)
@@ -307,8 +327,8 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       // the next op's matrix rows replace this op's in the same registers: the block was
       // requested an op ago, the LDS round trip overlaps the next op's scalar phase
       stage_rows(fa, pl, pr);
-      cur = fa;
-      fa = fb;
+      cur.take(fa);
+      fa.take(fb);
     }
   }
 }
