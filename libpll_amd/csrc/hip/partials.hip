@@ -545,11 +545,12 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
 
   // 4 states, more than one op, no site repeats: the whole list in one site-blocked
   // launch (partials_fused.hip)
-  // (a wave takes the list op by op, ~1.5 us each: with fewer tiles than about 1.5 per
-  // resident wave -- 49 k sites at 4 rate categories -- the per-level launches are faster;
-  // measured crossover for 64 taxa: 50 k sites)
+  // (a wave takes the list op by op, ~1.5 us each: with fewer tiles than about one per wave
+  // of the 8-waves-per-CU configuration -- 33 k sites at 4 rate categories -- the per-level
+  // launches are faster; measured for 64 taxa: 20 k sites 108 vs 90 us, 35 k 125 vs 136,
+  // 50 k 165 vs 174, 100 k 244 vs 333; 200-taxon random tree: equal from 20 k to 50 k)
   const size_t fused_tile_sites = (size_t)PLLHIP_FUSED_J * 64 / (2 * c->sh.rate_cats);
-  const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 8 * 3 / 2 || c->force_fused;
+  const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 8 || c->force_fused;
   // (8 rate categories: a tile is 8 sites only and the variant spills -- 5.6 against 10.2 G/s
   // for the per-level launches at 500 k sites; not used)
   if (dna_fast && c->sh.rate_cats <= 4 && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)

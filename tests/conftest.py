@@ -95,7 +95,7 @@ def aa_mode(request, monkeypatch):
 @pytest.fixture(params=["fused", "levels"])
 def dna_path(request, monkeypatch):
     """4-state CLV updates: the whole op list in one site-blocked launch (the default from
-    ~50 k sites on; forced here, PLLHIP_FUSED=2) or one launch per dependency level
+    ~33 k sites on; forced here, PLLHIP_FUSED=2) or one launch per dependency level
     (PLLHIP_FUSED=0).  Read when a partition is created.  Both must give the same bits."""
     monkeypatch.setenv("PLLHIP_FUSED", "2" if request.param == "fused" else "0")
     return request.param
