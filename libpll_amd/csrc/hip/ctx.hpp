@@ -56,6 +56,8 @@ struct pllhip_ctx
   // whole-list kernel (partials_fused.hip): the plan's device copy and two pinned staging buffers
   void * d_plan = nullptr;
   void * d_sink = nullptr; // 1 KB that the stores of lanes past the last site go to
+  double * d_pairtab = nullptr; // pair tables of the tip-tip ops of the current op list
+  size_t pairtab_elems = 0;
   void * h_plan[2] = {nullptr, nullptr};
   hipEvent_t plan_done[2] = {nullptr, nullptr};
   bool plan_pending[2] = {false, false};

@@ -48,6 +48,24 @@
 #include "numerics.hpp"
 #include "partials_fused.hpp"
 
+// Tip-tip ops: the parent entry of a site depends on its two tip characters only, 16 x 16
+// pairs.  One table per such op, [pair][rate][state] = masksum4(P_l row, code 1) *
+// masksum4(P_r row, code 2) -- the very product the kernel would form per site (30 VALU
+// instructions per tip operand and sub-step) -- built by one small launch ahead of the
+// list and read back by the list kernel with one 16-byte gather per lane and sub-step
+// (32 KB per op at 4 rate categories: L2-resident).
+template <int RC>
+__global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedOp * __restrict__ plan, unsigned int nops)
+{
+  const unsigned int i = blockIdx.x;
+  if (i >= nops || !plan[i].pair_tab) return;
+  const double * lm = plan[i].lmat, * rm = plan[i].rmat;
+  double * tab = const_cast<double *>(plan[i].pair_tab);
+  const unsigned int pair = threadIdx.x, c1 = pair >> 4, c2 = pair & 15u;
+  for (unsigned int ki = 0; ki < RC * 4u; ++ki)
+    tab[pair * RC * 4u + ki] = masksum4(lm + ki * 4u, c1) * masksum4(rm + ki * 4u, c2);
+}
+
 // what a lane requests for an op one op ahead of its use
 template <int PL, int J, bool EXT>
 struct FusedFetch
@@ -213,6 +231,20 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
     unsigned int * n_psc = plan[0].pscaler;
     const double * q_lmat = plan[2].lmat, * q_rmat = plan[2].rmat;
     const unsigned char * q_ltip = plan[2].ltip, * q_rtip = plan[2].rtip;
+    // tip-tip pair tables: the gather of op i+1 is issued at the top of op i, from the
+    // characters that arrived for it; what op i uses was gathered during op i-1
+    const double * x_pair = plan[1].pair_tab;
+    const double * n_pair = plan[0].pair_tab;
+    double2 pt_use[J], pt_next[J];
+    {
+      const double2 * t0 = reinterpret_cast<const double2 *>(n_pair);
+#pragma unroll
+      for (unsigned int j = 0; j < J; ++j)
+      {
+        const unsigned int pair = ((cur.codes_l[j] & 15u) << 4) | (cur.codes_r[j] & 15u);
+        pt_next[j] = t0 ? t0[pair * W + (lane & (W - 1))] : zero16[0];
+      }
+    }
     for (unsigned int i = 0; i < nops; ++i)
     {
       const int kind = n_kind, lslot = n_lslot, rslot = n_rslot, pslot = n_pslot;
@@ -221,8 +253,12 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       unsigned int * pscaler = n_psc;
       const double * r_lmat = q_lmat, * r_rmat = q_rmat;
       const unsigned char * r_ltip = q_ltip, * r_rtip = q_rtip;
+      const bool have_pairs = n_pair != nullptr; // this op takes its entries from its pair table
+      const double2 * pair_next = reinterpret_cast<const double2 *>(x_pair); // the table of op i+1
       asm volatile("" ::"s"(kind), "s"(lslot), "s"(rslot), "s"(pslot), "s"(lsc_slot), "s"(rsc_slot), "s"(out),
-                   "s"(pscaler), "s"(hbm_flags), "s"(r_lmat), "s"(r_rmat), "s"(r_ltip), "s"(r_rtip));
+                   "s"(pscaler), "s"(hbm_flags), "s"(r_lmat), "s"(r_rmat), "s"(r_ltip), "s"(r_rtip), "s"(pair_next));
+      n_pair = x_pair;
+      x_pair = plan[i + 2].pair_tab;
       n_kind = plan[i + 1].kind; n_lslot = plan[i + 1].lslot; n_rslot = plan[i + 1].rslot; n_pslot = plan[i + 1].pslot;
       n_lsc = plan[i + 1].lsc_slot; n_rsc = plan[i + 1].rsc_slot; n_flags = plan[i + 1].hbm_flags;
       n_out = plan[i + 1].parent; n_psc = plan[i + 1].pscaler;
@@ -230,6 +266,13 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       const bool scaling = MODE != SCALE_NONE && pscaler != nullptr;
       FusedFetch<PL, J, EXT> fb;
       request(fb, i + 2u, r_lmat, r_rmat, r_ltip, r_rtip);
+#pragma unroll
+      for (unsigned int j = 0; j < J; ++j)
+      {
+        pt_use[j] = pt_next[j];
+        const unsigned int pair = ((fa.codes_l[j] & 15u) << 4) | (fa.codes_r[j] & 15u);
+        pt_next[j] = pair_next ? pair_next[pair * W + (lane & (W - 1))] : zero16[0];
+      }
 
       double2 * out_tile = out + site0 * W;
       // (the counts of an op without a scale buffer go to a sink, so that every op issues the
@@ -259,7 +302,16 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
           if (lsc_slot < 0) lc = 0u;
           if (rsc_slot < 0) rc = 0u;
         }
-        double x0, x1, y0, y1;
+        double x0, x1, y0 = 1.0, y1 = 1.0;
+        if (have_pairs)
+        {
+          // tip-tip with a pair table: the finished entries
+          x0 = pt_use[j].x;
+          x1 = pt_use[j].y;
+          lc = rc = 0u;
+        }
+        else
+        {
         if (kind == 0)
         {
           const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
@@ -292,6 +344,8 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
           y1 = ((b0 ? pr.m[1][0] : 0.0) + (b1 ? pr.m[1][1] : 0.0)) + ((b2 ? pr.m[1][2] : 0.0) + (b3 ? pr.m[1][3] : 0.0));
           rc = 0u;
         }
+        }
+        // (with a pair table y is exactly 1.0: the product is the table entry itself)
         double p0 = x0 * y0, p1 = x1 * y1;
 
         // scaling rule of core_partials_avx.c:486-527; tip-tip never scales and clears
@@ -650,8 +704,30 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
   return 0;
 }
 
-int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots, bool ext)
+int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, unsigned int nslots, bool ext)
 {
+  // pair tables of the tip-tip ops (k_dna_pair_tables), carved from one device buffer
+  std::vector<FusedOp> plan = plan_in;
+  {
+    static const bool off = getenv("PLLHIP_FUSED_PAIRS") && atoi(getenv("PLLHIP_FUSED_PAIRS")) == 0;
+    const size_t per = (size_t)256 * c->sh.rate_cats * 4;
+    size_t ntt = 0;
+    for (const FusedOp & f : plan) ntt += (f.kind == 2);
+    if (!off && ntt)
+    {
+      if (c->pairtab_elems < ntt * per)
+      {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_pairtab) HIP_TRY(hipFree(c->d_pairtab));
+        c->d_pairtab = nullptr;
+        HIP_TRY(hipMalloc((void **)&c->d_pairtab, ntt * per * sizeof(double)));
+        c->pairtab_elems = ntt * per;
+      }
+      size_t t = 0;
+      for (FusedOp & f : plan)
+        if (f.kind == 2) f.pair_tab = c->d_pairtab + (t++) * per;
+    }
+  }
   const unsigned int count = (unsigned int)plan.size() - 3; // the last three entries are look-ahead sentinels
   // every op with a parent scaler scales the partition's way
   int mode = SCALE_NONE;
@@ -684,6 +760,14 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   c->plan_pending[b] = true;
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, 128 * sizeof(double2)));
   const FusedOp * d_plan = (const FusedOp *)c->d_plan;
+  switch (c->sh.rate_cats)
+  {
+    case 1: k_dna_pair_tables<1><<<(unsigned int)plan.size(), 256, 0, c->stream>>>(d_plan, (unsigned int)plan.size()); break;
+    case 2: k_dna_pair_tables<2><<<(unsigned int)plan.size(), 256, 0, c->stream>>>(d_plan, (unsigned int)plan.size()); break;
+    case 4: k_dna_pair_tables<4><<<(unsigned int)plan.size(), 256, 0, c->stream>>>(d_plan, (unsigned int)plan.size()); break;
+    default: k_dna_pair_tables<8><<<(unsigned int)plan.size(), 256, 0, c->stream>>>(d_plan, (unsigned int)plan.size()); break;
+  }
+  HIP_TRY(hipGetLastError());
   switch (c->sh.rate_cats)
   {
     case 1: return launch_fused_rc<1>(c, d_plan, count, nslots, mode, ext);

@@ -27,6 +27,8 @@ struct FusedOp
   int kind;                        // 0 inner-inner, 1 tip-inner, 2 tip-tip
   int hbm_flags;                   // bit 0 / 1: lsc_hbm / rsc_hbm present
   int pad;
+  const double * pair_tab;         // tip-tip ops: [256 code pairs][rate][state] parent entries, else nullptr
+  const double * pad2;
 };
 
 // Order the list, assign slots.  args/kinds/modes are resolve_op's results per op.
