@@ -62,8 +62,11 @@ __global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedOp * __restr
   const double * lm = plan[i].lmat, * rm = plan[i].rmat;
   double * tab = const_cast<double *>(plan[i].pair_tab);
   const unsigned int pair = threadIdx.x, c1 = pair >> 4, c2 = pair & 15u;
+  // (tip-inner ops: the tip's factor alone, in the entries [code 1][0] the kernel's index
+  // (code 1 << 4 | character of an absent tip = 0) reaches; x * 1.0 is x)
+  const bool tt = plan[i].kind == 2;
   for (unsigned int ki = 0; ki < RC * 4u; ++ki)
-    tab[pair * RC * 4u + ki] = masksum4(lm + ki * 4u, c1) * masksum4(rm + ki * 4u, c2);
+    tab[pair * RC * 4u + ki] = masksum4(lm + ki * 4u, c1) * (tt ? masksum4(rm + ki * 4u, c2) : 1.0);
 }
 
 // what a lane requests for an op one op ahead of its use
@@ -305,14 +308,12 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
         double x0, x1, y0 = 1.0, y1 = 1.0;
         if (have_pairs)
         {
-          // tip-tip with a pair table: the finished entries
+          // tip-tip with a pair table: the finished entries; tip-inner: the tip's factor
           x0 = pt_use[j].x;
           x1 = pt_use[j].y;
-          lc = rc = 0u;
+          lc = 0u;
         }
-        else
-        {
-        if (kind == 0)
+        else if (kind == 0)
         {
           const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
           x0 = pl.dot(0, lo, lp);
@@ -329,7 +330,9 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
           x1 = ((b0 ? pl.m[1][0] : 0.0) + (b1 ? pl.m[1][1] : 0.0)) + ((b2 ? pl.m[1][2] : 0.0) + (b3 ? pl.m[1][3] : 0.0));
           lc = 0u;
         }
-        if (kind != 2)
+        if (have_pairs && kind == 2)
+          rc = 0u;
+        else if (kind != 2)
         {
           const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
           y0 = pr.dot(0, ro, rp);
@@ -344,8 +347,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
           y1 = ((b0 ? pr.m[1][0] : 0.0) + (b1 ? pr.m[1][1] : 0.0)) + ((b2 ? pr.m[1][2] : 0.0) + (b3 ? pr.m[1][3] : 0.0));
           rc = 0u;
         }
-        }
-        // (with a pair table y is exactly 1.0: the product is the table entry itself)
+        // (tip-tip with a pair table: y is exactly 1.0, the product is the table entry itself)
         double p0 = x0 * y0, p1 = x1 * y1;
 
         // scaling rule of core_partials_avx.c:486-527; tip-tip never scales and clears
@@ -706,13 +708,15 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
 
 int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, unsigned int nslots, bool ext)
 {
-  // pair tables of the tip-tip ops (k_dna_pair_tables), carved from one device buffer
+  // pair tables of the tip-tip and tip-inner ops (k_dna_pair_tables), carved from one device buffer
   std::vector<FusedOp> plan = plan_in;
   {
-    static const bool off = getenv("PLLHIP_FUSED_PAIRS") && atoi(getenv("PLLHIP_FUSED_PAIRS")) == 0;
+    static const int level = getenv("PLLHIP_FUSED_PAIRS") ? atoi(getenv("PLLHIP_FUSED_PAIRS")) : 2; // 0 off, 1 tip-tip only
+    const bool off = level == 0;
+    const int min_kind = level == 1 ? 2 : 1;
     const size_t per = (size_t)256 * c->sh.rate_cats * 4;
     size_t ntt = 0;
-    for (const FusedOp & f : plan) ntt += (f.kind == 2);
+    for (const FusedOp & f : plan) ntt += (f.kind >= min_kind);
     if (!off && ntt)
     {
       if (c->pairtab_elems < ntt * per)
@@ -725,7 +729,7 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, un
       }
       size_t t = 0;
       for (FusedOp & f : plan)
-        if (f.kind == 2) f.pair_tab = c->d_pairtab + (t++) * per;
+        if (f.kind >= min_kind) f.pair_tab = c->d_pairtab + (t++) * per;
     }
   }
   const unsigned int count = (unsigned int)plan.size() - 3; // the last three entries are look-ahead sentinels
