@@ -64,6 +64,7 @@ struct pllhip_ctx
   size_t plan_cap = 0;
   int plan_next = 0;
   bool no_fused = false; // env PLLHIP_FUSED=0: one launch per dependency level instead
+  int fused_pairs = 2;      // env PLLHIP_FUSED_PAIRS
   bool force_fused = false; // env PLLHIP_FUSED=2: also for partitions too small for it to pay (tests)
 
   // reductions: per-block partial sums, then a fixed-order final pass

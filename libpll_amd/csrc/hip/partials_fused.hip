@@ -711,7 +711,7 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, un
   // pair tables of the tip-tip and tip-inner ops (k_dna_pair_tables), carved from one device buffer
   std::vector<FusedOp> plan = plan_in;
   {
-    static const int level = getenv("PLLHIP_FUSED_PAIRS") ? atoi(getenv("PLLHIP_FUSED_PAIRS")) : 2; // 0 off, 1 tip-tip only
+    const int level = c->fused_pairs; // env PLLHIP_FUSED_PAIRS: 0 off, 1 tip-tip only, 2 (default) tip-inner too
     const bool off = level == 0;
     const int min_kind = level == 1 ? 2 : 1;
     const size_t per = (size_t)256 * c->sh.rate_cats * 4;
