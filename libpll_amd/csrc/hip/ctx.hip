@@ -273,6 +273,8 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   if (c->d_plan) (void)hipFree(c->d_plan);
   if (c->d_sink) (void)hipFree(c->d_sink);
   if (c->d_pairtab) (void)hipFree(c->d_pairtab);
+  if (c->cherry_pool) (void)hipFree(c->cherry_pool);
+  if (c->cherry_codes) (void)hipFree(c->cherry_codes);
   for (int b = 0; b < 2; ++b)
   {
     if (c->h_plan[b]) (void)hipHostFree(c->h_plan[b]);

@@ -57,6 +57,9 @@ struct pllhip_ctx
   void * d_plan = nullptr;
   void * d_sink = nullptr; // 1 KB that the stores of lanes past the last site go to
   double * d_pairtab = nullptr; // pair tables of the tip-tip ops of the current op list
+  // 20 states: scratch of the lookup ops (partials_aa_mfma.hip, k_aa_cherry_rounds)
+  double * cherry_pool = nullptr;
+  unsigned char * cherry_codes = nullptr;
   size_t pairtab_elems = 0;
   void * h_plan[2] = {nullptr, nullptr};
   hipEvent_t plan_done[2] = {nullptr, nullptr};
@@ -250,3 +253,6 @@ int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);
 // independent ops of one kind and mode; returns 1 if the case is not covered
 bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind);
 int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count, int kind, int mode);
+bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode);
+int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
+                              const PartialsArgs * kid2, unsigned int count, int mode);

@@ -595,6 +595,11 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     unsigned int order;
   };
   std::vector<Planned> plan(count);
+  // 20 states: an inner-inner op whose children are both tip-tip results of this list is
+  // a table lookup (partials_aa_mfma.hip, k_aa_cherry_rounds): kind 3 here, with the two
+  // producing ops remembered
+  std::vector<int> tt_writer(c->clv.size(), -1);           // list op that wrote the CLV, if it was tip-tip
+  std::vector<std::pair<int, int>> cherry_kids(count, {-1, -1});
   // highest level that wrote / has read each buffer since its last write
   std::vector<unsigned int> clv_w(c->clv.size(), 0u), clv_r(c->clv.size(), 0u);
   std::vector<unsigned int> sc_w(c->sh.scale_buffers, 0u), sc_r(c->sh.scale_buffers, 0u);
@@ -629,8 +634,23 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     }
     if (op.child1_scaler >= 0) upto(sc_r[op.child1_scaler], lvl);
     if (op.child2_scaler >= 0) upto(sc_r[op.child2_scaler], lvl);
+    if (aa_fast && kind == 0 && tt_writer[op.child1_clv] >= 0 && tt_writer[op.child2_clv] >= 0 &&
+        pllhip_aa_cherry_covers(c, mode))
+    {
+      cherry_kids[i] = {tt_writer[op.child1_clv], tt_writer[op.child2_clv]};
+      kind = 3;
+    }
+    tt_writer[op.parent_clv] = (kind == 2) ? (int)i : -1;
     plan[i].key = (lvl << 8) | ((unsigned int)kind << 4) | (unsigned int)mode;
     plan[i].order = i;
+  }
+
+  // (the producers' arguments by list position: the sort below moves the entries)
+  std::vector<PartialsArgs> by_pos;
+  if (aa_fast)
+  {
+    by_pos.resize(count);
+    for (unsigned int i = 0; i < count; ++i) by_pos[i] = plan[i].a;
   }
   std::stable_sort(plan.begin(), plan.end(),
                    [](const Planned & x, const Planned & y) { return x.key < y.key; });
@@ -639,9 +659,24 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   for (unsigned int i = 0; i < count;)
   {
     const unsigned int key = plan[i].key;
+    const int kind = (int)((key >> 4) & 15u), mode = (int)(key & 15u);
+    if (kind == 3)
+    {
+      std::vector<PartialsArgs> cops, k1, k2;
+      while (i < count && plan[i].key == key)
+      {
+        cops.push_back(plan[i].a);
+        k1.push_back(by_pos[cherry_kids[plan[i].order].first]);
+        k2.push_back(by_pos[cherry_kids[plan[i].order].second]);
+        ++i;
+      }
+      pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
+      int rc = pllhip_launch_aa_cherries(c, cops.data(), k1.data(), k2.data(), (unsigned int)cops.size(), mode);
+      if (rc) return rc;
+      continue;
+    }
     unsigned int nb = 0;
     while (i < count && plan[i].key == key && nb < PLLHIP_BATCH_MAX) b.op[nb++] = plan[i++].a;
-    const int kind = (int)((key >> 4) & 15u), mode = (int)(key & 15u);
     pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II + kind);
     int rc = dna_fast ? pllhip_launch_dna_batch(c, b, nb, kind, mode)
              : aa_fast ? pllhip_launch_aa_batch(c, b, nb, kind, mode)

@@ -457,6 +457,101 @@ static int launch_tt(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   return 0;
 }
 
+// ---- inner-inner ops whose two children are tip-tip results of the same list
+//
+// Such a child is, per site, one of maxstates^2 vectors (one per pair of tip characters),
+// so "P x child" -- the factor the inner-inner kernel forms with 25 MFMAs per rate -- is
+// one of maxstates^2 vectors too.  They are tabulated with the SAME kernels that would have
+// produced them site by site (a tip-tip launch over all character pairs, then an
+// inner-inner launch whose other factor is exactly 1: identity matrix times a vector of
+// ones), so the entries are bit-identical to what k_aa_ii_mfma computes, and the op itself
+// becomes parent = TL[pair 1] (.) TR[pair 2] with the usual scaling test: a write stream
+// of 8 x states x rate_cats bytes per site instead of three times that (k_aa_cherry_rounds;
+// the tables, 338 KB each for 23 characters, are read through L2).
+struct CherryArgs
+{
+  const double * tl, * tr;                 // [pair][rate][state]
+  const unsigned char * t1, * t2, * t3, * t4; // characters of the four tips
+  double * parent;
+  unsigned int * pscaler;
+  unsigned int sites, maxstates;
+};
+struct CherryBatch
+{
+  CherryArgs op[PLLHIP_BATCH_MAX];
+};
+
+template <int RC, int MODE, bool NT> // MODE: SCALE_NONE or SCALE_SITE
+__global__ __launch_bounds__(256) void k_aa_cherry_rounds(CherryBatch batch)
+{
+  const CherryArgs & a = batch.op[blockIdx.y];
+  constexpr unsigned int GS = RC * 10; // 16-byte granules per site
+  const unsigned int lane = threadIdx.x & 63u;
+  const size_t sites = a.sites;
+  const size_t rounds = (sites + 63) / 64;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  double2 * __restrict__ out = reinterpret_cast<double2 *>(a.parent);
+  const double2 * __restrict__ tl = reinterpret_cast<const double2 *>(a.tl);
+  const double2 * __restrict__ tr = reinterpret_cast<const double2 *>(a.tr);
+  const unsigned int ms = a.maxstates;
+  for (size_t r = wave; r < rounds; r += nwaves)
+  {
+    const size_t site0 = r * 64;
+    const bool mine = site0 + lane < sites;
+    unsigned int c1 = mine ? a.t1[site0 + lane] : 0u, c2 = mine ? a.t2[site0 + lane] : 0u;
+    unsigned int c3 = mine ? a.t3[site0 + lane] : 0u, c4 = mine ? a.t4[site0 + lane] : 0u;
+    if (c1 >= ms) c1 = 0;
+    if (c2 >= ms) c2 = 0;
+    if (c3 >= ms) c3 = 0;
+    if (c4 >= ms) c4 = 0;
+    const unsigned int pl = c1 * ms + c2, pr = c3 * ms + c4;
+    const size_t gbase = site0 * GS, gend = sites * GS;
+    unsigned long long all_small = ~0ull; // bit s: every entry of site s of the round below the threshold
+#pragma unroll 10
+    for (unsigned int j = 0; j < GS; ++j)
+    {
+      const unsigned int gg = j * 64 + lane;              // granule within the round
+      const unsigned int sl = gg / GS, rr = gg - sl * GS; // site in round, granule in site
+      const unsigned int p1 = (unsigned int)__shfl((int)pl, (int)sl, 64);
+      const unsigned int p2 = (unsigned int)__shfl((int)pr, (int)sl, 64);
+      const double2 x = tl[(size_t)p1 * GS + rr];
+      const double2 y = tr[(size_t)p2 * GS + rr];
+      const double v0 = x.x * y.x, v1 = x.y * y.y;
+      const bool in = gbase + gg < gend;
+      if (in) st16<false>(out + gbase + gg, v0, v1);
+      if (MODE == SCALE_SITE)
+      {
+        // the 64 granules of this step belong to at most three consecutive sites
+        const bool big = in && !((v0 < PLLHIP_SCALE_THRESHOLD) & (v1 < PLLHIP_SCALE_THRESHOLD));
+        const unsigned int s0 = (j * 64u) / GS;
+#pragma unroll
+        for (unsigned int t = 0; t < 3; ++t)
+          if (__ballot(big && sl == s0 + t)) all_small &= ~(1ull << (s0 + t));
+      }
+    }
+    if (MODE == SCALE_SITE)
+    {
+      // rare: the sites whose entries are all small are multiplied by 2^256 in place
+      if (all_small)
+        for (unsigned int j = 0; j < GS; ++j)
+        {
+          const unsigned int gg = j * 64 + lane;
+          const unsigned int sl = gg / GS;
+          if (gbase + gg < gend && ((all_small >> sl) & 1ull))
+          {
+            double2 v = out[gbase + gg];
+            v.x *= PLLHIP_SCALE_FACTOR;
+            v.y *= PLLHIP_SCALE_FACTOR;
+            out[gbase + gg] = v;
+          }
+        }
+      // both children are tip-tip results: nothing to inherit
+      if (mine) a.pscaler[site0 + lane] = (unsigned int)((all_small >> lane) & 1ull);
+    }
+  }
+}
+
 bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind)
 {
   const unsigned int R = c->sh.rate_cats;
@@ -517,4 +612,133 @@ int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count
     case 2: return launch_rc<2, 0>(c, b, count, mode, nt);
     default: return launch_rc<4, 0>(c, b, count, mode, nt);
   }
+}
+
+// ---- host side of the lookup ops (see k_aa_cherry_rounds)
+//
+// ops[i]: the inner-inner op; kid1[i] / kid2[i]: the tip-tip ops that produced its children
+// (characters and matrices are taken from them).  mode: SCALE_NONE or SCALE_SITE.
+bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode)
+{
+  static const bool off = getenv("PLLHIP_AA_CHERRY") && atoi(getenv("PLLHIP_AA_CHERRY")) == 0;
+  return !off && c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
+         c->rows.empty() && mode != SCALE_RATE && c->maxstates >= 1 && c->maxstates <= 32 && !c->sh.asc_states;
+}
+
+static __global__ void k_aa_cherry_consts(unsigned char * hi, unsigned char * lo, double * ones, double * ident,
+                                          unsigned int ms, unsigned int rows, unsigned int RC)
+{
+  const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < rows)
+  {
+    hi[t] = (unsigned char)(t < ms * ms ? t / ms : 0);
+    lo[t] = (unsigned char)(t < ms * ms ? t % ms : 0);
+  }
+  if (t < rows * RC * 20) ones[t] = 1.0;
+  if (t < RC * 400) ident[t] = ((t % 400) / 20 == t % 20) ? 1.0 : 0.0;
+}
+
+int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
+                              const PartialsArgs * kid2, unsigned int count, int mode)
+{
+  const unsigned int R = c->sh.rate_cats, ms = c->maxstates;
+  const size_t pairs = (size_t)ms * ms;
+  const size_t rows = pairs + PLLHIP_TAIL_SITES; // the kernels load whole tiles
+  const size_t row_elems = (size_t)R * 20;
+  const unsigned int chunk = PLLHIP_BATCH_MAX / 2; // two table ops per lookup op and launch
+  if (!c->cherry_pool)
+  {
+    // per lookup op of a chunk: pair CLVs of the two children, TL, TR; then the constants
+    const size_t per_op = 4 * rows * row_elems;
+    HIP_TRY(hipMalloc((void **)&c->cherry_pool, (chunk * per_op + rows * row_elems + (size_t)R * 400) * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->cherry_codes, 2 * rows));
+    double * ones = c->cherry_pool + chunk * per_op;
+    k_aa_cherry_consts<<<(unsigned int)((rows * row_elems + 255) / 256), 256, 0, c->stream>>>(
+        c->cherry_codes, c->cherry_codes + rows, ones, ones + rows * row_elems, ms, (unsigned int)rows, R);
+    HIP_TRY(hipGetLastError());
+  }
+  const size_t per_op = 4 * rows * row_elems;
+  double * ones = c->cherry_pool + chunk * per_op;
+  double * ident = ones + rows * row_elems;
+  const bool nt = pllhip_use_nt(c);
+  for (unsigned int first = 0; first < count; first += chunk)
+  {
+    const unsigned int n = (count - first < chunk) ? count - first : chunk;
+    PartialsBatch tt, ii;
+    CherryBatch ch;
+    for (unsigned int i = 0; i < n; ++i)
+    {
+      const PartialsArgs & op = ops[first + i];
+      double * base = c->cherry_pool + i * per_op;
+      double * pair_clv[2] = {base, base + rows * row_elems};
+      double * table[2] = {base + 2 * rows * row_elems, base + 3 * rows * row_elems};
+      const PartialsArgs * kid[2] = {&kid1[first + i], &kid2[first + i]};
+      for (int s = 0; s < 2; ++s)
+      {
+        // the child over all character pairs, by the tip-tip kernel and the child op's matrices
+        PartialsArgs & t = tt.op[2 * i + s];
+        memset(&t, 0, sizeof(t));
+        t.parent = pair_clv[s];
+        t.ltip = c->cherry_codes;
+        t.rtip = c->cherry_codes + rows;
+        t.lmat = kid[s]->lmat;
+        t.rmat = kid[s]->rmat;
+        t.tipmap = c->tipmap;
+        t.zero = c->d_zero;
+        t.sites = (unsigned int)pairs;
+        t.rate_cats = R;
+        t.states = 20;
+        t.maxstates = ms;
+        // P x child by the inner-inner kernel; the other factor is identity x ones = 1
+        PartialsArgs & u = ii.op[2 * i + s];
+        memset(&u, 0, sizeof(u));
+        u.parent = table[s];
+        u.left = pair_clv[s];
+        u.right = ones;
+        u.lmat = s == 0 ? op.lmat : op.rmat;
+        u.rmat = ident;
+        u.tipmap = c->tipmap;
+        u.zero = c->d_zero;
+        u.sites = (unsigned int)pairs;
+        u.rate_cats = R;
+        u.states = 20;
+        u.maxstates = ms;
+      }
+      CherryArgs & k = ch.op[i];
+      k.tl = table[0];
+      k.tr = table[1];
+      k.t1 = kid[0]->ltip;
+      k.t2 = kid[0]->rtip;
+      k.t3 = kid[1]->ltip;
+      k.t4 = kid[1]->rtip;
+      k.parent = op.parent;
+      k.pscaler = op.pscaler;
+      k.sites = op.sites;
+      k.maxstates = ms;
+    }
+    int rc = pllhip_launch_aa_batch(c, tt, 2 * n, 2, SCALE_NONE);
+    if (rc) return rc;
+    rc = pllhip_launch_aa_batch(c, ii, 2 * n, 0, SCALE_NONE);
+    if (rc) return rc;
+    const size_t rounds = ((size_t)c->sh.sites + 63) / 64;
+    size_t blocks = (rounds + 3) / 4;
+    const size_t cap = (size_t)c->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    const dim3 grid((unsigned int)blocks, n);
+#define CHERRY_LAUNCH(RCV)                                                                                  \
+  do {                                                                                                      \
+    if (mode == SCALE_SITE) k_aa_cherry_rounds<RCV, SCALE_SITE, false><<<grid, 256, 0, c->stream>>>(ch);   \
+    else k_aa_cherry_rounds<RCV, SCALE_NONE, false><<<grid, 256, 0, c->stream>>>(ch);                      \
+  } while (0)
+    switch (R)
+    {
+      case 1: CHERRY_LAUNCH(1); break;
+      case 2: CHERRY_LAUNCH(2); break;
+      default: CHERRY_LAUNCH(4); break;
+    }
+#undef CHERRY_LAUNCH
+    HIP_TRY(hipGetLastError());
+    (void)nt;
+  }
+  return 0;
 }
