@@ -60,6 +60,7 @@ struct pllhip_ctx
   // 20 states: scratch of the lookup ops (partials_aa_mfma.hip, k_aa_cherry_rounds)
   double * cherry_pool = nullptr;
   unsigned char * cherry_codes = nullptr;
+  unsigned int cherry_ms = 0; // maxstates the scratch was sized for
   size_t pairtab_elems = 0;
   void * h_plan[2] = {nullptr, nullptr};
   hipEvent_t plan_done[2] = {nullptr, nullptr};

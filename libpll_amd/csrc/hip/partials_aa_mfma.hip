@@ -646,8 +646,18 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
   const size_t rows = pairs + PLLHIP_TAIL_SITES; // the kernels load whole tiles
   const size_t row_elems = (size_t)R * 20;
   const unsigned int chunk = PLLHIP_BATCH_MAX / 2; // two table ops per lookup op and launch
+  if (c->cherry_pool && c->cherry_ms != ms)
+  {
+    // (the character map was replaced by one with another number of codes)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(c->cherry_pool));
+    HIP_TRY(hipFree(c->cherry_codes));
+    c->cherry_pool = nullptr;
+    c->cherry_codes = nullptr;
+  }
   if (!c->cherry_pool)
   {
+    c->cherry_ms = ms;
     // per lookup op of a chunk: pair CLVs of the two children, TL, TR; then the constants
     const size_t per_op = 4 * rows * row_elems;
     HIP_TRY(hipMalloc((void **)&c->cherry_pool, (chunk * per_op + rows * row_elems + (size_t)R * 400) * sizeof(double)));
