@@ -522,12 +522,18 @@ __global__ __launch_bounds__(256) void k_aa_cherry_rounds(CherryBatch batch)
       if (in) st16<false>(out + gbase + gg, v0, v1);
       if (MODE == SCALE_SITE)
       {
-        // the 64 granules of this step belong to at most three consecutive sites
-        const bool big = in && !((v0 < PLLHIP_SCALE_THRESHOLD) & (v1 < PLLHIP_SCALE_THRESHOLD));
-        const unsigned int s0 = (j * 64u) / GS;
+        // the 64 granules of this step belong to at most three consecutive sites, s0..s1
+        const bool small = (v0 < PLLHIP_SCALE_THRESHOLD) & (v1 < PLLHIP_SCALE_THRESHOLD);
+        const unsigned int s0 = (j * 64u) / GS, s1 = (j * 64u + 63u) / GS;
+        if (!__ballot(small && in))
+          // the common case, one ballot: nothing here is small, none of these sites scales
+          all_small &= ~(((2ull << (s1 - s0)) - 1ull) << s0);
+        else
+        {
 #pragma unroll
-        for (unsigned int t = 0; t < 3; ++t)
-          if (__ballot(big && sl == s0 + t)) all_small &= ~(1ull << (s0 + t));
+          for (unsigned int t = 0; t < 3; ++t)
+            if (__ballot(in && !small && sl == s0 + t)) all_small &= ~(1ull << (s0 + t));
+        }
       }
     }
     if (MODE == SCALE_SITE)
