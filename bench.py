@@ -20,11 +20,12 @@ the site-updates the plain path would do and config.site_repeats the rows really
 
 Inputs are resident in HBM before the timed region starts.  `roofline` is for
 the dominant kernel.  4 states: the launch that runs the WHOLE op list site-blocked
-(k_dna_fused): SURVEY.md 8(d)'s algorithmic bytes of its ops (396 / 265 /
-134 B per inner-inner / tip-inner / tip-tip site-update) x sites / the launch's average
-duration from HIP events on the partition's own stream, against 8 TB/s; `traffic`
-(rocprofv3 PMC) and `moved_bytes_expected_per_site` say what the launch really moves
-(children stay on chip: about half).  20 states, and 4 states with PLLHIP_FUSED=0: the
+(k_dna_fused): its algorithmic bytes -- every CLV entry and scaler count
+written once, every tip character read once: 8248 B per site for the 62-op list, which
+the rocprofv3 PMC `traffic` confirms -- x sites / the launch's average duration from HIP
+events on the partition's own stream, against 8 TB/s (the per-op algorithm of SURVEY.md
+8(d), 396 / 265 / 134 B per site-update = 16168 B per site, is reported as
+`per_op_algorithm_equivalent_GBs`).  20 states, and 4 states with PLLHIP_FUSED=0: the
 inner-inner CLV update of one tree level, 1932 / 396 B per site-update x sites x ops per launch.
 `api_calls` times the two API calls of a step on their own (HIP events on the partition's
 stream and wall clock, median and minimum over the steps).
@@ -291,10 +292,10 @@ def main():
     roofline = None
     # 4 states: the library runs the WHOLE op list as one site-blocked launch (children are
     # read back from on-chip slots, partials_fused.hip); that launch is then the dominant
-    # kernel.  `achieved` stays what the contract defines -- SURVEY 8(d)'s algorithmic bytes
-    # of the ops (396 / 265 / 134 B per inner-inner / tip-inner / tip-tip site-update) over
-    # the launch time -- and `traffic` / `moved_bytes_expected` say how much of that the
-    # kernel still has to move through HBM.
+    # kernel.  Its algorithmic bytes are one write per CLV entry and scaler count and one
+    # read per tip character -- NOT SURVEY 8(d)'s 396 / 265 / 134 B per site-update, which
+    # describe the per-op algorithm and would put `frac` above 1; that equivalent is reported
+    # next to it.
     part.profile_enable(True)
     part.update_partials(plan.ops)
     prof_full = part.profile_read()
@@ -315,20 +316,26 @@ def main():
             part.update_partials(plan.ops)
         ms = part.timer_stop_ms()
         launch_s = ms / args.steps / 1e3
-        achieved = per_site * (hi - lo) / launch_s / 1e9
+        # the launch's own algorithmic bytes: every CLV and count written once, every tip
+        # character (or tip CLV) read once -- what `traffic` (PMC) is to be compared with
+        achieved = moved * (hi - lo) / launch_s / 1e9
+        per_op_equiv = per_site * (hi - lo) / launch_s / 1e9
         traffic = TRAFFIC_FUSED.get((R, hi - lo, T, args.tree, bool(args.tip_clv), bool(args.rate_scalers)))
         roofline = {"bound": "hbm", "kernel": "k_dna_fused: pll_update_partials, %d ops in one launch "
                                               "(%d inner-inner, %d tip-inner, %d tip-tip)" % (len(plan.ops), n_ii, n_ti, n_tt),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_site": per_site, "moved_bytes_expected_per_site": moved,
-                    "moved_GBs": round(moved * (hi - lo) / launch_s / 1e9, 1),
+                    "algorithmic_bytes_per_site": moved, "per_op_algorithm_bytes_per_site": per_site,
+                    "per_op_algorithm_equivalent_GBs": round(per_op_equiv, 1),
                     "site_updates_per_launch": (hi - lo) * len(plan.ops), "ops_per_launch": len(plan.ops),
                     "avg_launch_us": round(launch_s * 1e6, 2), "launches": args.steps,
                     "avg_op_us": round(launch_s * 1e6 / len(plan.ops), 2),
-                    "note": "achieved = SURVEY 8(d) algorithmic bytes of the ops / launch time, as the contract "
-                            "defines it; the launch keeps children on chip and MOVES only moved_bytes_expected "
-                            "(traffic = PMC), a mostly-write stream: moved_GBs against a 5.6 TB/s write ceiling"}
+                    "note": "one launch runs the whole op list site-blocked and keeps children on chip: its "
+                            "algorithmic bytes are one write per CLV entry and count + one read per tip character "
+                            "(algorithmic_bytes_per_site; traffic = PMC agrees), a write stream whose ceiling on "
+                            "this part is 5.6 TB/s.  Counting SURVEY 8(d)'s per-op bytes (396/265/134 B per "
+                            "site-update, per_op_algorithm_bytes_per_site) the same launch is worth "
+                            "per_op_algorithm_equivalent_GBs"}
     elif len(ii_ops):
         # how many kernel launches the library makes for this op list (independent
         # ops of one tree level are batched into one launch, blockIdx.y = op)
