@@ -272,6 +272,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
     if (p) (void)hipFree(p);
   if (c->d_plan) (void)hipFree(c->d_plan);
   if (c->d_sink) (void)hipFree(c->d_sink);
+  if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
   if (c->d_pairtab) (void)hipFree(c->d_pairtab);
   if (c->cherry_pool) (void)hipFree(c->cherry_pool);
   if (c->cherry_codes) (void)hipFree(c->cherry_codes);

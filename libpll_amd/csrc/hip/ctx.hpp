@@ -56,6 +56,7 @@ struct pllhip_ctx
   // whole-list kernel (partials_fused.hip): the plan's device copy and two pinned staging buffers
   void * d_plan = nullptr;
   void * d_sink = nullptr; // 1 KB that the stores of lanes past the last site go to
+  unsigned int * d_tile_counter = nullptr; // whole-list kernel: next tile to hand out
   double * d_pairtab = nullptr; // pair tables of the tip-tip ops of the current op list
   // 20 states: scratch of the lookup ops (partials_aa_mfma.hip, k_aa_cherry_rounds)
   double * cherry_pool = nullptr;

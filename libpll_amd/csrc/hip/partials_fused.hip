@@ -103,7 +103,8 @@ struct FusedFetch
 template <int RC, int J, int MODE, bool NT, bool EXT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restrict__ plan_g, unsigned int nops,
                                                    unsigned int sites, unsigned int nslots,
-                                                   const unsigned int * __restrict__ zero, double2 * sink)
+                                                   const unsigned int * __restrict__ zero, double2 * sink,
+                                                   unsigned int * next_tile)
 {
   constexpr unsigned int W = 2 * RC, SPS = 64 / W, TS = J * SPS;
   constexpr unsigned int MG = RC * 8;                   // 16-byte granules of one P-matrix
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
   const size_t wave = (size_t)blockIdx.x * 4u + wave_in_wg;
   const size_t nwaves = (size_t)gridDim.x * 4u;
 
-  for (size_t tile = wave; tile < tiles; tile += nwaves)
+  // A wave's first tile is its own number; further tiles come from a counter (starting at
+  // the number of waves), so that no wave idles while another still has a tile of ~100 us
+  // ahead of it (20 or 21 tiles per wave with a fixed stride: up to 5 % of tail).
+  for (size_t tile = wave; tile < tiles;)
   {
     const size_t site0 = tile * TS;
 
@@ -386,6 +390,14 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       cur.take(fa);
       fa.take(fb);
     }
+    if (!next_tile)
+    {
+      tile += nwaves; // (fixed stride: for measurements)
+      continue;
+    }
+    unsigned int nt = 0;
+    if (lane == 0) nt = atomicAdd(next_tile, 1u);
+    tile = (size_t)nwaves + (unsigned int)__builtin_amdgcn_readfirstlane((int)nt);
   }
 }
 
@@ -679,16 +691,17 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
   // (the EXT variant needs 212 registers to stay out of scratch: two waves per SIMD; it is
   // squeezed into three only for the 12-wave configuration)
   const bool three = nslots <= pllhip_fused_slots(c, 3);
+  unsigned int * tile_counter = getenv("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
 #define LAUNCH_FUSED(MODEV, NTV, EXTV)                                                                              \
   do {                                                                                                               \
     if (EXTV && !three)                                                                                              \
       k_dna_fused<RC, J, MODEV, NTV, EXTV, 2><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites,    \
                                                                                             nslots, c->d_zero,      \
-                                                                                            (double2 *)c->d_sink);   \
+                                                                                            (double2 *)c->d_sink, tile_counter);   \
     else                                                                                                             \
       k_dna_fused<RC, J, MODEV, NTV, EXTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites,    \
                                                                                             nslots, c->d_zero,      \
-                                                                                            (double2 *)c->d_sink);   \
+                                                                                            (double2 *)c->d_sink, tile_counter);   \
   } while (0)
 #define LAUNCH_FUSED_MODE(NTV, EXTV)                         \
   do {                                                        \
@@ -763,6 +776,8 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, un
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, 128 * sizeof(double2)));
+  if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, sizeof(unsigned int)));
+  HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
   const FusedOp * d_plan = (const FusedOp *)c->d_plan;
   switch (c->sh.rate_cats)
   {
