@@ -276,6 +276,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   if (c->d_pairtab) (void)hipFree(c->d_pairtab);
   if (c->cherry_pool) (void)hipFree(c->cherry_pool);
   if (c->cherry_codes) (void)hipFree(c->cherry_codes);
+  if (c->cherry_zero) (void)hipFree(c->cherry_zero);
   for (int b = 0; b < 2; ++b)
   {
     if (c->h_plan[b]) (void)hipHostFree(c->h_plan[b]);

@@ -62,6 +62,7 @@ struct pllhip_ctx
   double * cherry_pool = nullptr;
   unsigned char * cherry_codes = nullptr;
   unsigned int cherry_ms = 0; // maxstates the scratch was sized for
+  unsigned char * cherry_zero = nullptr;     // [sites] zero characters (the absent second tip of a tip-inner lookup op)
   size_t pairtab_elems = 0;
   void * h_plan[2] = {nullptr, nullptr};
   hipEvent_t plan_done[2] = {nullptr, nullptr};

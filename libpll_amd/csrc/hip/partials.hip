@@ -640,6 +640,16 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       cherry_kids[i] = {tt_writer[op.child1_clv], tt_writer[op.child2_clv]};
       kind = 3;
     }
+    else if (aa_fast && kind == 1 && pllhip_aa_cherry_covers(c, mode))
+    {
+      // tip-inner over a tip-tip result: the same lookup with the tip's own table on one side
+      const unsigned int inner = pllhip_is_tip(c, op.child1_clv) ? op.child2_clv : op.child1_clv;
+      if (tt_writer[inner] >= 0)
+      {
+        cherry_kids[i] = {-2, tt_writer[inner]};
+        kind = 3;
+      }
+    }
     tt_writer[op.parent_clv] = (kind == 2) ? (int)i : -1;
     plan[i].key = (lvl << 8) | ((unsigned int)kind << 4) | (unsigned int)mode;
     plan[i].order = i;
@@ -666,7 +676,13 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       while (i < count && plan[i].key == key)
       {
         cops.push_back(plan[i].a);
-        k1.push_back(by_pos[cherry_kids[plan[i].order].first]);
+        if (cherry_kids[plan[i].order].first >= 0) k1.push_back(by_pos[cherry_kids[plan[i].order].first]);
+        else
+        {
+          PartialsArgs none; // marks a tip-inner lookup op (no producing op on the tip's side)
+          memset(&none, 0, sizeof(none));
+          k1.push_back(none);
+        }
         k2.push_back(by_pos[cherry_kids[plan[i].order].second]);
         ++i;
       }

@@ -644,6 +644,29 @@ static __global__ void k_aa_cherry_consts(unsigned char * hi, unsigned char * lo
   if (t < RC * 400) ident[t] = ((t % 400) / 20 == t % 20) ? 1.0 : 0.0;
 }
 
+// tip-inner lookup ops: the tip's factor as "pair" table rows (code, 0): the row sums of
+// k_aa_tip_tables, same expression
+struct TipMats
+{
+  const double * m[PLLHIP_BATCH_MAX]; // nullptr: not a tip-inner lookup op
+};
+
+static __global__ void k_aa_tiprow_tables(CherryBatch batch, TipMats lmats,
+                                          const unsigned int * __restrict__ tipmap, unsigned int ms,
+                                          unsigned int RC)
+{
+  const CherryArgs & a = batch.op[blockIdx.y];
+  const double * lmat = lmats.m[blockIdx.y];
+  if (!lmat) return;
+  double * tl = const_cast<double *>(a.tl);
+  const unsigned int per = ms * RC * 20;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < per; t += gridDim.x * blockDim.x)
+  {
+    const unsigned int code = t / (RC * 20), ki = t % (RC * 20);
+    tl[((size_t)code * ms) * RC * 20 + ki] = masksum_seq(lmat + (size_t)ki * 20, tipmap[code], 20);
+  }
+}
+
 int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
                               const PartialsArgs * kid2, unsigned int count, int mode)
 {
@@ -668,6 +691,11 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
     const size_t per_op = 4 * rows * row_elems;
     HIP_TRY(hipMalloc((void **)&c->cherry_pool, (chunk * per_op + rows * row_elems + (size_t)R * 400) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->cherry_codes, 2 * rows));
+    if (!c->cherry_zero)
+    {
+      HIP_TRY(hipMalloc((void **)&c->cherry_zero, (size_t)c->sh.sites + PLLHIP_TAIL_SITES));
+      HIP_TRY(hipMemsetAsync(c->cherry_zero, 0, (size_t)c->sh.sites + PLLHIP_TAIL_SITES, c->stream));
+    }
     double * ones = c->cherry_pool + chunk * per_op;
     k_aa_cherry_consts<<<(unsigned int)((rows * row_elems + 255) / 256), 256, 0, c->stream>>>(
         c->cherry_codes, c->cherry_codes + rows, ones, ones + rows * row_elems, ms, (unsigned int)rows, R);
@@ -682,6 +710,10 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
     const unsigned int n = (count - first < chunk) ? count - first : chunk;
     PartialsBatch tt, ii;
     CherryBatch ch;
+    unsigned int ntab = 0;
+    TipMats h_lmats;
+    memset(&h_lmats, 0, sizeof(h_lmats));
+    bool any_tip_left = false;
     for (unsigned int i = 0; i < n; ++i)
     {
       const PartialsArgs & op = ops[first + i];
@@ -689,10 +721,14 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
       double * pair_clv[2] = {base, base + rows * row_elems};
       double * table[2] = {base + 2 * rows * row_elems, base + 3 * rows * row_elems};
       const PartialsArgs * kid[2] = {&kid1[first + i], &kid2[first + i]};
+      // tip-inner lookup op (kid 1 is a dummy): the left factor is the tip's own table
+      const bool tip_left = kid[0]->lmat == nullptr;
+      h_lmats.m[i] = tip_left ? op.lmat : nullptr;
       for (int s = 0; s < 2; ++s)
       {
+        if (s == 0 && tip_left) continue;
         // the child over all character pairs, by the tip-tip kernel and the child op's matrices
-        PartialsArgs & t = tt.op[2 * i + s];
+        PartialsArgs & t = tt.op[ntab];
         memset(&t, 0, sizeof(t));
         t.parent = pair_clv[s];
         t.ltip = c->cherry_codes;
@@ -706,7 +742,7 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
         t.states = 20;
         t.maxstates = ms;
         // P x child by the inner-inner kernel; the other factor is identity x ones = 1
-        PartialsArgs & u = ii.op[2 * i + s];
+        PartialsArgs & u = ii.op[ntab++];
         memset(&u, 0, sizeof(u));
         u.parent = table[s];
         u.left = pair_clv[s];
@@ -723,8 +759,8 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
       CherryArgs & k = ch.op[i];
       k.tl = table[0];
       k.tr = table[1];
-      k.t1 = kid[0]->ltip;
-      k.t2 = kid[0]->rtip;
+      k.t1 = tip_left ? op.ltip : kid[0]->ltip;
+      k.t2 = tip_left ? c->cherry_zero : kid[0]->rtip;
       k.t3 = kid[1]->ltip;
       k.t4 = kid[1]->rtip;
       k.parent = op.parent;
@@ -732,10 +768,16 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
       k.sites = op.sites;
       k.maxstates = ms;
     }
-    int rc = pllhip_launch_aa_batch(c, tt, 2 * n, 2, SCALE_NONE);
+    int rc = pllhip_launch_aa_batch(c, tt, ntab, 2, SCALE_NONE);
     if (rc) return rc;
-    rc = pllhip_launch_aa_batch(c, ii, 2 * n, 0, SCALE_NONE);
+    rc = pllhip_launch_aa_batch(c, ii, ntab, 0, SCALE_NONE);
     if (rc) return rc;
+    for (unsigned int i = 0; i < n; ++i) any_tip_left = any_tip_left || h_lmats.m[i];
+    if (any_tip_left)
+    {
+      k_aa_tiprow_tables<<<dim3(4, n), 256, 0, c->stream>>>(ch, h_lmats, c->tipmap, ms, R);
+      HIP_TRY(hipGetLastError());
+    }
     const size_t rounds = ((size_t)c->sh.sites + 63) / 64;
     size_t blocks = (rounds + 3) / 4;
     const size_t cap = (size_t)c->num_cus * 8;
