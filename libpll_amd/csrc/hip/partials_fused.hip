@@ -75,6 +75,8 @@ struct FusedFetch
 {
   double2 pm[PL];                   // its 16 bytes of the two P-matrices (a coalesced block per wave)
   unsigned int codes_l[J], codes_r[J]; // tip characters of the lane's own site in each sub-step
+  double2 kl[EXT ? J : 1], kr[EXT ? J : 1];     // EXT: operands from HBM
+  unsigned int cl[EXT ? J : 1], cr[EXT ? J : 1]; //      and inherited scaler counts from HBM
   // element by element: a plain struct assignment of the arrays goes through scratch memory
   __device__ __forceinline__ void take(const FusedFetch & o)
   {
@@ -86,20 +88,8 @@ struct FusedFetch
       codes_l[j] = o.codes_l[j];
       codes_r[j] = o.codes_r[j];
     }
-  }
-};
-
-// EXT: operands and inherited scaler counts that live in HBM, requested ONE op ahead (their
-// producers, if in the list, ran at least two ops earlier): two sets in flight, not three
-template <int J>
-struct FusedExt
-{
-  double2 kl[J], kr[J];
-  unsigned int cl[J], cr[J];
-  __device__ __forceinline__ void take(const FusedExt & o)
-  {
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+    for (int j = 0; j < (EXT ? J : 1); ++j)
     {
       kl[j] = o.kl[j];
       kr[j] = o.kr[j];
@@ -174,8 +164,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
         f.codes_l[j] = lt[ltip ? j * SPS + lane / W : 0u];
         f.codes_r[j] = rt[rtip ? j * SPS + lane / W : 0u];
       }
-    };
-    auto request_ext = [&](FusedExt<J> & f, unsigned int i) {
+      if (EXT)
       {
         const double2 * L = reinterpret_cast<const double2 *>(plan[i].left_hbm);
         const double2 * R = reinterpret_cast<const double2 *>(plan[i].right_hbm);
@@ -223,11 +212,6 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
     // and op i runs on registers filled one op ago.
     FusedFetch<PL, J, EXT> cur, fa;
     half_rows pl, pr;
-    FusedExt<J> ext_cur, ext_next;
-    if (EXT)
-    {
-      request_ext(ext_next, 0u);
-    }
     request(cur, 0u, plan[0].lmat, plan[0].rmat, plan[0].ltip, plan[0].rtip);
     request(fa, 1u, plan[1].lmat, plan[1].rmat, plan[1].ltip, plan[1].rtip);
     // The compiler counts the memory operations issued after a load to know how many may
@@ -289,11 +273,6 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       const bool scaling = MODE != SCALE_NONE && pscaler != nullptr;
       FusedFetch<PL, J, EXT> fb;
       request(fb, i + 2u, r_lmat, r_rmat, r_ltip, r_rtip);
-      if (EXT)
-      {
-        ext_cur.take(ext_next);
-        request_ext(ext_next, i + 1u);
-      }
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
@@ -320,10 +299,10 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
         unsigned int rc = cnt[((rsc_slot >= 0 ? rsc_slot : 0) * J + j) * CW + cw];
         if (EXT)
         {
-          if (lslot < 0) lo = ext_cur.kl[j];
-          if (rslot < 0) ro = ext_cur.kr[j];
-          if (lsc_slot < 0) lc = (hbm_flags & 1) ? ext_cur.cl[j] : 0u;
-          if (rsc_slot < 0) rc = (hbm_flags & 2) ? ext_cur.cr[j] : 0u;
+          if (lslot < 0) lo = cur.kl[j];
+          if (rslot < 0) ro = cur.kr[j];
+          if (lsc_slot < 0) lc = (hbm_flags & 1) ? cur.cl[j] : 0u;
+          if (rsc_slot < 0) rc = (hbm_flags & 2) ? cur.cr[j] : 0u;
         }
         else
         {
