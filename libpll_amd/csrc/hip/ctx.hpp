@@ -57,6 +57,13 @@ struct pllhip_ctx
   void * d_plan = nullptr;
   void * d_sink = nullptr; // 1 KB that the stores of lanes past the last site go to
   unsigned int * d_tile_counter = nullptr; // whole-list kernel: next tile to hand out
+  // the op list of the last whole-list launch (its plan is still on the device: an identical
+  // list -- the usual case while branch lengths or model parameters are optimised -- is
+  // launched again without planning or upload)
+  std::vector<pllhip_op_t> fused_last_ops;
+  unsigned int fused_last_entries = 0, fused_last_count = 0, fused_last_nslots = 0;
+  int fused_last_mode = 0;
+  bool fused_last_ext = false;
   double * d_pairtab = nullptr; // pair tables of the tip-tip ops of the current op list
   // 20 states: scratch of the lookup ops (partials_aa_mfma.hip, k_aa_cherry_rounds)
   double * cherry_pool = nullptr;

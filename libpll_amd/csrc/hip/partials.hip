@@ -555,6 +555,13 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // for the per-level launches at 500 k sites; not used)
   if (dna_fast && c->sh.rate_cats <= 4 && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
   {
+    if (c->fused_last_ops.size() == count && !getenv("PLLHIP_FUSED_DEBUG") &&
+        memcmp(c->fused_last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
+    {
+      pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
+      return pllhip_relaunch_fused(c);
+    }
+    c->fused_last_ops.clear();
     std::vector<PartialsArgs> args(count);
     std::vector<int> kinds(count), modes(count);
     for (unsigned int i = 0; i < count; ++i)
@@ -583,7 +590,9 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     if (rc == 0)
     {
       pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
-      return pllhip_launch_fused(c, fplan, nslots, ext);
+      rc = pllhip_launch_fused(c, fplan, nslots, ext);
+      if (rc == 0) c->fused_last_ops.assign(ops, ops + count);
+      return rc;
     }
     // (a list shape the kernel does not take: per-level launches below)
   }

@@ -777,14 +777,31 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, un
   c->plan_pending[b] = true;
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, 128 * sizeof(double2)));
   if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, sizeof(unsigned int)));
+  // what a repeated call with the same op list needs (pllhip_relaunch_fused)
+  c->fused_last_entries = (unsigned int)plan.size();
+  c->fused_last_count = count;
+  c->fused_last_nslots = nslots;
+  c->fused_last_mode = mode;
+  c->fused_last_ext = ext;
+  return pllhip_relaunch_fused(c);
+}
+
+// The device copy of the plan is still that of the previous call (same op list: the plan
+// holds addresses, not values -- P-matrices, tip characters and CLVs are read when the
+// kernels run): tip tables and the list kernel again, no planning, no upload.
+int pllhip_relaunch_fused(pllhip_ctx * c)
+{
+  const unsigned int entries = c->fused_last_entries, count = c->fused_last_count, nslots = c->fused_last_nslots;
+  const int mode = c->fused_last_mode;
+  const bool ext = c->fused_last_ext;
   HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
   const FusedOp * d_plan = (const FusedOp *)c->d_plan;
   switch (c->sh.rate_cats)
   {
-    case 1: k_dna_pair_tables<1><<<(unsigned int)plan.size(), 256, 0, c->stream>>>(d_plan, (unsigned int)plan.size()); break;
-    case 2: k_dna_pair_tables<2><<<(unsigned int)plan.size(), 256, 0, c->stream>>>(d_plan, (unsigned int)plan.size()); break;
-    case 4: k_dna_pair_tables<4><<<(unsigned int)plan.size(), 256, 0, c->stream>>>(d_plan, (unsigned int)plan.size()); break;
-    default: k_dna_pair_tables<8><<<(unsigned int)plan.size(), 256, 0, c->stream>>>(d_plan, (unsigned int)plan.size()); break;
+    case 1: k_dna_pair_tables<1><<<entries, 256, 0, c->stream>>>(d_plan, entries); break;
+    case 2: k_dna_pair_tables<2><<<entries, 256, 0, c->stream>>>(d_plan, entries); break;
+    case 4: k_dna_pair_tables<4><<<entries, 256, 0, c->stream>>>(d_plan, entries); break;
+    default: k_dna_pair_tables<8><<<entries, 256, 0, c->stream>>>(d_plan, entries); break;
   }
   HIP_TRY(hipGetLastError());
   switch (c->sh.rate_cats)

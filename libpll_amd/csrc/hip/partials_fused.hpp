@@ -40,5 +40,6 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
                       std::vector<FusedOp> & plan, bool * ext, unsigned int * evictions);
 unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int workgroups_per_cu);
 int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots, bool ext);
+int pllhip_relaunch_fused(pllhip_ctx * c); // the same op list as in the previous whole-list call of this context
 
 #endif

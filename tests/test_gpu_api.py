@@ -200,6 +200,43 @@ def test_random_op_sequences_other_state_counts(gpu, orc, states, rate_cats, see
     p.destroy()
 
 
+@pytest.mark.parametrize("states", [4, 20])
+def test_same_list_again_after_branch_lengths_changed(gpu, orc, states, monkeypatch):
+    """The whole-list kernel keeps the plan of the previous call when the op list is the same;
+    the plan holds addresses only, so new branch lengths (P-matrices) and new tip sequences must
+    show in the second call's results: compared with a partition that never ran the list before."""
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")
+    case = make_case(states, "random", 14, 210, seed=91)
+    plan = case["plan"]
+    R = case["rate_cats"]
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    p.update_partials(plan.ops)                       # (second call: the kept plan)
+    rng = np.random.default_rng(17)
+    plan.branch_lengths = rng.uniform(0.02, 0.8, len(plan.matrix_indices))
+    seqs = list(case["seqs"])
+    seqs[3], seqs[5] = seqs[5], seqs[3]
+    case["seqs"] = seqs
+    cmap = gpu.map("nt" if states == 4 else "aa")
+    p.set_tip_states(3, cmap, seqs[3])
+    p.set_tip_states(5, cmap, seqs[5])
+    p.update_prob_matrices([0] * R, plan.matrix_indices, plan.branch_lengths)
+    p.update_partials(plan.ops)                       # same list, new values
+    q = build_partition(gpu, case, ATTRIB_PATTERN_TIP)  # fresh: plans the list itself
+    q.update_partials(plan.ops)
+    for op in plan.ops:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        assert bits_equal(p.get_clv(node), q.get_clv(node)), "CLV %d" % node
+        if sc >= 0:
+            assert (p.get_scaler(sc) == q.get_scaler(sc)).all()
+    o = oracle_run(orc, gpu, q, case, ATTRIB_PATTERN_TIP)
+    o.update_partials()
+    last = int(plan.ops[-1]["parent_clv_index"])
+    assert bits_equal(p.get_clv(last), o.clv[last])
+    p.destroy()
+    q.destroy()
+
+
 @pytest.mark.parametrize("states,shape", [(4, "random"), (4, "caterpillar"), (20, "random")])
 def test_partial_traversal_after_branch_change(gpu, orc, states, shape, monkeypatch):
     """Incremental update (test/src/partial-traversal.c's use): after one branch
