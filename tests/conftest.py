@@ -89,6 +89,8 @@ def aa_mode(request, monkeypatch):
     """20-state kernels: bit-exact vector kernels (PLLHIP_AA_EXACT=1) or the
     default matrix-core kernels.  Read when a partition is created."""
     monkeypatch.setenv("PLLHIP_AA_EXACT", "1" if request.param == "exact" else "0")
+    # the table-lookup ops (used from 32 k sites on) also for the small test partitions
+    monkeypatch.setenv("PLLHIP_AA_CHERRY", "2")
     return request.param
 
 
