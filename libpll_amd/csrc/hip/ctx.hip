@@ -283,6 +283,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
     if (c->plan_done[b]) (void)hipEventDestroy(c->plan_done[b]);
   }
   pllhip_rep_work_free(c);
+  pllhip_level_cache_free(c);
   for (pllhip_ctx::node_rows & r : c->rows)
     for (void * p : {(void *)r.site_id, (void *)r.lrow, (void *)r.rrow})
       if (p) (void)hipFree(p);

@@ -61,6 +61,7 @@ struct pllhip_ctx
   // list -- the usual case while branch lengths or model parameters are optimised -- is
   // launched again without planning or upload)
   std::vector<pllhip_op_t> fused_last_ops;
+  struct pllhip_level_cache * level_cache = nullptr; // the same for the per-level path (partials.hip)
   unsigned int fused_last_entries = 0, fused_last_count = 0, fused_last_nslots = 0;
   int fused_last_mode = 0;
   bool fused_last_ext = false;
@@ -250,6 +251,7 @@ struct PartialsBatch
 enum { SCALE_NONE = 0, SCALE_SITE = 1, SCALE_RATE = 2 };
 
 void pllhip_rep_work_free(pllhip_ctx * c); // repeats.hip
+void pllhip_level_cache_free(pllhip_ctx * c); // partials.hip
 
 // partials_gen_tile.hip: state counts other than 4 and 20
 bool pllhip_gen_tile_covers(const pllhip_ctx * c);

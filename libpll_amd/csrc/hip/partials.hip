@@ -404,6 +404,27 @@ int pllhip_launch_partials(pllhip_ctx * c, const PartialsArgs & a_in, int kind, 
   return 0;
 }
 
+// the plan of the previous per-level call of a context (see pllhip_update_partials)
+struct pllhip_planned_op
+{
+  PartialsArgs a;
+  unsigned int key; // level << 8 | kind << 4 | mode
+  unsigned int order;
+};
+struct pllhip_level_cache
+{
+  std::vector<pllhip_op_t> last_ops;
+  unsigned int last_maxstates = 0;
+  std::vector<pllhip_planned_op> plan;
+  std::vector<PartialsArgs> by_pos;
+  std::vector<std::pair<int, int>> cherry;
+};
+void pllhip_level_cache_free(pllhip_ctx * c)
+{
+  delete c->level_cache;
+  c->level_cache = nullptr;
+}
+
 // resolves one op into kernel arguments; kind and mode as in pllhip_launch_partials
 static int resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, int & kind, int & mode)
 {
@@ -597,18 +618,26 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     // (a list shape the kernel does not take: per-level launches below)
   }
 
-  struct Planned
+  // The plan of the previous per-level call is kept: an identical op list (the usual case
+  // while branch lengths or model parameters are optimised) goes straight to the launches.
+  // (Not with site repeats: the row maps in the arguments change with the classes.)
+  typedef pllhip_planned_op Planned;
+  if (!c->level_cache) c->level_cache = new pllhip_level_cache();
+  pllhip_level_cache & lc = *c->level_cache;
+  std::vector<Planned> & plan = lc.plan;
+  std::vector<PartialsArgs> & by_pos = lc.by_pos;
+  std::vector<std::pair<int, int>> & cherry_kids = lc.cherry;
+  const bool plan_kept = c->rows.empty() && lc.last_ops.size() == count && lc.last_maxstates == c->maxstates &&
+                         memcmp(lc.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0;
+  if (!plan_kept)
   {
-    PartialsArgs a;
-    unsigned int key; // level << 8 | kind << 4 | mode
-    unsigned int order;
-  };
-  std::vector<Planned> plan(count);
+  lc.last_ops.clear();
+  plan.assign(count, Planned());
   // 20 states: an inner-inner op whose children are both tip-tip results of this list is
   // a table lookup (partials_aa_mfma.hip, k_aa_cherry_rounds): kind 3 here, with the two
   // producing ops remembered
   std::vector<int> tt_writer(c->clv.size(), -1);           // list op that wrote the CLV, if it was tip-tip
-  std::vector<std::pair<int, int>> cherry_kids(count, {-1, -1});
+  cherry_kids.assign(count, {-1, -1});
   // highest level that wrote / has read each buffer since its last write
   std::vector<unsigned int> clv_w(c->clv.size(), 0u), clv_r(c->clv.size(), 0u);
   std::vector<unsigned int> sc_w(c->sh.scale_buffers, 0u), sc_r(c->sh.scale_buffers, 0u);
@@ -665,7 +694,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   }
 
   // (the producers' arguments by list position: the sort below moves the entries)
-  std::vector<PartialsArgs> by_pos;
+  by_pos.clear();
   if (aa_fast)
   {
     by_pos.resize(count);
@@ -673,6 +702,12 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   }
   std::stable_sort(plan.begin(), plan.end(),
                    [](const Planned & x, const Planned & y) { return x.key < y.key; });
+  if (c->rows.empty())
+  {
+    lc.last_ops.assign(ops, ops + count);
+    lc.last_maxstates = c->maxstates;
+  }
+  } // !plan_kept
 
   PartialsBatch b;
   for (unsigned int i = 0; i < count;)
