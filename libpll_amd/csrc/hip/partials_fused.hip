@@ -135,10 +135,19 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
   const size_t tiles = ((size_t)sites + TS - 1) / TS;
   const size_t wave = (size_t)blockIdx.x * 4u + wave_in_wg;
   const size_t nwaves = (size_t)gridDim.x * 4u;
+  // every wave has 1280 bytes of sink of its own: thousands of waves storing to ONE block
+  // serialise on its cache lines (measured: ~0.7 ms per launch at 1 M sites, hidden behind a
+  // 62-op list but not behind a 5-op one)
+  sink += wave * 80;
 
-  // A wave's first tile is its own number; further tiles come from a counter (starting at
-  // the number of waves), so that no wave idles while another still has a tile of ~100 us
-  // ahead of it (20 or 21 tiles per wave with a fixed stride: up to 5 % of tail).
+  // All but the last two of a wave's share of the tiles are its own by a fixed stride; the
+  // rest come from a counter, so that no wave idles while another still has a tile of ~100 us
+  // ahead of it (20 or 21 tiles per wave with a fixed stride alone: up to 5 % of tail).
+  // All from the counter was measured too: atomics on one address serialise at ~12 ns, a
+  // floor of 0.7 ms per launch at 1 M sites -- hidden behind a 62-op list, not behind 15 ops.
+  size_t static_rounds = tiles / nwaves > 2 ? tiles / nwaves - 2 : 1; // (the last two rounds from the counter)
+  if (!next_tile) static_rounds = ~(size_t)0;
+  size_t round = 0;
   for (size_t tile = wave; tile < tiles;)
   {
     const size_t site0 = tile * TS;
@@ -222,8 +231,8 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
 #pragma unroll
     for (unsigned int j = 0; j < J; ++j)
     {
-      st16<NT>(sink + 64 + lane, 0.0, 0.0);
-      if (MODE != SCALE_NONE) reinterpret_cast<unsigned int *>(sink)[lane] = 0u;
+      st16<NT>(sink + lane, 0.0, 0.0);
+      if (MODE != SCALE_NONE) reinterpret_cast<unsigned int *>(sink + 64)[lane] = 0u;
     }
     stage_rows(cur, pl, pr);
     // The scalar (plan) fields are fetched one op ahead as well: what op i computes with and
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       // (the counts of an op without a scale buffer go to a sink, so that every op issues the
       // same number of stores, see below)
       unsigned int * cnt_tile = scaling ? pscaler + ((MODE == SCALE_RATE) ? site0 * RC : site0)
-                                        : reinterpret_cast<unsigned int *>(sink);
+                                        : reinterpret_cast<unsigned int *>(sink + 64);
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
@@ -390,14 +399,14 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       cur.take(fa);
       fa.take(fb);
     }
-    if (!next_tile)
+    if (++round < static_rounds)
     {
-      tile += nwaves; // (fixed stride: for measurements)
+      tile += nwaves;
       continue;
     }
     unsigned int nt = 0;
     if (lane == 0) nt = atomicAdd(next_tile, 1u);
-    tile = (size_t)nwaves + (unsigned int)__builtin_amdgcn_readfirstlane((int)nt);
+    tile = static_rounds * nwaves + (unsigned int)__builtin_amdgcn_readfirstlane((int)nt);
   }
 }
 
@@ -775,7 +784,7 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, un
   HIP_TRY(hipMemcpyAsync(c->d_plan, c->h_plan[b], bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
-  if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, 128 * sizeof(double2)));
+  if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 80 * sizeof(double2))); // 1280 B per wave
   if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, sizeof(unsigned int)));
   // what a repeated call with the same op list needs (pllhip_relaunch_fused)
   c->fused_last_entries = (unsigned int)plan.size();
