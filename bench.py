@@ -50,7 +50,7 @@ TRAFFIC_PER_OP = {4: 396.0e6, 20: 387.6e6}
 TRAFFIC_SITES = {4: 1_000_000, 20: 200_000}
 # the same for the whole-list launch of 4-state data, keyed by (rate_cats, sites, taxa, tree,
 # tip CLVs, per-rate scalers): bytes per launch
-TRAFFIC_FUSED = {(4, 1_000_000, 64, "balanced", False, False): 8476.6e6}  # profiles/r1_pmc_hbm_traffic.csv
+TRAFFIC_FUSED = {(4, 1_000_000, 64, "balanced", False, False): 8416.1e6}  # profiles/r1_pmc_hbm_traffic.csv
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
 
