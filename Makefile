@@ -18,9 +18,9 @@ HIP_OBJ  := $(patsubst libpll_amd/csrc/hip/%.hip,$(BUILD)/hip_%.o,$(HIP_SRC))
 CFLAGS   := -std=gnu11 -O2 -fPIC -g -Wall -Wextra -ffp-contract=off -fvisibility=hidden \
             -Iinclude -Ilibpll_amd/csrc/host
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -ffp-contract=off -fvisibility=hidden \
-            -Wall -Iinclude -Ilibpll_amd/csrc/hip
+            -Wall -Iinclude -Ilibpll_amd/csrc/hip $(EXTRA_HIPFLAGS)
 
-.PHONY: lib oracle all clean
+.PHONY: lib oracle all clean asan
 lib: $(OUT)
 all: lib oracle
 
@@ -39,6 +39,35 @@ $(OUT): $(HOST_OBJ) $(HIP_OBJ)
 
 oracle:
 	$(MAKE) -C oracle all
+
+# CPU-side sanitizer build (the reference's analogue: test/eval_valgrind.sh): the host C
+# layer and the oracle compiled with AddressSanitizer + UBSan, linked with the ordinary HIP
+# objects, and the whole non-GPU test suite run against them (host logic, the FASTA/PHYLIP
+# corpus, compression, tree builders, the planner's dry run).  CPU build only -- sanitizers
+# are not run on the GPU box.
+ASAN_DIR   := $(BUILD)/asan
+ASAN_FLAGS := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -O1
+ASAN_OBJ   := $(patsubst libpll_amd/csrc/host/%.c,$(ASAN_DIR)/host_%.o,$(HOST_SRC))
+
+$(ASAN_DIR):
+	mkdir -p $@
+
+$(ASAN_DIR)/host_%.o: libpll_amd/csrc/host/%.c include/pll_amd.h include/pllhip.h libpll_amd/csrc/host/internal.h | $(ASAN_DIR)
+	gcc $(filter-out -O2,$(CFLAGS)) $(ASAN_FLAGS) -c $< -o $@
+
+$(ASAN_DIR)/libpll_amd.so: $(ASAN_OBJ) $(HIP_OBJ)
+	g++ -shared -fPIC $(ASAN_FLAGS) -Wl,-Bsymbolic -Wl,-rpath,/opt/rocm/lib -o $@ $(ASAN_OBJ) $(HIP_OBJ) \
+	    -L/opt/rocm/lib -lamdhip64 -lm -ldl
+
+$(ASAN_DIR)/liboracle.so: $(wildcard oracle/*.c) oracle/oracle.h | $(ASAN_DIR)
+	gcc -std=c99 -fPIC -g -Wall -Wextra -ffp-contract=off -mfma -mavx2 -D_GNU_SOURCE $(ASAN_FLAGS) \
+	    -shared -Wl,-Bsymbolic -o $@ $(wildcard oracle/*.c) -lm
+
+asan: $(ASAN_DIR)/libpll_amd.so $(ASAN_DIR)/liboracle.so
+	LD_PRELOAD="$$(gcc -print-file-name=libasan.so) $$(gcc -print-file-name=libubsan.so)" \
+	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:allocator_may_return_null=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+	PLL_AMD_LIB=$(abspath $(ASAN_DIR)/libpll_amd.so) PLL_ORACLE_LIB=$(abspath $(ASAN_DIR)/liboracle.so) \
+	python3 -m pytest tests -x -q -m "not gpu" -p no:cacheprovider
 
 clean:
 	rm -rf $(BUILD) $(OUT)

@@ -103,6 +103,7 @@ extern "C" {
 #define PLL_ERROR_HIP_NODEVICE 200
 #define PLL_ERROR_HIP_RUNTIME 201
 #define PLL_ERROR_HIP_UNSUPPORTED 202
+#define PLL_ERROR_HIP_SUMTABLE_EVICTED 203
 
 #define PLL_GAMMA_RATES_MEAN 0
 #define PLL_GAMMA_RATES_MEDIAN 1
@@ -426,7 +427,13 @@ PLL_EXPORT double pll_compute_edge_loglikelihood(pll_partition_t * partition,
 /* `sumtable` is a caller-owned host buffer as in the reference.  The library
  * keeps the authoritative copy on the device, keyed by this pointer, and
  * writes the host buffer only when pll_amd_set_mirror_mode(1) is active or
- * pll_amd_sync_sumtable is called. */
+ * pll_amd_sync_sumtable is called.  One device table per live host buffer (one
+ * per branch is fine), up to a byte budget (32 GiB worth, at least 4; env
+ * PLL_AMD_SUMTABLE_SLOTS); beyond it the least recently used device table is
+ * recycled, and a later pll_compute_likelihood_derivatives / pll_amd_sync_sumtable
+ * on ITS buffer fails with PLL_ERROR_HIP_SUMTABLE_EVICTED (203) -- call
+ * pll_update_sumtable again.  A buffer the library has never seen is taken as
+ * filled by the caller and uploaded. */
 PLL_EXPORT int pll_update_sumtable(pll_partition_t * partition,
                                    unsigned int parent_clv_index,
                                    unsigned int child_clv_index,
@@ -508,6 +515,9 @@ PLL_EXPORT int pll_amd_sync_clv(pll_partition_t * partition, unsigned int clv_in
 PLL_EXPORT int pll_amd_sync_scaler(pll_partition_t * partition, unsigned int scaler_index);
 PLL_EXPORT int pll_amd_sync_pmatrix(pll_partition_t * partition, unsigned int matrix_index);
 PLL_EXPORT int pll_amd_sync_sumtable(pll_partition_t * partition, double * sumtable);
+/* Tell the library a sumtable buffer is about to be freed or refilled by hand: its key is
+ * forgotten, so a new buffer at the same address is not mistaken for the old table. */
+PLL_EXPORT int pll_amd_forget_sumtable(pll_partition_t * partition, const double * sumtable);
 /* block until all work enqueued for this partition has finished */
 PLL_EXPORT int pll_amd_wait(pll_partition_t * partition);
 

@@ -127,6 +127,23 @@ PLLHIP_EXPORT int pllhip_update_pmatrices(pllhip_ctx_t * ctx,
 PLLHIP_EXPORT int pllhip_update_partials(pllhip_ctx_t * ctx, const pllhip_op_t * h_ops,
                                          unsigned int count);
 
+/* The op-list planner of the 4-state whole-list kernel (partials_fused.hip) on its own -- host
+ * logic, no device needed: the order it gives the list (order_out[pos] = position in ops),
+ * how many inner operands would have no on-chip slot with `nslots` slots per wave, and how
+ * often a live value had to give its slot up (reload != 0: the plan in which such operands
+ * are copied back into a slot by LDS-DMA one op ahead of their reader; 0: the plan in which the
+ * reader fetches them into registers).  slots_out (nullable, 6 ints per op in the new order):
+ * left / right / parent slot, the slots the inherited counts are read from, and flags (bit 0 / 1:
+ * left / right operand comes from HBM; bits 2, 3: it is copied into its slot one op ahead).
+ * Returns 0, 1 if the kernel does not take the
+ * list's shape (the per-level launches run it then), -1 on bad indices. */
+PLLHIP_EXPORT int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buffers,
+                                        unsigned int scale_buffers, int pattern_tip,
+                                        const pllhip_op_t * ops, unsigned int count,
+                                        unsigned int nslots, int reload, unsigned int * order_out,
+                                        unsigned int * hbm_operands_out, unsigned int * evictions_out,
+                                        int * slots_out);
+
 /* replaces pll_core_edge_loglikelihood_ii / _ti / _ti_4x4
  * (core_likelihood.c:726,412,211).  A clv index < tips in pattern-tip mode
  * selects the tip-inner kernel.  h_persite_lnl may be NULL.  The returned
@@ -148,8 +165,13 @@ PLLHIP_EXPORT int pllhip_root_loglikelihood(pllhip_ctx_t * ctx,
                                             double * h_lnl);
 
 /* replaces pll_core_update_sumtable_ii / _ti (core_derivatives.c:125,277).
- * The table stays on the device in slot `slot` (0..PLLHIP_SUMTABLE_SLOTS-1). */
-#define PLLHIP_SUMTABLE_SLOTS 4
+ * The table stays on the device in slot `slot` (0..PLLHIP_SUMTABLE_MAX_SLOTS-1; a slot's
+ * buffer -- one CLV's size -- is allocated when it is first used and released by
+ * pllhip_release_sumtable or with the context).  pllhip_sumtable_budget: how many slots
+ * the host layer should keep alive at most (a byte budget, env PLL_AMD_SUMTABLE_SLOTS). */
+#define PLLHIP_SUMTABLE_MAX_SLOTS 256
+PLLHIP_EXPORT unsigned int pllhip_sumtable_budget(pllhip_ctx_t * ctx);
+PLLHIP_EXPORT int pllhip_release_sumtable(pllhip_ctx_t * ctx, unsigned int slot);
 PLLHIP_EXPORT int pllhip_update_sumtable(pllhip_ctx_t * ctx,
                                          unsigned int parent_clv, int parent_scaler,
                                          unsigned int child_clv, int child_scaler,

@@ -11,7 +11,8 @@ import os
 from .pllapi import PllLibrary, PllError  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpll_amd.so")
+# (PLL_AMD_LIB: another build of the same library, e.g. `make asan`'s sanitizer build)
+LIB_PATH = os.environ.get("PLL_AMD_LIB") or os.path.join(_HERE, "libpll_amd.so")
 _lib = None
 
 

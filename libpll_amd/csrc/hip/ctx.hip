@@ -93,6 +93,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_FUSED_PAIRS")) c->fused_pairs = atoi(e);
+  if (const char * e = getenv("PLLHIP_FUSED_RELOAD")) c->fused_reload = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_FUSED"))
   {
     c->no_fused = atoi(e) == 0;
@@ -267,7 +268,9 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
                    c->eigenvecs, c->inv_eigenvecs, c->freqs, c->prop_invar, c->rates,
                    c->rate_weights, c->pattern_weights, c->invariant, c->tipmap,
                    c->block_partials, c->d_result, c->d_counter, c->d_zero, c->d_tiptab, c->d_persite, c->d_stage, c->d_asc,
-                   c->sumtable[0], c->sumtable[1], c->sumtable[2], c->sumtable[3], c->lnl_scratch};
+                   c->lnl_scratch};
+  for (double * t : c->sumtable)
+    if (t) (void)hipFree(t);
   for (void * p : bufs)
     if (p) (void)hipFree(p);
   if (c->d_plan) (void)hipFree(c->d_plan);
@@ -470,7 +473,7 @@ extern "C" int pllhip_get_pmatrix(pllhip_ctx_t * c, unsigned int idx, double * h
 
 extern "C" int pllhip_put_sumtable(pllhip_ctx_t * c, unsigned int slot, const double * h)
 {
-  if (slot >= PLLHIP_SUMTABLE_SLOTS) { pllhip_set_error("sumtable slot %u", slot); return -1; }
+  if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS) { pllhip_set_error("sumtable slot %u", slot); return -1; }
   HIP_TRY(hipSetDevice(c->sh.device));
   if (!c->sumtable[slot]) HIP_TRY(hipMalloc((void **)&c->sumtable[slot], (c->clv_elems + PLLHIP_TAIL_SITES * c->span) * sizeof(double)));
   return h2d(c, c->sumtable[slot], h, c->clv_elems * sizeof(double));
@@ -478,12 +481,40 @@ extern "C" int pllhip_put_sumtable(pllhip_ctx_t * c, unsigned int slot, const do
 
 extern "C" int pllhip_get_sumtable(pllhip_ctx_t * c, unsigned int slot, double * h)
 {
-  if (slot >= PLLHIP_SUMTABLE_SLOTS || !c->sumtable[slot])
+  if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || !c->sumtable[slot])
   {
     pllhip_set_error("sumtable slot %u empty", slot);
     return -1;
   }
   return d2h(c, h, c->sumtable[slot], c->clv_elems * sizeof(double));
+}
+
+// Slots the host layer keeps alive before it recycles the least recently used one: what
+// fits 32 GiB (a table has the size of a CLV: 128 MB at 1 M sites x 4 x 4), at least 4, at
+// most all of them; env PLL_AMD_SUMTABLE_SLOTS overrides.
+extern "C" unsigned int pllhip_sumtable_budget(pllhip_ctx_t * c)
+{
+  if (const char * e = getenv("PLL_AMD_SUMTABLE_SLOTS"))
+  {
+    const int n = atoi(e);
+    if (n >= 1) return n > PLLHIP_SUMTABLE_MAX_SLOTS ? PLLHIP_SUMTABLE_MAX_SLOTS : (unsigned int)n;
+  }
+  const size_t bytes = c->clv_elems * sizeof(double);
+  size_t n = ((size_t)32 << 30) / (bytes ? bytes : 1);
+  if (n < 4) n = 4;
+  if (n > PLLHIP_SUMTABLE_MAX_SLOTS) n = PLLHIP_SUMTABLE_MAX_SLOTS;
+  return (unsigned int)n;
+}
+
+extern "C" int pllhip_release_sumtable(pllhip_ctx_t * c, unsigned int slot)
+{
+  if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS) { pllhip_set_error("sumtable slot %u", slot); return -1; }
+  if (!c->sumtable[slot]) return 0;
+  HIP_TRY(hipSetDevice(c->sh.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipFree(c->sumtable[slot]));
+  c->sumtable[slot] = nullptr;
+  return 0;
 }
 
 extern "C" void * pllhip_dev_clv(pllhip_ctx_t * c, unsigned int idx)

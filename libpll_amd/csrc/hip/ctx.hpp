@@ -51,7 +51,7 @@ struct pllhip_ctx
   std::vector<double> h_prop_invar;
   unsigned int * tipmap = nullptr;     // [256]
   unsigned int maxstates = 0;
-  double * sumtable[PLLHIP_SUMTABLE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  double * sumtable[PLLHIP_SUMTABLE_MAX_SLOTS] = {}; // allocated on first use
   double * lnl_scratch = nullptr; // CLV-sized: per-state lnL terms of the two-pass kernels (likelihood.hip)
   // whole-list kernel (partials_fused.hip): the plan's device copy and two pinned staging buffers
   void * d_plan = nullptr;
@@ -79,6 +79,7 @@ struct pllhip_ctx
   int plan_next = 0;
   bool no_fused = false; // env PLLHIP_FUSED=0: one launch per dependency level instead
   int fused_pairs = 2;      // env PLLHIP_FUSED_PAIRS
+  bool fused_reload = true; // env PLLHIP_FUSED_RELOAD=0: operands without a slot into registers (EXT plan) instead of LDS-DMA
   bool force_fused = false; // env PLLHIP_FUSED=2: also for partitions too small for it to pay (tests)
 
   // reductions: per-block partial sums, then a fixed-order final pass

@@ -88,7 +88,7 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
 {
   HIP_TRY(hipSetDevice(c->sh.device));
   const unsigned int nodes = (unsigned int)c->clv.size();
-  if (slot >= PLLHIP_SUMTABLE_SLOTS || parent_clv >= nodes || child_clv >= nodes ||
+  if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || parent_clv >= nodes || child_clv >= nodes ||
       parent_scaler >= (int)c->sh.scale_buffers || child_scaler >= (int)c->sh.scale_buffers)
   {
     pllhip_set_error("pllhip_update_sumtable: index out of range");
@@ -563,7 +563,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
                                              double * h_dd_f)
 {
   HIP_TRY(hipSetDevice(c->sh.device));
-  if (slot >= PLLHIP_SUMTABLE_SLOTS || !c->sumtable[slot])
+  if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || !c->sumtable[slot])
   {
     pllhip_set_error("pllhip_likelihood_derivatives: sumtable slot %u empty", slot);
     return -1;

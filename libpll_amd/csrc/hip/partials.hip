@@ -595,21 +595,41 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       if (rc) return rc;
     }
     // three workgroups per CU (12 waves) hide the per-op latencies better than two, but
-    // leave one LDS slot less per wave: taken when the list fits without giving a slot up
+    // leave one LDS slot less per wave (6 against 7 at 4 rate categories).
+    // First choice: the RELOAD plan -- every operand is read from a slot; the few that have
+    // none (a value that gave its slot up; operands written by earlier calls) are copied back
+    // into one by LDS-DMA one op ahead (no registers: the lean kernel variant).  Lists it does
+    // not take (counts that were not written together with their CLV) get the EXT plan, in
+    // which the reader fetches such operands into registers itself.
     std::vector<FusedOp> fplan;
     bool ext = false;
     unsigned int evictions = 0;
+    const FusedGeom geom = {c->clv.size(), c->sh.scale_buffers, c->sh.tips, c->sh.pattern_tip != 0};
     unsigned int nslots = pllhip_fused_slots(c, 3);
-    int rc = pllhip_fused_plan(c, ops, args.data(), kinds.data(), modes.data(), count, nslots, fplan, &ext, &evictions);
-    // (measured, 200-taxon random tree x 500 k sites: 8 operands of 396 without a slot on
-    // 12 waves 3.90 ms, 2 without on 8 waves 4.03 ms; a tip-CLV partition, where every tip
-    // operand comes from HBM anyway, 3.17 ms on 8 waves with 7 slots, 3.34 on 12 with 5)
-    unsigned int hbm_operands = 0;
-    for (const FusedOp & f : fplan) hbm_operands += (f.left_hbm != nullptr) + (f.right_hbm != nullptr);
-    if (rc > 0 || (rc == 0 && 10 * hbm_operands > 2 * count)) // more than a tenth of all operands
+    int rc = 1;
+    if (c->fused_reload)
     {
-      nslots = pllhip_fused_slots(c, 2);
-      rc = pllhip_fused_plan(c, ops, args.data(), kinds.data(), modes.data(), count, nslots, fplan, &ext, &evictions);
+      rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, true, fplan, &ext, &evictions);
+      if (rc > 0)
+      {
+        nslots = pllhip_fused_slots(c, 2);
+        rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, true, fplan, &ext, &evictions);
+      }
+    }
+    if (rc > 0)
+    {
+      nslots = pllhip_fused_slots(c, 3);
+      rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, false, fplan, &ext, &evictions);
+      // (measured in round 1, 200-taxon random tree x 500 k sites: 8 operands of 396 without a
+      // slot on 12 waves 3.90 ms, 2 without on 8 waves 4.03 ms; a tip-CLV partition, where every
+      // tip operand comes from HBM anyway, 3.17 ms on 8 waves with 7 slots, 3.34 on 12 with 5)
+      unsigned int hbm_operands = 0;
+      for (const FusedOp & f : fplan) hbm_operands += (f.left_hbm != nullptr) + (f.right_hbm != nullptr);
+      if (rc > 0 || (rc == 0 && 10 * hbm_operands > 2 * count)) // more than a tenth of all operands
+      {
+        nslots = pllhip_fused_slots(c, 2);
+        rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, false, fplan, &ext, &evictions);
+      }
     }
     if (rc < 0) return rc;
     if (rc == 0)

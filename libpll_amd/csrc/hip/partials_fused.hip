@@ -48,6 +48,8 @@
 #include "numerics.hpp"
 #include "partials_fused.hpp"
 
+#define PLL_LDS __attribute__((address_space(3)))
+
 // Tip-tip ops: the parent entry of a site depends on its two tip characters only, 16 x 16
 // pairs.  One table per such op, [pair][rate][state] = masksum4(P_l row, code 1) *
 // masksum4(P_r row, code 2) -- the very product the kernel would form per site (30 VALU
@@ -114,13 +116,19 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
   const unsigned int h = lane & 1u;
   const unsigned int k = (lane >> 1) & (RC - 1);
   const unsigned int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // per wave: [nslots][J][64] CLV granules | [2 * MG] matrix granules | counts
+  // per wave: [nslots][J][64] CLV granules | [MG] matrix granules (one matrix at a time) | counts
   // (counts: one word per site, or per (site, rate) with per-rate scalers, of a sub-step)
   constexpr unsigned int CW = (MODE == SCALE_RATE) ? 32u : (SPS < 4u ? 4u : SPS); // words per sub-step, 16-byte multiple
-  const size_t wave_g = (size_t)nslots * J * 64 + 2 * MG + (size_t)nslots * J * CW / 4;
+  const size_t wave_g = (size_t)nslots * J * 64 + MG + (size_t)nslots * J * CW / 4;
   double2 * clv = lds_fused + wave_in_wg * wave_g;
   double2 * pst = clv + (size_t)nslots * J * 64;
-  unsigned int * cnt = reinterpret_cast<unsigned int *>(pst + 2 * MG);
+  unsigned int * cnt = reinterpret_cast<unsigned int *>(pst + MG);
+  // the same places as LDS byte addresses (what the LDS-DMA of reload() takes in M0); computed
+  // from the array itself: casting a derived generic pointer back to LDS makes the compiler
+  // emit a null check it cannot always encode
+  const unsigned int clv_lds_b = __builtin_amdgcn_readfirstlane(
+      (unsigned int)(uintptr_t)(PLL_LDS char *)lds_fused + (unsigned int)(wave_in_wg * wave_g * 16));
+  const unsigned int cnt_lds_b = clv_lds_b + (unsigned int)(((size_t)nslots * J * 64 + MG) * 16);
   // the plan is the same for every lane: read it through the scalar path.  It carries one
   // entry more than there are ops (a copy of the last), so that "the next op" always exists.
   typedef const FusedOp __attribute__((address_space(4))) * plan_ptr;
@@ -133,6 +141,13 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
   // predicates, and every address is a wave-uniform tile base plus a lane offset that
   // never changes.
   const size_t tiles = ((size_t)sites + TS - 1) / TS;
+  // Tile = wave number: the four waves of a workgroup take four adjacent tiles, and neighbouring
+  // workgroups -- which the dispatcher deals to the eight XCDs in turn -- the next four.  Giving
+  // each XCD a region of its own instead (a contiguous eighth, or chunks of 16 ... 4096 tiles
+  // dealt round-robin, so that a 2 MB page is written by one XCD only) was measured on the
+  // 62-, 126- and 198-op lists and is slower the larger the chunk: 0.62 / 0.50 / 0.49 of the
+  // HBM peak with this mapping, 0.51 / 0.50 / 0.48 with chunks of 16 tiles, 0.46 / 0.46 / 0.45
+  // with 1024 (profiles/r2_xcd_tile_mapping.txt).
   const size_t wave = (size_t)blockIdx.x * 4u + wave_in_wg;
   const size_t nwaves = (size_t)gridDim.x * 4u;
   // every wave has 1280 bytes of sink of its own: thousands of waves storing to ONE block
@@ -199,20 +214,103 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
     };
 
     // the op's matrices: the wave's coalesced block goes through LDS (the previous op's rows are in registers by then),
-    // each lane takes rows 2h, 2h+1 of category k (own column pair first, then the partner's)
+    // each lane takes rows 2h, 2h+1 of category k (own column pair first, then the partner's).
+    // One matrix at a time through ONE staging block (LDS operations of a wave execute in
+    // order): the 512 bytes this saves per wave are what gives the 12-wave configuration
+    // its sixth slot (a balanced 128-taxon tree needs six).
     auto stage_rows = [&](const FusedFetch<PL, J, EXT> & f, half_rows & pl, half_rows & pr) {
       double2 * p = pst;
 #pragma unroll
       for (int t = 0; t < PL; ++t)
-        if (lane + 64u * t < 2 * MG) p[lane + 64u * t] = f.pm[t];
+        if (lane + 64u * t < MG) p[lane + 64u * t] = f.pm[t];
+      // (what a lane reads was written by OTHER lanes: the compiler, which reasons per
+      // thread, must not carry a value over these lines -- it once served the lanes that do
+      // not write in the second round with their first-round rows)
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 2; ++r)
       {
         const unsigned int row = k * 8 + (2 * h + r) * 2;
         const double2 lo = p[row + h], lp = p[row + 1 - h];
-        const double2 ro = p[MG + row + h], rp = p[MG + row + 1 - h];
         pl.m[r][0] = lo.x; pl.m[r][1] = lo.y; pl.m[r][2] = lp.x; pl.m[r][3] = lp.y;
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < PL; ++t)
+        if (lane + 64u * t >= MG && lane + 64u * t < 2 * MG) p[lane + 64u * t - MG] = f.pm[t];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+      {
+        const unsigned int row = k * 8 + (2 * h + r) * 2;
+        const double2 ro = p[row + h], rp = p[row + 1 - h];
         pr.m[r][0] = ro.x; pr.m[r][1] = ro.y; pr.m[r][2] = rp.x; pr.m[r][3] = rp.y;
+      }
+    };
+
+    // Reload (not EXT): an operand that has no slot -- a value that gave its slot up, or one
+    // written by an earlier call -- is copied from HBM straight into the slot the plan names
+    // for it, by LDS-DMA (global_load_lds: no registers), at the top of the op BEFORE its
+    // reader.  The instructions are inline assembly on purpose: the compiler does not count
+    // them, so they cost no wait of their own -- they are issued ahead of that iteration's
+    // look-ahead loads, memory operations return in order, and the next iteration's first
+    // statement waits for those loads before any slot is read.
+    auto reload = [&](unsigned int i) {
+      const double * src[2] = {plan[i].left_hbm, plan[i].right_hbm};
+      const unsigned int * csrc[2] = {plan[i].lsc_hbm, plan[i].rsc_hbm};
+      const int slot[2] = {plan[i].lslot, plan[i].rslot};
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+      {
+        if (src[o])
+        {
+          // (per-lane 64-bit addresses and `off`, the form the compiler itself emits for the
+          // builtin: the SGPR-base form did not deliver the data)
+          const double2 * base = reinterpret_cast<const double2 *>(src[o]) + site0 * W;
+#pragma unroll
+          for (unsigned int j = 0; j < J; ++j)
+          {
+            const unsigned int lds_b = clv_lds_b + ((unsigned int)slot[o] * J + j) * 1024u;
+            unsigned int m0_saved;
+#ifdef PLLHIP_RELOAD_SADDR
+            const unsigned int voff = (j * 64u + lane) * 16u;
+            if (NT)
+              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                           "global_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
+                           : "=&s"(m0_saved) : "s"(lds_b), "v"(voff), "s"(base) : "memory");
+            else
+              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                           "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                           : "=&s"(m0_saved) : "s"(lds_b), "v"(voff), "s"(base) : "memory");
+#else
+            const double2 * gsrc = base + j * 64u + lane;
+            if (NT)
+              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                           "global_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
+                           : "=&s"(m0_saved) : "s"(lds_b), "v"(gsrc) : "memory");
+            else
+              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                           "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                           : "=&s"(m0_saved) : "s"(lds_b), "v"(gsrc) : "memory");
+#endif
+          }
+        }
+#ifdef PLLHIP_RELOAD_DRAIN
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        if (MODE != SCALE_NONE && csrc[o])
+        {
+          // the tile's counts are J * CW consecutive words: the first so many lanes move one each
+          const unsigned int * cbase = csrc[o] + ((MODE == SCALE_RATE) ? site0 * RC : site0);
+          const unsigned int lds_b = cnt_lds_b + (unsigned int)slot[o] * (J * CW * 4u);
+          const unsigned long long mask = (J * CW >= 64u) ? ~0ull : ((1ull << (J * CW)) - 1ull);
+          const unsigned int * gsrc = cbase + lane;
+          unsigned long long exec_saved;
+          unsigned int m0_saved;
+          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 %1, m0\n\ts_mov_b64 exec, %2\n\ts_mov_b32 m0, %3\n\t"
+                       "s_nop 0\n\tglobal_load_lds_dword %4, off\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+                       : "=&s"(exec_saved), "=&s"(m0_saved) : "s"(mask), "s"(lds_b), "v"(gsrc) : "memory");
+        }
       }
     };
 
@@ -221,6 +319,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
     // and op i runs on registers filled one op ago.
     FusedFetch<PL, J, EXT> cur, fa;
     half_rows pl, pr;
+    if (!EXT && plan[0].dma_flags) reload(0u);
     request(cur, 0u, plan[0].lmat, plan[0].rmat, plan[0].ltip, plan[0].rtip);
     request(fa, 1u, plan[1].lmat, plan[1].rmat, plan[1].ltip, plan[1].rtip);
     // The compiler counts the memory operations issued after a load to know how many may
@@ -251,6 +350,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
     // characters that arrived for it; what op i uses was gathered during op i-1
     const double * x_pair = plan[1].pair_tab;
     const double * n_pair = plan[0].pair_tab;
+    int d_dma = EXT ? 0 : plan[1].dma_flags; // does the NEXT op reload an operand?
     double2 pt_use[J], pt_next[J];
     {
       const double2 * t0 = reinterpret_cast<const double2 *>(n_pair);
@@ -280,14 +380,27 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       n_out = plan[i + 1].parent; n_psc = plan[i + 1].pscaler;
       q_lmat = plan[i + 3].lmat; q_rmat = plan[i + 3].rmat; q_ltip = plan[i + 3].ltip; q_rtip = plan[i + 3].rtip;
       const bool scaling = MODE != SCALE_NONE && pscaler != nullptr;
+      // (rare, wave-uniform: the plan fields of the reload are read on the spot)
+      const int r_dma = d_dma;
+      if (!EXT)
+      {
+        d_dma = plan[i + 2].dma_flags;
+        if (r_dma) reload(i + 1u);
+      }
       FusedFetch<PL, J, EXT> fb;
       request(fb, i + 2u, r_lmat, r_rmat, r_ltip, r_rtip);
+      unsigned int pairs[J];
+#pragma unroll
+      for (unsigned int j = 0; j < J; ++j) pairs[j] = ((fa.codes_l[j] & 15u) << 4) | (fa.codes_r[j] & 15u);
+      // Everything requested one op ago has arrived once these characters are used -- and with
+      // it what that iteration's reload() copied into this op's slots (issued ahead of those
+      // requests; memory operations return in order).  No slot is read above this line.
+      if (!EXT) asm volatile("" ::"v"(pairs[J - 1]) : "memory");
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
         pt_use[j] = pt_next[j];
-        const unsigned int pair = ((fa.codes_l[j] & 15u) << 4) | (fa.codes_r[j] & 15u);
-        pt_next[j] = pair_next ? pair_next[pair * W + (lane & (W - 1))] : zero16[0];
+        pt_next[j] = pair_next ? pair_next[pairs[j] * W + (lane & (W - 1))] : zero16[0];
       }
 
       double2 * out_tile = out + site0 * W;
@@ -432,19 +545,231 @@ unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int wgs)
   const unsigned int sps = 64 / (2 * R);
   const size_t cw = c->sh.rate_scalers ? 32 : (sps < 4 ? 4 : sps);
   const size_t per_slot = (size_t)PLLHIP_FUSED_J * (64 * 16 + cw * 4);
-  const size_t pmat = 2 * (size_t)R * 16 * sizeof(double); // [P_l | P_r]
+  const size_t pmat = (size_t)R * 16 * sizeof(double); // one matrix at a time (stage_rows)
   const size_t budget = PLLHIP_FUSED_J == 1 ? 9472 : (wgs >= 3 ? 13312 : 16384); // J = 1: four workgroups per CU
   return (unsigned int)((budget - pmat) / per_slot);
 }
 
-int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArgs * args,
-                      const int * kinds, const int * modes, unsigned int count, unsigned int nslots,
+// Slot assignment of the RELOAD plan: every inner operand is read from a slot.  A value whose
+// slot was taken away (or that an earlier call wrote) is copied back from HBM into a slot by
+// the kernel's reload() at the top of the op BEFORE its reader; that slot must be free from
+// then on (not read by that op, not its parent's).  Belady's rule decides who gives a slot up:
+// the live value whose next reader is farthest away.
+static int assign_slots_reload(const FusedGeom & geom, const pllhip_op_t * ops, const PartialsArgs * args,
+                               const int * kinds, unsigned int count, unsigned int nslots,
+                               const std::vector<unsigned int> & order, const std::vector<unsigned int> & pos_of,
+                               const std::vector<Node> & node, std::vector<FusedOp> & plan,
+                               unsigned int * reloads_out)
+{
+  // inner operands of the op at each position: producing list op (-1: written by an earlier
+  // call), its HBM address, the HBM address of the counts the reader passes with it, and the
+  // list op that wrote those counts
+  struct Operand { int w; const double * hbm; const unsigned int * sc; int sw; };
+  auto operands = [&](unsigned int i, Operand (&o)[2]) {
+    o[0] = o[1] = Operand{-2, nullptr, nullptr, -1}; // -2: no such operand (a tip)
+    if (kinds[i] == 0)
+    {
+      o[0] = Operand{node[i].raw[0], args[i].left, args[i].lscaler, node[i].sraw[0]};
+      o[1] = Operand{node[i].raw[1], args[i].right, args[i].rscaler, node[i].sraw[1]};
+    }
+    else if (kinds[i] == 1)
+    {
+      const int inner = geom.is_tip(ops[i].child1_clv) ? 1 : 0;
+      o[1] = Operand{node[i].raw[inner], args[i].right, args[i].rscaler, node[i].sraw[inner]};
+    }
+  };
+  std::vector<std::vector<unsigned int>> uses(count); // positions at which each list value is read
+  for (unsigned int pos = 0; pos < count; ++pos)
+  {
+    Operand o[2];
+    operands(order[pos], o);
+    if (o[0].w >= 0) uses[o[0].w].push_back(pos);
+    if (o[1].w >= 0 && o[1].w != o[0].w) uses[o[1].w].push_back(pos);
+  }
+  std::vector<unsigned int> next_use(count, 0);
+  std::vector<int> slot_of(count, -1);
+  std::vector<int> free_slots;
+  for (int s = (int)nslots - 1; s >= 0; --s) free_slots.push_back(s);
+  std::vector<unsigned int> live;          // list values that hold a slot
+  std::vector<int> oneshot, oneshot_next;  // slots of operands from earlier calls (of this op / the next): free after their one reader
+  unsigned int reloads = 0;
+  const unsigned int NEVER = ~0u;
+  auto next_read = [&](unsigned int v) { return next_use[v] < uses[v].size() ? uses[v][next_use[v]] : NEVER; };
+  // a slot that may be written from position `pos` on: a free one, else that of the live
+  // value read farthest in the future -- but not before pos + 2 (its own reload is issued at
+  // the top of the op before its reader and needs a slot free by then)
+  auto take_slot = [&](unsigned int pos) -> int {
+    if (!free_slots.empty())
+    {
+      const int s = free_slots.back();
+      free_slots.pop_back();
+      return s;
+    }
+    int victim = -1;
+    unsigned int far = 0;
+    for (unsigned int v : live)
+    {
+      const unsigned int u = next_read(v);
+      if (u != NEVER && u >= pos + 2 && u >= far)
+      {
+        far = u;
+        victim = (int)v;
+      }
+    }
+    if (victim < 0) return -1;
+    const int s = slot_of[victim];
+    slot_of[victim] = -1;
+    live.erase(std::find(live.begin(), live.end(), (unsigned int)victim));
+    return s;
+  };
+  // operands of the op at position `pos` that are not in a slot: reloaded at the top of
+  // position pos - 1 (`at`; the kernel's prologue for pos 0)
+  auto place_reloads = [&](unsigned int pos, unsigned int at) -> int {
+    const unsigned int i = order[pos];
+    FusedOp & f = plan[pos];
+    Operand o[2];
+    operands(i, o);
+    for (int side = 0; side < 2; ++side)
+    {
+      const Operand & x = o[side];
+      if (x.w == -2) continue;
+      if (side == 1 && x.w >= 0 && x.w == o[0].w) continue; // the same value twice: one slot
+      if (x.w >= 0 && (pos_of[x.w] >= at || slot_of[x.w] >= 0)) continue; // still to come, or in a slot
+      if (x.w >= 0 && pos_of[x.w] + 2 >= pos) return 1; // (cannot happen: evicted values are read later)
+      const int s = take_slot(at);
+      if (s < 0) return 1;
+      ++reloads;
+      const unsigned int * counts = nullptr;
+      if (x.w >= 0)
+      {
+        // a value of this list: its counts are those its producer wrote, whoever reads it
+        counts = args[x.w].pscaler;
+        slot_of[x.w] = s;
+        live.push_back((unsigned int)x.w);
+      }
+      else
+      {
+        // written by an earlier call: the counts the reader passes, which no op of this list
+        // may have rewritten shortly before
+        if (x.sc && x.sw >= 0 && pos_of[x.sw] + 2 >= pos) return 1;
+        counts = x.sc;
+        oneshot_next.push_back(s);
+      }
+      if (side == 0) { f.left_hbm = x.hbm; f.lsc_hbm = counts; f.lslot = s; f.dma_flags |= 1; }
+      else { f.right_hbm = x.hbm; f.rsc_hbm = counts; f.rslot = s; f.dma_flags |= 2; }
+    }
+    return 0;
+  };
+
+  plan.resize(count);
+  for (unsigned int pos = 0; pos < count; ++pos)
+  {
+    const unsigned int i = order[pos];
+    const PartialsArgs & a = args[i];
+    FusedOp & f = plan[pos];
+    memset(&f, 0, sizeof(f));
+    f.parent = a.parent;
+    f.ltip = a.ltip;
+    f.rtip = a.rtip;
+    f.lmat = a.lmat;
+    f.rmat = a.rmat;
+    f.pscaler = a.pscaler;
+    f.kind = kinds[i];
+    f.list_pos = (int)i;
+    f.lslot = f.rslot = f.pslot = f.lsc_slot = f.rsc_slot = -1;
+  }
+  if (place_reloads(0, 0)) return 1;
+  oneshot.swap(oneshot_next);
+  for (unsigned int pos = 0; pos < count; ++pos)
+  {
+    const unsigned int i = order[pos];
+    FusedOp & f = plan[pos];
+    // top of the op: the next op's missing operands are requested into slots free NOW
+    if (pos + 1 < count && place_reloads(pos + 1, pos)) return 1;
+    Operand o[2];
+    operands(i, o);
+    for (int side = 0; side < 2; ++side)
+    {
+      const Operand & x = o[side];
+      if (x.w == -2) continue;
+      int & slot = side == 0 ? f.lslot : f.rslot;
+      int & sc_slot = side == 0 ? f.lsc_slot : f.rsc_slot;
+      if (x.w >= 0)
+      {
+        if (slot < 0) slot = slot_of[x.w];
+        if (slot < 0) return 1;
+        // counts: only those written together with the value live in its slot
+        if (x.sc)
+        {
+          if (x.sw != x.w || x.sc != args[x.w].pscaler) return 1;
+          sc_slot = slot;
+        }
+      }
+      else
+      {
+        if (slot < 0) return 1; // (placed by place_reloads)
+        if (x.sc) sc_slot = slot;
+      }
+    }
+    // operands read for the last time give their slots back
+    for (int side = 0; side < 2; ++side)
+    {
+      const int w = o[side].w;
+      if (w < 0 || (side == 1 && w == o[0].w)) continue;
+      if (next_use[w] < uses[w].size() && uses[w][next_use[w]] == pos) next_use[w]++;
+      if (next_use[w] >= uses[w].size() && slot_of[w] >= 0)
+      {
+        free_slots.push_back(slot_of[w]);
+        slot_of[w] = -1;
+        live.erase(std::find(live.begin(), live.end(), (unsigned int)w));
+      }
+    }
+    for (int s : oneshot) free_slots.push_back(s);
+    oneshot.clear();
+    oneshot.swap(oneshot_next);
+    // the parent: a slot if it has readers -- unless its first reader is far enough away for a
+    // reload (three ops: its stores must have left) and farther than every live value's next
+    if (!uses[i].empty())
+    {
+      const unsigned int first = uses[i][0];
+      bool wants = true;
+      if (free_slots.empty() && first >= pos + 3)
+      {
+        unsigned int far = 0;
+        for (unsigned int v : live)
+        {
+          const unsigned int u = next_read(v);
+          if (u != NEVER && u >= pos + 2 && u > far) far = u;
+        }
+        if (first >= far) wants = false;
+      }
+      if (wants)
+      {
+        const int s = take_slot(pos);
+        if (s < 0)
+        {
+          if (first < pos + 3) return 1;
+        }
+        else
+        {
+          f.pslot = s;
+          slot_of[i] = s;
+          live.push_back(i);
+        }
+      }
+    }
+  }
+  *reloads_out = reloads;
+  return 0;
+}
+
+int pllhip_fused_plan(const FusedGeom & geom, const pllhip_op_t * ops, const PartialsArgs * args,
+                      const int * kinds, unsigned int count, unsigned int nslots, bool reload,
                       std::vector<FusedOp> & plan, bool * ext_out, unsigned int * evictions_out)
 {
   unsigned int evictions = 0;
-  (void)modes;
   std::vector<Node> node(count);
-  const size_t nclv = c->clv.size(), nsc = c->sh.scale_buffers;
+  const size_t nclv = geom.nclv, nsc = geom.nsc;
   // last writer and readers-since of every CLV / scale buffer, in list order
   std::vector<int> clv_w(nclv, -1), sc_w(nsc, -1);
   std::vector<std::vector<unsigned int>> clv_r(nclv), sc_r(nsc);
@@ -537,7 +862,7 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
     }
     else if (kinds[i] == 1)
     {
-      const int inner = pllhip_is_tip(c, ops[i].child1_clv) ? 1 : 0;
+      const int inner = geom.is_tip(ops[i].child1_clv) ? 1 : 0;
       wr = node[i].raw[inner];
       swr = node[i].sraw[inner];
     }
@@ -552,6 +877,29 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
     if (wr >= 0 && wr != wl) uses[wr].push_back(pos);
   }
   std::vector<unsigned int> next_use(count, 0); // index into uses[]
+
+  if (reload)
+  {
+    const int rc = assign_slots_reload(geom, ops, args, kinds, count, nslots, order, pos_of, node, plan, evictions_out);
+    if (rc) return rc;
+    if (getenv("PLLHIP_FUSED_DEBUG"))
+    {
+      fprintf(stderr, "pllhip fused plan: %u ops, %u slots, %u operands reloaded from HBM\n", count, nslots, *evictions_out);
+      if (atoi(getenv("PLLHIP_FUSED_DEBUG")) > 1)
+        for (unsigned int pos = 0; pos < count; ++pos)
+        {
+          const FusedOp & f = plan[pos];
+          fprintf(stderr, "  %3u: op %3d kind %d  l %2d r %2d p %2d  lsc %2d rsc %2d  dma %d  hbm %p %p counts %p %p\n", pos,
+                  f.list_pos, f.kind, f.lslot, f.rslot, f.pslot, f.lsc_slot, f.rsc_slot, f.dma_flags,
+                  (const void *)f.left_hbm, (const void *)f.right_hbm, (const void *)f.lsc_hbm, (const void *)f.rsc_hbm);
+        }
+    }
+    FusedOp tail = plan.back(); // "the ops after the last": what the kernel's look-ahead requests
+    tail.dma_flags = 0;
+    for (int t = 0; t < 3; ++t) plan.push_back(tail);
+    *ext_out = false;
+    return 0;
+  }
 
   // slots: a value keeps one from the op that writes it to its last reader; when there is
   // none left the live value whose next reader is farthest away gives its slot up (its
@@ -576,6 +924,7 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
     f.rmat = a.rmat;
     f.pscaler = a.pscaler;
     f.kind = kinds[i];
+    f.list_pos = (int)i;
     int wl, wr, swl, swr;
     operands(i, wl, wr, swl, swr);
     f.lslot = wl >= 0 ? slot_of[wl] : -1;
@@ -682,6 +1031,72 @@ int pllhip_fused_plan(pllhip_ctx * c, const pllhip_op_t * ops, const PartialsArg
   return 0;
 }
 
+// The planner without a device (tests/test_host.py, tools): which order and how many
+// operands without a slot a list gets with `nslots` slots per wave.
+extern "C" int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buffers, unsigned int scale_buffers,
+                                     int pattern_tip, const pllhip_op_t * ops, unsigned int count,
+                                     unsigned int nslots, int reload, unsigned int * order_out,
+                                     unsigned int * hbm_operands_out, unsigned int * evictions_out,
+                                     int * slots_out)
+{
+  const FusedGeom geom = {(size_t)tips + clv_buffers, scale_buffers, tips, pattern_tip != 0};
+  std::vector<PartialsArgs> args(count);
+  std::vector<int> kinds(count);
+  unsigned int present = 0;
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    const pllhip_op_t & op = ops[i];
+    if (op.parent_clv >= geom.nclv || op.child1_clv >= geom.nclv || op.child2_clv >= geom.nclv ||
+        op.parent_scaler >= (int)scale_buffers || op.child1_scaler >= (int)scale_buffers ||
+        op.child2_scaler >= (int)scale_buffers)
+    {
+      pllhip_set_error("pllhip_fused_plan_dry: index out of range in op %u", i);
+      return -1;
+    }
+    const bool t1 = geom.is_tip(op.child1_clv), t2 = geom.is_tip(op.child2_clv);
+    memset(&args[i], 0, sizeof(PartialsArgs));
+    kinds[i] = (t1 && t2) ? 2 : (t1 || t2) ? 1 : 0;
+    // (distinct fake addresses per scale buffer: the reload plan compares them)
+    auto sc = [&](int idx) { return idx >= 0 ? reinterpret_cast<unsigned int *>((uintptr_t)4096 * (idx + 1)) : (unsigned int *)nullptr; };
+    (void)present;
+    args[i].pscaler = sc(op.parent_scaler);
+    auto clv = [&](unsigned int idx) { return reinterpret_cast<const double *>((uintptr_t)4096 * (idx + 1)); };
+    if (kinds[i] == 0)
+    {
+      args[i].left = clv(op.child1_clv);
+      args[i].right = clv(op.child2_clv);
+      args[i].lscaler = sc(op.child1_scaler);
+      args[i].rscaler = sc(op.child2_scaler);
+    }
+    else if (kinds[i] == 1)
+    {
+      args[i].right = clv(t1 ? op.child2_clv : op.child1_clv);
+      args[i].rscaler = sc(t1 ? op.child2_scaler : op.child1_scaler);
+    }
+  }
+  std::vector<FusedOp> plan;
+  bool ext = false;
+  unsigned int evictions = 0;
+  const int rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, reload != 0, plan, &ext, &evictions);
+  if (rc) return rc;
+  unsigned int hbm = 0;
+  for (unsigned int pos = 0; pos < count; ++pos)
+  {
+    if (order_out) order_out[pos] = (unsigned int)plan[pos].list_pos;
+    if (slots_out)
+    {
+      const FusedOp & f = plan[pos];
+      const int v[6] = {f.lslot, f.rslot, f.pslot, f.lsc_slot, f.rsc_slot,
+                        (f.left_hbm ? 1 : 0) | (f.right_hbm ? 2 : 0) | (f.dma_flags << 2)};
+      for (int t = 0; t < 6; ++t) slots_out[pos * 6 + t] = v[t];
+    }
+    hbm += (plan[pos].left_hbm != nullptr) + (plan[pos].right_hbm != nullptr);
+  }
+  if (hbm_operands_out) *hbm_operands_out = hbm;
+  if (evictions_out) *evictions_out = evictions;
+  return 0;
+}
+
 template <int RC>
 static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int count, unsigned int nslots,
                            int mode, bool ext)
@@ -691,7 +1106,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
   const size_t tile_sites = (size_t)J * (64 / (2 * RC));
   const size_t tiles = (sites + tile_sites - 1) / tile_sites;
   const size_t cw = c->sh.rate_scalers ? 32 : ((64 / (2 * RC)) < 4 ? 4 : (64 / (2 * RC)));
-  const size_t lds = 4 * ((size_t)nslots * J * (64 * 16 + cw * 4) + 2 * (size_t)RC * 16 * sizeof(double));
+  const size_t lds = 4 * ((size_t)nslots * J * (64 * 16 + cw * 4) + (size_t)RC * 16 * sizeof(double));
   // two workgroups (8 waves) per CU, each wave walking its share of the tiles
   size_t grid = (tiles + 3) / 4;
   const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));

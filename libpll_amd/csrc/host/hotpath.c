@@ -81,14 +81,70 @@ double pll_compute_root_loglikelihood(pll_partition_t * p, unsigned int clv_inde
   return lnl;
 }
 
-/* The caller's sumtable pointer is only a KEY here: the table itself is kept
- * in one of a few device slots (least recently produced slot is recycled). */
+/* The caller's sumtable pointer is only a KEY here: the table itself lives in a device
+ * slot.  Slots are handed out as tables appear (one per live host buffer, e.g. one per
+ * branch), up to the context's budget; beyond it the least recently used slot is recycled
+ * and its key remembered: the host buffer of such a table was never written (outside
+ * mirror mode), so using it again must fail loudly, not upload garbage. */
 static int slot_of(pll_amd_partition_t * q, const double * key)
 {
   unsigned int s;
-  for (s = 0; s < PLLHIP_SUMTABLE_SLOTS; ++s)
-    if (q->sumtable_key[s] == key) return (int)s;
+  for (s = 0; s < q->sumtable_used; ++s)
+    if (q->sumtable_key[s] == key)
+    {
+      q->sumtable_stamp[s] = ++q->sumtable_clock;
+      return (int)s;
+    }
   return -1;
+}
+
+static int was_evicted(const pll_amd_partition_t * q, const double * key)
+{
+  unsigned int i;
+  for (i = 0; i < PLL_AMD_EVICTED_KEYS; ++i)
+    if (key && q->sumtable_evicted[i] == key) return 1;
+  return 0;
+}
+
+/* a slot for a table that has none yet */
+static int slot_assign(pll_amd_partition_t * q, const double * key)
+{
+  unsigned int s, i;
+  if (!q->sumtable_cap) q->sumtable_cap = pllhip_sumtable_budget(q->ctx);
+  for (i = 0; i < PLL_AMD_EVICTED_KEYS; ++i)
+    if (q->sumtable_evicted[i] == key) q->sumtable_evicted[i] = NULL; /* it is alive again */
+  if (q->sumtable_used < q->sumtable_cap)
+    s = q->sumtable_used++;
+  else
+  {
+    s = 0;
+    for (i = 1; i < q->sumtable_used; ++i)
+      if (q->sumtable_stamp[i] < q->sumtable_stamp[s]) s = i;
+    if (q->sumtable_key[s])
+    {
+      q->sumtable_evicted[q->sumtable_evicted_next] = q->sumtable_key[s];
+      q->sumtable_evicted_next = (q->sumtable_evicted_next + 1) % PLL_AMD_EVICTED_KEYS;
+    }
+  }
+  q->sumtable_key[s] = key;
+  q->sumtable_stamp[s] = ++q->sumtable_clock;
+  return (int)s;
+}
+
+/* the client is done with this host buffer (e.g. about to free it): forget the key, so a
+   new buffer at the same address is not mistaken for it; the device buffer is kept for the
+   next table */
+int pll_amd_forget_sumtable(pll_partition_t * p, const double * sumtable)
+{
+  pll_amd_partition_t * q = pll_amd_priv(p);
+  unsigned int i;
+  int slot = slot_of(q, sumtable);
+  for (i = 0; i < PLL_AMD_EVICTED_KEYS; ++i)
+    if (q->sumtable_evicted[i] == sumtable) q->sumtable_evicted[i] = NULL;
+  if (slot < 0) return PLL_FAILURE;
+  q->sumtable_key[slot] = NULL;
+  q->sumtable_stamp[slot] = 0; /* first to be reused */
+  return PLL_SUCCESS;
 }
 
 int pll_update_sumtable(pll_partition_t * p, unsigned int parent_clv_index,
@@ -112,11 +168,7 @@ int pll_update_sumtable(pll_partition_t * p, unsigned int parent_clv_index,
       !pll_amd_repeats_scaler_ok(p, child_clv_index, child_scaler_index))
     return PLL_FAILURE;
   slot = slot_of(q, sumtable);
-  if (slot < 0)
-  {
-    slot = (int)(q->sumtable_next++ % PLLHIP_SUMTABLE_SLOTS);
-    q->sumtable_key[slot] = sumtable;
-  }
+  if (slot < 0) slot = slot_assign(q, sumtable);
   rc = pllhip_update_sumtable(q->ctx, parent_clv_index, parent_scaler_index, child_clv_index,
                               child_scaler_index, params_indices, (unsigned int)slot);
   if (rc)
@@ -134,7 +186,12 @@ int pll_amd_sync_sumtable(pll_partition_t * p, double * sumtable)
   int slot = slot_of(q, sumtable), rc;
   if (slot < 0)
   {
-    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "no device sumtable is associated with this buffer");
+    if (was_evicted(q, sumtable))
+      pll_amd_set_error(PLL_ERROR_HIP_SUMTABLE_EVICTED,
+                        "the device copy of this sumtable was recycled (more than %u live sumtables; "
+                        "PLL_AMD_SUMTABLE_SLOTS raises the limit)", q->sumtable_cap);
+    else
+      pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "no device sumtable is associated with this buffer");
     return PLL_FAILURE;
   }
   if ((rc = pllhip_get_sumtable(q->ctx, (unsigned int)slot, sumtable)))
@@ -157,11 +214,21 @@ int pll_compute_likelihood_derivatives(pll_partition_t * p, int parent_scaler_in
   slot = slot_of(q, sumtable);
   if (slot < 0)
   {
+    if (was_evicted(q, sumtable))
+    {
+      /* produced on the device, then recycled: the host buffer was never written */
+      pll_amd_set_error(PLL_ERROR_HIP_SUMTABLE_EVICTED,
+                        "the device copy of this sumtable was recycled (more than %u live sumtables; call "
+                        "pll_update_sumtable again, or raise PLL_AMD_SUMTABLE_SLOTS)", q->sumtable_cap);
+      return PLL_FAILURE;
+    }
     /* a table the caller filled itself: take the host contents */
-    slot = (int)(q->sumtable_next++ % PLLHIP_SUMTABLE_SLOTS);
+    slot = slot_assign(q, sumtable);
     if ((rc = pllhip_put_sumtable(q->ctx, (unsigned int)slot, sumtable)))
+    {
+      q->sumtable_key[slot] = NULL;
       return pll_amd_fail_hip(rc, "sumtable upload");
-    q->sumtable_key[slot] = sumtable;
+    }
   }
 
   /* e^{lambda r t}, its first and second t-derivative per (category, state):

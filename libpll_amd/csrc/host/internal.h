@@ -12,6 +12,7 @@
 #include "pll_amd.h"
 #include "pllhip.h"
 
+#define PLL_AMD_EVICTED_KEYS 64
 #define PLL_AMD_MAGIC 0x504c4c414d443031ull /* "PLLAMD01" */
 
 /* site repeats (repeats.c): classes of one CLV slot */
@@ -35,9 +36,16 @@ typedef struct pll_amd_partition
   int * model_dirty;            /* [rate_matrices] eigen/freqs/pinv need upload */
   int rates_dirty;
   int tipmap_dirty;
-  /* device sumtable slots keyed by the caller's host pointer */
-  const double * sumtable_key[PLLHIP_SUMTABLE_SLOTS];
-  unsigned int sumtable_next;
+  /* device sumtable slots keyed by the caller's host pointer: as many as are alive, up to
+     sumtable_cap (pllhip_sumtable_budget); then the least recently used one is recycled
+     and its key remembered, so that a later use of it fails instead of reading the
+     caller's never-written host buffer */
+  const double * sumtable_key[PLLHIP_SUMTABLE_MAX_SLOTS];
+  unsigned long long sumtable_stamp[PLLHIP_SUMTABLE_MAX_SLOTS];
+  unsigned int sumtable_used, sumtable_cap;
+  unsigned long long sumtable_clock;
+  const double * sumtable_evicted[PLL_AMD_EVICTED_KEYS];
+  unsigned int sumtable_evicted_next;
   /* PLL_ATTRIB_SITE_REPEATS: per CLV slot, and which CLV each scale buffer belongs to */
   pll_amd_node_repeats_t * rep;
   int * scaler_owner;

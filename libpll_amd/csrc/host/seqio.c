@@ -45,13 +45,13 @@ static long span_until(const char * s, int stop)
 
 static void report_fatal_char(int fasta, char c, long lineno)
 {
-  if (c >= 32)
+  if ((unsigned char)c >= 32)
     pll_amd_set_error(fasta ? PLL_ERROR_FASTA_ILLEGALCHAR : PLL_ERROR_PHYLIP_ILLEGALCHAR,
                       "illegal character '%c' on line %ld in the fasta file", c, lineno);
   else
     pll_amd_set_error(fasta ? PLL_ERROR_FASTA_UNPRINTABLECHAR : PLL_ERROR_PHYLIP_UNPRINTABLECHAR,
                       "illegal unprintable character %#.2x (hexadecimal) on line %ld in the fasta file",
-                      c, lineno);
+                      (unsigned int)(unsigned char)c, lineno);
 }
 
 static void clear_stripped(long * count, long * per_char)
@@ -216,12 +216,14 @@ int pll_fasta_getnext(pll_fasta_t * fd, char ** head, long * head_len, char ** s
   {
     for (const char * p = fd->line; *p; ++p)
     {
+      /* bytes >= 0x80 index the table's upper half (the reference's `(int)c` of a signed
+         char is a negative index there: fasta.c:219) */
       const char c = *p;
-      switch ((char)fd->chrstatus[(int)c])
+      switch ((char)fd->chrstatus[(unsigned char)c])
       {
         case 0:
           fd->stripped_count++;
-          fd->stripped[(int)c]++;
+          fd->stripped[(unsigned char)c]++;
           break;
         case 1:
           if (!record_reserve(&s, s.used + 1, RECORD_CHUNK))
@@ -428,11 +430,11 @@ static int phy_take(pll_phylip_t * fd, pll_msa_t * msa, const char * text, int r
   for (; *text; ++text)
   {
     const char c = *text;
-    switch ((char)fd->chrstatus[(int)c])
+    switch ((char)fd->chrstatus[(unsigned char)c])
     {
       case 0:
         fd->stripped_count++;
-        fd->stripped[(int)c]++;
+        fd->stripped[(unsigned char)c]++;
         break;
       case 1:
         if (col + n >= msa->length)

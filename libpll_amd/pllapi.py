@@ -144,6 +144,7 @@ class PllLibrary:
             lib.pll_amd_sync_scaler.argtypes = [_PP, C.c_uint]
             lib.pll_amd_sync_pmatrix.argtypes = [_PP, C.c_uint]
             lib.pll_amd_sync_sumtable.argtypes = [_PP, _dp]
+            lib.pll_amd_forget_sumtable.argtypes = [_PP, _dp]
             lib.pll_amd_wait.argtypes = [_PP]
             lib.pll_amd_timer_start.argtypes = [_PP]
             lib.pll_amd_timer_stop_ms.argtypes = [_PP, C.POINTER(C.c_float)]

@@ -19,8 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-LIB = os.path.join(ROOT, "libpll_amd", "libpll_amd.so")
-ORACLE = os.path.join(ROOT, "oracle", "liboracle.so")
+LIB = os.environ.get("PLL_AMD_LIB") or os.path.join(ROOT, "libpll_amd", "libpll_amd.so")
+ORACLE = os.environ.get("PLL_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")
 REF = os.path.join(ROOT, "oracle", "_ref", "libpll_ref.so")
 
 

@@ -9,7 +9,8 @@ import pytest
 
 from helpers import (make_case, build_partition, oracle_run, bits_equal, rel_err,
                      random_op_sequence, random_sequence_case)
-from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, OPS_DTYPE, SCALE_BUFFER_NONE
+from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, OPS_DTYPE, SCALE_BUFFER_NONE,
+                               PllError)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("dna_path")]
 
@@ -49,41 +50,92 @@ def test_mirrors_are_null_until_synced(gpu):
     p.destroy()
 
 
-def test_sumtable_slots_and_caller_filled_tables(gpu, orc):
-    """More host sumtable buffers than device slots (4), and a table the caller
-    computed itself (pll_compute_likelihood_derivatives must upload it)."""
+def _edges_for_sumtables(plan):
+    """(parent, parent scaler, child, child scaler) below each op's parent: three with an
+    inner child, three with a tip child (tip-inner tables)."""
+    edges = []
+    for op in plan.ops:
+        for ch in ("child1", "child2"):
+            edges.append((int(op["parent_clv_index"]), int(op["parent_scaler_index"]),
+                          int(op[ch + "_clv_index"]), int(op[ch + "_scaler_index"])))
+    edges = [e for e in edges if e[2] >= plan.tips][:3] + [e for e in edges if e[2] < plan.tips][:3]
+    assert len(edges) >= 5
+    return edges
+
+
+def test_many_live_sumtables_and_caller_filled_tables(gpu, orc):
+    """One sumtable per branch is a normal client pattern: every live host buffer keeps its
+    own device table (four round-robin slots silently served a recycled table's
+    never-written host buffer).  A buffer the library has never seen is a table the caller
+    computed itself and is uploaded; pll_amd_forget_sumtable drops a key."""
     case = make_case(4, "random", 10, 200, seed=7)
     plan = case["plan"]
     p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
     o = oracle_run(orc, gpu, p, case, ATTRIB_PATTERN_TIP)
     p.update_partials(plan.ops)
     o.update_partials()
-    # edges (parent, child) below each op's parent; tip children give tip-inner tables
-    inner_edges = []
-    for op in plan.ops:
-        for ch in ("child1", "child2"):
-            inner_edges.append((int(op["parent_clv_index"]), int(op["parent_scaler_index"]),
-                                int(op[ch + "_clv_index"]), int(op[ch + "_scaler_index"])))
-    inner_edges = [e for e in inner_edges if e[2] >= plan.tips][:3] + \
-                  [e for e in inner_edges if e[2] < plan.tips][:3]
-    assert len(inner_edges) >= 5
+    edges = _edges_for_sumtables(plan)
     tables = []
-    for (pc, ps, cc, cs) in inner_edges:
+    for (pc, ps, cc, cs) in edges:
         st = p.alloc_sumtable()
+        st[:] = 0.0
         p.update_sumtable(pc, cc, ps, cs, [0] * 4, st)
+        assert not st.any()                        # the host buffer is not written (no mirror mode)
         tables.append(st)
-    # the first table's device slot has been recycled by now: its host copy is stale
-    # (zeros), so fill it the way a caller could -- from the oracle -- and use it
-    pc, ps, cc, cs = inner_edges[0]
+    # all of them are still resident, oldest first
+    for (pc, ps, cc, cs), st in zip(edges, tables):
+        got = p.compute_likelihood_derivatives(ps, cs, 0.3, [0] * 4, st)
+        assert rel_err(got, o.derivatives(o.sumtable(pc, cc, ps, cs), 0.3)) < 1e-10
+    # a table the caller filled itself, in a buffer the library has not seen
+    pc, ps, cc, cs = edges[1]
+    own = p.alloc_sumtable()
     want = o.sumtable(pc, cc, ps, cs)
+    own[:] = want.reshape(-1)
+    got = p.compute_likelihood_derivatives(ps, cs, 0.3, [0] * 4, own)
+    assert rel_err(got, o.derivatives(want, 0.3)) < 1e-10
+    # a known buffer refilled by hand: the key must be dropped first
+    pc, ps, cc, cs = edges[2]
+    want = o.sumtable(pc, cc, ps, cs)
+    assert gpu.lib.pll_amd_forget_sumtable(p.ptr, tables[0].ctypes.data_as(C.POINTER(C.c_double))) == 1
     tables[0][:] = want.reshape(-1)
     got = p.compute_likelihood_derivatives(ps, cs, 0.3, [0] * 4, tables[0])
     assert rel_err(got, o.derivatives(want, 0.3)) < 1e-10
-    # the most recent table is still resident
-    pc, ps, cc, cs = inner_edges[-1]
-    want = o.sumtable(pc, cc, ps, cs)
+    p.destroy()
+
+
+def test_recycled_sumtable_fails_loudly(gpu, orc, monkeypatch):
+    """Beyond the slot budget (forced down to 4 here) the least recently used device table
+    is recycled; using ITS host buffer afterwards is an error (203), not a silent upload of
+    a buffer nobody wrote; pll_update_sumtable brings it back."""
+    monkeypatch.setenv("PLL_AMD_SUMTABLE_SLOTS", "4")
+    case = make_case(4, "random", 10, 200, seed=8)
+    plan = case["plan"]
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    o = oracle_run(orc, gpu, p, case, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    o.update_partials()
+    edges = _edges_for_sumtables(plan)
+    tables = []
+    for (pc, ps, cc, cs) in edges:
+        st = p.alloc_sumtable()
+        p.update_sumtable(pc, cc, ps, cs, [0] * 4, st)
+        tables.append(st)
+    assert len(tables) >= 5
+    pc, ps, cc, cs = edges[0]
+    with pytest.raises(PllError):
+        p.compute_likelihood_derivatives(ps, cs, 0.3, [0] * 4, tables[0])
+    assert gpu.errno() == 203
+    assert gpu.lib.pll_amd_sync_sumtable(p.ptr, tables[0].ctypes.data_as(C.POINTER(C.c_double))) == 0
+    assert gpu.errno() == 203
+    # the most recent ones are resident
+    pc, ps, cc, cs = edges[-1]
     got = p.compute_likelihood_derivatives(ps, cs, 0.3, [0] * 4, tables[-1])
-    assert rel_err(got, o.derivatives(want, 0.3)) < 1e-10
+    assert rel_err(got, o.derivatives(o.sumtable(pc, cc, ps, cs), 0.3)) < 1e-10
+    # producing it again makes it usable again
+    pc, ps, cc, cs = edges[0]
+    p.update_sumtable(pc, cc, ps, cs, [0] * 4, tables[0])
+    got = p.compute_likelihood_derivatives(ps, cs, 0.3, [0] * 4, tables[0])
+    assert rel_err(got, o.derivatives(o.sumtable(pc, cc, ps, cs), 0.3)) < 1e-10
     p.destroy()
 
 

@@ -181,3 +181,153 @@ def test_bench_cpu_baseline_leg(ref):
     rate = bench.cpu_all_cores(ref_path, plan, seqs, 4, 4, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2, 2, 3)
     assert rate is not None and 1.0 < rate < 1e5      # M site-updates/s on two cores
     assert set(bench.BYTES_PER_SITE["ii"]) == {4, 20}
+
+
+# ---------------------------------------------------------------- the op-list planner (host logic)
+
+def _plan_dry(amd, ops, tips, clv_buffers, scale_buffers, pattern_tip, nslots, reload=1):
+    """(rc, order, operands without a slot, evictions) from pllhip_fused_plan_dry."""
+    ops = np.ascontiguousarray(ops)
+    n = len(ops)
+    order = (C.c_uint * n)()
+    slots = (C.c_int * (6 * n))()
+    hbm, ev = C.c_uint(), C.c_uint()
+    rc = amd.lib.pllhip_fused_plan_dry(C.c_uint(tips), C.c_uint(clv_buffers), C.c_uint(scale_buffers),
+                                       C.c_int(pattern_tip), ops.ctypes.data_as(C.c_void_p), C.c_uint(n),
+                                       C.c_uint(nslots), C.c_int(reload), order, C.byref(hbm), C.byref(ev), slots)
+    if rc == 0:
+        _simulate_slots(ops, tips if pattern_tip else 0, list(order), np.array(slots).reshape(n, 6), nslots, reload)
+    return rc, list(order), hbm.value, ev.value
+
+
+def _simulate_slots(ops, pattern_tips, order, slots, nslots, reload):
+    """Walk a plan the way the kernel does and check that every inner operand is found where
+    the plan says: in the slot its producer (or, reload plans, the copy from HBM issued at the
+    top of the op before) left it in, with nothing having overwritten it in between."""
+    content = [None] * nslots            # what each slot holds: ("v", list op) or ("hbm", clv index)
+    written = {}                         # clv index -> list op that wrote it last (in plan order)
+
+    def inner_operands(i):
+        op = ops[i]
+        c = [int(op["child1_clv_index"]), int(op["child2_clv_index"])]
+        inner = [x for x in c if x >= pattern_tips]
+        if len(inner) == 2:
+            return {0: c[0], 1: c[1]}     # left, right
+        if len(inner) == 1:
+            return {1: inner[0]}          # a tip-inner op presents its inner child on the right
+        return {}
+
+    def expect(clv):
+        return ("v", written[clv]) if clv in written else ("hbm", clv)
+
+    def copy_in(pos):
+        i = order[pos]
+        for side, clv in inner_operands(i).items():
+            if slots[pos][5] & (4 << side):
+                s = int(slots[pos][side])
+                assert 0 <= s < nslots
+                content[s] = ("arriving", expect(clv), pos)
+
+    if reload:
+        copy_in(0)
+    for pos, i in enumerate(order):
+        if reload and pos + 1 < len(order):
+            before = list(content)
+            copy_in(pos + 1)              # top of the op: the next op's copies are issued
+            for s in range(nslots):
+                if content[s] != before[s]:
+                    # the slot must not be read or written by the op that runs meanwhile
+                    assert s not in (int(slots[pos][0]), int(slots[pos][1]), int(slots[pos][2])), (pos, s)
+        for side, clv in inner_operands(i).items():
+            s = int(slots[pos][side])
+            from_hbm = bool(slots[pos][5] & (1 << side))
+            if s < 0:
+                assert from_hbm and not reload, (pos, side)   # EXT plan: fetched into registers
+                # its producer must have run at least three ops earlier (the fetch is two ops ahead)
+                if clv in written:
+                    assert order.index(written[clv]) + 2 < pos
+                continue
+            want = expect(clv)
+            got = content[s]
+            if got is not None and got[0] == "arriving":
+                assert got[2] <= pos      # (a value copied back for an earlier reader stays for later ones)
+                got = got[1]
+            assert got == want, (pos, side, s, got, want)
+        ps = int(slots[pos][2])
+        if ps >= 0:
+            content[ps] = ("v", i)
+        written[int(ops[i]["parent_clv_index"])] = i
+
+
+def _order_respects_hazards(ops, order):
+    """The planner may re-order a list in any way that keeps every read-after-write,
+    write-after-read and write-after-write pair on CLV and scale-buffer indices in list order."""
+    pos = {i: p for p, i in enumerate(order)}
+    if sorted(order) != list(range(len(ops))):
+        return False
+    for kind in ("clv", "sc"):
+        last_w, readers = {}, {}
+        for i, op in enumerate(ops):
+            if kind == "clv":
+                reads = [int(op["child1_clv_index"]), int(op["child2_clv_index"])]
+                write = int(op["parent_clv_index"])
+            else:
+                reads = [int(x) for x in (op["child1_scaler_index"], op["child2_scaler_index"]) if x >= 0]
+                write = int(op["parent_scaler_index"])
+            for r in reads:
+                if r in last_w and not pos[last_w[r]] < pos[i]:
+                    return False
+                readers.setdefault(r, []).append(i)
+            if write >= 0:
+                if write in last_w and last_w[write] != i and not pos[last_w[write]] < pos[i]:
+                    return False
+                for r in readers.get(write, []):
+                    if r != i and not pos[r] < pos[i]:
+                        return False
+                last_w[write] = i
+                readers[write] = []
+    return True
+
+
+@pytest.mark.parametrize("reload", [1, 0])
+def test_fused_planner_on_tree_shapes(amd, reload):
+    """Depth-first, heavier subtree first bounds the live values by the tree's Strahler
+    number: a balanced 64-taxon list needs no operand from HBM with 5 slots, a balanced
+    128-taxon list (BASELINE config 4) none with 6 -- what the 12-wave configuration of
+    the whole-list kernel has -- and a random 200-taxon list (config 5's shape) a handful."""
+    for plan, nslots, most in ((W.balanced_tree(64), 5, 0), (W.balanced_tree(128), 6, 0),
+                               (W.balanced_tree(128), 5, 4), (W.random_tree(200, seed=42), 6, 8),
+                               (W.caterpillar_tree(300), 5, 0)):
+        rc, order, hbm, _ = _plan_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 1,
+                                      nslots, reload)
+        assert rc == 0
+        assert _order_respects_hazards(plan.ops, order)
+        assert hbm <= most, (plan.shape, plan.tips, nslots, hbm)
+    # tips as CLVs: every tip operand comes from HBM, nothing else does with 7 slots
+    plan = W.balanced_tree(64)
+    rc, order, hbm, _ = _plan_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 0, 7, reload)
+    assert rc == 0 and hbm == 64 and _order_respects_hazards(plan.ops, order)
+
+
+def test_fused_planner_on_random_op_sequences(amd):
+    """Arbitrary lists with heavy CLV / scale-buffer reuse: whatever the planner accepts
+    (rc 0) is a hazard-respecting permutation; a list it declines (rc 1: e.g. counts that
+    were not written together with their CLV) goes to the per-level launches."""
+    from helpers import random_op_sequence
+    taken = 0
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        tips, inner, scalers = 12, 10, 10
+        ops = random_op_sequence(rng, tips, inner, scalers, 2 * tips - 3, 60 + seed)
+        for pattern_tip in (0, 1):
+            for reload in (0, 1):
+                rc, order, _, _ = _plan_dry(amd, ops, tips, inner, scalers, pattern_tip, 6, reload)
+                assert rc in (0, 1)
+                if rc == 0:
+                    taken += 1
+                    assert _order_respects_hazards(ops, order), (seed, pattern_tip, reload)
+    assert taken > 40
+    # indices out of range are refused, not read
+    bad = W.balanced_tree(8).ops.copy()
+    bad[0]["child1_clv_index"] = 1000
+    assert _plan_dry(amd, bad, 8, 6, 6, 1, 5)[0] == -1
