@@ -128,21 +128,18 @@ PLLHIP_EXPORT int pllhip_update_partials(pllhip_ctx_t * ctx, const pllhip_op_t *
                                          unsigned int count);
 
 /* The op-list planner of the 4-state whole-list kernel (partials_fused.hip) on its own -- host
- * logic, no device needed: the order it gives the list (order_out[pos] = position in ops),
- * how many inner operands would have no on-chip slot with `nslots` slots per wave, and how
- * often a live value had to give its slot up (reload != 0: the plan in which such operands
- * are copied back into a slot by LDS-DMA one op ahead of their reader; 0: the plan in which the
- * reader fetches them into registers).  slots_out (nullable, 6 ints per op in the new order):
- * left / right / parent slot, the slots the inherited counts are read from, and flags (bit 0 / 1:
- * left / right operand comes from HBM; bits 2, 3: it is copied into its slot one op ahead).
- * Returns 0, 1 if the kernel does not take the
- * list's shape (the per-level launches run it then), -1 on bad indices. */
+ * logic, no device needed: the order it gives the list (order_out[pos] = position in ops), how
+ * many inner operands have to be copied back from HBM with `nslots` slots per wave (values
+ * that gave their slot up, operands written by earlier calls), and, if slots_out is not NULL,
+ * 6 ints per op in the new order: left / right / parent slot, the slots the inherited counts
+ * are read from, and flags (bit 0 / 1: the left / right operand is copied into its slot at the
+ * top of the op before).  Returns 0, 1 if the kernel does not take the list's shape (the
+ * per-level launches run it then), -1 on bad indices. */
 PLLHIP_EXPORT int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buffers,
                                         unsigned int scale_buffers, int pattern_tip,
                                         const pllhip_op_t * ops, unsigned int count,
-                                        unsigned int nslots, int reload, unsigned int * order_out,
-                                        unsigned int * hbm_operands_out, unsigned int * evictions_out,
-                                        int * slots_out);
+                                        unsigned int nslots, unsigned int * order_out,
+                                        unsigned int * reloads_out, int * slots_out);
 
 /* replaces pll_core_edge_loglikelihood_ii / _ti / _ti_4x4
  * (core_likelihood.c:726,412,211).  A clv index < tips in pattern-tip mode

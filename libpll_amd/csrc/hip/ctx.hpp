@@ -64,7 +64,10 @@ struct pllhip_ctx
   struct pllhip_level_cache * level_cache = nullptr; // the same for the per-level path (partials.hip)
   unsigned int fused_last_entries = 0, fused_last_count = 0, fused_last_nslots = 0;
   int fused_last_mode = 0;
-  bool fused_last_ext = false;
+  // Kept plans (the whole-list kernel's records, the per-level path's arguments) hold device
+  // addresses and indices.  Whatever reallocates a buffer such a plan may reference bumps
+  // layout_epoch; a kept plan is only reused while its epoch is the current one.
+  unsigned int layout_epoch = 0, fused_last_epoch = 0;
   double * d_pairtab = nullptr; // pair tables of the tip-tip ops of the current op list
   // 20 states: scratch of the lookup ops (partials_aa_mfma.hip, k_aa_cherry_rounds)
   double * cherry_pool = nullptr;
@@ -79,7 +82,8 @@ struct pllhip_ctx
   int plan_next = 0;
   bool no_fused = false; // env PLLHIP_FUSED=0: one launch per dependency level instead
   int fused_pairs = 2;      // env PLLHIP_FUSED_PAIRS
-  bool fused_reload = true; // env PLLHIP_FUSED_RELOAD=0: operands without a slot into registers (EXT plan) instead of LDS-DMA
+  bool fused_pingpong = true; // env PLLHIP_FUSED_PINGPONG=0: every whole-list launch walks the tiles forwards
+  unsigned int fused_launches = 0;
   bool force_fused = false; // env PLLHIP_FUSED=2: also for partitions too small for it to pay (tests)
 
   // reductions: per-block partial sums, then a fixed-order final pass

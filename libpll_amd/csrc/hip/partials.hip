@@ -415,6 +415,7 @@ struct pllhip_level_cache
 {
   std::vector<pllhip_op_t> last_ops;
   unsigned int last_maxstates = 0;
+  unsigned int epoch = 0; // ctx->layout_epoch the plan was made under
   std::vector<pllhip_planned_op> plan;
   std::vector<PartialsArgs> by_pos;
   std::vector<std::pair<int, int>> cherry;
@@ -581,6 +582,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       (count >= 7 || (c->force_fused && count >= 2)))
   {
     if (c->fused_last_ops.size() == count && !getenv("PLLHIP_FUSED_DEBUG") &&
+        c->fused_last_epoch == c->layout_epoch &&
         memcmp(c->fused_last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
     {
       pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
@@ -594,50 +596,29 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       int rc = resolve_op(c, ops[i], args[i], kinds[i], modes[i]);
       if (rc) return rc;
     }
-    // three workgroups per CU (12 waves) hide the per-op latencies better than two, but
-    // leave one LDS slot less per wave (6 against 7 at 4 rate categories).
-    // First choice: the RELOAD plan -- every operand is read from a slot; the few that have
-    // none (a value that gave its slot up; operands written by earlier calls) are copied back
-    // into one by LDS-DMA one op ahead (no registers: the lean kernel variant).  Lists it does
-    // not take (counts that were not written together with their CLV) get the EXT plan, in
-    // which the reader fetches such operands into registers itself.
+    // Three workgroups per CU (12 waves) hide the per-op latencies better than two, but
+    // leave one LDS slot less per wave (6 against 7 at 4 rate categories): the 12-wave
+    // configuration whenever the planner can keep every operand in a slot with it (values
+    // that give their slot up, and operands written by earlier calls, are copied back from
+    // HBM by LDS-DMA one op ahead).  A list the planner does not take -- counts that were not
+    // written together with their CLV -- runs per level.
     std::vector<FusedOp> fplan;
-    bool ext = false;
-    unsigned int evictions = 0;
+    unsigned int reloads = 0;
     const FusedGeom geom = {c->clv.size(), c->sh.scale_buffers, c->sh.tips, c->sh.pattern_tip != 0};
     unsigned int nslots = pllhip_fused_slots(c, 3);
-    int rc = 1;
-    if (c->fused_reload)
-    {
-      rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, true, fplan, &ext, &evictions);
-      if (rc > 0)
-      {
-        nslots = pllhip_fused_slots(c, 2);
-        rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, true, fplan, &ext, &evictions);
-      }
-    }
+    int rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, fplan, &reloads);
     if (rc > 0)
     {
-      nslots = pllhip_fused_slots(c, 3);
-      rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, false, fplan, &ext, &evictions);
-      // (measured in round 1, 200-taxon random tree x 500 k sites: 8 operands of 396 without a
-      // slot on 12 waves 3.90 ms, 2 without on 8 waves 4.03 ms; a tip-CLV partition, where every
-      // tip operand comes from HBM anyway, 3.17 ms on 8 waves with 7 slots, 3.34 on 12 with 5)
-      unsigned int hbm_operands = 0;
-      for (const FusedOp & f : fplan) hbm_operands += (f.left_hbm != nullptr) + (f.right_hbm != nullptr);
-      if (rc > 0 || (rc == 0 && 10 * hbm_operands > 2 * count)) // more than a tenth of all operands
-      {
-        nslots = pllhip_fused_slots(c, 2);
-        rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, false, fplan, &ext, &evictions);
-      }
+      nslots = pllhip_fused_slots(c, 2);
+      rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, fplan, &reloads);
     }
     if (rc < 0) return rc;
     if (rc == 0)
     {
       pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
-      rc = pllhip_launch_fused(c, fplan, nslots, ext);
+      rc = pllhip_launch_fused(c, fplan, nslots);
       if (rc == 0) c->fused_last_ops.assign(ops, ops + count);
-      return rc;
+      if (rc <= 0) return rc;
     }
     // (a list shape the kernel does not take: per-level launches below)
   }
@@ -652,6 +633,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   std::vector<PartialsArgs> & by_pos = lc.by_pos;
   std::vector<std::pair<int, int>> & cherry_kids = lc.cherry;
   const bool plan_kept = c->rows.empty() && lc.last_ops.size() == count && lc.last_maxstates == c->maxstates &&
+                         lc.epoch == c->layout_epoch &&
                          memcmp(lc.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0;
   if (!plan_kept)
   {
@@ -730,6 +712,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   {
     lc.last_ops.assign(ops, ops + count);
     lc.last_maxstates = c->maxstates;
+    lc.epoch = c->layout_epoch;
   }
   } // !plan_kept
 

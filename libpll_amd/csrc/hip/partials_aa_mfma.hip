@@ -583,6 +583,7 @@ int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count
       if (c->d_tiptab) HIP_TRY(hipFree(c->d_tiptab));
       c->d_tiptab = nullptr;
       HIP_TRY(hipMalloc((void **)&c->d_tiptab, need * sizeof(double)));
+      ++c->layout_epoch;
       c->tiptab_elems = need;
     }
     k_aa_tip_tables<<<dim3(8, count), 256, 0, c->stream>>>(b, c->d_tiptab, b.op[0].maxstates, R,
@@ -694,6 +695,7 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
     const size_t per_op = 4 * rows * row_elems;
     HIP_TRY(hipMalloc((void **)&c->cherry_pool, (chunk * per_op + rows * row_elems + (size_t)R * 400) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->cherry_codes, 2 * rows));
+    ++c->layout_epoch;
     if (!c->cherry_zero)
     {
       HIP_TRY(hipMalloc((void **)&c->cherry_zero, (size_t)c->sh.sites + PLLHIP_TAIL_SITES));

@@ -16,21 +16,25 @@
 // list becomes a WRITE stream.
 //
 //   tile      J sub-steps of 64 lanes x 16 B (J x 64 / (2 rate_cats) sites)
-//   slots     tiles per wave in LDS (6 x 2.5 KB for 4 rate categories); the host assigns
-//             them: a value keeps its slot until its last reader in the list has run; a
-//             value that loses its slot is read from HBM by its later readers
+//   slots     tiles per wave in LDS (6 x 2.1 KB for 4 rate categories on 12 waves per CU, 7 on 8); the
+//             host assigns them: a value keeps its slot until its last reader in the list has run
 //   op order  any order that respects the list's read/write hazards on CLV and scale
 //             buffer indices is equivalent; the host re-orders the list depth-first,
 //             heavier subtree first (Sethi-Ullman), which bounds the number of live
-//             values by the tree's Strahler number (5 for a balanced 64-taxon tree, not
-//             the 32 of a level-by-level list)
+//             values by the tree's Strahler number (5 for a balanced 64-taxon tree, 6 for 128
+//             taxa, not the 32 / 64 of a level-by-level list)
+//   reload    EVERY inner operand is read from a slot.  A value that had to give its slot up
+//             (random trees: a handful per list), and every operand written by an earlier call
+//             (partial traversals; tip CLVs), is copied from HBM into a slot by LDS-DMA
+//             (global_load_lds: no registers) at the top of the op BEFORE its reader.
 //   look-ahead  vector-memory loads and stores retire in ONE in-order queue, so a load
 //             issued after a store cannot be consumed before that store is acknowledged.
-//             Everything an op needs from memory (its two P-matrices, tip characters, and
-//             -- EXT variant -- operands that live in HBM) is therefore requested at the
-//             top of the PREVIOUS op, ahead of that op's stores, with unconditional loads
-//             (absent operands read a zero block); the op itself contains LDS traffic and
-//             stores only.
+//             Everything an op needs from memory (its two P-matrices, tip characters) is
+//             therefore requested at the top of the op two before it, ahead of that op's stores,
+//             with unconditional loads (absent operands read a zero block); the op itself
+//             contains LDS traffic and stores only.
+//   plan      32 bytes per op (indices, not pointers), read through the scalar data cache, a whole
+//             record three ops ahead: see FusedRec in partials_fused.hpp for why it is that small.
 //
 // The arithmetic per site is that of k_dna_partials, statement for statement (dot4 /
 // masksum4 order, scaling rule of core_partials_avx.c:486-527), so results are
@@ -38,7 +42,7 @@
 // tests run through this kernel.
 //
 // Roofline: HBM writes.  132 B per site-update (128 B CLV + 4 B scaler count) + 1 B per
-// tip character read; operands without a slot add 128 B each.
+// tip character read; operands that are reloaded add 128 B each.
 #include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,19 +54,62 @@
 
 #define PLL_LDS __attribute__((address_space(3)))
 
-// Tip-tip ops: the parent entry of a site depends on its two tip characters only, 16 x 16
+// ---- a plan record, word by word (all of this is scalar arithmetic on wave-uniform values) ----
+typedef const unsigned int __attribute__((address_space(4))) * const_words;
+typedef const unsigned long long __attribute__((address_space(4))) * const_quads;
+struct RecAhead // words 0, 1 of a FusedRec: what request() needs
+{
+  unsigned int w0, w1;
+};
+struct RecOp // words 4..7: what the op and the op before it need
+{
+  unsigned int w4, w5, w6, w7;
+};
+// (constant address space: scalar loads; adjacent words, the compiler merges them)
+__device__ __forceinline__ RecAhead rec_ahead(const FusedRec * plan, unsigned int i)
+{
+  const const_words w = (const_words)(unsigned long long)(plan + i);
+  RecAhead r;
+  r.w0 = w[0]; r.w1 = w[1];
+  return r;
+}
+__device__ __forceinline__ RecOp rec_op(const FusedRec * plan, unsigned int i)
+{
+  const const_words w = (const_words)(unsigned long long)(plan + i);
+  RecOp r;
+  r.w4 = w[4]; r.w5 = w[5]; r.w6 = w[6]; r.w7 = w[7];
+  return r;
+}
+__device__ __forceinline__ unsigned int rec_ltip(const RecAhead & r) { return r.w0 & 0xffffu; }
+__device__ __forceinline__ unsigned int rec_rtip(const RecAhead & r) { return r.w0 >> 16; }
+__device__ __forceinline__ unsigned int rec_lmat(const RecAhead & r) { return r.w1 & 0xffffu; }
+__device__ __forceinline__ unsigned int rec_rmat(const RecAhead & r) { return r.w1 >> 16; }
+__device__ __forceinline__ unsigned int rec_parent(const RecOp & r) { return r.w4 & 0xffffu; }
+__device__ __forceinline__ unsigned int rec_pscaler(const RecOp & r) { return r.w4 >> 16; }
+__device__ __forceinline__ unsigned int rec_pair(const RecOp & r) { return r.w5 & 0xffffu; }
+__device__ __forceinline__ unsigned int rec_src(const RecOp & r) { return r.w5 >> 16; }
+__device__ __forceinline__ int rec_lslot(const RecOp & r) { return (int)(r.w6 << 24) >> 24; }
+__device__ __forceinline__ int rec_rslot(const RecOp & r) { return (int)(r.w6 << 16) >> 24; }
+__device__ __forceinline__ int rec_pslot(const RecOp & r) { return (int)(r.w6 << 8) >> 24; }
+__device__ __forceinline__ int rec_kind(const RecOp & r) { return (int)(r.w6 >> 24); }
+__device__ __forceinline__ int rec_lsc(const RecOp & r) { return (int)(r.w7 << 24) >> 24; }
+__device__ __forceinline__ int rec_rsc(const RecOp & r) { return (int)(r.w7 << 16) >> 24; }
+__device__ __forceinline__ unsigned int rec_dma(const RecOp & r) { return (r.w7 >> 16) & 0xffu; }
+
+// Tip operands: the parent entry of a tip-tip op depends on its two tip characters only, 16 x 16
 // pairs.  One table per such op, [pair][rate][state] = masksum4(P_l row, code 1) *
 // masksum4(P_r row, code 2) -- the very product the kernel would form per site (30 VALU
 // instructions per tip operand and sub-step) -- built by one small launch ahead of the
 // list and read back by the list kernel with one 16-byte gather per lane and sub-step
 // (32 KB per op at 4 rate categories: L2-resident).
 template <int RC>
-__global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedOp * __restrict__ plan, unsigned int nops)
+__global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedRec * __restrict__ plan, unsigned int nops,
+                                                         FusedBases b)
 {
   const unsigned int i = blockIdx.x;
-  if (i >= nops || !plan[i].pair_tab) return;
-  const double * lm = plan[i].lmat, * rm = plan[i].rmat;
-  double * tab = const_cast<double *>(plan[i].pair_tab);
+  if (i >= nops || plan[i].pair == PLLHIP_FUSED_NONE) return;
+  const double * lm = b.pmat + (size_t)plan[i].lmat * (RC * 16), * rm = b.pmat + (size_t)plan[i].rmat * (RC * 16);
+  double * tab = b.pairtab + (size_t)plan[i].pair * (256 * RC * 4);
   const unsigned int pair = threadIdx.x, c1 = pair >> 4, c2 = pair & 15u;
   // (tip-inner ops: the tip's factor alone, in the entries [code 1][0] the kernel's index
   // (code 1 << 4 | character of an absent tip = 0) reaches; x * 1.0 is x)
@@ -71,14 +118,12 @@ __global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedOp * __restr
     tab[pair * RC * 4u + ki] = masksum4(lm + ki * 4u, c1) * (tt ? masksum4(rm + ki * 4u, c2) : 1.0);
 }
 
-// what a lane requests for an op one op ahead of its use
-template <int PL, int J, bool EXT>
+// what a lane requests for an op ahead of its use
+template <int PL, int J>
 struct FusedFetch
 {
-  double2 pm[PL];                   // its 16 bytes of the two P-matrices (a coalesced block per wave)
+  double2 pm[PL];                      // its 16 bytes of the two P-matrices (a coalesced block per wave)
   unsigned int codes_l[J], codes_r[J]; // tip characters of the lane's own site in each sub-step
-  double2 kl[EXT ? J : 1], kr[EXT ? J : 1];     // EXT: operands from HBM
-  unsigned int cl[EXT ? J : 1], cr[EXT ? J : 1]; //      and inherited scaler counts from HBM
   // element by element: a plain struct assignment of the arrays goes through scratch memory
   __device__ __forceinline__ void take(const FusedFetch & o)
   {
@@ -90,23 +135,15 @@ struct FusedFetch
       codes_l[j] = o.codes_l[j];
       codes_r[j] = o.codes_r[j];
     }
-#pragma unroll
-    for (int j = 0; j < (EXT ? J : 1); ++j)
-    {
-      kl[j] = o.kl[j];
-      kr[j] = o.kr[j];
-      cl[j] = o.cl[j];
-      cr[j] = o.cr[j];
-    }
   }
 };
 
 // WPS: waves per SIMD the register budget is sized for (3 = 168 VGPRs: twelve waves per CU)
-template <int RC, int J, int MODE, bool NT, bool EXT, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restrict__ plan_g, unsigned int nops,
-                                                   unsigned int sites, unsigned int nslots,
-                                                   const unsigned int * __restrict__ zero, double2 * sink,
-                                                   unsigned int * next_tile)
+template <int RC, int J, int MODE, bool NT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan, FusedBases bases,
+                                                        unsigned int nops, unsigned int sites, unsigned int nslots,
+                                                        const unsigned int * __restrict__ zero, double2 * sink,
+                                                        unsigned int * next_tile, unsigned int backwards)
 {
   constexpr unsigned int W = 2 * RC, SPS = 64 / W, TS = J * SPS;
   constexpr unsigned int MG = RC * 8;                   // 16-byte granules of one P-matrix
@@ -129,10 +166,6 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
   const unsigned int clv_lds_b = __builtin_amdgcn_readfirstlane(
       (unsigned int)(uintptr_t)(PLL_LDS char *)lds_fused + (unsigned int)(wave_in_wg * wave_g * 16));
   const unsigned int cnt_lds_b = clv_lds_b + (unsigned int)(((size_t)nslots * J * 64 + MG) * 16);
-  // the plan is the same for every lane: read it through the scalar path.  It carries one
-  // entry more than there are ops (a copy of the last), so that "the next op" always exists.
-  typedef const FusedOp __attribute__((address_space(4))) * plan_ptr;
-  const plan_ptr plan = (plan_ptr)(unsigned long long)plan_g;
   const double2 * zero16 = reinterpret_cast<const double2 *>(zero);
   const unsigned char * zero8 = reinterpret_cast<const unsigned char *>(zero);
 
@@ -165,14 +198,14 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
   size_t round = 0;
   for (size_t tile = wave; tile < tiles;)
   {
-    const size_t site0 = tile * TS;
+    // (every other launch of a context walks the tiles from the far end: see pllhip_relaunch_fused)
+    const size_t site0 = (backwards ? tiles - 1 - tile : tile) * TS;
 
     // every load is unconditional (absent operands read the zero block): a load inside a
     // branch makes the compiler wait for everything in flight
-    auto request = [&](FusedFetch<PL, J, EXT> & f, unsigned int i, const double * lmat, const double * rmat,
-                       const unsigned char * ltip, const unsigned char * rtip) {
-      const double2 * lm = reinterpret_cast<const double2 *>(lmat);
-      const double2 * rm = reinterpret_cast<const double2 *>(rmat);
+    auto request = [&](FusedFetch<PL, J> & f, const RecAhead & r) {
+      const double2 * lm = reinterpret_cast<const double2 *>(bases.pmat + (size_t)rec_lmat(r) * (RC * 16));
+      const double2 * rm = reinterpret_cast<const double2 *>(bases.pmat + (size_t)rec_rmat(r) * (RC * 16));
 #pragma unroll
       for (int t = 0; t < PL; ++t)
       {
@@ -180,36 +213,15 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
         const double2 * src = (q < MG) ? lm + q : (q < 2 * MG) ? rm + (q - MG) : zero16;
         f.pm[t] = *src;
       }
-      const unsigned char * lt = ltip ? ltip + site0 : zero8; // (uniform: tile base or the zero block)
-      const unsigned char * rt = rtip ? rtip + site0 : zero8;
+      const bool has_l = rec_ltip(r) != PLLHIP_FUSED_NONE, has_r = rec_rtip(r) != PLLHIP_FUSED_NONE;
+      // (uniform: tile base or the zero block)
+      const unsigned char * lt = has_l ? bases.tips + (size_t)rec_ltip(r) * bases.tip_stride + site0 : zero8;
+      const unsigned char * rt = has_r ? bases.tips + (size_t)rec_rtip(r) * bases.tip_stride + site0 : zero8;
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
-        f.codes_l[j] = lt[ltip ? j * SPS + lane / W : 0u];
-        f.codes_r[j] = rt[rtip ? j * SPS + lane / W : 0u];
-      }
-      if (EXT)
-      {
-        const double2 * L = reinterpret_cast<const double2 *>(plan[i].left_hbm);
-        const double2 * R = reinterpret_cast<const double2 *>(plan[i].right_hbm);
-        const unsigned int * ls = plan[i].lsc_hbm;
-        const unsigned int * rs = plan[i].rsc_hbm;
-        // (only the few ops that have such an operand issue these loads: a wave-uniform
-        // branch; their destination registers are written nowhere else)
-        if (L || R || ls || rs)
-        {
-#pragma unroll
-          for (unsigned int j = 0; j < J; ++j)
-          {
-            const unsigned int g = j * 64u + lane;                              // granule within the tile
-            const unsigned int e = (MODE == SCALE_RATE) ? (g >> 1) : g / W;     // count within the tile
-            const size_t e0 = (MODE == SCALE_RATE) ? site0 * RC : site0;        // first count of the tile
-            f.kl[j] = ld16<NT>(L ? L + site0 * W + g : zero16);
-            f.kr[j] = ld16<NT>(R ? R + site0 * W + g : zero16);
-            f.cl[j] = (ls ? ls + e0 : zero)[ls ? e : 0u];
-            f.cr[j] = (rs ? rs + e0 : zero)[rs ? e : 0u];
-          }
-        }
+        f.codes_l[j] = lt[has_l ? j * SPS + lane / W : 0u];
+        f.codes_r[j] = rt[has_r ? j * SPS + lane / W : 0u];
       }
     };
 
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
     // One matrix at a time through ONE staging block (LDS operations of a wave execute in
     // order): the 512 bytes this saves per wave are what gives the 12-wave configuration
     // its sixth slot (a balanced 128-taxon tree needs six).
-    auto stage_rows = [&](const FusedFetch<PL, J, EXT> & f, half_rows & pl, half_rows & pr) {
+    auto stage_rows = [&](const FusedFetch<PL, J> & f, half_rows & pl, half_rows & pr) {
       double2 * p = pst;
 #pragma unroll
       for (int t = 0; t < PL; ++t)
@@ -248,42 +260,32 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       }
     };
 
-    // Reload (not EXT): an operand that has no slot -- a value that gave its slot up, or one
-    // written by an earlier call -- is copied from HBM straight into the slot the plan names
-    // for it, by LDS-DMA (global_load_lds: no registers), at the top of the op BEFORE its
-    // reader.  The instructions are inline assembly on purpose: the compiler does not count
-    // them, so they cost no wait of their own -- they are issued ahead of that iteration's
-    // look-ahead loads, memory operations return in order, and the next iteration's first
-    // statement waits for those loads before any slot is read.
-    auto reload = [&](unsigned int i) {
-      const double * src[2] = {plan[i].left_hbm, plan[i].right_hbm};
-      const unsigned int * csrc[2] = {plan[i].lsc_hbm, plan[i].rsc_hbm};
-      const int slot[2] = {plan[i].lslot, plan[i].rslot};
+    // Reload: an operand that has no slot -- a value that gave its slot up, or one written by
+    // an earlier call -- is copied from HBM straight into the slot the plan names for it, by
+    // LDS-DMA (global_load_lds: no registers), at the top of the op BEFORE its reader.  The
+    // instructions are inline assembly on purpose: the compiler does not count them, so they
+    // cost no wait of their own -- they are issued ahead of that iteration's look-ahead
+    // loads, memory operations return in order, and the next iteration's first statement
+    // waits for those loads before any slot is read.  (Per-lane 64-bit addresses and `off`:
+    // the form the compiler itself emits for the builtin.)
+    auto reload = [&](const RecOp & r) {
+      // (the sources follow the records and their three look-ahead copies)
+      const const_quads q = (const_quads)(unsigned long long)(reinterpret_cast<const FusedSrc *>(plan + nops + 3) + rec_src(r));
+      const double * src[2] = {(const double *)q[0], (const double *)q[1]};
+      const unsigned int * csrc[2] = {(const unsigned int *)q[2], (const unsigned int *)q[3]};
+      const int slot[2] = {rec_lslot(r), rec_rslot(r)};
 #pragma unroll
       for (int o = 0; o < 2; ++o)
       {
         if (src[o])
         {
-          // (per-lane 64-bit addresses and `off`, the form the compiler itself emits for the
-          // builtin: the SGPR-base form did not deliver the data)
           const double2 * base = reinterpret_cast<const double2 *>(src[o]) + site0 * W;
 #pragma unroll
           for (unsigned int j = 0; j < J; ++j)
           {
             const unsigned int lds_b = clv_lds_b + ((unsigned int)slot[o] * J + j) * 1024u;
-            unsigned int m0_saved;
-#ifdef PLLHIP_RELOAD_SADDR
-            const unsigned int voff = (j * 64u + lane) * 16u;
-            if (NT)
-              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                           "global_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
-                           : "=&s"(m0_saved) : "s"(lds_b), "v"(voff), "s"(base) : "memory");
-            else
-              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                           "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                           : "=&s"(m0_saved) : "s"(lds_b), "v"(voff), "s"(base) : "memory");
-#else
             const double2 * gsrc = base + j * 64u + lane;
+            unsigned int m0_saved;
             if (NT)
               asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
                            "global_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
@@ -292,12 +294,8 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
               asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
                            "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                            : "=&s"(m0_saved) : "s"(lds_b), "v"(gsrc) : "memory");
-#endif
           }
         }
-#ifdef PLLHIP_RELOAD_DRAIN
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         if (MODE != SCALE_NONE && csrc[o])
         {
           // the tile's counts are J * CW consecutive words: the first so many lanes move one each
@@ -313,15 +311,27 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
         }
       }
     };
+    auto pair_table = [&](const RecOp & r) -> const double2 * {
+      return rec_pair(r) != PLLHIP_FUSED_NONE
+                 ? reinterpret_cast<const double2 *>(bases.pairtab + (size_t)rec_pair(r) * (256 * RC * 4))
+                 : nullptr;
+    };
 
     // Two ops of look-ahead: at the top of op i the block of op i+2 is requested, the block
     // of op i+1 (requested one op ago) goes through LDS into the registers op i+1 will use,
-    // and op i runs on registers filled one op ago.
-    FusedFetch<PL, J, EXT> cur, fa;
+    // and op i runs on registers filled one op ago.  The plan records of ops i .. i+2 are in
+    // SGPRs when they are needed: the op's own words for ops i and i+1 (r0, r1; those of op i+2
+    // are requested at the top of op i), the look-ahead words of op i+2 (a2; op i+3's requested
+    // at the top of op i).  (Scalar loads return out of order and share a counter with LDS, so
+    // a plan field consumed right after its load would drain the LDS reads in flight.)  The
+    // plan carries three copies of the last op behind it.
+    RecOp r0 = rec_op(plan, 0), r1 = rec_op(plan, 1);
+    RecAhead a2 = rec_ahead(plan, 2);
+    FusedFetch<PL, J> cur, fa;
     half_rows pl, pr;
-    if (!EXT && plan[0].dma_flags) reload(0u);
-    request(cur, 0u, plan[0].lmat, plan[0].rmat, plan[0].ltip, plan[0].rtip);
-    request(fa, 1u, plan[1].lmat, plan[1].rmat, plan[1].ltip, plan[1].rtip);
+    if (rec_dma(r0)) reload(r0);
+    request(cur, rec_ahead(plan, 0));
+    request(fa, rec_ahead(plan, 1));
     // The compiler counts the memory operations issued after a load to know how many may
     // stay in flight when the load is consumed, and takes the minimum over all paths into
     // the loop.  On the path through the loop an op's stores follow the look-ahead loads;
@@ -334,26 +344,11 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       if (MODE != SCALE_NONE) reinterpret_cast<unsigned int *>(sink + 64)[lane] = 0u;
     }
     stage_rows(cur, pl, pr);
-    // The scalar (plan) fields are fetched one op ahead as well: what op i computes with and
-    // what it requests (for op i+2) was loaded during op i-1.  Scalar loads return out of
-    // order and share a counter with LDS, so a plan field consumed in the middle of an op
-    // would drain the LDS reads in flight; and the plan of a large tree (22 KB for 200 taxa)
-    // does not stay in the scalar cache, so a field consumed right after its load would
-    // expose an L2 round trip per op.
-    int n_kind = plan[0].kind, n_lslot = plan[0].lslot, n_rslot = plan[0].rslot, n_pslot = plan[0].pslot;
-    int n_lsc = plan[0].lsc_slot, n_rsc = plan[0].rsc_slot, n_flags = plan[0].hbm_flags;
-    double * n_out = plan[0].parent;
-    unsigned int * n_psc = plan[0].pscaler;
-    const double * q_lmat = plan[2].lmat, * q_rmat = plan[2].rmat;
-    const unsigned char * q_ltip = plan[2].ltip, * q_rtip = plan[2].rtip;
-    // tip-tip pair tables: the gather of op i+1 is issued at the top of op i, from the
+    // tip operands' pair tables: the gather of op i+1 is issued at the top of op i, from the
     // characters that arrived for it; what op i uses was gathered during op i-1
-    const double * x_pair = plan[1].pair_tab;
-    const double * n_pair = plan[0].pair_tab;
-    int d_dma = EXT ? 0 : plan[1].dma_flags; // does the NEXT op reload an operand?
     double2 pt_use[J], pt_next[J];
     {
-      const double2 * t0 = reinterpret_cast<const double2 *>(n_pair);
+      const double2 * t0 = pair_table(r0);
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
@@ -363,39 +358,26 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
     }
     for (unsigned int i = 0; i < nops; ++i)
     {
-      const int kind = n_kind, lslot = n_lslot, rslot = n_rslot, pslot = n_pslot;
-      const int lsc_slot = n_lsc, rsc_slot = n_rsc, hbm_flags = n_flags;
-      double2 * out = reinterpret_cast<double2 *>(n_out);
-      unsigned int * pscaler = n_psc;
-      const double * r_lmat = q_lmat, * r_rmat = q_rmat;
-      const unsigned char * r_ltip = q_ltip, * r_rtip = q_rtip;
-      const bool have_pairs = n_pair != nullptr; // this op takes its entries from its pair table
-      const double2 * pair_next = reinterpret_cast<const double2 *>(x_pair); // the table of op i+1
-      asm volatile("" ::"s"(kind), "s"(lslot), "s"(rslot), "s"(pslot), "s"(lsc_slot), "s"(rsc_slot), "s"(out),
-                   "s"(pscaler), "s"(hbm_flags), "s"(r_lmat), "s"(r_rmat), "s"(r_ltip), "s"(r_rtip), "s"(pair_next));
-      n_pair = x_pair;
-      x_pair = plan[i + 2].pair_tab;
-      n_kind = plan[i + 1].kind; n_lslot = plan[i + 1].lslot; n_rslot = plan[i + 1].rslot; n_pslot = plan[i + 1].pslot;
-      n_lsc = plan[i + 1].lsc_slot; n_rsc = plan[i + 1].rsc_slot; n_flags = plan[i + 1].hbm_flags;
-      n_out = plan[i + 1].parent; n_psc = plan[i + 1].pscaler;
-      q_lmat = plan[i + 3].lmat; q_rmat = plan[i + 3].rmat; q_ltip = plan[i + 3].ltip; q_rtip = plan[i + 3].rtip;
-      const bool scaling = MODE != SCALE_NONE && pscaler != nullptr;
-      // (rare, wave-uniform: the plan fields of the reload are read on the spot)
-      const int r_dma = d_dma;
-      if (!EXT)
-      {
-        d_dma = plan[i + 2].dma_flags;
-        if (r_dma) reload(i + 1u);
-      }
-      FusedFetch<PL, J, EXT> fb;
-      request(fb, i + 2u, r_lmat, r_rmat, r_ltip, r_rtip);
+      const RecOp r2 = rec_op(plan, i + 2);
+      const RecAhead a3 = rec_ahead(plan, i + 3);
+      const int kind = rec_kind(r0), lslot = rec_lslot(r0), rslot = rec_rslot(r0), pslot = rec_pslot(r0);
+      const int lsc_slot = rec_lsc(r0), rsc_slot = rec_rsc(r0);
+      double2 * out = reinterpret_cast<double2 *>(bases.clv + (size_t)rec_parent(r0) * bases.site_stride * (RC * 4));
+      const bool scaling = MODE != SCALE_NONE && rec_pscaler(r0) != PLLHIP_FUSED_NONE;
+      unsigned int * pscaler = bases.scaler + (size_t)rec_pscaler(r0) * bases.site_stride * (MODE == SCALE_RATE ? RC : 1); // (used if scaling)
+      const bool have_pairs = rec_pair(r0) != PLLHIP_FUSED_NONE; // this op takes its entries from its pair table
+      const double2 * pair_next = pair_table(r1);                // the table of op i+1
+      // (rare, wave-uniform: the sources of the reload are read on the spot)
+      if (rec_dma(r1)) reload(r1);
+      FusedFetch<PL, J> fb;
+      request(fb, a2);
       unsigned int pairs[J];
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j) pairs[j] = ((fa.codes_l[j] & 15u) << 4) | (fa.codes_r[j] & 15u);
       // Everything requested one op ago has arrived once these characters are used -- and with
       // it what that iteration's reload() copied into this op's slots (issued ahead of those
       // requests; memory operations return in order).  No slot is read above this line.
-      if (!EXT) asm volatile("" ::"v"(pairs[J - 1]) : "memory");
+      asm volatile("" ::"v"(pairs[J - 1]) : "memory");
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
@@ -412,25 +394,14 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       for (unsigned int j = 0; j < J; ++j)
       {
         const unsigned int g = j * 64u + lane; // granule within the tile
-        // operands and inherited counts: LDS slot (slot 0 is read when there is none), or
-        // what the look-ahead fetched from HBM
-        double2 lo = clv[((lslot >= 0 ? lslot : 0) * J + j) * 64 + lane];
-        double2 ro = clv[((rslot >= 0 ? rslot : 0) * J + j) * 64 + lane];
+        // operands and inherited counts: LDS slots (slot 0 is read when there is none)
+        const double2 lo = clv[((lslot >= 0 ? lslot : 0) * J + j) * 64 + lane];
+        const double2 ro = clv[((rslot >= 0 ? rslot : 0) * J + j) * 64 + lane];
         const unsigned int cw = (MODE == SCALE_RATE) ? lane >> 1 : lane / W; // this lane's count within a sub-step
         unsigned int lc = cnt[((lsc_slot >= 0 ? lsc_slot : 0) * J + j) * CW + cw];
         unsigned int rc = cnt[((rsc_slot >= 0 ? rsc_slot : 0) * J + j) * CW + cw];
-        if (EXT)
-        {
-          if (lslot < 0) lo = cur.kl[j];
-          if (rslot < 0) ro = cur.kr[j];
-          if (lsc_slot < 0) lc = (hbm_flags & 1) ? cur.cl[j] : 0u;
-          if (rsc_slot < 0) rc = (hbm_flags & 2) ? cur.cr[j] : 0u;
-        }
-        else
-        {
-          if (lsc_slot < 0) lc = 0u;
-          if (rsc_slot < 0) rc = 0u;
-        }
+        if (lsc_slot < 0) lc = 0u;
+        if (rsc_slot < 0) rc = 0u;
         double x0, x1, y0 = 1.0, y1 = 1.0;
         if (have_pairs)
         {
@@ -511,6 +482,9 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedOp * __restri
       stage_rows(fa, pl, pr);
       cur.take(fa);
       fa.take(fb);
+      r0 = r1;
+      r1 = r2;
+      a2 = a3;
     }
     if (++round < static_rounds)
     {
@@ -550,7 +524,7 @@ unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int wgs)
   return (unsigned int)((budget - pmat) / per_slot);
 }
 
-// Slot assignment of the RELOAD plan: every inner operand is read from a slot.  A value whose
+// Slot assignment: every inner operand is read from a slot.  A value whose
 // slot was taken away (or that an earlier call wrote) is copied back from HBM into a slot by
 // the kernel's reload() at the top of the op BEFORE its reader; that slot must be free from
 // then on (not read by that op, not its parent's).  Belady's rule decides who gives a slot up:
@@ -764,10 +738,9 @@ static int assign_slots_reload(const FusedGeom & geom, const pllhip_op_t * ops, 
 }
 
 int pllhip_fused_plan(const FusedGeom & geom, const pllhip_op_t * ops, const PartialsArgs * args,
-                      const int * kinds, unsigned int count, unsigned int nslots, bool reload,
-                      std::vector<FusedOp> & plan, bool * ext_out, unsigned int * evictions_out)
+                      const int * kinds, unsigned int count, unsigned int nslots,
+                      std::vector<FusedOp> & plan, unsigned int * reloads_out)
 {
-  unsigned int evictions = 0;
   std::vector<Node> node(count);
   const size_t nclv = geom.nclv, nsc = geom.nsc;
   // last writer and readers-since of every CLV / scale buffer, in list order
@@ -851,183 +824,20 @@ int pllhip_fused_plan(const FusedGeom & geom, const pllhip_op_t * ops, const Par
   std::vector<unsigned int> pos_of(count);
   for (unsigned int pos = 0; pos < count; ++pos) pos_of[order[pos]] = pos;
 
-  // which list op produced each inner operand of op i, as the kernel sees them (a tip is
-  // always presented as the LEFT child of a tip-inner op, resolve_op)
-  auto operands = [&](unsigned int i, int & wl, int & wr, int & swl, int & swr) {
-    wl = wr = swl = swr = -1;
-    if (kinds[i] == 0)
-    {
-      wl = node[i].raw[0]; wr = node[i].raw[1];
-      swl = node[i].sraw[0]; swr = node[i].sraw[1];
-    }
-    else if (kinds[i] == 1)
-    {
-      const int inner = geom.is_tip(ops[i].child1_clv) ? 1 : 0;
-      wr = node[i].raw[inner];
-      swr = node[i].sraw[inner];
-    }
-  };
-  // positions (in the new order) at which each value is read
-  std::vector<std::vector<unsigned int>> uses(count);
-  for (unsigned int pos = 0; pos < count; ++pos)
-  {
-    int wl, wr, swl, swr;
-    operands(order[pos], wl, wr, swl, swr);
-    if (wl >= 0) uses[wl].push_back(pos);
-    if (wr >= 0 && wr != wl) uses[wr].push_back(pos);
-  }
-  std::vector<unsigned int> next_use(count, 0); // index into uses[]
-
-  if (reload)
-  {
-    const int rc = assign_slots_reload(geom, ops, args, kinds, count, nslots, order, pos_of, node, plan, evictions_out);
-    if (rc) return rc;
-    if (getenv("PLLHIP_FUSED_DEBUG"))
-    {
-      fprintf(stderr, "pllhip fused plan: %u ops, %u slots, %u operands reloaded from HBM\n", count, nslots, *evictions_out);
-      if (atoi(getenv("PLLHIP_FUSED_DEBUG")) > 1)
-        for (unsigned int pos = 0; pos < count; ++pos)
-        {
-          const FusedOp & f = plan[pos];
-          fprintf(stderr, "  %3u: op %3d kind %d  l %2d r %2d p %2d  lsc %2d rsc %2d  dma %d  hbm %p %p counts %p %p\n", pos,
-                  f.list_pos, f.kind, f.lslot, f.rslot, f.pslot, f.lsc_slot, f.rsc_slot, f.dma_flags,
-                  (const void *)f.left_hbm, (const void *)f.right_hbm, (const void *)f.lsc_hbm, (const void *)f.rsc_hbm);
-        }
-    }
-    FusedOp tail = plan.back(); // "the ops after the last": what the kernel's look-ahead requests
-    tail.dma_flags = 0;
-    for (int t = 0; t < 3; ++t) plan.push_back(tail);
-    *ext_out = false;
-    return 0;
-  }
-
-  // slots: a value keeps one from the op that writes it to its last reader; when there is
-  // none left the live value whose next reader is farthest away gives its slot up (its
-  // later readers fetch it from HBM, one op ahead) -- a value read by the very next op
-  // always has one, because that read would be issued before the value is stored
-  std::vector<int> slot_of(count, -1);
-  std::vector<int> free_slots;
-  for (int s = (int)nslots - 1; s >= 0; --s) free_slots.push_back(s);
-  std::vector<unsigned int> live; // values that hold a slot
-  bool ext = false;
-  plan.resize(count);
-  for (unsigned int pos = 0; pos < count; ++pos)
-  {
-    const unsigned int i = order[pos];
-    const PartialsArgs & a = args[i];
-    FusedOp & f = plan[pos];
-    memset(&f, 0, sizeof(f));
-    f.parent = a.parent;
-    f.ltip = a.ltip;
-    f.rtip = a.rtip;
-    f.lmat = a.lmat;
-    f.rmat = a.rmat;
-    f.pscaler = a.pscaler;
-    f.kind = kinds[i];
-    f.list_pos = (int)i;
-    int wl, wr, swl, swr;
-    operands(i, wl, wr, swl, swr);
-    f.lslot = wl >= 0 ? slot_of[wl] : -1;
-    f.rslot = wr >= 0 ? slot_of[wr] : -1;
-    // an operand without a slot comes from HBM, requested two ops ahead: its producer must
-    // have stored it before that
-    auto hbm_ok = [&](int w) { return w < 0 || pos_of[w] + 2 < pos; };
-    if (f.kind == 0 && f.lslot < 0)
-    {
-      if (!hbm_ok(wl)) return 1;
-      f.left_hbm = a.left;
-      ext = true;
-    }
-    if (f.kind != 2 && f.rslot < 0)
-    {
-      if (!hbm_ok(wr)) return 1;
-      f.right_hbm = a.right;
-      ext = true;
-    }
-    // inherited counts: from the slot of the operand they were written with, else from HBM
-    f.lsc_slot = f.rsc_slot = -1;
-    if (a.lscaler)
-    {
-      if (swl >= 0 && swl == wl && f.lslot >= 0) f.lsc_slot = f.lslot;
-      else if (!hbm_ok(swl)) return 1;
-      else { f.lsc_hbm = a.lscaler; f.hbm_flags |= 1; ext = true; }
-    }
-    if (a.rscaler)
-    {
-      if (swr >= 0 && swr == wr && f.rslot >= 0) f.rsc_slot = f.rslot;
-      else if (!hbm_ok(swr)) return 1;
-      else { f.rsc_hbm = a.rscaler; f.hbm_flags |= 2; ext = true; }
-    }
-    // operands read for the last time give their slots back
-    for (int w : {wl, (wr != wl ? wr : -1)})
-      if (w >= 0)
-      {
-        if (next_use[w] < uses[w].size() && uses[w][next_use[w]] == pos) next_use[w]++;
-        if (next_use[w] >= uses[w].size() && slot_of[w] >= 0)
-        {
-          free_slots.push_back(slot_of[w]);
-          slot_of[w] = -1;
-          live.erase(std::find(live.begin(), live.end(), (unsigned int)w));
-        }
-      }
-    f.pslot = -1;
-    if (!uses[i].empty())
-    {
-      if (free_slots.empty())
-      {
-        // farthest next reader among the live values and the new one
-        unsigned int victim = i, far = uses[i][0];
-        for (unsigned int v : live)
-          if (uses[v][next_use[v]] > far)
-          {
-            far = uses[v][next_use[v]];
-            victim = v;
-          }
-        if (victim == i && uses[i][0] <= pos + 2)
-        {
-          // one of the next two ops reads the new value: take the slot of the farthest other one
-          far = 0;
-          for (unsigned int v : live)
-            if (uses[v][next_use[v]] >= far)
-            {
-              far = uses[v][next_use[v]];
-              victim = v;
-            }
-        }
-        if (victim != i)
-        {
-          if (uses[victim][next_use[victim]] <= pos + 2) return 1; // (cannot happen with >= 5 slots)
-          free_slots.push_back(slot_of[victim]);
-          slot_of[victim] = -1;
-          live.erase(std::find(live.begin(), live.end(), victim));
-        }
-        ++evictions; // (a value that has readers goes without a slot, or another loses its own)
-      }
-      if (!free_slots.empty())
-      {
-        f.pslot = free_slots.back();
-        free_slots.pop_back();
-        slot_of[i] = f.pslot;
-        live.push_back(i);
-      }
-    }
-  }
+  const int rc = assign_slots_reload(geom, ops, args, kinds, count, nslots, order, pos_of, node, plan, reloads_out);
+  if (rc) return rc;
   if (getenv("PLLHIP_FUSED_DEBUG"))
   {
-    unsigned int hbm = 0, slotted = 0;
-    for (const FusedOp & f : plan)
-    {
-      hbm += (f.left_hbm != nullptr) + (f.right_hbm != nullptr);
-      slotted += (f.lslot >= 0) + (f.rslot >= 0);
-    }
-    fprintf(stderr, "pllhip fused plan: %u ops, %u slots, operands from LDS %u, from HBM %u, ext %d, evictions %u\n",
-            count, nslots, slotted, hbm, (int)ext, evictions);
+    fprintf(stderr, "pllhip fused plan: %u ops, %u slots, %u operands reloaded from HBM\n", count, nslots, *reloads_out);
+    if (atoi(getenv("PLLHIP_FUSED_DEBUG")) > 1)
+      for (unsigned int pos = 0; pos < count; ++pos)
+      {
+        const FusedOp & f = plan[pos];
+        fprintf(stderr, "  %3u: op %3d kind %d  l %2d r %2d p %2d  lsc %2d rsc %2d  dma %d  hbm %p %p counts %p %p\n", pos,
+                f.list_pos, f.kind, f.lslot, f.rslot, f.pslot, f.lsc_slot, f.rsc_slot, f.dma_flags,
+                (const void *)f.left_hbm, (const void *)f.right_hbm, (const void *)f.lsc_hbm, (const void *)f.rsc_hbm);
+      }
   }
-  plan.push_back(plan.back()); // "the ops after the last": what the kernel's look-ahead requests
-  plan.push_back(plan.back());
-  plan.push_back(plan.back());
-  *ext_out = ext;
-  *evictions_out = evictions;
   return 0;
 }
 
@@ -1035,14 +845,12 @@ int pllhip_fused_plan(const FusedGeom & geom, const pllhip_op_t * ops, const Par
 // operands without a slot a list gets with `nslots` slots per wave.
 extern "C" int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buffers, unsigned int scale_buffers,
                                      int pattern_tip, const pllhip_op_t * ops, unsigned int count,
-                                     unsigned int nslots, int reload, unsigned int * order_out,
-                                     unsigned int * hbm_operands_out, unsigned int * evictions_out,
-                                     int * slots_out)
+                                     unsigned int nslots, unsigned int * order_out,
+                                     unsigned int * reloads_out, int * slots_out)
 {
   const FusedGeom geom = {(size_t)tips + clv_buffers, scale_buffers, tips, pattern_tip != 0};
   std::vector<PartialsArgs> args(count);
   std::vector<int> kinds(count);
-  unsigned int present = 0;
   for (unsigned int i = 0; i < count; ++i)
   {
     const pllhip_op_t & op = ops[i];
@@ -1058,7 +866,6 @@ extern "C" int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buffers
     kinds[i] = (t1 && t2) ? 2 : (t1 || t2) ? 1 : 0;
     // (distinct fake addresses per scale buffer: the reload plan compares them)
     auto sc = [&](int idx) { return idx >= 0 ? reinterpret_cast<unsigned int *>((uintptr_t)4096 * (idx + 1)) : (unsigned int *)nullptr; };
-    (void)present;
     args[i].pscaler = sc(op.parent_scaler);
     auto clv = [&](unsigned int idx) { return reinterpret_cast<const double *>((uintptr_t)4096 * (idx + 1)); };
     if (kinds[i] == 0)
@@ -1075,31 +882,26 @@ extern "C" int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buffers
     }
   }
   std::vector<FusedOp> plan;
-  bool ext = false;
-  unsigned int evictions = 0;
-  const int rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, reload != 0, plan, &ext, &evictions);
+  unsigned int reloads = 0;
+  const int rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, plan, &reloads);
   if (rc) return rc;
-  unsigned int hbm = 0;
   for (unsigned int pos = 0; pos < count; ++pos)
   {
     if (order_out) order_out[pos] = (unsigned int)plan[pos].list_pos;
     if (slots_out)
     {
       const FusedOp & f = plan[pos];
-      const int v[6] = {f.lslot, f.rslot, f.pslot, f.lsc_slot, f.rsc_slot,
-                        (f.left_hbm ? 1 : 0) | (f.right_hbm ? 2 : 0) | (f.dma_flags << 2)};
+      const int v[6] = {f.lslot, f.rslot, f.pslot, f.lsc_slot, f.rsc_slot, f.dma_flags};
       for (int t = 0; t < 6; ++t) slots_out[pos * 6 + t] = v[t];
     }
-    hbm += (plan[pos].left_hbm != nullptr) + (plan[pos].right_hbm != nullptr);
   }
-  if (hbm_operands_out) *hbm_operands_out = hbm;
-  if (evictions_out) *evictions_out = evictions;
+  if (reloads_out) *reloads_out = reloads;
   return 0;
 }
 
 template <int RC>
-static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int count, unsigned int nslots,
-                           int mode, bool ext)
+static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedBases & bases, unsigned int count,
+                           unsigned int nslots, int mode)
 {
   constexpr int J = PLLHIP_FUSED_J;
   const unsigned int sites = c->sh.sites;
@@ -1107,74 +909,119 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedOp * d_plan, unsigned int 
   const size_t tiles = (sites + tile_sites - 1) / tile_sites;
   const size_t cw = c->sh.rate_scalers ? 32 : ((64 / (2 * RC)) < 4 ? 4 : (64 / (2 * RC)));
   const size_t lds = 4 * ((size_t)nslots * J * (64 * 16 + cw * 4) + (size_t)RC * 16 * sizeof(double));
-  // two workgroups (8 waves) per CU, each wave walking its share of the tiles
+  // three workgroups (12 waves) per CU when the slots leave room for them, else two; each wave
+  // walks its share of the tiles
   size_t grid = (tiles + 3) / 4;
   const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
-  // (the EXT variant needs 212 registers to stay out of scratch: two waves per SIMD; it is
-  // squeezed into three only for the 12-wave configuration)
-  const bool three = nslots <= pllhip_fused_slots(c, 3);
   unsigned int * tile_counter = getenv("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
-#define LAUNCH_FUSED(MODEV, NTV, EXTV)                                                                              \
-  do {                                                                                                               \
-    if (EXTV && !three)                                                                                              \
-      k_dna_fused<RC, J, MODEV, NTV, EXTV, 2><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites,    \
-                                                                                            nslots, c->d_zero,      \
-                                                                                            (double2 *)c->d_sink, tile_counter);   \
-    else                                                                                                             \
-      k_dna_fused<RC, J, MODEV, NTV, EXTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(d_plan, count, sites,    \
-                                                                                            nslots, c->d_zero,      \
-                                                                                            (double2 *)c->d_sink, tile_counter);   \
+  // Address translations: the translation caches reach about 8 GB (4096 pages of 2 MB).  A
+  // partition whose CLVs exceed that is swept from end to end by every launch, so a launch
+  // that starts where the previous one started finds none of its pages cached (measured:
+  // every shape runs at 0.59-0.64 of the HBM peak up to 8 GB of CLVs and at 0.46-0.50 beyond,
+  // whatever the tree -- profiles/r2_footprint.txt).  Every other launch therefore walks the
+  // tiles backwards: it starts in the pages the previous launch touched last.
+  const unsigned int backwards = (c->fused_pingpong && c->clv_arena_bytes > ((size_t)6 << 30)) ? (c->fused_launches++ & 1u) : 0u;
+#define LAUNCH_FUSED(MODEV, NTV)                                                                                  \
+  k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(                 \
+      d_plan, bases, count, sites, nslots, c->d_zero, (double2 *)c->d_sink, tile_counter, backwards)
+#define LAUNCH_FUSED_MODE(NTV)                         \
+  do {                                                  \
+    if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV);       \
+    else if (mode == SCALE_SITE) LAUNCH_FUSED(1, NTV);  \
+    else LAUNCH_FUSED(2, NTV);                          \
   } while (0)
-#define LAUNCH_FUSED_MODE(NTV, EXTV)                         \
-  do {                                                        \
-    if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV, EXTV);       \
-    else if (mode == SCALE_SITE) LAUNCH_FUSED(1, NTV, EXTV);  \
-    else LAUNCH_FUSED(2, NTV, EXTV);                          \
-  } while (0)
-  if (nt && ext) LAUNCH_FUSED_MODE(true, true);
-  else if (nt) LAUNCH_FUSED_MODE(true, false);
-  else if (ext) LAUNCH_FUSED_MODE(false, true);
-  else LAUNCH_FUSED_MODE(false, false);
+  if (nt) LAUNCH_FUSED_MODE(true);
+  else LAUNCH_FUSED_MODE(false);
 #undef LAUNCH_FUSED_MODE
 #undef LAUNCH_FUSED
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
-int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, unsigned int nslots, bool ext)
+// what the indices of the plan records are relative to
+static FusedBases fused_bases(const pllhip_ctx * c)
 {
+  FusedBases b;
+  b.clv = c->clv_arena;
+  b.scaler = c->scaler_arena;
+  b.tips = c->tipchars;
+  b.pmat = c->pmatrix;
+  b.pairtab = c->d_pairtab;
+  b.site_stride = c->sh.sites + PLLHIP_TAIL_SITES;
+  b.tip_stride = (unsigned int)c->tip_stride;
+  return b;
+}
+
+int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots)
+{
+  const unsigned int count = (unsigned int)plan.size();
   // pair tables of the tip-tip and tip-inner ops (k_dna_pair_tables), carved from one device buffer
-  std::vector<FusedOp> plan = plan_in;
+  const int level = c->fused_pairs; // env PLLHIP_FUSED_PAIRS: 0 off, 1 tip-tip only, 2 (default) tip-inner too
+  const int min_kind = level == 0 ? 3 : (level == 1 ? 2 : 1);
+  const size_t per = (size_t)256 * c->sh.rate_cats * 4;
+  size_t ntab = 0;
+  for (const FusedOp & f : plan) ntab += (f.kind >= min_kind);
+  if (ntab > PLLHIP_FUSED_MAX_INDEX) return 1;
+  if (ntab && c->pairtab_elems < ntab * per)
   {
-    const int level = c->fused_pairs; // env PLLHIP_FUSED_PAIRS: 0 off, 1 tip-tip only, 2 (default) tip-inner too
-    const bool off = level == 0;
-    const int min_kind = level == 1 ? 2 : 1;
-    const size_t per = (size_t)256 * c->sh.rate_cats * 4;
-    size_t ntt = 0;
-    for (const FusedOp & f : plan) ntt += (f.kind >= min_kind);
-    if (!off && ntt)
-    {
-      if (c->pairtab_elems < ntt * per)
-      {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->d_pairtab) HIP_TRY(hipFree(c->d_pairtab));
-        c->d_pairtab = nullptr;
-        HIP_TRY(hipMalloc((void **)&c->d_pairtab, ntt * per * sizeof(double)));
-        c->pairtab_elems = ntt * per;
-      }
-      size_t t = 0;
-      for (FusedOp & f : plan)
-        if (f.kind >= min_kind) f.pair_tab = c->d_pairtab + (t++) * per;
-    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_pairtab) HIP_TRY(hipFree(c->d_pairtab));
+    c->d_pairtab = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->d_pairtab, ntab * per * sizeof(double)));
+    c->pairtab_elems = ntab * per;
+    ++c->layout_epoch;
   }
-  const unsigned int count = (unsigned int)plan.size() - 3; // the last three entries are look-ahead sentinels
-  // every op with a parent scaler scales the partition's way
+  // the records: indices relative to the arenas (a list whose indices do not fit 16 bits
+  // runs per level), then three copies of the last op (what the kernel's look-ahead
+  // requests beyond the end), then the sources of the reloads
+  const unsigned int first_clv = c->sh.pattern_tip ? c->sh.tips : 0;
+  if (c->clv.size() - first_clv > PLLHIP_FUSED_MAX_INDEX || c->sh.scale_buffers > PLLHIP_FUSED_MAX_INDEX ||
+      c->sh.tips > PLLHIP_FUSED_MAX_INDEX || c->sh.prob_matrices > PLLHIP_FUSED_MAX_INDEX)
+    return 1;
+  std::vector<FusedRec> recs(count + 3);
+  std::vector<FusedSrc> srcs;
   int mode = SCALE_NONE;
-  for (const FusedOp & f : plan)
+  size_t tab = 0;
+  for (unsigned int pos = 0; pos < count; ++pos)
+  {
+    const FusedOp & f = plan[pos];
+    FusedRec & r = recs[pos];
+    memset(&r, 0, sizeof(r));
+    r.parent = (unsigned short)((f.parent - c->clv_arena) / c->clv_stride);
+    r.pscaler = f.pscaler ? (unsigned short)((f.pscaler - c->scaler_arena) / c->scaler_stride) : PLLHIP_FUSED_NONE;
+    r.ltip = f.ltip ? (unsigned short)((f.ltip - c->tipchars) / c->tip_stride) : PLLHIP_FUSED_NONE;
+    r.rtip = f.rtip ? (unsigned short)((f.rtip - c->tipchars) / c->tip_stride) : PLLHIP_FUSED_NONE;
+    r.lmat = (unsigned short)((f.lmat - c->pmatrix) / c->pmat_elems);
+    r.rmat = (unsigned short)((f.rmat - c->pmatrix) / c->pmat_elems);
+    r.pair = f.kind >= min_kind ? (unsigned short)(tab++) : PLLHIP_FUSED_NONE;
+    r.src = PLLHIP_FUSED_NONE;
+    if (f.dma_flags)
+    {
+      if (srcs.size() >= PLLHIP_FUSED_MAX_INDEX) return 1;
+      r.src = (unsigned short)srcs.size();
+      srcs.push_back(FusedSrc{f.left_hbm, f.right_hbm, f.lsc_hbm, f.rsc_hbm});
+    }
+    r.lslot = (signed char)f.lslot;
+    r.rslot = (signed char)f.rslot;
+    r.pslot = (signed char)f.pslot;
+    r.kind = (signed char)f.kind;
+    r.lsc_slot = (signed char)f.lsc_slot;
+    r.rsc_slot = (signed char)f.rsc_slot;
+    r.dma_flags = (unsigned char)f.dma_flags;
+    r.list_pos = (unsigned int)f.list_pos;
+    // every op with a parent scaler scales the partition's way
     if (f.pscaler) mode = c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE;
-  const size_t bytes = plan.size() * sizeof(FusedOp);
+  }
+  for (unsigned int t = 0; t < 3; ++t)
+  {
+    recs[count + t] = recs[count - 1];
+    recs[count + t].dma_flags = 0;
+    recs[count + t].src = PLLHIP_FUSED_NONE;
+  }
+  const size_t rec_bytes = recs.size() * sizeof(FusedRec);
+  const size_t bytes = rec_bytes + (srcs.size() + 1) * sizeof(FusedSrc);
   if (c->plan_cap < bytes)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1190,49 +1037,49 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan_in, un
     c->d_plan = nullptr;
     HIP_TRY(hipMalloc(&c->d_plan, bytes * 2));
     c->plan_cap = bytes * 2;
+    ++c->layout_epoch;
   }
   // two pinned staging buffers in turn: the copy of the call before last has long finished
   const int b = c->plan_next;
   c->plan_next ^= 1;
   if (c->plan_pending[b]) HIP_TRY(hipEventSynchronize(c->plan_done[b]));
-  memcpy(c->h_plan[b], plan.data(), bytes);
+  memcpy(c->h_plan[b], recs.data(), rec_bytes);
+  if (!srcs.empty()) memcpy(static_cast<char *>(c->h_plan[b]) + rec_bytes, srcs.data(), srcs.size() * sizeof(FusedSrc));
   HIP_TRY(hipMemcpyAsync(c->d_plan, c->h_plan[b], bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 80 * sizeof(double2))); // 1280 B per wave
   if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, sizeof(unsigned int)));
   // what a repeated call with the same op list needs (pllhip_relaunch_fused)
-  c->fused_last_entries = (unsigned int)plan.size();
+  c->fused_last_entries = (unsigned int)recs.size();
   c->fused_last_count = count;
   c->fused_last_nslots = nslots;
   c->fused_last_mode = mode;
-  c->fused_last_ext = ext;
+  c->fused_last_epoch = c->layout_epoch;
   return pllhip_relaunch_fused(c);
 }
 
 // The device copy of the plan is still that of the previous call (same op list: the plan
-// holds addresses, not values -- P-matrices, tip characters and CLVs are read when the
+// holds buffer indices, not values -- P-matrices, tip characters and CLVs are read when the
 // kernels run): tip tables and the list kernel again, no planning, no upload.
 int pllhip_relaunch_fused(pllhip_ctx * c)
 {
   const unsigned int entries = c->fused_last_entries, count = c->fused_last_count, nslots = c->fused_last_nslots;
   const int mode = c->fused_last_mode;
-  const bool ext = c->fused_last_ext;
   HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
-  const FusedOp * d_plan = (const FusedOp *)c->d_plan;
+  const FusedRec * d_plan = (const FusedRec *)c->d_plan;
+  const FusedBases bases = fused_bases(c);
   switch (c->sh.rate_cats)
   {
-    case 1: k_dna_pair_tables<1><<<entries, 256, 0, c->stream>>>(d_plan, entries); break;
-    case 2: k_dna_pair_tables<2><<<entries, 256, 0, c->stream>>>(d_plan, entries); break;
-    case 4: k_dna_pair_tables<4><<<entries, 256, 0, c->stream>>>(d_plan, entries); break;
-    default: k_dna_pair_tables<8><<<entries, 256, 0, c->stream>>>(d_plan, entries); break;
+    case 1: k_dna_pair_tables<1><<<entries, 256, 0, c->stream>>>(d_plan, entries, bases); break;
+    case 2: k_dna_pair_tables<2><<<entries, 256, 0, c->stream>>>(d_plan, entries, bases); break;
+    default: k_dna_pair_tables<4><<<entries, 256, 0, c->stream>>>(d_plan, entries, bases); break;
   }
   HIP_TRY(hipGetLastError());
   switch (c->sh.rate_cats)
   {
-    case 1: return launch_fused_rc<1>(c, d_plan, count, nslots, mode, ext);
-    case 2: return launch_fused_rc<2>(c, d_plan, count, nslots, mode, ext);
-    case 4: return launch_fused_rc<4>(c, d_plan, count, nslots, mode, ext);
-    default: return launch_fused_rc<8>(c, d_plan, count, nslots, mode, ext);
+    case 1: return launch_fused_rc<1>(c, d_plan, bases, count, nslots, mode);
+    case 2: return launch_fused_rc<2>(c, d_plan, bases, count, nslots, mode);
+    default: return launch_fused_rc<4>(c, d_plan, bases, count, nslots, mode);
   }
 }

@@ -596,6 +596,7 @@ static int launch_gen_wide(pllhip_ctx * c, const PartialsBatch & b_in, unsigned 
       if (c->d_tiptab) HIP_TRY(hipFree(c->d_tiptab));
       c->d_tiptab = nullptr;
       HIP_TRY(hipMalloc((void **)&c->d_tiptab, need * sizeof(double)));
+      ++c->layout_epoch;
       c->tiptab_elems = need;
     }
     k_gen_tip_tables<<<dim3(8, count), 256, 0, c->stream>>>(b, c->d_tiptab, c->maxstates, KIND == 2 ? 1 : 0);

@@ -185,25 +185,25 @@ def test_bench_cpu_baseline_leg(ref):
 
 # ---------------------------------------------------------------- the op-list planner (host logic)
 
-def _plan_dry(amd, ops, tips, clv_buffers, scale_buffers, pattern_tip, nslots, reload=1):
-    """(rc, order, operands without a slot, evictions) from pllhip_fused_plan_dry."""
+def _plan_dry(amd, ops, tips, clv_buffers, scale_buffers, pattern_tip, nslots):
+    """(rc, order, operands copied back from HBM) from pllhip_fused_plan_dry."""
     ops = np.ascontiguousarray(ops)
     n = len(ops)
     order = (C.c_uint * n)()
     slots = (C.c_int * (6 * n))()
-    hbm, ev = C.c_uint(), C.c_uint()
+    hbm = C.c_uint()
     rc = amd.lib.pllhip_fused_plan_dry(C.c_uint(tips), C.c_uint(clv_buffers), C.c_uint(scale_buffers),
                                        C.c_int(pattern_tip), ops.ctypes.data_as(C.c_void_p), C.c_uint(n),
-                                       C.c_uint(nslots), C.c_int(reload), order, C.byref(hbm), C.byref(ev), slots)
+                                       C.c_uint(nslots), order, C.byref(hbm), slots)
     if rc == 0:
-        _simulate_slots(ops, tips if pattern_tip else 0, list(order), np.array(slots).reshape(n, 6), nslots, reload)
-    return rc, list(order), hbm.value, ev.value
+        _simulate_slots(ops, tips if pattern_tip else 0, list(order), np.array(slots).reshape(n, 6), nslots)
+    return rc, list(order), hbm.value
 
 
-def _simulate_slots(ops, pattern_tips, order, slots, nslots, reload):
+def _simulate_slots(ops, pattern_tips, order, slots, nslots):
     """Walk a plan the way the kernel does and check that every inner operand is found where
-    the plan says: in the slot its producer (or, reload plans, the copy from HBM issued at the
-    top of the op before) left it in, with nothing having overwritten it in between."""
+    the plan says: in the slot its producer (or the copy from HBM issued at the top of the op
+    before) left it in, with nothing having overwritten it in between."""
     content = [None] * nslots            # what each slot holds: ("v", list op) or ("hbm", clv index)
     written = {}                         # clv index -> list op that wrote it last (in plan order)
 
@@ -223,15 +223,14 @@ def _simulate_slots(ops, pattern_tips, order, slots, nslots, reload):
     def copy_in(pos):
         i = order[pos]
         for side, clv in inner_operands(i).items():
-            if slots[pos][5] & (4 << side):
+            if slots[pos][5] & (1 << side):
                 s = int(slots[pos][side])
                 assert 0 <= s < nslots
                 content[s] = ("arriving", expect(clv), pos)
 
-    if reload:
-        copy_in(0)
+    copy_in(0)
     for pos, i in enumerate(order):
-        if reload and pos + 1 < len(order):
+        if pos + 1 < len(order):
             before = list(content)
             copy_in(pos + 1)              # top of the op: the next op's copies are issued
             for s in range(nslots):
@@ -240,13 +239,11 @@ def _simulate_slots(ops, pattern_tips, order, slots, nslots, reload):
                     assert s not in (int(slots[pos][0]), int(slots[pos][1]), int(slots[pos][2])), (pos, s)
         for side, clv in inner_operands(i).items():
             s = int(slots[pos][side])
-            from_hbm = bool(slots[pos][5] & (1 << side))
-            if s < 0:
-                assert from_hbm and not reload, (pos, side)   # EXT plan: fetched into registers
-                # its producer must have run at least three ops earlier (the fetch is two ops ahead)
-                if clv in written:
-                    assert order.index(written[clv]) + 2 < pos
-                continue
+            assert 0 <= s < nslots, (pos, side)
+            if slots[pos][5] & (1 << side) and clv in written:
+                # copied back from HBM at the top of the op before: its producer's stores must
+                # have left by then
+                assert order.index(written[clv]) + 2 < pos
             want = expect(clv)
             got = content[s]
             if got is not None and got[0] == "arriving":
@@ -289,8 +286,7 @@ def _order_respects_hazards(ops, order):
     return True
 
 
-@pytest.mark.parametrize("reload", [1, 0])
-def test_fused_planner_on_tree_shapes(amd, reload):
+def test_fused_planner_on_tree_shapes(amd):
     """Depth-first, heavier subtree first bounds the live values by the tree's Strahler
     number: a balanced 64-taxon list needs no operand from HBM with 5 slots, a balanced
     128-taxon list (BASELINE config 4) none with 6 -- what the 12-wave configuration of
@@ -298,14 +294,13 @@ def test_fused_planner_on_tree_shapes(amd, reload):
     for plan, nslots, most in ((W.balanced_tree(64), 5, 0), (W.balanced_tree(128), 6, 0),
                                (W.balanced_tree(128), 5, 4), (W.random_tree(200, seed=42), 6, 8),
                                (W.caterpillar_tree(300), 5, 0)):
-        rc, order, hbm, _ = _plan_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 1,
-                                      nslots, reload)
+        rc, order, hbm = _plan_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 1, nslots)
         assert rc == 0
         assert _order_respects_hazards(plan.ops, order)
         assert hbm <= most, (plan.shape, plan.tips, nslots, hbm)
     # tips as CLVs: every tip operand comes from HBM, nothing else does with 7 slots
     plan = W.balanced_tree(64)
-    rc, order, hbm, _ = _plan_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 0, 7, reload)
+    rc, order, hbm = _plan_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 0, 7)
     assert rc == 0 and hbm == 64 and _order_respects_hazards(plan.ops, order)
 
 
@@ -320,12 +315,12 @@ def test_fused_planner_on_random_op_sequences(amd):
         tips, inner, scalers = 12, 10, 10
         ops = random_op_sequence(rng, tips, inner, scalers, 2 * tips - 3, 60 + seed)
         for pattern_tip in (0, 1):
-            for reload in (0, 1):
-                rc, order, _, _ = _plan_dry(amd, ops, tips, inner, scalers, pattern_tip, 6, reload)
+            for nslots in (5, 6, 7):
+                rc, order, _ = _plan_dry(amd, ops, tips, inner, scalers, pattern_tip, nslots)
                 assert rc in (0, 1)
                 if rc == 0:
                     taken += 1
-                    assert _order_respects_hazards(ops, order), (seed, pattern_tip, reload)
+                    assert _order_respects_hazards(ops, order), (seed, pattern_tip, nslots)
     assert taken > 40
     # indices out of range are refused, not read
     bad = W.balanced_tree(8).ops.copy()
