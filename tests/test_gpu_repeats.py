@@ -6,7 +6,7 @@ directly."""
 import numpy as np
 import pytest
 
-from helpers import make_case, build_partition, bits_equal
+from helpers import make_case, build_partition, bits_equal, oracle_run, rel_err
 from libpll_amd import workload as W
 from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_SITE_REPEATS,
                                ATTRIB_AB_LEWIS, OPS_DTYPE, SCALE_BUFFER_NONE, PllError)
@@ -83,6 +83,51 @@ def test_repeats_equal_plain(gpu, monkeypatch, states, shape, tips, sites, rate_
     lb = rep.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
     assert la == lb and la != a[0]
     plain.destroy()
+    rep.destroy()
+
+
+@pytest.mark.parametrize("states,shape,tips,sites,rate_cats,rate_scalers",
+                         [(4, "balanced", 16, 1200, 4, False), (4, "random", 30, 911, 4, True),
+                          (4, "caterpillar", 60, 700, 4, False), (20, "random", 14, 400, 4, False),
+                          (20, "balanced", 8, 300, 2, True)])
+def test_repeats_against_the_oracle(gpu, orc, monkeypatch, states, shape, tips, sites, rate_cats, rate_scalers):
+    """Not a self-comparison: the partition WITH site repeats against liboracle.so directly
+    (which knows nothing of repeats) -- expanded CLVs and scale buffers of every op bitwise,
+    per-site lnL to 1e-13, lnL, sumtable and derivatives to the tolerances of the plain tests."""
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")   # compare CLVs bit for bit
+    case = make_case(states, shape, tips, sites, rate_cats=rate_cats, seed=3 * tips + sites, gap_frac=0.02)
+    rng = np.random.default_rng(sites + 1)
+    pool = rng.integers(0, sites, size=sites // 5 + 1)
+    pick = pool[rng.integers(0, len(pool), size=sites)]
+    case["seqs"] = [bytes(np.frombuffer(s, dtype=np.uint8)[pick]) for s in case["seqs"]]
+    plan, R = case["plan"], rate_cats
+    attrs = ATTRIB_PATTERN_TIP | (ATTRIB_RATE_SCALERS if rate_scalers else 0)
+    rep = build_partition(gpu, case, attrs | ATTRIB_SITE_REPEATS)
+    o = oracle_run(orc, gpu, rep, case, attrs)
+    rep.update_partials(plan.ops)
+    o.update_partials()
+    stored_by_class = 0
+    for op in plan.ops:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        stored_by_class += 1 if rep.repeats_classes(node) else 0
+        assert bits_equal(rep.get_clv(node), o.clv[node]), "CLV %d" % node
+        assert (rep.get_scaler(sc) == o.scalers[sc]).all(), "scaler %d" % sc
+    if states == 4:
+        assert stored_by_class >= len(plan.ops) // 2   # (20 states, exact kernels: stored per site)
+    e = plan.root_edge
+    lnl, ps = rep.compute_edge_loglikelihood(*e, [0] * R, persite=True)
+    ref_lnl, ref_ps = o.edge_loglikelihood(*e, persite=True)
+    assert rel_err(ps, ref_ps) < 1e-13
+    assert abs(lnl - ref_lnl) <= 1e-12 * abs(ref_lnl)
+    st = rep.alloc_sumtable()
+    rep.update_sumtable(e[0], e[2], e[1], e[3], [0] * R, st)
+    want = o.sumtable(e[0], e[2], e[1], e[3])
+    got = rep.get_sumtable(st).reshape(want.shape)
+    scale = np.abs(want).max(axis=2, keepdims=True) + 1e-300
+    assert float(np.max(np.abs(got - want) / scale)) < 1e-12
+    for t in (0.05, 0.7):
+        d = rep.compute_likelihood_derivatives(e[1], e[3], t, [0] * R, st)
+        assert rel_err(np.array(d), np.array(o.derivatives(want, t))) < 1e-10
     rep.destroy()
 
 
