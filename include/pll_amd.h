@@ -504,6 +504,16 @@ PLL_EXPORT void pll_show_clv(const pll_partition_t * partition,
  * PLL_AMD_DEVICE, else LOCAL_RANK, else 0). */
 PLL_EXPORT int pll_amd_set_device(int device);
 PLL_EXPORT int pll_amd_device_count(void);
+/* One partition over several GPUs of this process: the NEXT pll_partition_create splits its
+ * sites into contiguous ranges over these devices (default: env PLL_AMD_DEVICES = "0-7",
+ * "0,1,2" or "all"; count 0 clears the list; an ordinal may repeat).  Nothing else changes for
+ * the client: pll_update_partials runs every range's op list on its device,
+ * pll_compute_edge_loglikelihood / pll_compute_likelihood_derivatives return the sum over the
+ * ranges (added on the host in range order: deterministic), the pll_amd_sync_* mirrors and
+ * persite_lnl are gathered.  Not combined with PLL_ATTRIB_SITE_REPEATS or pll_amd_comm_init. */
+PLL_EXPORT int pll_amd_set_devices(const int * devices, unsigned int count);
+/* shards of a partition (1 = one device) */
+PLL_EXPORT unsigned int pll_amd_shard_count(const pll_partition_t * partition);
 
 /* Mirror mode: 1 = after every mutating call copy the touched CLVs, scale
  * buffers, P-matrices and sumtables back to the host mirrors (lets unmodified

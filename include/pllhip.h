@@ -68,6 +68,19 @@ PLLHIP_EXPORT int pllhip_device_count(int * count);
 
 /* ---- context: owns every device buffer of one partition ---- */
 PLLHIP_EXPORT int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** out);
+/* One partition over several devices of this process: the sites are split into contiguous
+ * ranges (boundaries on multiples of 256 sites; the ascertainment-bias sites stay with the last
+ * range), one ordinary context per entry of `devices` (an ordinal may repeat: two shards then
+ * share a device -- how the sharding is tested on a one-GPU box).  The returned context is used
+ * like any other: every call fans out to the shards, per-site arrays are split / gathered, P-matrices
+ * and model are replicated, and lnL / derivative results are the host sum, in shard order, of
+ * the per-shard values (deterministic; 8 doubles).  shape->device is ignored.  Not available
+ * to such a context: site repeats, pllhip_comm_init, pllhip_dev_clv. */
+PLLHIP_EXPORT int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int * devices,
+                                            unsigned int ndevices, pllhip_ctx_t ** out);
+/* how many shards a context has (1 for an ordinary one) and the first site of shard i */
+PLLHIP_EXPORT unsigned int pllhip_shard_count(pllhip_ctx_t * ctx);
+PLLHIP_EXPORT unsigned int pllhip_shard_first_site(pllhip_ctx_t * ctx, unsigned int shard);
 PLLHIP_EXPORT void pllhip_ctx_destroy(pllhip_ctx_t * ctx);
 PLLHIP_EXPORT int pllhip_wait(pllhip_ctx_t * ctx);
 

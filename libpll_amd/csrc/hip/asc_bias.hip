@@ -252,6 +252,13 @@ int pllhip_asc_derivatives(pllhip_ctx * c, const double * sumtable, const double
 
 extern "C" int pllhip_set_asc(pllhip_ctx_t * c, int asc_type, unsigned int pattern_weight_sum)
 {
+  if (!c->shards.empty())
+  {
+    // the per-state sites live on the last shard; the correction is added to that shard's sum
+    c->asc_type = asc_type;
+    c->asc_weight_sum = pattern_weight_sum;
+    return pllhip_set_asc(c->shards.back(), asc_type, pattern_weight_sum);
+  }
   if (asc_type & ~PLLHIP_AB_MASK)
   {
     pllhip_set_error("pllhip_set_asc: not an ascertainment-bias type (%d)", asc_type);

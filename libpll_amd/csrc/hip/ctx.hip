@@ -16,6 +16,8 @@
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
+
 #include "ctx.hpp"
 
 static thread_local char g_err[512] = "";
@@ -233,6 +235,11 @@ extern "C" int pllhip_comm_unique_id(void * id128)
 
 extern "C" int pllhip_comm_init(pllhip_ctx_t * c, int rank, int nranks, const void * id128)
 {
+  if (!c->shards.empty())
+  {
+    pllhip_set_error("pllhip_comm_init: this context is already sharded over the devices of the process");
+    return -1;
+  }
   if (nranks < 1 || rank < 0 || rank >= nranks)
   {
     pllhip_set_error("pllhip_comm_init: bad rank %d of %d", rank, nranks);
@@ -260,6 +267,7 @@ int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count)
 
 extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
 {
+  if (c && !c->shards.empty()) { pllhip_group_destroy(c); return; }
   if (!c) return;
   (void)hipSetDevice(c->sh.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -301,6 +309,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
 
 extern "C" int pllhip_wait(pllhip_ctx_t * c)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_wait(s));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -325,6 +334,7 @@ static int d2h(pllhip_ctx * c, void * dst, const void * src, size_t bytes)
 
 extern "C" int pllhip_put_tipchars(pllhip_ctx_t * c, unsigned int tip, const unsigned char * h)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_put_tipchars(s, tip, h + lo));
   if (!c->sh.pattern_tip || tip >= c->sh.tips)
   {
     pllhip_set_error("pllhip_put_tipchars: tip %u invalid", tip);
@@ -335,6 +345,8 @@ extern "C" int pllhip_put_tipchars(pllhip_ctx_t * c, unsigned int tip, const uns
 
 extern "C" int pllhip_put_tipmap(pllhip_ctx_t * c, const unsigned int * h, unsigned int maxstates)
 {
+  if (!c->shards.empty()) c->maxstates = maxstates;
+  PLLHIP_ALL_SHARDS(c, pllhip_put_tipmap(s, h, maxstates));
   if (maxstates > 256) { pllhip_set_error("tipmap too large"); return -1; }
   c->maxstates = maxstates;
   return h2d(c, c->tipmap, h, maxstates * sizeof(unsigned int));
@@ -342,6 +354,7 @@ extern "C" int pllhip_put_tipmap(pllhip_ctx_t * c, const unsigned int * h, unsig
 
 extern "C" int pllhip_put_clv(pllhip_ctx_t * c, unsigned int idx, const double * h)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_put_clv(s, idx, h + lo * c->span));
   if (idx >= c->clv.size() || !c->clv[idx])
   {
     pllhip_set_error("pllhip_put_clv: index %u has no CLV", idx);
@@ -367,6 +380,7 @@ __global__ void k_replicate_tip_clv(double * __restrict__ clv, const double * __
 extern "C" int pllhip_put_tip_clv_persite(pllhip_ctx_t * c, unsigned int idx,
                                           const double * h, unsigned int stride)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_put_tip_clv_persite(s, idx, h + lo * stride, stride));
   if (idx >= c->clv.size() || !c->clv[idx])
   {
     pllhip_set_error("pllhip_put_tip_clv_persite: index %u has no CLV", idx);
@@ -401,11 +415,13 @@ extern "C" int pllhip_put_tip_clv_persite(pllhip_ctx_t * c, unsigned int idx,
 
 extern "C" int pllhip_put_pattern_weights(pllhip_ctx_t * c, const unsigned int * h)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_put_pattern_weights(s, h + lo));
   return h2d(c, c->pattern_weights, h, (size_t)c->sh.sites * sizeof(unsigned int));
 }
 
 extern "C" int pllhip_put_invariant(pllhip_ctx_t * c, const int * h)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_put_invariant(s, h ? h + lo : nullptr));
   HIP_TRY(hipSetDevice(c->sh.device));
   if (!h)
   {
@@ -424,6 +440,7 @@ extern "C" int pllhip_put_invariant(pllhip_ctx_t * c, const int * h)
 
 extern "C" int pllhip_put_rates(pllhip_ctx_t * c, const double * r, const double * w)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_put_rates(s, r, w));
   int rc = 0;
   if (r) rc = h2d(c, c->rates, r, c->sh.rate_cats * sizeof(double));
   if (!rc && w) rc = h2d(c, c->rate_weights, w, c->sh.rate_cats * sizeof(double));
@@ -434,6 +451,7 @@ extern "C" int pllhip_put_model(pllhip_ctx_t * c, unsigned int pi, const double 
                                 const double * evecs, const double * inv_evecs,
                                 const double * freqs, double prop_invar)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_put_model(s, pi, evals, evecs, inv_evecs, freqs, prop_invar));
   if (pi >= c->sh.rate_matrices) { pllhip_set_error("pllhip_put_model: index %u", pi); return -1; }
   const size_t S = c->sh.states;
   int rc = 0;
@@ -451,6 +469,7 @@ extern "C" int pllhip_put_model(pllhip_ctx_t * c, unsigned int pi, const double 
 
 extern "C" int pllhip_get_clv(pllhip_ctx_t * c, unsigned int idx, double * h)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_get_clv(s, idx, h + lo * c->span));
   if (idx >= c->clv.size() || !c->clv[idx])
   {
     pllhip_set_error("pllhip_get_clv: index %u has no CLV", idx);
@@ -461,18 +480,21 @@ extern "C" int pllhip_get_clv(pllhip_ctx_t * c, unsigned int idx, double * h)
 
 extern "C" int pllhip_get_scaler(pllhip_ctx_t * c, unsigned int idx, unsigned int * h)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_get_scaler(s, idx, h + lo * (c->sh.rate_scalers ? c->sh.rate_cats : 1)));
   if (idx >= c->sh.scale_buffers) { pllhip_set_error("pllhip_get_scaler: index %u", idx); return -1; }
   return d2h(c, h, pllhip_scaler_ptr(c, (int)idx), c->scaler_elems * sizeof(unsigned int));
 }
 
 extern "C" int pllhip_get_pmatrix(pllhip_ctx_t * c, unsigned int idx, double * h)
 {
+  if (!c->shards.empty()) return pllhip_get_pmatrix(c->shards[0], idx, h); // (replicated: identical bits on every shard)
   if (idx >= c->sh.prob_matrices) { pllhip_set_error("pllhip_get_pmatrix: index %u", idx); return -1; }
   return d2h(c, h, pllhip_pmat_ptr(c, idx), c->pmat_elems * sizeof(double));
 }
 
 extern "C" int pllhip_put_sumtable(pllhip_ctx_t * c, unsigned int slot, const double * h)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_put_sumtable(s, slot, h + lo * c->span));
   if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS) { pllhip_set_error("sumtable slot %u", slot); return -1; }
   HIP_TRY(hipSetDevice(c->sh.device));
   if (!c->sumtable[slot]) HIP_TRY(hipMalloc((void **)&c->sumtable[slot], (c->clv_elems + PLLHIP_TAIL_SITES * c->span) * sizeof(double)));
@@ -481,6 +503,7 @@ extern "C" int pllhip_put_sumtable(pllhip_ctx_t * c, unsigned int slot, const do
 
 extern "C" int pllhip_get_sumtable(pllhip_ctx_t * c, unsigned int slot, double * h)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_get_sumtable(s, slot, h + lo * c->span));
   if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || !c->sumtable[slot])
   {
     pllhip_set_error("sumtable slot %u empty", slot);
@@ -494,6 +517,12 @@ extern "C" int pllhip_get_sumtable(pllhip_ctx_t * c, unsigned int slot, double *
 // most all of them; env PLL_AMD_SUMTABLE_SLOTS overrides.
 extern "C" unsigned int pllhip_sumtable_budget(pllhip_ctx_t * c)
 {
+  if (!c->shards.empty())
+  {
+    unsigned int n = PLLHIP_SUMTABLE_MAX_SLOTS;
+    for (pllhip_ctx * s : c->shards) n = std::min(n, pllhip_sumtable_budget(s));
+    return n;
+  }
   if (const char * e = getenv("PLL_AMD_SUMTABLE_SLOTS"))
   {
     const int n = atoi(e);
@@ -508,6 +537,7 @@ extern "C" unsigned int pllhip_sumtable_budget(pllhip_ctx_t * c)
 
 extern "C" int pllhip_release_sumtable(pllhip_ctx_t * c, unsigned int slot)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_release_sumtable(s, slot));
   if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS) { pllhip_set_error("sumtable slot %u", slot); return -1; }
   if (!c->sumtable[slot]) return 0;
   HIP_TRY(hipSetDevice(c->sh.device));
@@ -519,6 +549,7 @@ extern "C" int pllhip_release_sumtable(pllhip_ctx_t * c, unsigned int slot)
 
 extern "C" void * pllhip_dev_clv(pllhip_ctx_t * c, unsigned int idx)
 {
+  if (!c->shards.empty()) return nullptr; // (one CLV lives on several devices)
   return idx < c->clv.size() ? (void *)c->clv[idx] : nullptr;
 }
 
@@ -547,6 +578,7 @@ void pllhip_prof_scope::stop()
 
 extern "C" int pllhip_profile_enable(pllhip_ctx_t * c, int on)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_profile_enable(s, on));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->profiling = on != 0;
   c->prof_used = 0;
@@ -555,6 +587,16 @@ extern "C" int pllhip_profile_enable(pllhip_ctx_t * c, int on)
 
 extern "C" int pllhip_profile_read(pllhip_ctx_t * c, unsigned int * launches, double * total_ms)
 {
+  if (!c->shards.empty())
+  {
+    // the launches of the first shard (all shards make the same ones); the others are drained
+    for (size_t i = c->shards.size(); i-- > 0;)
+    {
+      const int rc = pllhip_profile_read(c->shards[i], launches, total_ms);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (int k = 0; k < PLLHIP_PROF_KINDS; ++k) { launches[k] = 0; total_ms[k] = 0.0; }
   for (size_t i = 0; i < c->prof_used; ++i)
@@ -571,12 +613,26 @@ extern "C" int pllhip_profile_read(pllhip_ctx_t * c, unsigned int * launches, do
 
 extern "C" int pllhip_timer_start(pllhip_ctx_t * c)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_timer_start(s));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   return 0;
 }
 
 extern "C" int pllhip_timer_stop_ms(pllhip_ctx_t * c, float * ms)
 {
+  if (!c->shards.empty())
+  {
+    // the slowest shard (they run side by side)
+    *ms = 0.f;
+    for (pllhip_ctx * s : c->shards)
+    {
+      float t = 0.f;
+      const int rc = pllhip_timer_stop_ms(s, &t);
+      if (rc) return rc;
+      if (t > *ms) *ms = t;
+    }
+    return 0;
+  }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));

@@ -22,6 +22,17 @@ struct pllhip_ctx
   pllhip_shape_t sh;
   hipStream_t stream = nullptr;
 
+  // A context made by pllhip_ctx_create_sharded owns no device memory itself: it is a GROUP of
+  // ordinary contexts, one per device, each holding a contiguous range of the sites
+  // (shard i: [shard_lo[i], shard_lo[i + 1]) of the group's sites; boundaries on multiples of
+  // 256 sites).  Every entry point of pllhip.h called on a group fans out (shard.hip;
+  // PLLHIP_ALL_SHARDS below); results that are sums over sites are added on the host in shard
+  // order.  `defer`: set on a shard while its group collects -- the result-returning calls then
+  // enqueue everything and return without waiting (pllhip_result_wait fetches).
+  std::vector<pllhip_ctx *> shards;
+  std::vector<size_t> shard_lo;
+  bool defer = false;
+
   size_t span = 0;         // states * rate_cats doubles per site
   size_t clv_elems = 0;    // sites * span
   size_t scaler_elems = 0; // sites (per-site mode) or sites * rate_cats
@@ -156,6 +167,33 @@ struct pllhip_prof_scope
 };
 
 void pllhip_set_error(const char * fmt, ...);
+
+// Run `expr` on every shard of a group context and return (inside `expr`: s = the shard, lo =
+// its first site within the group); falls through for an ordinary context.
+#define PLLHIP_ALL_SHARDS(c, expr)                              \
+  do {                                                          \
+    if (!(c)->shards.empty()) {                                 \
+      for (size_t si_ = 0; si_ < (c)->shards.size(); ++si_) {   \
+        pllhip_ctx * s = (c)->shards[si_];                      \
+        const size_t lo = (c)->shard_lo[si_];                   \
+        (void)lo;                                               \
+        const int rc_ = (expr);                                 \
+        if (rc_) return rc_;                                    \
+      }                                                         \
+      return 0;                                                 \
+    }                                                           \
+  } while (0)
+
+// shard.hip: the group forms of the calls that return sums over sites
+int pllhip_group_edge_loglikelihood(pllhip_ctx * c, unsigned int parent_clv, int parent_scaler,
+                                    unsigned int child_clv, int child_scaler, unsigned int matrix_index,
+                                    const unsigned int * h_freqs_indices, double * h_persite_lnl, double * h_lnl);
+int pllhip_group_root_loglikelihood(pllhip_ctx * c, unsigned int clv_index, int scaler_index,
+                                    const unsigned int * h_freqs_indices, double * h_persite_lnl, double * h_lnl);
+int pllhip_group_likelihood_derivatives(pllhip_ctx * c, unsigned int slot, int parent_scaler, int child_scaler,
+                                        const unsigned int * h_params_indices, const double * h_diagptable,
+                                        double * h_d_f, double * h_dd_f);
+void pllhip_group_destroy(pllhip_ctx * c);
 
 #define HIP_TRY(expr)                                                         \
   do {                                                                        \

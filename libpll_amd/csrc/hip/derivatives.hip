@@ -86,6 +86,7 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
                                       int child_scaler, const unsigned int * h_params_indices,
                                       unsigned int slot)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_update_sumtable(s, parent_clv, parent_scaler, child_clv, child_scaler, h_params_indices, slot));
   HIP_TRY(hipSetDevice(c->sh.device));
   const unsigned int nodes = (unsigned int)c->clv.size();
   if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || parent_clv >= nodes || child_clv >= nodes ||
@@ -562,6 +563,8 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
                                              const double * h_diagptable, double * h_d_f,
                                              double * h_dd_f)
 {
+  if (!c->shards.empty())
+    return pllhip_group_likelihood_derivatives(c, slot, parent_scaler, child_scaler, h_params_indices, h_diagptable, h_d_f, h_dd_f);
   HIP_TRY(hipSetDevice(c->sh.device));
   if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || !c->sumtable[slot])
   {
@@ -700,6 +703,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost,
                            c->stream));
   }
+  if (c->defer) return 0; // a shard of a group: the group waits for all of them
   HIP_TRY(hipStreamSynchronize(c->stream));
   *h_d_f = c->h_result[0];
   *h_dd_f = c->h_result[1];

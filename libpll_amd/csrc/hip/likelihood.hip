@@ -907,6 +907,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   if (h_persite)
     HIP_TRY(hipMemcpyAsync(h_persite, c->d_persite, (size_t)a.sites * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
+  if (c->defer) return 0; // a shard of a group: the group waits for all of them (pllhip_result_wait)
   HIP_TRY(hipStreamSynchronize(c->stream));
   *h_lnl = c->h_result[0];
   return 0;
@@ -932,6 +933,8 @@ extern "C" int pllhip_edge_loglikelihood(pllhip_ctx_t * c, unsigned int parent_c
                                          const unsigned int * h_freqs_indices,
                                          double * h_persite_lnl, double * h_lnl)
 {
+  if (!c->shards.empty())
+    return pllhip_group_edge_loglikelihood(c, parent_clv, parent_scaler, child_clv, child_scaler, matrix_index, h_freqs_indices, h_persite_lnl, h_lnl);
   const unsigned int nodes = (unsigned int)c->clv.size();
   if (parent_clv >= nodes || child_clv >= nodes || matrix_index >= c->sh.prob_matrices ||
       parent_scaler >= (int)c->sh.scale_buffers || child_scaler >= (int)c->sh.scale_buffers)
@@ -985,6 +988,8 @@ extern "C" int pllhip_root_loglikelihood(pllhip_ctx_t * c, unsigned int clv_inde
                                          int scaler_index, const unsigned int * h_freqs_indices,
                                          double * h_persite_lnl, double * h_lnl)
 {
+  if (!c->shards.empty())
+    return pllhip_group_root_loglikelihood(c, clv_index, scaler_index, h_freqs_indices, h_persite_lnl, h_lnl);
   if (clv_index >= c->clv.size() || !c->clv[clv_index] ||
       scaler_index >= (int)c->sh.scale_buffers)
   {

@@ -535,6 +535,7 @@ static int resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, 
 
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_update_partials(s, ops, count)); // (enqueued on every device; nothing waits)
   HIP_TRY(hipSetDevice(c->sh.device));
   // Dependencies between the ops of a list follow BUFFER INDICES, not tree shape
   // (unrooted trees reuse CLV slots, partials.c:184-212).  Each op gets a level:

@@ -106,6 +106,7 @@ extern "C" int pllhip_update_pmatrices(pllhip_ctx_t * c, const unsigned int * h_
                                        const unsigned int * h_matrix_indices,
                                        const double * h_branch_lengths, unsigned int count)
 {
+  PLLHIP_ALL_SHARDS(c, pllhip_update_pmatrices(s, h_params_indices, h_matrix_indices, h_branch_lengths, count));
   if (!count) return 0;
   HIP_TRY(hipSetDevice(c->sh.device));
   for (unsigned int i = 0; i < count; ++i)

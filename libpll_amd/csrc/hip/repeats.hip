@@ -117,6 +117,11 @@ extern "C" int pllhip_identify_repeats(pllhip_ctx_t * c, unsigned int parent, un
                                        unsigned int child2, unsigned int max_classes,
                                        unsigned int * classes_out)
 {
+  if (!c->shards.empty())
+  {
+    pllhip_set_error("site repeats are not available to a partition sharded over several devices");
+    return -1;
+  }
   HIP_TRY(hipSetDevice(c->sh.device));
   *classes_out = 0;
   const unsigned int nodes = (unsigned int)c->clv.size();
@@ -207,6 +212,11 @@ extern "C" int pllhip_identify_repeats(pllhip_ctx_t * c, unsigned int parent, un
 
 extern "C" int pllhip_get_site_id(pllhip_ctx_t * c, unsigned int idx, unsigned int * h_site_id)
 {
+  if (!c->shards.empty())
+  {
+    pllhip_set_error("site repeats are not available to a partition sharded over several devices");
+    return -1;
+  }
   if (c->rows.empty() || idx >= c->rows.size() || !c->rows[idx].classes)
   {
     pllhip_set_error("pllhip_get_site_id: CLV %u is not stored by class", idx);

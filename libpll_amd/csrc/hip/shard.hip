@@ -1,0 +1,150 @@
+// shard.hip -- ONE partition over several devices of one process (north_star: "sites
+// of one partition shard naturally across the 8 GPUs of a single node").
+//
+// The reference has no counterpart (it is single-threaded, one address space): a client calls
+// pll_partition_create (pll.h:530) once and gets one partition.  Here that one partition may be
+// a GROUP: one ordinary device context per entry of the device list, each holding a contiguous
+// range of the sites (boundaries on multiples of 256 sites, every per-site array stays 16-byte
+// aligned).  What is per site is split (CLVs, scale buffers, tip characters, pattern weights,
+// invariant-site indices, sumtables, per-site lnL); what is not is replicated (P-matrices: every
+// device computes them itself from the same host eigen data -> identical bits; model, rates,
+// tipmap); an op list is enqueued on every device in turn -- with the whole-list kernel that is
+// three launches per device per pll_update_partials, so one host thread keeps eight devices busy.
+// The only cross-device operation is the sum of the per-shard lnL (or d, dd): each shard's
+// final-sum kernel writes its value into host-mapped memory, the host adds the (at most 8)
+// doubles in shard order -- deterministic, and cheaper than a collective for 8 bytes.  (The
+// one-process-per-GPU mode, pllhip_comm_init, sums the same values with one RCCL all-reduce.)
+#include <algorithm>
+
+#include "ctx.hpp"
+
+extern "C" int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int * devices,
+                                         unsigned int ndevices, pllhip_ctx_t ** out)
+{
+  *out = nullptr;
+  if (!shape || !devices || ndevices < 1 || shape->sites <= shape->asc_states)
+  {
+    pllhip_set_error("pllhip_ctx_create_sharded: bad arguments");
+    return -1;
+  }
+  // contiguous ranges of the ordinary sites, boundaries on multiples of 256 sites; fewer
+  // shards than devices when the partition is too small to give everyone a range
+  const size_t ordinary = shape->sites - shape->asc_states;
+  size_t per = (ordinary + ndevices - 1) / ndevices;
+  per = (per + 255) / 256 * 256;
+  std::vector<size_t> lo;
+  for (size_t b = 0; b < ordinary; b += per) lo.push_back(b);
+  pllhip_ctx * g = new pllhip_ctx();
+  g->sh = *shape;
+  g->sh.device = devices[0];
+  g->span = (size_t)shape->states * shape->rate_cats;
+  g->clv_elems = (size_t)shape->sites * g->span;
+  g->scaler_elems = shape->rate_scalers ? (size_t)shape->sites * shape->rate_cats : shape->sites;
+  for (size_t i = 0; i < lo.size(); ++i)
+  {
+    const bool last = i + 1 == lo.size();
+    pllhip_shape_t sh = *shape;
+    sh.device = devices[i];
+    sh.sites = (unsigned int)((last ? ordinary : lo[i + 1]) - lo[i]) + (last ? shape->asc_states : 0u);
+    sh.asc_states = last ? shape->asc_states : 0u;
+    pllhip_ctx * s = nullptr;
+    const int rc = pllhip_ctx_create(&sh, &s);
+    if (rc)
+    {
+      pllhip_group_destroy(g);
+      return rc;
+    }
+    g->shards.push_back(s);
+    g->shard_lo.push_back(lo[i]);
+  }
+  g->shard_lo.push_back(shape->sites);
+  *out = g;
+  return 0;
+}
+
+void pllhip_group_destroy(pllhip_ctx * g)
+{
+  for (pllhip_ctx * s : g->shards) pllhip_ctx_destroy(s);
+  g->shards.clear();
+  delete g;
+}
+
+extern "C" unsigned int pllhip_shard_count(pllhip_ctx_t * c)
+{
+  return c->shards.empty() ? 1u : (unsigned int)c->shards.size();
+}
+
+extern "C" unsigned int pllhip_shard_first_site(pllhip_ctx_t * c, unsigned int shard)
+{
+  return (c->shards.empty() || shard >= c->shards.size()) ? 0u : (unsigned int)c->shard_lo[shard];
+}
+
+// wait for a shard's enqueued result-returning call and take its sums
+static int result_wait(pllhip_ctx * s, unsigned int count, double * out)
+{
+  HIP_TRY(hipSetDevice(s->sh.device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  for (unsigned int i = 0; i < count; ++i) out[i] = s->h_result[i];
+  return 0;
+}
+
+namespace
+{
+// enqueue on every shard (no waiting in between: the devices run side by side), then collect
+template <typename Enqueue>
+int fan_out_and_sum(pllhip_ctx * g, unsigned int ncomp, double * sums, Enqueue enqueue)
+{
+  int rc = 0;
+  for (size_t i = 0; i < g->shards.size() && !rc; ++i)
+  {
+    pllhip_ctx * s = g->shards[i];
+    s->defer = true;
+    rc = enqueue(s, g->shard_lo[i]);
+    s->defer = false;
+  }
+  for (unsigned int k = 0; k < ncomp; ++k) sums[k] = 0.0;
+  // (also after a failure: nothing may still be writing into the caller's per-site buffer)
+  for (pllhip_ctx * s : g->shards)
+  {
+    double v[2] = {0.0, 0.0};
+    const int rw = result_wait(s, ncomp, v);
+    if (!rc) rc = rw;
+    for (unsigned int k = 0; k < ncomp; ++k) sums[k] += v[k];
+  }
+  return rc;
+}
+}
+
+int pllhip_group_edge_loglikelihood(pllhip_ctx * g, unsigned int parent_clv, int parent_scaler,
+                                    unsigned int child_clv, int child_scaler, unsigned int matrix_index,
+                                    const unsigned int * h_freqs_indices, double * h_persite_lnl, double * h_lnl)
+{
+  double unused = 0.0;
+  return fan_out_and_sum(g, 1, h_lnl, [&](pllhip_ctx * s, size_t lo) {
+    return pllhip_edge_loglikelihood(s, parent_clv, parent_scaler, child_clv, child_scaler, matrix_index,
+                                     h_freqs_indices, h_persite_lnl ? h_persite_lnl + lo : nullptr, &unused);
+  });
+}
+
+int pllhip_group_root_loglikelihood(pllhip_ctx * g, unsigned int clv_index, int scaler_index,
+                                    const unsigned int * h_freqs_indices, double * h_persite_lnl, double * h_lnl)
+{
+  double unused = 0.0;
+  return fan_out_and_sum(g, 1, h_lnl, [&](pllhip_ctx * s, size_t lo) {
+    return pllhip_root_loglikelihood(s, clv_index, scaler_index, h_freqs_indices,
+                                     h_persite_lnl ? h_persite_lnl + lo : nullptr, &unused);
+  });
+}
+
+int pllhip_group_likelihood_derivatives(pllhip_ctx * g, unsigned int slot, int parent_scaler, int child_scaler,
+                                        const unsigned int * h_params_indices, const double * h_diagptable,
+                                        double * h_d_f, double * h_dd_f)
+{
+  double sums[2] = {0.0, 0.0}, u0 = 0.0, u1 = 0.0;
+  const int rc = fan_out_and_sum(g, 2, sums, [&](pllhip_ctx * s, size_t) {
+    return pllhip_likelihood_derivatives(s, slot, parent_scaler, child_scaler, h_params_indices, h_diagptable, &u0, &u1);
+  });
+  *h_d_f = sums[0];
+  *h_dd_f = sums[1];
+  return rc;
+}

@@ -59,6 +59,70 @@ int pll_amd_set_device(int device)
 
 void pll_amd_set_mirror_mode(int on) { pll_amd_mirror_mode = on ? 1 : 0; }
 
+unsigned int pll_amd_shard_count(const pll_partition_t * p) { return pllhip_shard_count(pll_amd_priv(p)->ctx); }
+
+/* Devices the NEXT pll_partition_create shards its sites over (pll_amd_set_devices, else env
+ * PLL_AMD_DEVICES = "0-7" / "0,1,2" / "all"; an ordinal may repeat).  One entry or none: the
+ * partition lives on one device as before. */
+#define PLL_AMD_MAX_DEVICES 64
+static int g_devices[PLL_AMD_MAX_DEVICES];
+static int g_ndevices = -1; /* -1: not set by the API, look at the environment */
+
+int pll_amd_set_devices(const int * devices, unsigned int count)
+{
+  unsigned int i;
+  if (count > PLL_AMD_MAX_DEVICES || (count && !devices))
+  {
+    pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "pll_amd_set_devices: at most %d devices", PLL_AMD_MAX_DEVICES);
+    return PLL_FAILURE;
+  }
+  for (i = 0; i < count; ++i) g_devices[i] = devices[i];
+  g_ndevices = count ? (int)count : -1; /* an empty list: back to the environment's */
+  return PLL_SUCCESS;
+}
+
+/* fills list[], returns how many (0: no sharding requested), -1 on a malformed PLL_AMD_DEVICES */
+static int device_list(int * list)
+{
+  const char * e;
+  int n = 0;
+  if (g_ndevices >= 0)
+  {
+    memcpy(list, g_devices, (size_t)g_ndevices * sizeof(int));
+    return g_ndevices;
+  }
+  e = getenv("PLL_AMD_DEVICES");
+  if (!e || !*e) return 0;
+  if (!strcmp(e, "all"))
+  {
+    const int have = pll_amd_device_count();
+    for (n = 0; n < have && n < PLL_AMD_MAX_DEVICES; ++n) list[n] = n;
+    return n;
+  }
+  while (*e)
+  {
+    char * end;
+    long a = strtol(e, &end, 10), b;
+    if (end == e || a < 0) return -1;
+    b = a;
+    if (*end == '-')
+    {
+      e = end + 1;
+      b = strtol(e, &end, 10);
+      if (end == e || b < a) return -1;
+    }
+    for (; a <= b; ++a)
+    {
+      if (n >= PLL_AMD_MAX_DEVICES) return -1;
+      list[n++] = (int)a;
+    }
+    if (*end == ',') ++end;
+    else if (*end) return -1;
+    e = end;
+  }
+  return n;
+}
+
 static int default_device(void)
 {
   if (g_device >= 0) return g_device;
@@ -262,7 +326,29 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
   sh.pattern_tip = (attributes & PLL_ATTRIB_PATTERN_TIP) ? 1 : 0;
   sh.rate_scalers = (attributes & PLL_ATTRIB_RATE_SCALERS) ? 1 : 0;
   sh.asc_states = p->asc_bias_alloc ? states : 0;
-  rc = pllhip_ctx_create(&sh, &q->ctx);
+  {
+    int devices[PLL_AMD_MAX_DEVICES];
+    const int ndev = device_list(devices);
+    if (ndev < 0)
+    {
+      pll_partition_destroy(p);
+      pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "PLL_AMD_DEVICES: expected a list like 0-7 or 0,2,3");
+      return NULL;
+    }
+    if (ndev > 1 && (attributes & PLL_ATTRIB_SITE_REPEATS))
+    {
+      pll_partition_destroy(p);
+      pll_amd_set_error(PLL_ERROR_HIP_UNSUPPORTED,
+                        "PLL_ATTRIB_SITE_REPEATS is not available to a partition sharded over several devices");
+      return NULL;
+    }
+    if (ndev > 1) rc = pllhip_ctx_create_sharded(&sh, devices, (unsigned int)ndev, &q->ctx);
+    else
+    {
+      if (ndev == 1) sh.device = devices[0];
+      rc = pllhip_ctx_create(&sh, &q->ctx);
+    }
+  }
   if (rc)
   {
     pll_amd_set_error(rc == -1 ? PLL_ERROR_HIP_UNSUPPORTED : PLL_ERROR_HIP_RUNTIME,

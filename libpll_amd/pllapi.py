@@ -146,6 +146,9 @@ class PllLibrary:
             lib.pll_amd_sync_sumtable.argtypes = [_PP, _dp]
             lib.pll_amd_forget_sumtable.argtypes = [_PP, _dp]
             lib.pll_amd_wait.argtypes = [_PP]
+            lib.pll_amd_set_devices.argtypes = [C.POINTER(C.c_int), C.c_uint]
+            lib.pll_amd_shard_count.argtypes = [_PP]
+            lib.pll_amd_shard_count.restype = C.c_uint
             lib.pll_amd_timer_start.argtypes = [_PP]
             lib.pll_amd_timer_stop_ms.argtypes = [_PP, C.POINTER(C.c_float)]
             lib.pll_amd_comm_unique_id.argtypes = [C.c_void_p]
