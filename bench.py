@@ -14,6 +14,14 @@ per-site scalers.  For N>1 every rank holds its own 1,000,000-site shard of an
 N x 1,000,000-site alignment (weak scaling, no data-path collective; one
 8-byte RCCL all-reduce of lnL per step).
 
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself -- a fresh
+`python -m torch.distributed.run` child, before this process has touched a GPU -- and fails if
+fewer than N devices are visible.  For N>1 the line also carries `c4_strong`: BASELINE
+config 4 (8,000,000 sites, 128 taxa) divided over the N GPUs, with the speed-up against the
+recorded one-GPU time of that workload (profiles/r2_bench_c4_one_gpu.json).
+`--in-process` instead drives the N GPUs from ONE process through the library's own sharding of
+a partition (PLL_AMD_DEVICES; host sum of the per-device lnL, no RCCL).
+
 `--site-repeats` (not the default; libpll 0.3.2 has no site repeats) switches on the
 PLL_ATTRIB_SITE_REPEATS extension: same results, CLVs stored by class; the rate then counts
 the site-updates the plain path would do and config.site_repeats the rows really computed.
@@ -42,15 +50,28 @@ import time
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# HBM bytes per OP of the dominant kernel from rocprofv3 PMC passes of this command
-# (profiles/r1_pmc_hbm_traffic*.csv): FETCH_SIZE x 2 (gfx950 counts 128-B requests
-# at 64 B) + WRITE_SIZE, KB -> bytes, divided by the ops a launch carries.  Valid for
-# the site counts they were taken at; None otherwise.
-TRAFFIC_PER_OP = {4: 396.0e6, 20: 387.6e6}
-TRAFFIC_SITES = {4: 1_000_000, 20: 200_000}
-# the same for the whole-list launch of 4-state data, keyed by (rate_cats, sites, taxa, tree,
-# tip CLVs, per-rate scalers): bytes per launch
-TRAFFIC_FUSED = {(4, 1_000_000, 64, "balanced", False, False): 8416.1e6}  # profiles/r1_pmc_hbm_traffic.csv
+# `roofline.traffic`: HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes
+# (FETCH_SIZE x 2 -- gfx950 counts 128-B requests at 64 B -- + WRITE_SIZE, separate passes),
+# looked up in profiles/pmc_traffic.json, which tools/summarize_rocprof.py writes from the
+# committed CSVs; null when no pass was taken for the workload being run.
+def pmc_traffic(root, **key):
+    try:
+        index = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    for entry in index:
+        if all(entry["workload"].get(k) == v for k, v in key.items()):
+            return {"bytes_per_launch": entry["hbm_MB_per_launch"] * 1e6, "kernel": entry["kernel"],
+                    "source": entry["source"], "ops_per_launch": entry.get("ops_per_launch")}
+    return None
+
+
+def pmc_ops_per_launch(pmc, ops_per_launch):
+    """ops one launch of the profiled kernel carried (recorded with the PMC pass; the level
+    batching of the run being reported is the fallback)"""
+    return pmc.get("ops_per_launch") or ops_per_launch
+
+
 BYTES_PER_SITE = {"ii": {4: 396, 20: 1932}, "ti": {4: 265, 20: 1289}, "tt": {4: 134, 20: 646}}
 
 
@@ -133,6 +154,12 @@ def main():
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: take the RCCL path (process group, communicator, lnL all-reduce) "
                          "even with one rank")
+    ap.add_argument("--in-process", action="store_true",
+                    help="with --gpus N > 1: no launcher, ONE process whose partition the library shards over "
+                         "the N devices itself (PLL_AMD_DEVICES; an unmodified client's view)")
+    ap.add_argument("--devices", default="",
+                    help="with --in-process: the device list (default 0..N-1; an ordinal may repeat, e.g. 0,0)")
+    ap.add_argument("--no-c4", action="store_true", help="N>1: skip the BASELINE config 4 strong-scaling section")
     ap.add_argument("--tree", default="balanced", choices=("balanced", "random", "caterpillar"))
     ap.add_argument("--newton", type=int, default=0,
                     help="also time pll_update_sumtable + N x pll_compute_likelihood_derivatives "
@@ -142,8 +169,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    launched = "WORLD_SIZE" in os.environ
+    if launched and args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and not launched:
+        # Nobody launched the ranks: do it here, or drive the devices from this one process.
+        # Either way BEFORE anything in this process touches a GPU (device_count() does not).
+        import torch
+        have = torch.cuda.device_count()
+        need = args.gpus if not (args.in_process and args.devices) else 1
+        if have < need:
+            raise SystemExit("--gpus %d but %d device(s) visible" % (args.gpus, have))
+        if not args.in_process:
+            import socket
+            import subprocess
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+            sock.close()
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.setdefault("OMP_NUM_THREADS", "1")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                   "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    inproc = args.gpus if (args.in_process and args.gpus > 1 and not launched) else 1
 
     root = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, root)
@@ -157,7 +209,7 @@ def main():
     plan = {"balanced": W.balanced_tree, "random": W.random_tree,
             "caterpillar": W.caterpillar_tree}[args.tree](T, seed=42)
     strong = args.total_sites > 0
-    total_sites = args.total_sites if strong else args.sites * world
+    total_sites = args.total_sites if strong else args.sites * world * inproc
     lo, hi = W.shard_bounds(total_sites, world)[rank:rank + 2]
     ref_path = os.path.join(root, "oracle", "_ref", "libpll_ref.so")
     ref = PllLibrary(ref_path) if os.path.exists(ref_path) else None
@@ -231,6 +283,11 @@ def main():
     import libpll_amd
     amd = libpll_amd.load()
     amd.lib.pll_amd_set_device(local_rank)
+    if inproc > 1:
+        import ctypes
+        devs = [int(x) for x in args.devices.split(",")] if args.devices else list(range(inproc))
+        if not amd.lib.pll_amd_set_devices((ctypes.c_int * len(devs))(*devs), len(devs)):
+            raise SystemExit("pll_amd_set_devices failed: " + amd.errmsg())
 
     part = W.setup_partition(amd, plan, seqs, S, R,
                              attrs | (ATTRIB_SITE_REPEATS if args.site_repeats else 0))
@@ -320,11 +377,15 @@ def main():
         # character (or tip CLV) read once -- what `traffic` (PMC) is to be compared with
         achieved = moved * (hi - lo) / launch_s / 1e9
         per_op_equiv = per_site * (hi - lo) / launch_s / 1e9
-        traffic = TRAFFIC_FUSED.get((R, hi - lo, T, args.tree, bool(args.tip_clv), bool(args.rate_scalers)))
+        pmc = pmc_traffic(root, states=S, rate_cats=R, sites=hi - lo, taxa=T, tree=args.tree,
+                          tip_clv=bool(args.tip_clv), rate_scalers=bool(args.rate_scalers),
+                          kernel_class="whole-list") if inproc == 1 else None
+        traffic = pmc["bytes_per_launch"] if pmc else None
         roofline = {"bound": "hbm", "kernel": "k_dna_fused: pll_update_partials, %d ops in one launch "
                                               "(%d inner-inner, %d tip-inner, %d tip-tip)" % (len(plan.ops), n_ii, n_ti, n_tt),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": pmc["source"] if pmc else None,
                     "algorithmic_bytes_per_site": moved, "per_op_algorithm_bytes_per_site": per_site,
                     "per_op_algorithm_equivalent_GBs": round(per_op_equiv, 1),
                     "site_updates_per_launch": (hi - lo) * len(plan.ops), "ops_per_launch": len(plan.ops),
@@ -356,15 +417,25 @@ def main():
         # three CLV rows of 8 * states * rate_cats bytes + three per-site scaler words
         # (396 / 1932 B at the 4 rate categories the configs name)
         ii_bytes = 3 * 8 * S * R + 12
-        algo_bytes = ii_bytes * (hi - lo) * ops_per_launch   # per launch
+        # rows a launch really computes: the sites, or -- with site repeats -- the classes of
+        # each parent (so that `frac` prices the bytes this run moved, not the plain path's)
+        rows_ii = float(hi - lo) * len(ii_ops)
+        if args.site_repeats:
+            rows_ii = float(sum(part.repeats_classes(int(op["parent_clv_index"])) or (hi - lo) for op in ii_ops))
+        algo_bytes = ii_bytes * rows_ii / launches_per_pass   # per launch
         achieved = algo_bytes / avg_launch_s / 1e9
-        traffic = TRAFFIC_PER_OP.get(S) if (hi - lo) == TRAFFIC_SITES.get(S) and R == 4 else None
+        pmc = pmc_traffic(root, states=S, rate_cats=R, sites=hi - lo, taxa=T, tree=args.tree,
+                          tip_clv=bool(args.tip_clv), rate_scalers=bool(args.rate_scalers),
+                          kernel_class="inner-inner") if not args.site_repeats else None
+        # (the PMC figure is per launch of the level-batched kernel: per op = / ops that launch carried)
+        traffic = pmc["bytes_per_launch"] / pmc_ops_per_launch(pmc, ops_per_launch) if pmc else None
         roofline = {"bound": "hbm", "kernel": "pll_core_update_partial_ii (%d states)" % S,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic * ops_per_launch if traffic else None,
+                    "traffic_source": pmc["source"] if pmc else None,
                     "bytes_per_site_update": ii_bytes,
-                    "site_updates_per_launch": (hi - lo) * ops_per_launch,
+                    "site_updates_per_launch": rows_ii / launches_per_pass,
                     "ops_per_launch": round(ops_per_launch, 2),
                     "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": n_launch,
                     "avg_op_us": round(ms / n_ops * 1e3, 2)}
@@ -435,12 +506,76 @@ def main():
         repeats = {"rows_computed_per_evaluation": int(sum(rows)),
                    "rows_plain": ops_per_eval * (hi - lo),
                    "ops_stored_by_class": int(sum(1 for r in rows if r < hi - lo))}
+    # ---- N > 1: BASELINE config 4 as a strong-scaling job (fixed 8,000,000 sites x 128 taxa
+    # divided over the GPUs), next to the weak-scaling headline above
+    c4 = None
+    if world * inproc > 1 and not args.no_c4 and S == 4:
+        part.destroy()
+        part = None
+        c4_sites, c4_taxa = 8_000_000, 128
+        plan4 = W.balanced_tree(c4_taxa, seed=42)
+        lo4, hi4 = W.shard_bounds(c4_sites, world)[rank:rank + 2]
+        # a 250,000-site block simulated down the tree, repeated to the shard's length
+        block = W.simulated_alignment(plan4, 250_000, W.GTR_RATES, W.GTR_FREQS, cat_rates, seed=4242 + rank)
+        reps4 = -(-(hi4 - lo4) // 250_000)
+        seqs4 = [(b * reps4)[:hi4 - lo4] for b in block]
+        p4 = W.setup_partition(amd, plan4, seqs4, 4, R, ATTRIB_PATTERN_TIP)
+        if use_comm:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                import ctypes
+                buf = ctypes.create_string_buffer(128)
+                if not amd.lib.pll_amd_comm_unique_id(buf):
+                    raise SystemExit("pll_amd_comm_unique_id failed: " + amd.errmsg())
+                uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            p4.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+        steps4 = max(3, min(args.steps, 10))
+        lnl4 = None
+        for _ in range(2):
+            p4.update_partials(plan4.ops)
+            lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
+        p4.wait()
+        torch.cuda.synchronize()
+        if use_comm:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(steps4):
+            p4.update_partials(plan4.ops)
+            lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
+        p4.wait()
+        torch.cuda.synchronize()
+        if use_comm:
+            dist.barrier()
+        t4 = time.perf_counter() - t1
+        if use_comm:
+            t = torch.tensor([t4], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t4 = float(t.item())
+        p4.destroy()
+        one = None
+        try:
+            one = json.load(open(os.path.join(root, "profiles", "r2_bench_c4_one_gpu.json")))
+        except (OSError, ValueError):
+            pass
+        ms4 = t4 / steps4 * 1e3
+        c4 = {"workload": "BASELINE config 4: 4-state GTR, 4 rates, %d sites, %d-taxon balanced tree, PATTERN_TIP, "
+                          "divided over %d GPUs (%s)" % (c4_sites, c4_taxa, world * inproc,
+                                                         "one process, library-sharded partition" if inproc > 1
+                                                         else "one process per GPU, RCCL lnL all-reduce"),
+              "scaling": "strong", "n_gpus": world * inproc, "steps": steps4,
+              "value": round((c4_taxa - 2) * c4_sites * steps4 / t4 / 1e6, 2), "unit": "M CLV-site-updates/s",
+              "ms_per_step": round(ms4, 4), "lnl": lnl4,
+              "one_gpu_ms_per_step": one["ms_per_step"] if one else None,
+              "one_gpu_source": "profiles/r2_bench_c4_one_gpu.json (recorded: python bench.py --total-sites "
+                                "8000000 --taxa 128 --cpu-sites 0)" if one else None,
+              "speedup_vs_one_gpu": round(one["ms_per_step"] / ms4, 3) if one else None}
     if rank == 0:
         tt, ti, ii = plan.op_kinds() if not args.tip_clv else (0, 0, ops_per_eval)
         out = {
             "metric": "M CLV-site-updates/s (%dx%d states x rates)" % (S, R),
             "value": round(value, 2), "unit": "M CLV-site-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world * inproc, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -449,19 +584,23 @@ def main():
                                    "tree, %s, %s scalers; step = pll_update_partials(%d ops: %d "
                                    "tip-tip, %d tip-inner, %d inner-inner) + "
                                    "pll_compute_edge_loglikelihood"
-                                   % (S, "GTR" if S == 4 else "LG", R, hi - lo, T, args.tree,
+                                   % (S, "GTR" if S == 4 else "LG", R, (hi - lo) // inproc, T, args.tree,
                                       "tip CLVs" if args.tip_clv else "PATTERN_TIP",
                                       "per-rate" if args.rate_scalers else "per-site",
                                       ops_per_eval, tt, ti, ii),
-                       "sites_total": total_sites, "parallelism": "site-sharded x%d" % world,
+                       "sites_total": total_sites,
+                       "parallelism": "site-sharded x%d (%s)" % (world * inproc,
+                                                                  "one process, PLL_AMD_DEVICES" if inproc > 1 else
+                                                                  "one process per GPU" if world > 1 else "single GPU"),
                        "site_repeats": repeats},
             "lnl": lnl, "lnl_rel_err_vs_reference": lnl_rel_err,
             "first_evaluation_ms": round(first_ms, 2),
             "roofline": roofline, "api_calls": api, "kernels": per_kernel, "cpu_baseline": cpu,
-            "newton": newton,
+            "newton": newton, "c4_strong": c4,
         }
         print(json.dumps(out))
-    part.destroy()
+    if part is not None:
+        part.destroy()
     if use_comm:
         dist.destroy_process_group()
 

@@ -245,7 +245,13 @@ def shard_bounds(sites, nranks, granule=256):
     nranks+1 offsets."""
     per = -(-sites // nranks)
     per = -(-per // granule) * granule
-    return [min(sites, r * per) for r in range(nranks)] + [sites]
+    bounds = [min(sites, r * per) for r in range(nranks)] + [sites]
+    if any(bounds[r + 1] <= bounds[r] for r in range(nranks)):
+        # every rank computes the same bounds, so every rank raises here -- before any
+        # collective a rank with an empty range would leave the others waiting in
+        raise ValueError("%d sites cannot be split into %d non-empty ranges on multiples of %d sites"
+                         % (sites, nranks, granule))
+    return bounds
 
 
 # ---- one-call setup used by tests and bench.py -----------------------------------------

@@ -12,6 +12,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -81,3 +82,99 @@ def test_site_sharding_two_ranks_gloo(tmp_path, orc, amd):
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "SHARDED_OK" in out.stdout
+
+
+# ---------------------------------------------------------------- the product, one rank per GPU
+
+PRODUCT_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+import ctypes
+import libpll_amd
+from libpll_amd import workload as W
+from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, ATTRIB_AB_LEWIS
+from oracle_api import Oracle
+from helpers import make_case, build_partition, oracle_run, rel_err
+amd = libpll_amd.load()
+amd.lib.pll_amd_set_device(local)
+orc = Oracle(os.path.join(sys.argv[1], "oracle", "liboracle.so"))
+
+def sliced(case, lo, hi):
+    c = dict(case)
+    c["seqs"] = [s[lo:hi] for s in case["seqs"]]
+    c["pw"] = case["pw"][lo:hi]
+    c["sites"] = hi - lo
+    return c
+
+def leg(p, plan, R):
+    p.update_partials(plan.ops)
+    e = plan.root_edge
+    lnl = p.compute_edge_loglikelihood(*e, [0] * R)
+    st = p.alloc_sumtable()
+    p.update_sumtable(e[0], e[2], e[1], e[3], [0] * R, st)
+    d, dd = p.compute_likelihood_derivatives(e[1], e[3], 0.1, [0] * R, st)
+    return np.array([lnl, d, dd])
+
+for states, sites in ((4, 5000), (20, 1500)):
+    case = make_case(states, "random", 14, sites, seed=31 + states)
+    plan, R = case["plan"], case["rate_cats"]
+    # the unsharded product and the oracle, on every rank (no communicator yet)
+    whole = build_partition(amd, case, ATTRIB_PATTERN_TIP)
+    o = oracle_run(orc, amd, whole, case, ATTRIB_PATTERN_TIP)
+    full = leg(whole, plan, R)
+    o.update_partials()
+    e = plan.root_edge
+    want = np.array([o.edge_loglikelihood(*e), *o.derivatives(o.sumtable(e[0], e[2], e[1], e[3]), 0.1)])
+    whole.destroy()
+    assert rel_err(full, want) < 1e-10, (full, want)
+    # this rank's range as a partition of its own, summed over the ranks by RCCL inside the library
+    b = W.shard_bounds(sites, world, granule=256)
+    mine = build_partition(amd, sliced(case, b[rank], b[rank + 1]), ATTRIB_PATTERN_TIP)
+    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        buf = ctypes.create_string_buffer(128)
+        assert amd.lib.pll_amd_comm_unique_id(buf)
+        uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+    dist.broadcast(uid, src=0)
+    mine.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+    got = leg(mine, plan, R)
+    assert rel_err(got, full) < 1e-12, (rank, got, full)
+    # every rank holds the SAME sum (all-reduce, not reduce)
+    t = torch.tensor(got, dtype=torch.float64, device="cuda")
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert torch.equal(lo, hi)
+    mine.destroy()
+if rank == 0:
+    print("PRODUCT_SHARDED_OK world=%d" % world)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_product_site_sharding_over_rccl(tmp_path):
+    """The product's one-process-per-GPU path with more than one rank: every rank builds a
+    partition for its site range, pll_amd_comm_init joins them, and lnL / d / dd returned by
+    the ordinary API calls are the RCCL sum -- equal to the unsharded product (1e-12) and the
+    oracle (1e-10) on every rank.  Needs two devices; the ranks are fresh child processes
+    (started before this process has touched a GPU through torch)."""
+    import torch
+    n = torch.cuda.device_count()      # (does not initialise the GPU)
+    if n < 2:
+        pytest.skip("one device visible: the multi-rank RCCL path needs two")
+    script = tmp_path / "product_worker.py"
+    script.write_text(PRODUCT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PLLHIP_AA_EXACT="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node=%d" % min(n, 4), "--master-addr", "127.0.0.1", "--master-port",
+                          str(free_port()), str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "PRODUCT_SHARDED_OK" in out.stdout

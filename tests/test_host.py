@@ -154,11 +154,16 @@ def test_tree_plans():
 
 
 def test_shard_bounds():
-    for sites, n in ((1_000_000, 8), (8_000_000, 8), (1000, 3), (255, 2), (1, 4)):
+    for sites, n in ((1_000_000, 8), (8_000_000, 8), (1000, 2), (1300, 3), (255, 1)):
         b = W.shard_bounds(sites, n)
         assert b[0] == 0 and b[-1] == sites and len(b) == n + 1
-        assert all(b[i] <= b[i + 1] for i in range(n))
-        assert all(x % 256 == 0 for x in b[1:-1] if x != sites)
+        assert all(b[i] < b[i + 1] for i in range(n))
+        assert all(x % 256 == 0 for x in b[1:-1])
+    # a rank without sites would leave the others waiting in the first collective: refused,
+    # identically on every rank
+    for sites, n in ((1000, 3), (255, 2), (1, 4), (512, 3)):
+        with pytest.raises(ValueError):
+            W.shard_bounds(sites, n)
 
 
 def test_bench_cpu_baseline_leg(ref):

@@ -1,34 +1,72 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun) from the repo root:  bash tools/profile_round.sh <tag>
-# Takes the bench line and the rocprofv3 evidence for the two headline workloads
-# (4-state C2, 20-state C3) into gpurun_out/<tag>/; tools/summarize_rocprof.py then
-# condenses those directories into profiles/.  Counters are collected in their own
-# passes (no trace domains next to --pmc).
+# Takes, for each BASELINE workload, the plain bench line, the rocprofv3 kernel statistics of
+# the same command and the HBM traffic counters (FETCH_SIZE and WRITE_SIZE in passes of their
+# own: no trace domains next to --pmc), condenses them with tools/summarize_rocprof.py into
+# gpurun_out/<tag>/summary/ (what gets copied into profiles/) and writes the index bench.py reads
+# `roofline.traffic` from.
 set -u
-tag=${1:-r1}
+tag=${1:-r2}
 root=$(pwd)
 out=$root/gpurun_out/$tag
-mkdir -p "$out"
+sum=$out/summary
+mkdir -p "$sum"
 export TMPDIR=/tmp
 cd /tmp
 
-run() { # name, bench args...
+run() { # name, [ENV=VAL ...] -- bench args...
   local name=$1; shift
-  (cd "$root" && python3 bench.py "$@" > "$out/bench_$name.json" 2> "$out/bench_$name.err")
+  local envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done
+  shift
+  for e in "${envs[@]}"; do export "$e"; done
+  (cd "$root" && python3 bench.py "$@" > "$sum/${tag}_bench_$name.json" 2> "$out/bench_$name.err")
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$name" -- \
-      python3 "$root/bench.py" --steps 20 --warmup 3 --cpu-sites 0 "$@" > "$out/bench_${name}_under_rocprof.json" 2> "$out/trace_$name.err"
+      python3 "$root/bench.py" --steps 20 --warmup 3 --cpu-sites 0 "$@" > "$sum/${tag}_bench_${name}_under_rocprof.json" 2> "$out/trace_$name.err"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_$name" -- \
       python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 "$@" > /dev/null 2> "$out/fetch_$name.err"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write_$name" -- \
       python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 "$@" > /dev/null 2> "$out/write_$name.err"
-  # keep what travels back small: the per-dispatch trace is not needed
-  find "$out/trace_$name" -name '*_kernel_trace.csv' -delete
+  python3 "$root/tools/summarize_rocprof.py" stats "$out/trace_$name" "$sum/${tag}_bench_${name}_kernel_stats.csv"
+  python3 "$root/tools/summarize_rocprof.py" hbm "$out/fetch_$name" "$out/write_$name" "$sum/${tag}_pmc_hbm_traffic_$name.csv" \
+      "${envs[*]} python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 $*"
+  for e in "${envs[@]}"; do unset "${e%%=*}"; done
+  # keep what travels back small
+  rm -rf "$out/trace_$name" "$out/fetch_$name" "$out/write_$name"
 }
 
-run c2
-run c3 --states 20 --sites 200000
+run c2 --
+run c2_per_level PLLHIP_FUSED=0 --
+run c3 -- --states 20 --sites 200000
+run c4_shard -- --taxa 128
+run c5_shape -- --sites 500000 --taxa 200 --tree random --newton 5
+run c2_tip_clv -- --tip-clv
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/mfma_c3" -- \
     python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --states 20 --sites 200000 > /dev/null 2> "$out/mfma_c3.err"
-ls "$out"
-# BASELINE config 5's shape (200-taxon random tree, 500 k sites) with the Newton inner loop
-(cd "$root" && python3 bench.py --sites 500000 --taxa 200 --tree random --newton 5 --cpu-sites 0 > "$out/bench_c5shape.json" 2> "$out/bench_c5shape.err")
+python3 "$root/tools/summarize_rocprof.py" pmc "$out/mfma_c3" "$sum/${tag}_pmc_mfma_c3.csv" "python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 --states 20 --sites 200000"
+rm -rf "$out/mfma_c3"
+# BASELINE config 4 on ONE GPU (133 GB): the strong-scaling reference point
+(cd "$root" && python3 bench.py --total-sites 8000000 --taxa 128 --cpu-sites 0 --steps 10 > "$sum/${tag}_bench_c4_one_gpu.json" 2> "$out/bench_c4_one_gpu.err")
+# site repeats on the C5 shape
+(cd "$root" && python3 bench.py --sites 500000 --taxa 200 --tree random --site-repeats --cpu-sites 0 > "$sum/${tag}_bench_c5_shape_site_repeats.json" 2> "$out/bench_c5rep.err")
+
+cat > "$sum/pmc_spec.json" <<EOF
+[
+ {"csv": "${tag}_pmc_hbm_traffic_c2.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
+  "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
+ {"csv": "${tag}_pmc_hbm_traffic_c4_shard.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
+  "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 128, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
+ {"csv": "${tag}_pmc_hbm_traffic_c5_shape.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
+  "workload": {"states": 4, "rate_cats": 4, "sites": 500000, "taxa": 200, "tree": "random", "tip_clv": false, "rate_scalers": false}},
+ {"csv": "${tag}_pmc_hbm_traffic_c2_tip_clv.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
+  "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 64, "tree": "balanced", "tip_clv": true, "rate_scalers": false}},
+ {"csv": "${tag}_pmc_hbm_traffic_c2_per_level.csv", "kernel_match": "k_dna_partials<4, 1, true, 0", "kernel_class": "inner-inner",
+  "bench_json": "${tag}_bench_c2_per_level_under_rocprof.json",
+  "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
+ {"csv": "${tag}_pmc_hbm_traffic_c3.csv", "kernel_match": "k_aa_ii_mfma<4, 1", "kernel_class": "inner-inner",
+  "bench_json": "${tag}_bench_c3_under_rocprof.json",
+  "workload": {"states": 20, "rate_cats": 4, "sites": 200000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}}
+]
+EOF
+python3 "$root/tools/summarize_rocprof.py" index "$sum/pmc_spec.json" "$sum/pmc_traffic.json"
+ls -la "$sum"

@@ -14,6 +14,12 @@
 
   generic PMC   summarize_rocprof.py pmc DIR OUT.csv ["command line"]
       per kernel and counter: dispatches, mean, sum
+
+  traffic index summarize_rocprof.py index SPEC.json OUT.json
+      SPEC: list of {"csv": hbm summary, "kernel_match": substring of the kernel name,
+      "kernel_class": "whole-list" | "inner-inner", "workload": {states, rate_cats, sites, taxa,
+      tree, tip_clv, rate_scalers}, "bench_json": optional bench line of the same command (its
+      roofline.ops_per_launch is recorded)} -> the list bench.py looks `roofline.traffic` up in
 """
 import csv
 import glob
@@ -86,12 +92,48 @@ def cmd_pmc(d, out, command=""):
                 f.write('"%s",%s,%d,%.3f,%.3f\n' % (k, name, len(v), mean(v), sum(v)))
 
 
+def cmd_index(spec_path, out):
+    import json
+    spec = json.load(open(spec_path))
+    base = os.path.dirname(os.path.abspath(out))
+    index = []
+    for e in spec:
+        path = e["csv"] if os.path.isabs(e["csv"]) else os.path.join(base, e["csv"])
+        if not os.path.exists(path):
+            continue
+        best = None
+        with open(path, newline="") as f:
+            rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))]
+        for r in rows[1:]:
+            if e["kernel_match"] in r[0] and (best is None or float(r[4]) > float(best[4])):
+                best = r
+        if best is None:
+            continue
+        entry = {"workload": dict(e["workload"], kernel_class=e["kernel_class"]), "kernel": best[0],
+                 "dispatches": int(best[1]), "hbm_MB_per_launch": float(best[4]),
+                 "source": "profiles/" + os.path.basename(path)}
+        bj = e.get("bench_json")
+        if bj:
+            bj = bj if os.path.isabs(bj) else os.path.join(base, bj)
+            try:
+                line = [l for l in open(bj).read().splitlines() if l.startswith("{")][-1]
+                entry["ops_per_launch"] = json.loads(line)["roofline"].get("ops_per_launch")
+            except (OSError, ValueError, IndexError, KeyError):
+                pass
+        index.append(entry)
+    with open(out, "w") as f:
+        json.dump(index, f, indent=1)
+        f.write("\n")
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
     if len(a) >= 3 and a[0] == "stats":
         cmd_stats(a[1], a[2])
     elif len(a) >= 4 and a[0] == "hbm":
         cmd_hbm(a[1], a[2], a[3], a[4] if len(a) > 4 else "")
+    elif len(a) >= 3 and a[0] == "index":
+        cmd_index(a[1], a[2])
     elif len(a) >= 3 and a[0] == "pmc":
         cmd_pmc(a[1], a[2], a[3] if len(a) > 3 else "")
     else:
