@@ -498,6 +498,115 @@ PLL_EXPORT void pll_show_clv(const pll_partition_t * partition,
                              int scaler_index,
                              unsigned int float_precision);
 
+/* ---- the array-level entry points (reference: src/pll.h:827-1013, 1659) ----
+ *
+ * Same names, argument order and meaning as the reference's pll_core_* functions; every
+ * operand is a host array.  Each call stages its operands into a per-thread scratch device
+ * context, runs the kernels the partition-level calls run, and copies the results back
+ * (PCIe-bound by construction: keep data in a partition where speed matters).  Arrays are
+ * unpadded (states_padded == states) whatever ISA bit `attrib` carries; of `attrib` only
+ * PLL_ATTRIB_RATE_SCALERS is looked at.  Errors: pll_errno / pll_errmsg (PLL_ERROR_HIP_*),
+ * -INFINITY from the double functions, PLL_FAILURE from the int functions.
+ * pll_amd_core_release frees the calling thread's scratch context. */
+PLL_EXPORT void pll_core_create_lookup(unsigned int states, unsigned int rate_cats, double * lookup,
+                                       const double * left_matrix, const double * right_matrix,
+                                       const unsigned int * tipmap, unsigned int tipmap_size,
+                                       unsigned int attrib);                       /* pll.h:829, core_partials.c:725 */
+PLL_EXPORT void pll_core_update_partial_tt(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                           double * parent_clv, unsigned int * parent_scaler,
+                                           const unsigned char * left_tipchars,
+                                           const unsigned char * right_tipchars, const unsigned int * tipmap,
+                                           unsigned int tipmap_size, const double * lookup,
+                                           unsigned int attrib);                   /* pll.h:838, core_partials.c:82 */
+PLL_EXPORT void pll_core_update_partial_ti(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                           double * parent_clv, unsigned int * parent_scaler,
+                                           const unsigned char * left_tipchars, const double * right_clv,
+                                           const double * left_matrix, const double * right_matrix,
+                                           const unsigned int * right_scaler, const unsigned int * tipmap,
+                                           unsigned int tipmap_size, unsigned int attrib); /* pll.h:850, core_partials.c:354 */
+PLL_EXPORT void pll_core_update_partial_ii(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                           double * parent_clv, unsigned int * parent_scaler,
+                                           const double * left_clv, const double * right_clv,
+                                           const double * left_matrix, const double * right_matrix,
+                                           const unsigned int * left_scaler, const unsigned int * right_scaler,
+                                           unsigned int attrib);                   /* pll.h:864, core_partials.c:510 */
+PLL_EXPORT void pll_core_create_lookup_4x4(unsigned int rate_cats, double * lookup, const double * left_matrix,
+                                           const double * right_matrix);           /* pll.h:877 */
+PLL_EXPORT void pll_core_update_partial_tt_4x4(unsigned int sites, unsigned int rate_cats, double * parent_clv,
+                                               unsigned int * parent_scaler, const unsigned char * left_tipchars,
+                                               const unsigned char * right_tipchars, const double * lookup,
+                                               unsigned int attrib);               /* pll.h:882 */
+PLL_EXPORT void pll_core_update_partial_ti_4x4(unsigned int sites, unsigned int rate_cats, double * parent_clv,
+                                               unsigned int * parent_scaler, const unsigned char * left_tipchars,
+                                               const double * right_clv, const double * left_matrix,
+                                               const double * right_matrix, const unsigned int * right_scaler,
+                                               unsigned int attrib);               /* pll.h:891 */
+PLL_EXPORT int pll_core_update_sumtable_ti_4x4(unsigned int sites, unsigned int rate_cats, const double * parent_clv,
+                                               const unsigned char * left_tipchars,
+                                               const unsigned int * parent_scaler, double * const * eigenvecs,
+                                               double * const * inv_eigenvecs, double * const * freqs,
+                                               const unsigned int * tipmap, double * sumtable,
+                                               unsigned int attrib);               /* pll.h:904 */
+PLL_EXPORT int pll_core_update_sumtable_ii(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                           const double * parent_clv, const double * child_clv,
+                                           const unsigned int * parent_scaler, const unsigned int * child_scaler,
+                                           double * const * eigenvecs, double * const * inv_eigenvecs,
+                                           double * const * freqs, double * sumtable,
+                                           unsigned int attrib);                   /* pll.h:916, core_derivatives.c:125 */
+PLL_EXPORT int pll_core_update_sumtable_ti(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                           const double * parent_clv, const unsigned char * left_tipchars,
+                                           const unsigned int * parent_scaler, double * const * eigenvecs,
+                                           double * const * inv_eigenvecs, double * const * freqs,
+                                           const unsigned int * tipmap, unsigned int tipmap_size,
+                                           double * sumtable, unsigned int attrib); /* pll.h:929, core_derivatives.c:277 */
+PLL_EXPORT int pll_core_likelihood_derivatives(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                               const double * rate_weights, const unsigned int * parent_scaler,
+                                               const unsigned int * child_scaler, const int * invariant,
+                                               const unsigned int * pattern_weights, double branch_length,
+                                               const double * prop_invar, double * const * freqs,
+                                               const double * rates, double * const * eigenvals,
+                                               const double * sumtable, double * d_f, double * dd_f,
+                                               unsigned int attrib);               /* pll.h:943, core_derivatives.c:501 */
+PLL_EXPORT double pll_core_edge_loglikelihood_ii(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                                 const double * parent_clv, const unsigned int * parent_scaler,
+                                                 const double * child_clv, const unsigned int * child_scaler,
+                                                 const double * pmatrix, double * const * frequencies,
+                                                 const double * rate_weights, const unsigned int * pattern_weights,
+                                                 const double * invar_proportion, const int * invar_indices,
+                                                 const unsigned int * freqs_indices, double * persite_lnl,
+                                                 unsigned int attrib);             /* pll.h:963, core_likelihood.c:726 */
+PLL_EXPORT double pll_core_edge_loglikelihood_ti(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                                 const double * parent_clv, const unsigned int * parent_scaler,
+                                                 const unsigned char * tipchars, const unsigned int * tipmap,
+                                                 unsigned int tipmap_size, const double * pmatrix,
+                                                 double * const * frequencies, const double * rate_weights,
+                                                 const unsigned int * pattern_weights,
+                                                 const double * invar_proportion, const int * invar_indices,
+                                                 const unsigned int * freqs_indices, double * persite_lnl,
+                                                 unsigned int attrib);             /* pll.h:980, core_likelihood.c:412 */
+PLL_EXPORT double pll_core_edge_loglikelihood_ti_4x4(unsigned int sites, unsigned int rate_cats,
+                                                     const double * parent_clv, const unsigned int * parent_scaler,
+                                                     const unsigned char * tipchars, const double * pmatrix,
+                                                     double * const * frequencies, const double * rate_weights,
+                                                     const unsigned int * pattern_weights,
+                                                     const double * invar_proportion, const int * invar_indices,
+                                                     const unsigned int * freqs_indices, double * persite_lnl,
+                                                     unsigned int attrib);         /* pll.h:998, core_likelihood.c:211 */
+PLL_EXPORT double pll_core_root_loglikelihood(unsigned int states, unsigned int sites, unsigned int rate_cats,
+                                              const double * clv, const unsigned int * scaler,
+                                              double * const * frequencies, const double * rate_weights,
+                                              const unsigned int * pattern_weights,
+                                              const double * invar_proportion, const int * invar_indices,
+                                              const unsigned int * freqs_indices, double * persite_lnl,
+                                              unsigned int attrib);                /* pll.h:1013, core_likelihood.c:25 */
+PLL_EXPORT int pll_core_update_pmatrix(double ** pmatrix, unsigned int states, unsigned int rate_cats,
+                                       const double * rates, const double * branch_lengths,
+                                       const unsigned int * matrix_indices, const unsigned int * params_indices,
+                                       const double * prop_invar, double * const * eigenvals,
+                                       double * const * eigenvecs, double * const * inv_eigenvecs,
+                                       unsigned int count, unsigned int attrib);   /* pll.h:1659, core_pmatrix.c:24 */
+PLL_EXPORT void pll_amd_core_release(void);
+
 /* ---- additions of this library (no reference counterpart) ---- */
 
 /* Device the NEXT pll_partition_create binds to (default: env

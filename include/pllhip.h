@@ -114,6 +114,11 @@ PLLHIP_EXPORT int pllhip_put_model(pllhip_ctx_t * ctx, unsigned int params_index
                                    const double * h_freqs,
                                    double prop_invar);
 
+/* a P-matrix / a scale buffer given by the caller (the array-level pll_core_* entry points, whose
+ * operands all come from the host) */
+PLLHIP_EXPORT int pllhip_put_pmatrix(pllhip_ctx_t * ctx, unsigned int matrix_index, const double * h_pmatrix);
+PLLHIP_EXPORT int pllhip_put_scaler(pllhip_ctx_t * ctx, unsigned int scaler_index, const unsigned int * h_scaler);
+
 /* ---- device -> host ---- */
 PLLHIP_EXPORT int pllhip_get_clv(pllhip_ctx_t * ctx, unsigned int clv_index, double * h_clv);
 PLLHIP_EXPORT int pllhip_get_scaler(pllhip_ctx_t * ctx, unsigned int scaler_index,
@@ -153,6 +158,15 @@ PLLHIP_EXPORT int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buff
                                         const pllhip_op_t * ops, unsigned int count,
                                         unsigned int nslots, unsigned int * order_out,
                                         unsigned int * reloads_out, int * slots_out);
+
+/* replaces pll_core_update_partial_tt proper (core_partials.c:82-200): the parent CLV of a tip-tip
+ * node is, per site, row ((code1 << log2_maxstates) + code2) of the lookup table the caller built
+ * with pll_core_create_lookup -- a gather on the device from the uploaded table (h_lookup:
+ * `rows` rows of rate_cats * states doubles) by the two tips' characters already in the
+ * context; the parent's scale buffer (if >= 0) is cleared. */
+PLLHIP_EXPORT int pllhip_partial_tt_from_lookup(pllhip_ctx_t * ctx, unsigned int parent_clv, int parent_scaler,
+                                                unsigned int tip1, unsigned int tip2, const double * h_lookup,
+                                                size_t rows, unsigned int log2_maxstates);
 
 /* replaces pll_core_edge_loglikelihood_ii / _ti / _ti_4x4
  * (core_likelihood.c:726,412,211).  A clv index < tips in pattern-tip mode

@@ -467,6 +467,74 @@ extern "C" int pllhip_put_model(pllhip_ctx_t * c, unsigned int pi, const double 
   return rc;
 }
 
+extern "C" int pllhip_put_pmatrix(pllhip_ctx_t * c, unsigned int idx, const double * h)
+{
+  PLLHIP_ALL_SHARDS(c, pllhip_put_pmatrix(s, idx, h));
+  if (idx >= c->sh.prob_matrices) { pllhip_set_error("pllhip_put_pmatrix: index %u", idx); return -1; }
+  return h2d(c, pllhip_pmat_ptr(c, idx), h, c->pmat_elems * sizeof(double));
+}
+
+extern "C" int pllhip_put_scaler(pllhip_ctx_t * c, unsigned int idx, const unsigned int * h)
+{
+  PLLHIP_ALL_SHARDS(c, pllhip_put_scaler(s, idx, h + lo * (c->sh.rate_scalers ? c->sh.rate_cats : 1)));
+  if (idx >= c->sh.scale_buffers) { pllhip_set_error("pllhip_put_scaler: index %u", idx); return -1; }
+  return h2d(c, pllhip_scaler_ptr(c, (int)idx), h, c->scaler_elems * sizeof(unsigned int));
+}
+
+// parent[n] = lookup[(code1[n] << shift) + code2[n]]: one lane per 16 bytes of the parent row
+// (T = double2; T = double for rows of an odd number of doubles)
+template <typename T>
+__global__ void k_rows_from_lookup(T * __restrict__ parent, const T * __restrict__ lookup,
+                                   const unsigned char * __restrict__ c1, const unsigned char * __restrict__ c2,
+                                   size_t sites, unsigned int span2, unsigned int shift, size_t rows)
+{
+  const size_t total = sites * span2;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x)
+  {
+    const size_t n = t / span2;
+    const unsigned int g = (unsigned int)(t - n * span2);
+    size_t row = ((size_t)c1[n] << shift) + c2[n];
+    if (row >= rows) row = 0; // (characters outside the table: the reference would read past it)
+    parent[t] = lookup[row * span2 + g];
+  }
+}
+
+extern "C" int pllhip_partial_tt_from_lookup(pllhip_ctx_t * c, unsigned int parent_clv, int parent_scaler,
+                                             unsigned int tip1, unsigned int tip2, const double * h_lookup,
+                                             size_t rows, unsigned int log2_maxstates)
+{
+  if (!c->shards.empty()) { pllhip_set_error("pllhip_partial_tt_from_lookup: not for a sharded context"); return -1; }
+  if (parent_clv >= c->clv.size() || !c->clv[parent_clv] || !c->sh.pattern_tip || tip1 >= c->sh.tips ||
+      tip2 >= c->sh.tips || parent_scaler >= (int)c->sh.scale_buffers)
+  {
+    pllhip_set_error("pllhip_partial_tt_from_lookup: bad arguments");
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(c->sh.device));
+  double * d_lookup = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_lookup, rows * c->span * sizeof(double)));
+  int rc = h2d(c, d_lookup, h_lookup, rows * c->span * sizeof(double));
+  if (!rc)
+  {
+    if (c->span & 1)
+      k_rows_from_lookup<double><<<pllhip_stream_grid(c, (size_t)c->sh.sites * c->span, 256), 256, 0, c->stream>>>(
+          c->clv[parent_clv], d_lookup, pllhip_tip_ptr(c, tip1), pllhip_tip_ptr(c, tip2), c->sh.sites,
+          (unsigned int)c->span, log2_maxstates, rows);
+    else
+      k_rows_from_lookup<double2><<<pllhip_stream_grid(c, (size_t)c->sh.sites * (c->span / 2), 256), 256, 0, c->stream>>>(
+          reinterpret_cast<double2 *>(c->clv[parent_clv]), reinterpret_cast<const double2 *>(d_lookup),
+          pllhip_tip_ptr(c, tip1), pllhip_tip_ptr(c, tip2), c->sh.sites, (unsigned int)(c->span / 2),
+          log2_maxstates, rows);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && parent_scaler >= 0)
+      e = hipMemsetAsync(pllhip_scaler_ptr(c, parent_scaler), 0, c->scaler_elems * sizeof(unsigned int), c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { pllhip_set_error("rows from lookup: %s", hipGetErrorString(e)); rc = (int)e; }
+  }
+  (void)hipFree(d_lookup);
+  return rc;
+}
+
 extern "C" int pllhip_get_clv(pllhip_ctx_t * c, unsigned int idx, double * h)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_get_clv(s, idx, h + lo * c->span));

@@ -13,6 +13,7 @@
 #include "pllhip.h"
 
 #define PLL_AMD_EVICTED_KEYS 64
+#define PLL_AMD_MAX_RATE_CATS 64 /* = PLLHIP_MAX_RATE_CATS of the shim */
 #define PLL_AMD_MAGIC 0x504c4c414d443031ull /* "PLLAMD01" */
 
 /* site repeats (repeats.c): classes of one CLV slot */

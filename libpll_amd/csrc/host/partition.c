@@ -137,6 +137,8 @@ static int default_device(void)
   return 0;
 }
 
+int pll_amd_core_device(void) { return default_device(); }
+
 static void free_ptr_array(void ** a, unsigned int n)
 {
   unsigned int i;
