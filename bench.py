@@ -316,6 +316,12 @@ def main():
     lnl = step()
     sync()
     first_ms = (time.perf_counter() - t_first) * 1e3
+    # the GPU sat idle while the CPU baseline ran (tens of seconds): let its clocks come back up
+    # before the W warm-up steps (untimed either way; without this a 20-step timed region of
+    # a few ms each was measured at half speed right after the CPU leg)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.3:
+        lnl = step()
     for _ in range(args.warmup):
         lnl = step()
     sync()
