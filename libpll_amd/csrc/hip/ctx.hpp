@@ -231,10 +231,11 @@ static inline double * pllhip_pmat_ptr(const pllhip_ctx * c, unsigned int idx)
 // non-temporal loads and stores are faster.  Measured (4 states, 64 taxa, whole
 // evaluation, G site-updates/s, default / non-temporal): 25 k sites (200 MB of CLVs)
 // 15.0 / 13.7; 50 k (400 MB) 17.1 / 17.9; 100 k 17.3 / 18.8; 250 k 18.7 / 20.1.
+#define PLLHIP_INFINITY_CACHE_BYTES ((size_t)256 << 20) /* MI355X: 256 MiB memory-side cache */
 static inline bool pllhip_use_nt(const pllhip_ctx * c)
 {
   if (c->nt_override >= 0) return c->nt_override != 0;
-  return c->clv_arena_bytes >= ((size_t)256 << 20);
+  return c->clv_arena_bytes >= PLLHIP_INFINITY_CACHE_BYTES;
 }
 
 // Grid size for a streaming kernel over `items` lanes-worth of work: all of it
@@ -309,5 +310,6 @@ int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);
 bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind);
 int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count, int kind, int mode);
 bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode);
+bool pllhip_aa_cherry_pays(const pllhip_ctx * c, unsigned int lookups, unsigned int levels);
 int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
                               const PartialsArgs * kid2, unsigned int count, int mode);

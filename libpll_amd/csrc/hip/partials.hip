@@ -409,6 +409,7 @@ struct pllhip_planned_op
 {
   PartialsArgs a;
   unsigned int key; // level << 8 | kind << 4 | mode
+  unsigned int plain_key; // the same without the lookup kind (20 states)
   unsigned int order;
 };
 struct pllhip_level_cache
@@ -679,6 +680,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     }
     if (op.child1_scaler >= 0) upto(sc_r[op.child1_scaler], lvl);
     if (op.child2_scaler >= 0) upto(sc_r[op.child2_scaler], lvl);
+    const int plain_kind = kind;
     if (aa_fast && kind == 0 && tt_writer[op.child1_clv] >= 0 && tt_writer[op.child2_clv] >= 0 &&
         pllhip_aa_cherry_covers(c, mode))
     {
@@ -695,9 +697,29 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
         kind = 3;
       }
     }
-    tt_writer[op.parent_clv] = (kind == 2) ? (int)i : -1;
+    tt_writer[op.parent_clv] = (plain_kind == 2) ? (int)i : -1;
     plan[i].key = (lvl << 8) | ((unsigned int)kind << 4) | (unsigned int)mode;
+    plan[i].plain_key = (lvl << 8) | ((unsigned int)plain_kind << 4) | (unsigned int)mode;
     plan[i].order = i;
+  }
+  // Lookup ops or not: they save (1932 - 646) bytes per site and op at the kernels' ~5.5 TB/s,
+  // and cost about eight small launches (~6 us each, tables for up to 12 ops) per tree level
+  // that has any.  Used when the saving is at least twice the cost -- 64 taxa (16 such ops on
+  // one level): from ~26 k sites on, measured crossover 20-30 k (20 k sites 425 vs 398 us per
+  // evaluation, 50 k 766 vs 901).  PLLHIP_AA_CHERRY=0 / 2: never / whatever the size.
+  {
+    unsigned int lookups = 0;
+    std::vector<unsigned int> levels;
+    for (unsigned int i = 0; i < count; ++i)
+      if (((plan[i].key >> 4) & 15u) == 3)
+      {
+        ++lookups;
+        levels.push_back(plan[i].key >> 8);
+      }
+    std::sort(levels.begin(), levels.end());
+    const size_t nlevels = std::unique(levels.begin(), levels.end()) - levels.begin();
+    if (lookups && !pllhip_aa_cherry_pays(c, lookups, (unsigned int)nlevels))
+      for (unsigned int i = 0; i < count; ++i) plan[i].key = plan[i].plain_key;
   }
 
   // (the producers' arguments by list position: the sort below moves the entries)

@@ -628,11 +628,19 @@ int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count
 bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode)
 {
   const char * e = getenv("PLLHIP_AA_CHERRY"); // 0: never, 2: whatever the partition's size (tests)
-  const bool off = e && atoi(e) == 0, force = e && atoi(e) == 2;
-  // (the tables cost about eight small launches per tree level: measured against the ordinary
-  // path, 64 taxa: 1 k sites 191 vs 113 us per evaluation, 20 k 425 vs 398, 50 k 766 vs 901)
-  return !off && (force || c->sh.sites >= 32768) && c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
+  const bool off = e && atoi(e) == 0;
+  return !off && c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
          c->rows.empty() && mode != SCALE_RATE && c->maxstates >= 1 && c->maxstates <= 32 && !c->sh.asc_states;
+}
+
+// Do `lookups` lookup ops on `levels` tree levels pay for their tables?  (partials.hip: the model)
+bool pllhip_aa_cherry_pays(const pllhip_ctx * c, unsigned int lookups, unsigned int levels)
+{
+  const char * e = getenv("PLLHIP_AA_CHERRY");
+  if (e && atoi(e) == 2) return true;
+  const double saved_us = (double)lookups * c->sh.sites * (1932.0 - 646.0) / 5.5e6; // bytes / (bytes per us)
+  const double cost_us = 8.0 * 6.0 * levels;
+  return saved_us >= 2.0 * cost_us;
 }
 
 static __global__ void k_aa_cherry_consts(unsigned char * hi, unsigned char * lo, double * ones, double * ident,
