@@ -289,6 +289,44 @@ def test_same_list_again_after_branch_lengths_changed(gpu, orc, states, monkeypa
     q.destroy()
 
 
+def test_kept_plans_survive_other_lists_in_between(gpu, orc, monkeypatch):
+    """Two kept plans live in a context -- the whole-list kernel's and the per-level path's.  A
+    full traversal (whole-list), then a short partial traversal (fewer than seven ops: per level),
+    then the full list again and the short one again, with branch lengths changing in between:
+    every call must see current values, whichever plan it reuses (nothing but
+    destroy invalidated them)."""
+    monkeypatch.delenv("PLLHIP_FUSED", raising=False)      # the library's own choice of path
+    case = make_case(4, "random", 16, 40_000, seed=123, weights=False)
+    plan, R = case["plan"], case["rate_cats"]
+    p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    q = build_partition(gpu, case, ATTRIB_PATTERN_TIP)     # the control: always a fresh full traversal
+    rng = np.random.default_rng(5)
+    short = plan.ops[-4:]
+    touched = [int(short[0]["child1_matrix_index"]), int(short[0]["child2_matrix_index"])]
+    p.update_partials(plan.ops)
+    for round_ in range(3):
+        bl = rng.uniform(0.02, 0.6, len(touched))
+        for x in (p, q):
+            x.update_prob_matrices([0] * R, touched, bl)
+        p.update_partials(short)                            # per-level path, its kept plan from round 2 on
+        q.update_partials(plan.ops)
+        top, tsc = int(plan.ops[-1]["parent_clv_index"]), int(plan.ops[-1]["parent_scaler_index"])
+        assert bits_equal(p.get_clv(top), q.get_clv(top)), "after the short list, round %d" % round_
+        assert (p.get_scaler(tsc) == q.get_scaler(tsc)).all()
+        bl_all = rng.uniform(0.02, 0.6, len(plan.matrix_indices))
+        for x in (p, q):
+            x.update_prob_matrices([0] * R, plan.matrix_indices, bl_all)
+            x.update_partials(plan.ops)                     # whole-list kernel, kept plan on p
+        for op in plan.ops[::3]:
+            node = int(op["parent_clv_index"])
+            assert bits_equal(p.get_clv(node), q.get_clv(node)), "after the full list, round %d" % round_
+    a = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    b = q.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    assert a == b
+    p.destroy()
+    q.destroy()
+
+
 @pytest.mark.parametrize("states,shape", [(4, "random"), (4, "caterpillar"), (20, "random")])
 def test_partial_traversal_after_branch_change(gpu, orc, states, shape, monkeypatch):
     """Incremental update (test/src/partial-traversal.c's use): after one branch
