@@ -143,7 +143,7 @@ template <int RC, int J, int MODE, bool NT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan, FusedBases bases,
                                                         unsigned int nops, unsigned int sites, unsigned int nslots,
                                                         const unsigned int * __restrict__ zero, double2 * sink,
-                                                        unsigned int * next_tile, unsigned int backwards)
+                                                        unsigned int * next_tile, unsigned int backwards, unsigned int dynamic_rounds)
 {
   constexpr unsigned int W = 2 * RC, SPS = 64 / W, TS = J * SPS;
   constexpr unsigned int MG = RC * 8;                   // 16-byte granules of one P-matrix
@@ -188,12 +188,17 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   // 62-op list but not behind a 5-op one)
   sink += wave * 80;
 
-  // All but the last two of a wave's share of the tiles are its own by a fixed stride; the
-  // rest come from a counter, so that no wave idles while another still has a tile of ~100 us
-  // ahead of it (20 or 21 tiles per wave with a fixed stride alone: up to 5 % of tail).
-  // All from the counter was measured too: atomics on one address serialise at ~12 ns, a
-  // floor of 0.7 ms per launch at 1 M sites -- hidden behind a 62-op list, not behind 15 ops.
-  size_t static_rounds = tiles / nwaves > 2 ? tiles / nwaves - 2 : 1; // (the last two rounds from the counter)
+  // A wave's first tiles are its own by a fixed stride; the last `dynamic_rounds` rounds' worth come
+  // from a counter.  Not only for the tail: the eight XCDs do not write at the same rate -- on
+  // every box measured the odd-numbered ones take ~20 % longer for the same tiles
+  // (tools/xcd_balance_bench.hip: last workgroup of XCDs 0/2/4/6 done at 0.92 ms, of 1/3/5/7
+  // at 1.13 ms) -- so with equal shares the fast half of the chip idles at the end.  Seven
+  // rounds of ~20 from the counter let it take the difference (two rounds, round 1's choice,
+  // covered the tail only): 62 / 126 / 198-op lists 0.616 / 0.526 / 0.514 -> 0.635 / 0.580 / 0.546 of
+  // the HBM peak (same box).  All tiles from the counter is slower again (atomics on one
+  // address serialise at ~12 ns: 0.75 ms of them per launch at 1 M sites), and short lists keep
+  // two rounds for that reason.
+  size_t static_rounds = tiles / nwaves > dynamic_rounds ? tiles / nwaves - dynamic_rounds : 1; // (the last rounds from the counter)
   if (!next_tile) static_rounds = ~(size_t)0;
   size_t round = 0;
   for (size_t tile = wave; tile < tiles;)
@@ -923,9 +928,11 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   // whatever the tree -- profiles/r2_footprint.txt).  Every other launch therefore walks the
   // tiles backwards: it starts in the pages the previous launch touched last.
   const unsigned int backwards = (c->fused_pingpong && c->clv_arena_bytes > ((size_t)6 << 30)) ? (c->fused_launches++ & 1u) : 0u;
+  const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
+                                      : (count >= 32 ? 7u : 2u);
 #define LAUNCH_FUSED(MODEV, NTV)                                                                                  \
   k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(                 \
-      d_plan, bases, count, sites, nslots, c->d_zero, (double2 *)c->d_sink, tile_counter, backwards)
+      d_plan, bases, count, sites, nslots, c->d_zero, (double2 *)c->d_sink, tile_counter, backwards, dynamic_rounds)
 #define LAUNCH_FUSED_MODE(NTV)                         \
   do {                                                  \
     if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV);       \
