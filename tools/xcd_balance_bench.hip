@@ -52,6 +52,34 @@ __global__ __launch_bounds__(256, 3) void k_pattern(v2d * base, size_t stride_g,
   }
 }
 
+// one pass: as many workgroups as it takes, each wave ONE tile position (all K streams): does the
+// dispatcher hand a finished XCD new workgroups, or does every XCD get blockIdx % 8 whatever happens?
+__global__ __launch_bounds__(256, 3) void k_one_pass(v2d * base, size_t stride_g, unsigned int K, size_t all_tiles,
+                                                     unsigned long long * per_xcd_last, unsigned int * per_xcd_count)
+{
+  const unsigned int lane = threadIdx.x & 63u;
+  const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t < all_tiles)
+  {
+    v2d acc = {(double)t, (double)lane};
+    for (unsigned int k = 0; k < K; ++k)
+    {
+      v2d * out = base + (size_t)k * stride_g + t * 128;
+      __builtin_nontemporal_store(acc, out + lane);
+      __builtin_nontemporal_store(acc, out + 64 + lane);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    unsigned int id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    id &= 0xf;
+    atomicMax(per_xcd_last + id, wall_clock64());
+    atomicAdd(per_xcd_count + id, 1u);
+  }
+}
+
 int main()
 {
   const unsigned int grid = 768;
@@ -100,6 +128,31 @@ int main()
         for (int i = 0; i < 8; ++i) printf(" %7.1f", n[i] ? mean[i] / n[i] : 0.0);
         printf("\n");
       }
+    {
+      unsigned long long * d_last; unsigned int * d_cnt;
+      CK(hipMalloc((void **)&d_last, 16 * 8)); CK(hipMalloc((void **)&d_cnt, 16 * 4));
+      const size_t tiles = s.sites / 16;
+      const unsigned int g1 = (unsigned int)((tiles + 3) / 4);
+      for (int rep = 0; rep < 3; ++rep)
+      {
+        CK(hipMemset(d_last, 0, 16 * 8)); CK(hipMemset(d_cnt, 0, 16 * 4));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0));
+        k_one_pass<<<g1, 256>>>(d, stride_g, s.K, tiles, d_last, d_cnt);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long last[16]; unsigned int cnt[16];
+        CK(hipMemcpy(last, d_last, 16 * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(cnt, d_cnt, 16 * 4, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < 8; ++i) { if (last[i] < t0) t0 = last[i]; if (last[i] > t1) t1 = last[i]; }
+        const double bytes = (double)s.K * tiles * 2048;
+        printf("K %3u, ONE PASS (%u workgroups): %8.1f us  %5.2f TB/s; workgroups per XCD:", s.K, g1, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        for (int i = 0; i < 8; ++i) printf(" %u", cnt[i]);
+        printf("; last finish relative to the earliest XCD (us):");
+        for (int i = 0; i < 8; ++i) printf(" %.0f", (double)(last[i] - t0) / 100.0);
+        printf("\n");
+      }
+    }
     CK(hipFree(d));
   }
   return 0;
