@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--rate-cats", type=int, default=4)
     ap.add_argument("--tip-clv", action="store_true", help="tips as CLVs (all ops inner-inner)")
     ap.add_argument("--rate-scalers", action="store_true")
+    ap.add_argument("--no-scalers", action="store_true",
+                    help="diagnostic: ops without scale buffers (PLL_SCALE_BUFFER_NONE everywhere)")
     ap.add_argument("--site-repeats", action="store_true",
                     help="PLL_ATTRIB_SITE_REPEATS (an extension: libpll 0.3.2 has none).  The "
                          "reported rate then counts the site-updates the plain path would do; "
@@ -207,7 +209,7 @@ def main():
     attrs = (0 if args.tip_clv else ATTRIB_PATTERN_TIP) | \
             (ATTRIB_RATE_SCALERS if args.rate_scalers else 0)
     plan = {"balanced": W.balanced_tree, "random": W.random_tree,
-            "caterpillar": W.caterpillar_tree}[args.tree](T, seed=42)
+            "caterpillar": W.caterpillar_tree}[args.tree](T, seed=42, use_scalers=not args.no_scalers)
     strong = args.total_sites > 0
     total_sites = args.total_sites if strong else args.sites * world * inproc
     lo, hi = W.shard_bounds(total_sites, world)[rank:rank + 2]

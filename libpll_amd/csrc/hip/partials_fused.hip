@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       // same number of stores, see below)
       unsigned int * cnt_tile = scaling ? pscaler + ((MODE == SCALE_RATE) ? site0 * RC : site0)
                                         : reinterpret_cast<unsigned int *>(sink + 64);
+      unsigned long long scaled[J];
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
@@ -402,18 +403,12 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
         // operands and inherited counts: LDS slots (slot 0 is read when there is none)
         const double2 lo = clv[((lslot >= 0 ? lslot : 0) * J + j) * 64 + lane];
         const double2 ro = clv[((rslot >= 0 ? rslot : 0) * J + j) * 64 + lane];
-        const unsigned int cw = (MODE == SCALE_RATE) ? lane >> 1 : lane / W; // this lane's count within a sub-step
-        unsigned int lc = cnt[((lsc_slot >= 0 ? lsc_slot : 0) * J + j) * CW + cw];
-        unsigned int rc = cnt[((rsc_slot >= 0 ? rsc_slot : 0) * J + j) * CW + cw];
-        if (lsc_slot < 0) lc = 0u;
-        if (rsc_slot < 0) rc = 0u;
         double x0, x1, y0 = 1.0, y1 = 1.0;
         if (have_pairs)
         {
           // tip-tip with a pair table: the finished entries; tip-inner: the tip's factor
           x0 = pt_use[j].x;
           x1 = pt_use[j].y;
-          lc = 0u;
         }
         else if (kind == 0)
         {
@@ -430,10 +425,9 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
           const unsigned int b2 = (code >> (2 - 2 * h)) & 1u, b3 = (code >> (3 - 2 * h)) & 1u;
           x0 = ((b0 ? pl.m[0][0] : 0.0) + (b1 ? pl.m[0][1] : 0.0)) + ((b2 ? pl.m[0][2] : 0.0) + (b3 ? pl.m[0][3] : 0.0));
           x1 = ((b0 ? pl.m[1][0] : 0.0) + (b1 ? pl.m[1][1] : 0.0)) + ((b2 ? pl.m[1][2] : 0.0) + (b3 ? pl.m[1][3] : 0.0));
-          lc = 0u;
         }
         if (have_pairs && kind == 2)
-          rc = 0u;
+          ;
         else if (kind != 2)
         {
           const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
@@ -447,7 +441,6 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
           const unsigned int b2 = (code >> (2 - 2 * h)) & 1u, b3 = (code >> (3 - 2 * h)) & 1u;
           y0 = ((b0 ? pr.m[0][0] : 0.0) + (b1 ? pr.m[0][1] : 0.0)) + ((b2 ? pr.m[0][2] : 0.0) + (b3 ? pr.m[0][3] : 0.0));
           y1 = ((b0 ? pr.m[1][0] : 0.0) + (b1 ? pr.m[1][1] : 0.0)) + ((b2 ? pr.m[1][2] : 0.0) + (b3 ? pr.m[1][3] : 0.0));
-          rc = 0u;
         }
         // (tip-tip with a pair table: y is exactly 1.0, the product is the table entry itself)
         double p0 = x0 * y0, p1 = x1 * y1;
@@ -465,22 +458,40 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
             p1 *= PLLHIP_SCALE_FACTOR;
           }
         }
-        const unsigned int count = lc + rc + (scale ? 1u : 0u);
+        scaled[j] = __ballot(scale); // (wave-uniform: which groups of this sub-step were scaled)
         // The NUMBER of stores per op is fixed (a store under a branch forces a full drain
         // of the memory queue): the compiler can then wait for the look-ahead loads by count
         // and leave this op's stores in flight.
         st16<NT>(out_tile + g, p0, p1);
-        if (pslot >= 0)
-        {
-          clv[(pslot * J + j) * 64 + lane] = make_double2(p0, p1);
-          cnt[(pslot * J + j) * CW + cw] = scaling ? count : 0u;
-        }
-        if (MODE != SCALE_NONE)
-        {
-          // one count per site (all W lanes of the site write the same word) or per (site, rate)
-          const unsigned int e = (MODE == SCALE_SITE) ? g / W : g >> 1;
-          cnt_tile[scaling ? e : lane] = count;
-        }
+        if (pslot >= 0) clv[(pslot * J + j) * 64 + lane] = make_double2(p0, p1);
+      }
+      // The tile's counts, once per op: entry t (a site, or a (site, rate) with per-rate
+      // scalers) is handled by lane t -- inherited counts from the operands' slots, plus
+      // one if the sub-step that held the entry scaled its group -- and all of them leave in ONE
+      // store (64 contiguous bytes per tile with per-site counts).  (Round 1 did this per
+      // sub-step with all 64 lanes: two LDS reads, an LDS write and a 32-byte store each.  Measured:
+      // the same speed either way.  A list without scale buffers runs 10-14 % faster than one
+      // with them -- 500 k sites x 64 taxa 712 against 832 us -- but no single piece explains it:
+      // counts stored to a sink instead 820, not stored at all 806, no scaling test 816.)
+      if (MODE != SCALE_NONE)
+      {
+        constexpr unsigned int GW = (MODE == SCALE_RATE) ? 2u : W; // lanes that share a count
+        constexpr unsigned int EPS = 64u / GW, E = J * EPS;        // entries per sub-step / per tile
+        static_assert(CW == EPS, "one count word per entry of a sub-step");
+        const unsigned int t = lane < E ? lane : 0u;
+        unsigned long long mine = scaled[0];
+#pragma unroll
+        for (unsigned int j = 1; j < J; ++j) mine = (t / EPS == j) ? scaled[j] : mine;
+        const unsigned int bit = (unsigned int)(mine >> ((t % EPS) * GW)) & 1u;
+        // (tip operands and tip-tip ops inherit nothing; tip-tip never scales and clears its counts)
+        unsigned int lc = cnt[(lsc_slot >= 0 ? lsc_slot : 0) * (J * CW) + t];
+        unsigned int rc = cnt[(rsc_slot >= 0 ? rsc_slot : 0) * (J * CW) + t];
+        if (lsc_slot < 0 || have_pairs || kind != 0) lc = 0u;
+        if (rsc_slot < 0 || kind == 2) rc = 0u;
+        const unsigned int count = lc + rc + ((scaling && kind != 2) ? bit : 0u);
+        if (pslot >= 0 && lane < E) cnt[pslot * (J * CW) + t] = scaling ? count : 0u;
+        unsigned int * dst = (scaling && lane < E) ? cnt_tile + lane : reinterpret_cast<unsigned int *>(sink + 64) + lane;
+        *dst = count;
       }
       // the next op's matrix rows replace this op's in the same registers: the block was
       // requested an op ago, the LDS round trip overlaps the next op's scalar phase
