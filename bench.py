@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--devices", default="",
                     help="with --in-process: the device list (default 0..N-1; an ordinal may repeat, e.g. 0,0)")
     ap.add_argument("--no-c4", action="store_true", help="N>1: skip the BASELINE config 4 strong-scaling section")
+    ap.add_argument("--force-c4", action="store_true", help="diagnostic: run that section with one GPU as well")
     ap.add_argument("--tree", default="balanced", choices=("balanced", "random", "caterpillar"))
     ap.add_argument("--newton", type=int, default=0,
                     help="also time pll_update_sumtable + N x pll_compute_likelihood_derivatives "
@@ -517,67 +518,70 @@ def main():
     # ---- N > 1: BASELINE config 4 as a strong-scaling job (fixed 8,000,000 sites x 128 taxa
     # divided over the GPUs), next to the weak-scaling headline above
     c4 = None
-    if world * inproc > 1 and not args.no_c4 and S == 4:
+    if (world * inproc > 1 or args.force_c4) and not args.no_c4 and S == 4:
         part.destroy()
         part = None
-        c4_sites, c4_taxa = 8_000_000, 128
-        plan4 = W.balanced_tree(c4_taxa, seed=42)
-        lo4, hi4 = W.shard_bounds(c4_sites, world)[rank:rank + 2]
-        # a 250,000-site block simulated down the tree, repeated to the shard's length
-        block = W.simulated_alignment(plan4, 250_000, W.GTR_RATES, W.GTR_FREQS, cat_rates, seed=4242 + rank)
-        reps4 = -(-(hi4 - lo4) // 250_000)
-        seqs4 = [(b * reps4)[:hi4 - lo4] for b in block]
-        p4 = W.setup_partition(amd, plan4, seqs4, 4, R, ATTRIB_PATTERN_TIP)
-        if use_comm:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                import ctypes
-                buf = ctypes.create_string_buffer(128)
-                if not amd.lib.pll_amd_comm_unique_id(buf):
-                    raise SystemExit("pll_amd_comm_unique_id failed: " + amd.errmsg())
-                uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
-            dist.broadcast(uid, src=0)
-            p4.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-        steps4 = max(3, min(args.steps, 10))
-        lnl4 = None
-        for _ in range(2):
-            p4.update_partials(plan4.ops)
-            lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
-        p4.wait()
-        torch.cuda.synchronize()
-        if use_comm:
-            dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(steps4):
-            p4.update_partials(plan4.ops)
-            lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
-        p4.wait()
-        torch.cuda.synchronize()
-        if use_comm:
-            dist.barrier()
-        t4 = time.perf_counter() - t1
-        if use_comm:
-            t = torch.tensor([t4], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t4 = float(t.item())
-        p4.destroy()
-        one = None
         try:
-            one = json.load(open(os.path.join(root, "profiles", "r2_bench_c4_one_gpu.json")))
-        except (OSError, ValueError):
-            pass
-        ms4 = t4 / steps4 * 1e3
-        c4 = {"workload": "BASELINE config 4: 4-state GTR, 4 rates, %d sites, %d-taxon balanced tree, PATTERN_TIP, "
-                          "divided over %d GPUs (%s)" % (c4_sites, c4_taxa, world * inproc,
-                                                         "one process, library-sharded partition" if inproc > 1
-                                                         else "one process per GPU, RCCL lnL all-reduce"),
-              "scaling": "strong", "n_gpus": world * inproc, "steps": steps4,
-              "value": round((c4_taxa - 2) * c4_sites * steps4 / t4 / 1e6, 2), "unit": "M CLV-site-updates/s",
-              "ms_per_step": round(ms4, 4), "lnl": lnl4,
-              "one_gpu_ms_per_step": one["ms_per_step"] if one else None,
-              "one_gpu_source": "profiles/r2_bench_c4_one_gpu.json (recorded: python bench.py --total-sites "
-                                "8000000 --taxa 128 --cpu-sites 0)" if one else None,
-              "speedup_vs_one_gpu": round(one["ms_per_step"] / ms4, 3) if one else None}
+            c4_sites, c4_taxa = 8_000_000, 128
+            plan4 = W.balanced_tree(c4_taxa, seed=42)
+            lo4, hi4 = W.shard_bounds(c4_sites, world)[rank:rank + 2]
+            # a 250,000-site block simulated down the tree, repeated to the shard's length
+            block = W.simulated_alignment(plan4, 250_000, W.GTR_RATES, W.GTR_FREQS, cat_rates, seed=4242 + rank)
+            reps4 = -(-(hi4 - lo4) // 250_000)
+            seqs4 = [(b * reps4)[:hi4 - lo4] for b in block]
+            p4 = W.setup_partition(amd, plan4, seqs4, 4, R, ATTRIB_PATTERN_TIP)
+            if use_comm:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    import ctypes
+                    buf = ctypes.create_string_buffer(128)
+                    if not amd.lib.pll_amd_comm_unique_id(buf):
+                        raise SystemExit("pll_amd_comm_unique_id failed: " + amd.errmsg())
+                    uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                dist.broadcast(uid, src=0)
+                p4.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            steps4 = max(3, min(args.steps, 10))
+            lnl4 = None
+            for _ in range(2):
+                p4.update_partials(plan4.ops)
+                lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
+            p4.wait()
+            torch.cuda.synchronize()
+            if use_comm:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(steps4):
+                p4.update_partials(plan4.ops)
+                lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
+            p4.wait()
+            torch.cuda.synchronize()
+            if use_comm:
+                dist.barrier()
+            t4 = time.perf_counter() - t1
+            if use_comm:
+                t = torch.tensor([t4], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                t4 = float(t.item())
+            p4.destroy()
+            one = None
+            try:
+                one = json.load(open(os.path.join(root, "profiles", "r2_bench_c4_one_gpu.json")))
+            except (OSError, ValueError):
+                pass
+            ms4 = t4 / steps4 * 1e3
+            c4 = {"workload": "BASELINE config 4: 4-state GTR, 4 rates, %d sites, %d-taxon balanced tree, PATTERN_TIP, "
+                              "divided over %d GPUs (%s)" % (c4_sites, c4_taxa, world * inproc,
+                                                             "one process, library-sharded partition" if inproc > 1
+                                                             else "one process per GPU, RCCL lnL all-reduce"),
+                  "scaling": "strong", "n_gpus": world * inproc, "steps": steps4,
+                  "value": round((c4_taxa - 2) * c4_sites * steps4 / t4 / 1e6, 2), "unit": "M CLV-site-updates/s",
+                  "ms_per_step": round(ms4, 4), "lnl": lnl4,
+                  "one_gpu_ms_per_step": one["ms_per_step"] if one else None,
+                  "one_gpu_source": "profiles/r2_bench_c4_one_gpu.json (recorded: python bench.py --total-sites "
+                                    "8000000 --taxa 128 --cpu-sites 0)" if one else None,
+                  "speedup_vs_one_gpu": round(one["ms_per_step"] / ms4, 3) if one else None}
+        except Exception as exc:  # the headline line must survive a failure of this extra section
+            c4 = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
         tt, ti, ii = plan.op_kinds() if not args.tip_clv else (0, 0, ops_per_eval)
         out = {
