@@ -94,7 +94,6 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
-  if (const char * e = getenv("PLLHIP_FUSED_PAIRS")) c->fused_pairs = atoi(e);
   if (const char * e = getenv("PLLHIP_FUSED_PINGPONG")) c->fused_pingpong = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_FUSED"))
   {
@@ -283,6 +282,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
     if (p) (void)hipFree(p);
   if (c->d_plan) (void)hipFree(c->d_plan);
   if (c->d_sink) (void)hipFree(c->d_sink);
+  if (c->fused_zero_row) (void)hipFree(c->fused_zero_row);
   if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
   if (c->d_pairtab) (void)hipFree(c->d_pairtab);
   if (c->cherry_pool) (void)hipFree(c->cherry_pool);

@@ -73,7 +73,9 @@ struct pllhip_ctx
   // launched again without planning or upload)
   std::vector<pllhip_op_t> fused_last_ops;
   struct pllhip_level_cache * level_cache = nullptr; // the same for the per-level path (partials.hip)
-  unsigned int fused_last_entries = 0, fused_last_count = 0, fused_last_nslots = 0;
+  unsigned int fused_last_jobs = 0, fused_last_count = 0, fused_last_nslots = 0;
+  size_t fused_last_jobs_offset = 0; // pair-table jobs within d_plan
+  unsigned char * fused_zero_row = nullptr; // [sites + slack] zeros: the "tip" of an op without one
   int fused_last_mode = 0;
   // Kept plans (the whole-list kernel's records, the per-level path's arguments) hold device
   // addresses and indices.  Whatever reallocates a buffer such a plan may reference bumps
@@ -92,7 +94,6 @@ struct pllhip_ctx
   size_t plan_cap = 0;
   int plan_next = 0;
   bool no_fused = false; // env PLLHIP_FUSED=0: one launch per dependency level instead
-  int fused_pairs = 2;      // env PLLHIP_FUSED_PAIRS
   bool fused_pingpong = true; // env PLLHIP_FUSED_PINGPONG=0: every whole-list launch walks the tiles forwards
   unsigned int fused_launches = 0;
   bool force_fused = false; // env PLLHIP_FUSED=2: also for partitions too small for it to pay (tests)

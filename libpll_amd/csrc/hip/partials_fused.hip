@@ -53,82 +53,84 @@
 #include "partials_fused.hpp"
 
 #define PLL_LDS __attribute__((address_space(3)))
+// The plan holds addresses as integers; a pointer made from one must say that it points to global
+// memory, or its accesses become FLAT ones (which count as LDS operations too and drain both queues).
+#define PLL_GLOBAL __attribute__((address_space(1)))
+typedef pll_v2d PLL_GLOBAL * global_v2d;
+template <bool NT>
+__device__ __forceinline__ void st16g(unsigned long long base, unsigned int byte_offset, double a, double b)
+{
+  const global_v2d p = (global_v2d)(base + byte_offset);
+  const pll_v2d v = {a, b};
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
-// ---- a plan record, word by word (all of this is scalar arithmetic on wave-uniform values) ----
+// ---- a plan record: sixteen words, one scalar load (all of this is wave-uniform) ----
 typedef const unsigned int __attribute__((address_space(4))) * const_words;
 typedef const unsigned long long __attribute__((address_space(4))) * const_quads;
-struct RecAhead // words 0, 1 of a FusedRec: what request() needs
+struct Rec
 {
-  unsigned int w0, w1;
+  unsigned int w[16];
 };
-struct RecOp // words 4..7: what the op and the op before it need
+// (constant address space: a scalar load; adjacent words, the compiler merges them into one)
+__device__ __forceinline__ Rec rec_load(const FusedRec * plan, unsigned int i)
 {
-  unsigned int w4, w5, w6, w7;
-};
-// (constant address space: scalar loads; adjacent words, the compiler merges them)
-__device__ __forceinline__ RecAhead rec_ahead(const FusedRec * plan, unsigned int i)
-{
-  const const_words w = (const_words)(unsigned long long)(plan + i);
-  RecAhead r;
-  r.w0 = w[0]; r.w1 = w[1];
+  const const_words p = (const_words)(unsigned long long)(plan + i);
+  Rec r;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) r.w[t] = p[t];
   return r;
 }
-__device__ __forceinline__ RecOp rec_op(const FusedRec * plan, unsigned int i)
-{
-  const const_words w = (const_words)(unsigned long long)(plan + i);
-  RecOp r;
-  r.w4 = w[4]; r.w5 = w[5]; r.w6 = w[6]; r.w7 = w[7];
-  return r;
-}
-__device__ __forceinline__ unsigned int rec_ltip(const RecAhead & r) { return r.w0 & 0xffffu; }
-__device__ __forceinline__ unsigned int rec_rtip(const RecAhead & r) { return r.w0 >> 16; }
-__device__ __forceinline__ unsigned int rec_lmat(const RecAhead & r) { return r.w1 & 0xffffu; }
-__device__ __forceinline__ unsigned int rec_rmat(const RecAhead & r) { return r.w1 >> 16; }
-__device__ __forceinline__ unsigned int rec_parent(const RecOp & r) { return r.w4 & 0xffffu; }
-__device__ __forceinline__ unsigned int rec_pscaler(const RecOp & r) { return r.w4 >> 16; }
-__device__ __forceinline__ unsigned int rec_pair(const RecOp & r) { return r.w5 & 0xffffu; }
-__device__ __forceinline__ unsigned int rec_src(const RecOp & r) { return r.w5 >> 16; }
-__device__ __forceinline__ int rec_lslot(const RecOp & r) { return (int)(r.w6 << 24) >> 24; }
-__device__ __forceinline__ int rec_rslot(const RecOp & r) { return (int)(r.w6 << 16) >> 24; }
-__device__ __forceinline__ int rec_pslot(const RecOp & r) { return (int)(r.w6 << 8) >> 24; }
-__device__ __forceinline__ int rec_kind(const RecOp & r) { return (int)(r.w6 >> 24); }
-__device__ __forceinline__ int rec_lsc(const RecOp & r) { return (int)(r.w7 << 24) >> 24; }
-__device__ __forceinline__ int rec_rsc(const RecOp & r) { return (int)(r.w7 << 16) >> 24; }
-__device__ __forceinline__ unsigned int rec_dma(const RecOp & r) { return (r.w7 >> 16) & 0xffu; }
+__device__ __forceinline__ unsigned long long rec_quad(const Rec & r, int t) { return (unsigned long long)r.w[t] | ((unsigned long long)r.w[t + 1] << 32); }
+__device__ __forceinline__ unsigned long long rec_req_ltip(const Rec & r) { return rec_quad(r, 0); }
+__device__ __forceinline__ unsigned long long rec_req_rtip(const Rec & r) { return rec_quad(r, 2); }
+__device__ __forceinline__ unsigned int rec_req_lmat(const Rec & r) { return r.w[4]; }
+__device__ __forceinline__ unsigned int rec_req_rmat(const Rec & r) { return r.w[5]; }
+__device__ __forceinline__ unsigned int rec_gather(const Rec & r) { return r.w[6]; }
+__device__ __forceinline__ unsigned int rec_flags(const Rec & r) { return r.w[7]; }
+__device__ __forceinline__ unsigned long long rec_parent(const Rec & r) { return rec_quad(r, 8); }
+__device__ __forceinline__ unsigned long long rec_pscaler(const Rec & r) { return rec_quad(r, 10); }
+__device__ __forceinline__ unsigned int rec_lslot(const Rec & r) { return r.w[12] & 0xffffu; }
+__device__ __forceinline__ unsigned int rec_rslot(const Rec & r) { return r.w[12] >> 16; }
+__device__ __forceinline__ unsigned int rec_pslot(const Rec & r) { return r.w[13] & 0xffffu; }
+__device__ __forceinline__ unsigned int rec_src(const Rec & r) { return r.w[13] >> 16; }
+__device__ __forceinline__ unsigned int rec_lcnt(const Rec & r) { return r.w[14] & 0xffffu; }
+__device__ __forceinline__ unsigned int rec_rcnt(const Rec & r) { return r.w[14] >> 16; }
+__device__ __forceinline__ unsigned int rec_pcnt(const Rec & r) { return r.w[15] & 0xffffu; }
 
 // Tip operands: the parent entry of a tip-tip op depends on its two tip characters only, 16 x 16
-// pairs.  One table per such op, [pair][rate][state] = masksum4(P_l row, code 1) *
+// pairs.  One table per op with a tip, [pair][rate][state] = masksum4(P_l row, code 1) *
 // masksum4(P_r row, code 2) -- the very product the kernel would form per site (30 VALU
 // instructions per tip operand and sub-step) -- built by one small launch ahead of the
 // list and read back by the list kernel with one 16-byte gather per lane and sub-step
-// (32 KB per op at 4 rate categories: L2-resident).
+// (32 KB per op at 4 rate categories: L2-resident).  Table 0 is all zeros: what ops without a
+// tip gather from (every op issues the same loads).
 template <int RC>
-__global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedRec * __restrict__ plan, unsigned int nops,
-                                                         FusedBases b)
+__global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedPairJob * __restrict__ jobs, unsigned int njobs)
 {
   const unsigned int i = blockIdx.x;
-  if (i >= nops || plan[i].pair == PLLHIP_FUSED_NONE) return;
-  const double * lm = b.pmat + (size_t)plan[i].lmat * (RC * 16), * rm = b.pmat + (size_t)plan[i].rmat * (RC * 16);
-  double * tab = b.pairtab + (size_t)plan[i].pair * (256 * RC * 4);
+  if (i >= njobs) return;
+  const double * lm = jobs[i].lmat, * rm = jobs[i].rmat;
+  double * tab = jobs[i].tab;
   const unsigned int pair = threadIdx.x, c1 = pair >> 4, c2 = pair & 15u;
   // (tip-inner ops: the tip's factor alone, in the entries [code 1][0] the kernel's index
   // (code 1 << 4 | character of an absent tip = 0) reaches; x * 1.0 is x)
-  const bool tt = plan[i].kind == 2;
+  const bool tt = jobs[i].tip_tip != 0;
   for (unsigned int ki = 0; ki < RC * 4u; ++ki)
     tab[pair * RC * 4u + ki] = masksum4(lm + ki * 4u, c1) * (tt ? masksum4(rm + ki * 4u, c2) : 1.0);
 }
 
 // what a lane requests for an op ahead of its use
-template <int PL, int J>
+template <int J>
 struct FusedFetch
 {
-  double2 pm[PL];                      // its 16 bytes of the two P-matrices (a coalesced block per wave)
+  double2 pm;                          // its 16 bytes of [P_l | P_r] (a coalesced block per wave)
   unsigned int codes_l[J], codes_r[J]; // tip characters of the lane's own site in each sub-step
   // element by element: a plain struct assignment of the arrays goes through scratch memory
   __device__ __forceinline__ void take(const FusedFetch & o)
   {
-#pragma unroll
-    for (int t = 0; t < PL; ++t) pm[t] = o.pm[t];
+    pm = o.pm;
 #pragma unroll
     for (int j = 0; j < J; ++j)
     {
@@ -138,16 +140,26 @@ struct FusedFetch
   }
 };
 
+// all lanes of a group of W (2, 4 or 8: a site's lanes, or a rate's) hold x != 0?  DPP, no ballot
+template <int W>
+__device__ __forceinline__ unsigned int group_and(unsigned int x)
+{
+  x &= (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);                // lane ^ 1
+  if (W >= 4) x &= (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);    // lane ^ 2
+  if (W >= 8) x &= (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);   // lane <-> 7 - lane
+  return x;
+}
+
 // WPS: waves per SIMD the register budget is sized for (3 = 168 VGPRs: twelve waves per CU)
 template <int RC, int J, int MODE, bool NT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan, FusedBases bases,
                                                         unsigned int nops, unsigned int sites, unsigned int nslots,
-                                                        const unsigned int * __restrict__ zero, double2 * sink,
-                                                        unsigned int * next_tile, unsigned int backwards, unsigned int dynamic_rounds)
+                                                        double2 * sink, unsigned int * next_tile, unsigned int backwards,
+                                                        unsigned int dynamic_rounds)
 {
+  static_assert(RC == 1 || RC == 2 || RC == 4, "lane groups of 2, 4 or 8");
   constexpr unsigned int W = 2 * RC, SPS = 64 / W, TS = J * SPS;
   constexpr unsigned int MG = RC * 8;                   // 16-byte granules of one P-matrix
-  constexpr int PL = (2 * MG + 63) / 64;                // granules of [P_l | P_r] per lane
   extern __shared__ double2 lds_fused[];
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned int h = lane & 1u;
@@ -166,8 +178,12 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   const unsigned int clv_lds_b = __builtin_amdgcn_readfirstlane(
       (unsigned int)(uintptr_t)(PLL_LDS char *)lds_fused + (unsigned int)(wave_in_wg * wave_g * 16));
   const unsigned int cnt_lds_b = clv_lds_b + (unsigned int)(((size_t)nslots * J * 64 + MG) * 16);
-  const double2 * zero16 = reinterpret_cast<const double2 *>(zero);
-  const unsigned char * zero8 = reinterpret_cast<const unsigned char *>(zero);
+  // what never changes for a lane: its byte offsets into a tile, a tip row, a pair-table entry, a matrix block
+  const unsigned int lane16 = lane * 16u;
+  const unsigned int tip_lane = lane / W;
+  const unsigned int gat_lane = (lane & (W - 1)) * 16u;
+  const unsigned int pm_lane = (lane & (MG - 1)) * 16u;
+  const bool pm_left = lane < MG;
 
   // Every CLV, scale buffer and tip row has PLLHIP_TAIL_SITES sites of slack of its own
   // behind its last site (ctx.hip), so the last tile is loaded and STORED whole: no lane
@@ -187,6 +203,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   // serialise on its cache lines (measured: ~0.7 ms per launch at 1 M sites, hidden behind a
   // 62-op list but not behind a 5-op one)
   sink += wave * 80;
+  unsigned int * sink_cnt = reinterpret_cast<unsigned int *>(sink + 64);
 
   // A wave's first tiles are its own by a fixed stride; the last `dynamic_rounds` rounds' worth come
   // from a counter.  Not only for the tail: the eight XCDs do not write at the same rate -- on
@@ -205,63 +222,71 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   {
     // (every other launch of a context walks the tiles from the far end: see pllhip_relaunch_fused)
     const size_t site0 = (backwards ? tiles - 1 - tile : tile) * TS;
+    const size_t clv_off = site0 * (W * 16u);                             // bytes into a CLV
+    const size_t cnt_off = site0 * ((MODE == SCALE_RATE) ? RC * 4u : 4u); // bytes into a scale buffer
 
-    // every load is unconditional (absent operands read the zero block): a load inside a
-    // branch makes the compiler wait for everything in flight
-    auto request = [&](FusedFetch<PL, J> & f, const RecAhead & r) {
-      const double2 * lm = reinterpret_cast<const double2 *>(bases.pmat + (size_t)rec_lmat(r) * (RC * 16));
-      const double2 * rm = reinterpret_cast<const double2 *>(bases.pmat + (size_t)rec_rmat(r) * (RC * 16));
-#pragma unroll
-      for (int t = 0; t < PL; ++t)
-      {
-        const unsigned int q = lane + 64u * t;
-        const double2 * src = (q < MG) ? lm + q : (q < 2 * MG) ? rm + (q - MG) : zero16;
-        f.pm[t] = *src;
-      }
-      const bool has_l = rec_ltip(r) != PLLHIP_FUSED_NONE, has_r = rec_rtip(r) != PLLHIP_FUSED_NONE;
-      // (uniform: tile base or the zero block)
-      const unsigned char * lt = has_l ? bases.tips + (size_t)rec_ltip(r) * bases.tip_stride + site0 : zero8;
-      const unsigned char * rt = has_r ? bases.tips + (size_t)rec_rtip(r) * bases.tip_stride + site0 : zero8;
+    // What an op needs from memory is requested TWO ops ahead of it: its 16 bytes of [P_l | P_r]
+    // and its tip characters.  Every load is unconditional (an op without a tip reads a row of
+    // zeros): a load inside a branch makes the compiler wait for everything in flight.
+    auto request = [&](FusedFetch<J> & f, const Rec & r) {
+      const unsigned int off = (pm_left ? rec_req_lmat(r) : rec_req_rmat(r)) + pm_lane;
+      f.pm = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(bases.pmat) + off);
+      const unsigned char PLL_GLOBAL * lt = (const unsigned char PLL_GLOBAL *)(rec_req_ltip(r) + site0); // (uniform)
+      const unsigned char PLL_GLOBAL * rt = (const unsigned char PLL_GLOBAL *)(rec_req_rtip(r) + site0);
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
-        f.codes_l[j] = lt[has_l ? j * SPS + lane / W : 0u];
-        f.codes_r[j] = rt[has_r ? j * SPS + lane / W : 0u];
+        f.codes_l[j] = lt[j * SPS + tip_lane];
+        f.codes_r[j] = rt[j * SPS + tip_lane];
+      }
+    };
+    // ... and ONE op ahead its entries of the pair table are gathered with the characters that
+    // have arrived by then (table 0, all zeros, for an op without a tip)
+    auto gather = [&](double2 (&pt)[J], const FusedFetch<J> & f, const Rec & r) {
+#pragma unroll
+      for (unsigned int j = 0; j < J; ++j)
+      {
+        const unsigned int pair = ((f.codes_l[j] << 4) | f.codes_r[j]) & 255u;
+        const unsigned int off = pair * (W * 16u) + gat_lane + rec_gather(r);
+        pt[j] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(bases.pairtab) + off);
       }
     };
 
-    // the op's matrices: the wave's coalesced block goes through LDS (the previous op's rows are in registers by then),
-    // each lane takes rows 2h, 2h+1 of category k (own column pair first, then the partner's).
-    // One matrix at a time through ONE staging block (LDS operations of a wave execute in
-    // order): the 512 bytes this saves per wave are what gives the 12-wave configuration
-    // its sixth slot (a balanced 128-taxon tree needs six).
-    auto stage_rows = [&](const FusedFetch<PL, J> & f, half_rows & pl, half_rows & pr) {
+    // The next op's matrices: the wave's coalesced block goes through LDS, each lane takes rows
+    // 2h, 2h+1 of category k (own column pair first, then the partner's).  One matrix at a time
+    // through ONE staging block (LDS operations of a wave execute in order): the 512 bytes
+    // this saves per wave are what gives the 12-wave configuration its sixth slot (a balanced
+    // 128-taxon tree needs six).  `need`: 2 both matrices, 1 the right one only (the tip of a
+    // tip-inner op comes from its pair table), 0 none (tip-tip).
+    auto stage_rows = [&](const FusedFetch<J> & f, unsigned int need, half_rows & pl, half_rows & pr) {
       double2 * p = pst;
-#pragma unroll
-      for (int t = 0; t < PL; ++t)
-        if (lane + 64u * t < MG) p[lane + 64u * t] = f.pm[t];
-      // (what a lane reads was written by OTHER lanes: the compiler, which reasons per
-      // thread, must not carry a value over these lines -- it once served the lanes that do
-      // not write in the second round with their first-round rows)
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
+      if (need >= 2)
       {
-        const unsigned int row = k * 8 + (2 * h + r) * 2;
-        const double2 lo = p[row + h], lp = p[row + 1 - h];
-        pl.m[r][0] = lo.x; pl.m[r][1] = lo.y; pl.m[r][2] = lp.x; pl.m[r][3] = lp.y;
+        if (lane < MG) p[lane] = f.pm;
+        // (what a lane reads was written by OTHER lanes: the compiler, which reasons per
+        // thread, must not carry a value over these lines)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+        {
+          const unsigned int row = k * 8 + (2 * h + r) * 2;
+          const double2 lo = p[row + h], lp = p[row + 1 - h];
+          pl.m[r][0] = lo.x; pl.m[r][1] = lo.y; pl.m[r][2] = lp.x; pl.m[r][3] = lp.y;
+        }
+        asm volatile("" ::: "memory");
       }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int t = 0; t < PL; ++t)
-        if (lane + 64u * t >= MG && lane + 64u * t < 2 * MG) p[lane + 64u * t - MG] = f.pm[t];
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
+      if (need >= 1)
       {
-        const unsigned int row = k * 8 + (2 * h + r) * 2;
-        const double2 ro = p[row + h], rp = p[row + 1 - h];
-        pr.m[r][0] = ro.x; pr.m[r][1] = ro.y; pr.m[r][2] = rp.x; pr.m[r][3] = rp.y;
+        if (lane >= MG && lane < 2 * MG) p[lane - MG] = f.pm;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+        {
+          const unsigned int row = k * 8 + (2 * h + r) * 2;
+          const double2 ro = p[row + h], rp = p[row + 1 - h];
+          pr.m[r][0] = ro.x; pr.m[r][1] = ro.y; pr.m[r][2] = rp.x; pr.m[r][3] = rp.y;
+        }
+        asm volatile("" ::: "memory");
       }
     };
 
@@ -273,23 +298,24 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     // loads, memory operations return in order, and the next iteration's first statement
     // waits for those loads before any slot is read.  (Per-lane 64-bit addresses and `off`:
     // the form the compiler itself emits for the builtin.)
-    auto reload = [&](const RecOp & r) {
-      // (the sources follow the records and their three look-ahead copies)
-      const const_quads q = (const_quads)(unsigned long long)(reinterpret_cast<const FusedSrc *>(plan + nops + 3) + rec_src(r));
-      const double * src[2] = {(const double *)q[0], (const double *)q[1]};
-      const unsigned int * csrc[2] = {(const unsigned int *)q[2], (const unsigned int *)q[3]};
-      const int slot[2] = {rec_lslot(r), rec_rslot(r)};
+    auto reload = [&](unsigned int src_index) {
+      // (the sources follow the two headers, the records and one record of padding)
+      const const_quads q = (const_quads)(unsigned long long)(reinterpret_cast<const FusedSrc *>(plan + nops + 3) + src_index);
+      const unsigned long long src[2] = {q[0], q[1]}, csrc[2] = {q[2], q[3]};
+      const unsigned long long where = q[4]; // lslot_b | rslot_b << 16 | lcnt_b << 32 | rcnt_b << 48
+      const unsigned int slot_b[2] = {(unsigned int)where & 0xffffu, (unsigned int)(where >> 16) & 0xffffu};
+      const unsigned int count_b[2] = {(unsigned int)(where >> 32) & 0xffffu, (unsigned int)(where >> 48)};
 #pragma unroll
       for (int o = 0; o < 2; ++o)
       {
         if (src[o])
         {
-          const double2 * base = reinterpret_cast<const double2 *>(src[o]) + site0 * W;
+          const char * base = reinterpret_cast<const char *>(src[o]) + clv_off;
 #pragma unroll
           for (unsigned int j = 0; j < J; ++j)
           {
-            const unsigned int lds_b = clv_lds_b + ((unsigned int)slot[o] * J + j) * 1024u;
-            const double2 * gsrc = base + j * 64u + lane;
+            const unsigned int lds_b = clv_lds_b + slot_b[o] + j * 1024u;
+            const char * gsrc = base + j * 1024u + lane16;
             unsigned int m0_saved;
             if (NT)
               asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
@@ -304,10 +330,10 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
         if (MODE != SCALE_NONE && csrc[o])
         {
           // the tile's counts are J * CW consecutive words: the first so many lanes move one each
-          const unsigned int * cbase = csrc[o] + ((MODE == SCALE_RATE) ? site0 * RC : site0);
-          const unsigned int lds_b = cnt_lds_b + (unsigned int)slot[o] * (J * CW * 4u);
+          const char * cbase = reinterpret_cast<const char *>(csrc[o]) + cnt_off;
+          const unsigned int lds_b = cnt_lds_b + count_b[o];
           const unsigned long long mask = (J * CW >= 64u) ? ~0ull : ((1ull << (J * CW)) - 1ull);
-          const unsigned int * gsrc = cbase + lane;
+          const char * gsrc = cbase + lane * 4u;
           unsigned long long exec_saved;
           unsigned int m0_saved;
           asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 %1, m0\n\ts_mov_b64 exec, %2\n\ts_mov_b32 m0, %3\n\t"
@@ -316,191 +342,177 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
         }
       }
     };
-    auto pair_table = [&](const RecOp & r) -> const double2 * {
-      return rec_pair(r) != PLLHIP_FUSED_NONE
-                 ? reinterpret_cast<const double2 *>(bases.pairtab + (size_t)rec_pair(r) * (256 * RC * 4))
-                 : nullptr;
-    };
 
-    // Two ops of look-ahead: at the top of op i the block of op i+2 is requested, the block
-    // of op i+1 (requested one op ago) goes through LDS into the registers op i+1 will use,
-    // and op i runs on registers filled one op ago.  The plan records of ops i .. i+2 are in
-    // SGPRs when they are needed: the op's own words for ops i and i+1 (r0, r1; those of op i+2
-    // are requested at the top of op i), the look-ahead words of op i+2 (a2; op i+3's requested
-    // at the top of op i).  (Scalar loads return out of order and share a counter with LDS, so
-    // a plan field consumed right after its load would drain the LDS reads in flight.)  The
-    // plan carries three copies of the last op behind it.
-    RecOp r0 = rec_op(plan, 0), r1 = rec_op(plan, 1);
-    RecAhead a2 = rec_ahead(plan, 2);
-    FusedFetch<PL, J> cur, fa;
+    // The pipeline.  While op i runs, the wave has in registers: the matrix rows of op i (pl, pr)
+    // and its pair-table entries (pt_use), both fetched during op i-1; the block and characters
+    // of op i+1 (fa), requested during op i-1; and it requests those of op i+2 (fb).  Record i
+    // says all of that -- what to request for op i+2, which table to gather from for op i+1,
+    // what op i+1 reloads and which matrices it needs, and op i itself -- so ONE record is live
+    // per op and the next one is in flight (scalar loads return out of order and share a
+    // counter with LDS, so a field consumed right after its load would drain the LDS reads in
+    // flight).  Two header records ahead of the list do for ops 0 and 1 what the records of
+    // ops -2 and -1 would.
+    const Rec h0 = rec_load(plan, 0), h1 = rec_load(plan, 1);
+    Rec ra = rec_load(plan, 2), rb;
+    FusedFetch<J> fa, fb;
     half_rows pl, pr;
-    if (rec_dma(r0)) reload(r0);
-    request(cur, rec_ahead(plan, 0));
-    request(fa, rec_ahead(plan, 1));
-    // The compiler counts the memory operations issued after a load to know how many may
-    // stay in flight when the load is consumed, and takes the minimum over all paths into
-    // the loop.  On the path through the loop an op's stores follow the look-ahead loads;
-    // these stores to the sink give the entry path the same shape, so that the wait at the
-    // top of an op leaves the previous op's stores in flight.
-#pragma unroll
-    for (unsigned int j = 0; j < J; ++j)
-    {
-      st16<NT>(sink + lane, 0.0, 0.0);
-      if (MODE != SCALE_NONE) reinterpret_cast<unsigned int *>(sink + 64)[lane] = 0u;
-    }
-    stage_rows(cur, pl, pr);
-    // tip operands' pair tables: the gather of op i+1 is issued at the top of op i, from the
-    // characters that arrived for it; what op i uses was gathered during op i-1
-    double2 pt_use[J], pt_next[J];
-    {
-      const double2 * t0 = pair_table(r0);
+    double2 pta[J], ptb[J];
+    // The prologue issues its memory operations in the order two ops would -- requests, gather,
+    // stores (to the sink) -- because the compiler counts the operations issued after a load to
+    // know how many may stay in flight when the load is consumed, and takes the minimum over
+    // all paths into the loop: with the same shape on the entry path, the wait at the top of
+    // an op leaves the previous op's stores in flight.
+    auto sink_stores = [&]() {
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
-        const unsigned int pair = ((cur.codes_l[j] & 15u) << 4) | (cur.codes_r[j] & 15u);
-        pt_next[j] = t0 ? t0[pair * W + (lane & (W - 1))] : zero16[0];
+        st16<NT>(sink + lane, 0.0, 0.0);
+        asm volatile("" ::: "memory"); // (J stores, not one)
       }
-    }
-    for (unsigned int i = 0; i < nops; ++i)
-    {
-      const RecOp r2 = rec_op(plan, i + 2);
-      const RecAhead a3 = rec_ahead(plan, i + 3);
-      const int kind = rec_kind(r0), lslot = rec_lslot(r0), rslot = rec_rslot(r0), pslot = rec_pslot(r0);
-      const int lsc_slot = rec_lsc(r0), rsc_slot = rec_rsc(r0);
-      double2 * out = reinterpret_cast<double2 *>(bases.clv + (size_t)rec_parent(r0) * bases.site_stride * (RC * 4));
-      const bool scaling = MODE != SCALE_NONE && rec_pscaler(r0) != PLLHIP_FUSED_NONE;
-      unsigned int * pscaler = bases.scaler + (size_t)rec_pscaler(r0) * bases.site_stride * (MODE == SCALE_RATE ? RC : 1); // (used if scaling)
-      const bool have_pairs = rec_pair(r0) != PLLHIP_FUSED_NONE; // this op takes its entries from its pair table
-      const double2 * pair_next = pair_table(r1);                // the table of op i+1
+      if (MODE != SCALE_NONE) sink_cnt[lane] = 0u;
+    };
+    request(fb, h0);
+    sink_stores();
+    if (rec_flags(h1) & PLLHIP_FUSED_RELOAD_NEXT) reload(rec_src(h1));
+    request(fa, h1);
+    asm volatile("" ::"v"(fb.codes_r[J - 1]) : "memory");
+    gather(pta, fb, h1);
+    sink_stores();
+    stage_rows(fb, (rec_flags(h1) >> PLLHIP_FUSED_STAGE_SHIFT) & 3u, pl, pr);
+
+    // One op.  r0: its record, r1: where the next one is loaded to; fu: the fetch of op i+1,
+    // ff: where that of op i+2 goes; pu: its pair-table entries, pf: where those of op i+1 go.
+    // The caller alternates the two of each, so that nothing loaded is ever copied (a copy
+    // would have to wait for the load).
+    auto step = [&](const Rec & r0, Rec & r1, const FusedFetch<J> & fu, FusedFetch<J> & ff, const double2 (&pu)[J],
+                    double2 (&pf)[J], unsigned int i) __attribute__((always_inline)) {
+      r1 = rec_load(plan, i + 3);
+      const unsigned int fl = rec_flags(r0);
       // (rare, wave-uniform: the sources of the reload are read on the spot)
-      if (rec_dma(r1)) reload(r1);
-      FusedFetch<PL, J> fb;
-      request(fb, a2);
-      unsigned int pairs[J];
-#pragma unroll
-      for (unsigned int j = 0; j < J; ++j) pairs[j] = ((fa.codes_l[j] & 15u) << 4) | (fa.codes_r[j] & 15u);
-      // Everything requested one op ago has arrived once these characters are used -- and with
+      if (fl & PLLHIP_FUSED_RELOAD_NEXT) reload(rec_src(r0));
+      request(ff, r0);
+      // Everything requested one op ago has arrived once fu's characters are used -- and with
       // it what that iteration's reload() copied into this op's slots (issued ahead of those
       // requests; memory operations return in order).  No slot is read above this line.
-      asm volatile("" ::"v"(pairs[J - 1]) : "memory");
-#pragma unroll
-      for (unsigned int j = 0; j < J; ++j)
-      {
-        pt_use[j] = pt_next[j];
-        pt_next[j] = pair_next ? pair_next[pairs[j] * W + (lane & (W - 1))] : zero16[0];
-      }
+      asm volatile("" ::"v"(fu.codes_r[J - 1]) : "memory");
+      gather(pf, fu, r0);
 
-      double2 * out_tile = out + site0 * W;
-      // (the counts of an op without a scale buffer go to a sink, so that every op issues the
-      // same number of stores, see below)
-      unsigned int * cnt_tile = scaling ? pscaler + ((MODE == SCALE_RATE) ? site0 * RC : site0)
-                                        : reinterpret_cast<unsigned int *>(sink + 64);
+      const unsigned int kind = fl & PLLHIP_FUSED_KIND_MASK;
+      const bool has_slot = fl & PLLHIP_FUSED_HAS_PSLOT;
+      const bool scaling = MODE != SCALE_NONE && (fl & PLLHIP_FUSED_SCALING);
+      const unsigned long long out = rec_parent(r0) + clv_off; // (uniform)
+      char * lds_l = reinterpret_cast<char *>(clv) + rec_lslot(r0) + lane16;
+      char * lds_r = reinterpret_cast<char *>(clv) + rec_rslot(r0) + lane16;
+      char * lds_p = reinterpret_cast<char *>(clv) + rec_pslot(r0) + lane16;
+      // the counts: entry t of the tile (a site, or a (site, rate) with per-rate scalers) is
+      // lane t's; what the operands bring along is read here, ahead of the arithmetic
+      constexpr unsigned int GW = (MODE == SCALE_RATE) ? 2u : W; // lanes that share a count
+      constexpr unsigned int EPS = 64u / GW, E = J * EPS;        // entries per sub-step / per tile
+      static_assert(MODE == SCALE_NONE || CW == EPS, "one count word per entry of a sub-step");
+      const unsigned int t = lane < E ? lane : 0u;
+      unsigned int lc = 0u, rc = 0u;
+      if (MODE != SCALE_NONE && kind != 2)
+      {
+        lc = *reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + rec_lcnt(r0) + t * 4u);
+        rc = *reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + rec_rcnt(r0) + t * 4u);
+      }
+      // (every load is consumed on every path, needed or not: the registers of a load that
+      // nobody waited for stay "pending" for the compiler, and it drains the queue -- this op's
+      // predecessor's stores included -- when it next reuses them)
+#pragma unroll
+      for (unsigned int j = 0; j < J; ++j) asm volatile("" ::"v"(pu[j].x), "v"(pu[j].y));
       unsigned long long scaled[J];
+      double p0[J], p1[J];
+      if (kind == 2)
+      {
+        // tip-tip: the finished entries come from the pair table; never scales, clears its counts
+        // (core_partials_avx.c:598-599)
+#pragma unroll
+        for (unsigned int j = 0; j < J; ++j)
+        {
+          scaled[j] = 0;
+          p0[j] = pu[j].x;
+          p1[j] = pu[j].y;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (unsigned int j = 0; j < J; ++j)
+        {
+          const double2 ro = *reinterpret_cast<const double2 *>(lds_r + j * 1024u);
+          const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
+          double x0, x1;
+          if (kind == 1)
+          {
+            // tip-inner: the tip's factor is its pair-table entry
+            x0 = pu[j].x;
+            x1 = pu[j].y;
+          }
+          else
+          {
+            const double2 lo = *reinterpret_cast<const double2 *>(lds_l + j * 1024u);
+            const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
+            x0 = pl.dot(0, lo, lp);
+            x1 = pl.dot(1, lo, lp);
+          }
+          double q0 = x0 * pr.dot(0, ro, rp), q1 = x1 * pr.dot(1, ro, rp);
+          // scaling rule of core_partials_avx.c:486-527: all entries of the site (of the rate,
+          // with per-rate scalers) below the threshold; x * 1.0 is x
+          scaled[j] = 0;
+          if (MODE != SCALE_NONE)
+          {
+            const unsigned int small = ((q0 < PLLHIP_SCALE_THRESHOLD) & (q1 < PLLHIP_SCALE_THRESHOLD)) ? 1u : 0u;
+            const bool scale = scaling && group_and<(int)GW>(small) != 0u;
+            const double factor = __hiloint2double(scale ? 0x4ff00000 : 0x3ff00000, 0); // 2^256 : 1.0
+            q0 *= factor;
+            q1 *= factor;
+            scaled[j] = __ballot(scale); // (wave-uniform: which groups of this sub-step were scaled)
+          }
+          p0[j] = q0;
+          p1[j] = q1;
+        }
+      }
+      // The stores are common to all kinds and under no branch: the compiler counts the memory
+      // operations of the path with the FEWEST of them to decide how many may stay in flight at a
+      // wait, and a path without this op's stores would make the next op wait for the stores of
+      // the op before.
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
-        const unsigned int g = j * 64u + lane; // granule within the tile
-        // operands and inherited counts: LDS slots (slot 0 is read when there is none)
-        const double2 lo = clv[((lslot >= 0 ? lslot : 0) * J + j) * 64 + lane];
-        const double2 ro = clv[((rslot >= 0 ? rslot : 0) * J + j) * 64 + lane];
-        double x0, x1, y0 = 1.0, y1 = 1.0;
-        if (have_pairs)
-        {
-          // tip-tip with a pair table: the finished entries; tip-inner: the tip's factor
-          x0 = pt_use[j].x;
-          x1 = pt_use[j].y;
-        }
-        else if (kind == 0)
-        {
-          const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
-          x0 = pl.dot(0, lo, lp);
-          x1 = pl.dot(1, lo, lp);
-        }
-        else
-        {
-          // tip: the entries of rows 2h, 2h+1 that the character's state mask selects, in
-          // the pairwise order of masksum4 (own pair + partner pair; commutative)
-          const unsigned int code = cur.codes_l[j] & 15u;
-          const unsigned int b0 = (code >> (2 * h)) & 1u, b1 = (code >> (2 * h + 1)) & 1u;
-          const unsigned int b2 = (code >> (2 - 2 * h)) & 1u, b3 = (code >> (3 - 2 * h)) & 1u;
-          x0 = ((b0 ? pl.m[0][0] : 0.0) + (b1 ? pl.m[0][1] : 0.0)) + ((b2 ? pl.m[0][2] : 0.0) + (b3 ? pl.m[0][3] : 0.0));
-          x1 = ((b0 ? pl.m[1][0] : 0.0) + (b1 ? pl.m[1][1] : 0.0)) + ((b2 ? pl.m[1][2] : 0.0) + (b3 ? pl.m[1][3] : 0.0));
-        }
-        if (have_pairs && kind == 2)
-          ;
-        else if (kind != 2)
-        {
-          const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
-          y0 = pr.dot(0, ro, rp);
-          y1 = pr.dot(1, ro, rp);
-        }
-        else
-        {
-          const unsigned int code = cur.codes_r[j] & 15u;
-          const unsigned int b0 = (code >> (2 * h)) & 1u, b1 = (code >> (2 * h + 1)) & 1u;
-          const unsigned int b2 = (code >> (2 - 2 * h)) & 1u, b3 = (code >> (3 - 2 * h)) & 1u;
-          y0 = ((b0 ? pr.m[0][0] : 0.0) + (b1 ? pr.m[0][1] : 0.0)) + ((b2 ? pr.m[0][2] : 0.0) + (b3 ? pr.m[0][3] : 0.0));
-          y1 = ((b0 ? pr.m[1][0] : 0.0) + (b1 ? pr.m[1][1] : 0.0)) + ((b2 ? pr.m[1][2] : 0.0) + (b3 ? pr.m[1][3] : 0.0));
-        }
-        // (tip-tip with a pair table: y is exactly 1.0, the product is the table entry itself)
-        double p0 = x0 * y0, p1 = x1 * y1;
-
-        // scaling rule of core_partials_avx.c:486-527; tip-tip never scales and clears
-        // its scaler (core_partials_avx.c:598-599)
-        bool scale = false;
-        if (scaling && kind != 2)
-        {
-          const bool small = (p0 < PLLHIP_SCALE_THRESHOLD) & (p1 < PLLHIP_SCALE_THRESHOLD);
-          scale = (MODE == SCALE_RATE) ? group_all<2>(small) : group_all<W>(small);
-          if (scale)
-          {
-            p0 *= PLLHIP_SCALE_FACTOR;
-            p1 *= PLLHIP_SCALE_FACTOR;
-          }
-        }
-        scaled[j] = __ballot(scale); // (wave-uniform: which groups of this sub-step were scaled)
-        // The NUMBER of stores per op is fixed (a store under a branch forces a full drain
-        // of the memory queue): the compiler can then wait for the look-ahead loads by count
-        // and leave this op's stores in flight.
-        st16<NT>(out_tile + g, p0, p1);
-        if (pslot >= 0) clv[(pslot * J + j) * 64 + lane] = make_double2(p0, p1);
+        st16g<NT>(out, j * 1024u + lane16, p0[j], p1[j]);
+        if (has_slot) *reinterpret_cast<double2 *>(lds_p + j * 1024u) = make_double2(p0[j], p1[j]);
       }
-      // The tile's counts, once per op: entry t (a site, or a (site, rate) with per-rate
-      // scalers) is handled by lane t -- inherited counts from the operands' slots, plus
-      // one if the sub-step that held the entry scaled its group -- and all of them leave in ONE
-      // store (64 contiguous bytes per tile with per-site counts).  (Round 1 did this per
-      // sub-step with all 64 lanes: two LDS reads, an LDS write and a 32-byte store each.  Measured:
-      // the same speed either way.  A list without scale buffers runs 10-14 % faster than one
-      // with them -- 500 k sites x 64 taxa 712 against 832 us -- but no single piece explains it:
-      // counts stored to a sink instead 820, not stored at all 806, no scaling test 816.)
+      // The tile's counts, once per op: inherited counts plus one if the sub-step that held the
+      // entry scaled its group; all of them leave in ONE store (64 contiguous bytes per tile
+      // with per-site counts).  (An op without a scale buffer stores to the sink.)
       if (MODE != SCALE_NONE)
       {
-        constexpr unsigned int GW = (MODE == SCALE_RATE) ? 2u : W; // lanes that share a count
-        constexpr unsigned int EPS = 64u / GW, E = J * EPS;        // entries per sub-step / per tile
-        static_assert(CW == EPS, "one count word per entry of a sub-step");
-        const unsigned int t = lane < E ? lane : 0u;
         unsigned long long mine = scaled[0];
 #pragma unroll
         for (unsigned int j = 1; j < J; ++j) mine = (t / EPS == j) ? scaled[j] : mine;
         const unsigned int bit = (unsigned int)(mine >> ((t % EPS) * GW)) & 1u;
-        // (tip operands and tip-tip ops inherit nothing; tip-tip never scales and clears its counts)
-        unsigned int lc = cnt[(lsc_slot >= 0 ? lsc_slot : 0) * (J * CW) + t];
-        unsigned int rc = cnt[(rsc_slot >= 0 ? rsc_slot : 0) * (J * CW) + t];
-        if (lsc_slot < 0 || have_pairs || kind != 0) lc = 0u;
-        if (rsc_slot < 0 || kind == 2) rc = 0u;
-        const unsigned int count = lc + rc + ((scaling && kind != 2) ? bit : 0u);
-        if (pslot >= 0 && lane < E) cnt[pslot * (J * CW) + t] = scaling ? count : 0u;
-        unsigned int * dst = (scaling && lane < E) ? cnt_tile + lane : reinterpret_cast<unsigned int *>(sink + 64) + lane;
+        // (tip operands inherit nothing)
+        if (!(fl & PLLHIP_FUSED_LCNT)) lc = 0u;
+        if (!(fl & PLLHIP_FUSED_RCNT)) rc = 0u;
+        const unsigned int count = scaling ? lc + rc + bit : 0u;
+        if (has_slot && lane < E) *reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + rec_pcnt(r0) + t * 4u) = count;
+        const unsigned long long cdst = scaling ? rec_pscaler(r0) + cnt_off : (unsigned long long)(uintptr_t)sink_cnt; // (uniform)
+        unsigned int PLL_GLOBAL * dst = lane < E ? (unsigned int PLL_GLOBAL *)(cdst + lane * 4u)
+                                                 : (unsigned int PLL_GLOBAL *)((unsigned long long)(uintptr_t)sink_cnt + lane * 4u);
         *dst = count;
       }
       // the next op's matrix rows replace this op's in the same registers: the block was
       // requested an op ago, the LDS round trip overlaps the next op's scalar phase
-      stage_rows(fa, pl, pr);
-      cur.take(fa);
-      fa.take(fb);
-      r0 = r1;
-      r1 = r2;
-      a2 = a3;
+      asm volatile("" ::"v"(fu.pm.x), "v"(fu.pm.y));
+      stage_rows(fu, (fl >> PLLHIP_FUSED_STAGE_SHIFT) & 3u, pl, pr);
+    };
+    for (unsigned int i = 0;;)
+    {
+      step(ra, rb, fa, fb, pta, ptb, i);
+      if (++i == nops) break;
+      step(rb, ra, fb, fa, ptb, pta, i);
+      if (++i == nops) break;
     }
     if (++round < static_rounds)
     {
@@ -943,7 +955,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
                                       : (count >= 32 ? 7u : 2u);
 #define LAUNCH_FUSED(MODEV, NTV)                                                                                  \
   k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(                 \
-      d_plan, bases, count, sites, nslots, c->d_zero, (double2 *)c->d_sink, tile_counter, backwards, dynamic_rounds)
+      d_plan, bases, count, sites, nslots, (double2 *)c->d_sink, tile_counter, backwards, dynamic_rounds)
 #define LAUNCH_FUSED_MODE(NTV)                         \
   do {                                                  \
     if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV);       \
@@ -958,88 +970,127 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   return 0;
 }
 
-// what the indices of the plan records are relative to
-static FusedBases fused_bases(const pllhip_ctx * c)
-{
-  FusedBases b;
-  b.clv = c->clv_arena;
-  b.scaler = c->scaler_arena;
-  b.tips = c->tipchars;
-  b.pmat = c->pmatrix;
-  b.pairtab = c->d_pairtab;
-  b.site_stride = c->sh.sites + PLLHIP_TAIL_SITES;
-  b.tip_stride = (unsigned int)c->tip_stride;
-  return b;
-}
-
+// Encode the plan for the device (FusedRec in partials_fused.hpp): two header records that
+// stand for ops -2 and -1, one record per op, one of padding (the last op's look-ahead load), the
+// reload sources, the pair-table jobs.  Returns 1 if the list is not one the kernel takes.
 int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots)
 {
   const unsigned int count = (unsigned int)plan.size();
-  // pair tables of the tip-tip and tip-inner ops (k_dna_pair_tables), carved from one device buffer
-  const int level = c->fused_pairs; // env PLLHIP_FUSED_PAIRS: 0 off, 1 tip-tip only, 2 (default) tip-inner too
-  const int min_kind = level == 0 ? 3 : (level == 1 ? 2 : 1);
-  const size_t per = (size_t)256 * c->sh.rate_cats * 4;
-  size_t ntab = 0;
-  for (const FusedOp & f : plan) ntab += (f.kind >= min_kind);
-  if (ntab > PLLHIP_FUSED_MAX_INDEX) return 1;
-  if (ntab && c->pairtab_elems < ntab * per)
+  const unsigned int R = c->sh.rate_cats;
+  if (count > PLLHIP_FUSED_MAX_OPS) return 1;
+  // pair tables of the ops with a tip (k_dna_pair_tables), carved from one device buffer behind a
+  // table of zeros
+  const size_t per = (size_t)256 * R * 4; // doubles per table
+  size_t ntab = 1;
+  for (const FusedOp & f : plan) ntab += (f.kind >= 1);
+  if (ntab * per * sizeof(double) > 0xffffffffull ||
+      (size_t)c->sh.prob_matrices * c->pmat_elems * sizeof(double) > 0xffffffffull)
+    return 1;
+  if (c->pairtab_elems < ntab * per)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_pairtab) HIP_TRY(hipFree(c->d_pairtab));
     c->d_pairtab = nullptr;
     HIP_TRY(hipMalloc((void **)&c->d_pairtab, ntab * per * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->d_pairtab, 0, per * sizeof(double), c->stream));
     c->pairtab_elems = ntab * per;
     ++c->layout_epoch;
   }
-  // the records: indices relative to the arenas (a list whose indices do not fit 16 bits
-  // runs per level), then three copies of the last op (what the kernel's look-ahead
-  // requests beyond the end), then the sources of the reloads
-  const unsigned int first_clv = c->sh.pattern_tip ? c->sh.tips : 0;
-  if (c->clv.size() - first_clv > PLLHIP_FUSED_MAX_INDEX || c->sh.scale_buffers > PLLHIP_FUSED_MAX_INDEX ||
-      c->sh.tips > PLLHIP_FUSED_MAX_INDEX || c->sh.prob_matrices > PLLHIP_FUSED_MAX_INDEX)
-    return 1;
+  // the row of zeros an op without a tip reads its "characters" from
+  if (!c->fused_zero_row)
+  {
+    const size_t bytes = (size_t)c->sh.sites + PLLHIP_TAIL_SITES + 256;
+    HIP_TRY(hipMalloc((void **)&c->fused_zero_row, bytes));
+    HIP_TRY(hipMemsetAsync(c->fused_zero_row, 0, bytes, c->stream));
+  }
+  const unsigned int J = PLLHIP_FUSED_J;
+  const unsigned int sps = 64 / (2 * R);
+  const unsigned int cw = c->sh.rate_scalers ? 32 : (sps < 4 ? 4 : sps);
+  const unsigned int slot_bytes = J * 1024u, count_bytes = J * cw * 4u;
+  if ((size_t)nslots * slot_bytes > 0xffffu) return 1;
+
   std::vector<FusedRec> recs(count + 3);
   std::vector<FusedSrc> srcs;
+  std::vector<FusedPairJob> jobs;
+  std::vector<unsigned int> table_of(count, 0); // byte offset of each op's pair table (0: zeros)
   int mode = SCALE_NONE;
-  size_t tab = 0;
   for (unsigned int pos = 0; pos < count; ++pos)
   {
     const FusedOp & f = plan[pos];
-    FusedRec & r = recs[pos];
-    memset(&r, 0, sizeof(r));
-    r.parent = (unsigned short)((f.parent - c->clv_arena) / c->clv_stride);
-    r.pscaler = f.pscaler ? (unsigned short)((f.pscaler - c->scaler_arena) / c->scaler_stride) : PLLHIP_FUSED_NONE;
-    r.ltip = f.ltip ? (unsigned short)((f.ltip - c->tipchars) / c->tip_stride) : PLLHIP_FUSED_NONE;
-    r.rtip = f.rtip ? (unsigned short)((f.rtip - c->tipchars) / c->tip_stride) : PLLHIP_FUSED_NONE;
-    r.lmat = (unsigned short)((f.lmat - c->pmatrix) / c->pmat_elems);
-    r.rmat = (unsigned short)((f.rmat - c->pmatrix) / c->pmat_elems);
-    r.pair = f.kind >= min_kind ? (unsigned short)(tab++) : PLLHIP_FUSED_NONE;
-    r.src = PLLHIP_FUSED_NONE;
-    if (f.dma_flags)
+    if (f.kind >= 1)
     {
-      if (srcs.size() >= PLLHIP_FUSED_MAX_INDEX) return 1;
-      r.src = (unsigned short)srcs.size();
-      srcs.push_back(FusedSrc{f.left_hbm, f.right_hbm, f.lsc_hbm, f.rsc_hbm});
+      const size_t index = jobs.size() + 1;
+      table_of[pos] = (unsigned int)(index * per * sizeof(double));
+      jobs.push_back(FusedPairJob{f.lmat, f.rmat, c->d_pairtab + index * per, f.kind == 2 ? 1ull : 0ull});
     }
-    r.lslot = (signed char)f.lslot;
-    r.rslot = (signed char)f.rslot;
-    r.pslot = (signed char)f.pslot;
-    r.kind = (signed char)f.kind;
-    r.lsc_slot = (signed char)f.lsc_slot;
-    r.rsc_slot = (signed char)f.rsc_slot;
-    r.dma_flags = (unsigned char)f.dma_flags;
-    r.list_pos = (unsigned int)f.list_pos;
     // every op with a parent scaler scales the partition's way
     if (f.pscaler) mode = c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE;
   }
-  for (unsigned int t = 0; t < 3; ++t)
+  // what record `r` says about the ops ahead of position `pos` (pos may be -2, -1: the headers)
+  auto look_ahead = [&](FusedRec & r, long pos) -> int {
+    r.req_ltip = r.req_rtip = (unsigned long long)(uintptr_t)c->fused_zero_row;
+    r.req_lmat = r.req_rmat = 0;
+    if (pos + 2 < (long)count)
+    {
+      const FusedOp & f = plan[pos + 2];
+      if (f.ltip) r.req_ltip = (unsigned long long)(uintptr_t)f.ltip;
+      if (f.rtip) r.req_rtip = (unsigned long long)(uintptr_t)f.rtip;
+      r.req_lmat = (unsigned int)((f.lmat - c->pmatrix) * sizeof(double));
+      r.req_rmat = (unsigned int)((f.rmat - c->pmatrix) * sizeof(double));
+    }
+    r.src = 0;
+    if (pos + 1 >= 0 && pos + 1 < (long)count)
+    {
+      const FusedOp & f = plan[pos + 1];
+      r.gather_off = table_of[pos + 1];
+      r.flags |= (f.kind == 0 ? 2u : f.kind == 1 ? 1u : 0u) << PLLHIP_FUSED_STAGE_SHIFT;
+      if (f.dma_flags)
+      {
+        if (srcs.size() >= 0xffffu) return 1;
+        r.flags |= PLLHIP_FUSED_RELOAD_NEXT;
+        r.src = (unsigned short)srcs.size();
+        FusedSrc s;
+        memset(&s, 0, sizeof(s));
+        if (f.dma_flags & 1) { s.left_hbm = f.left_hbm; s.lsc_hbm = f.lsc_hbm; }
+        if (f.dma_flags & 2) { s.right_hbm = f.right_hbm; s.rsc_hbm = f.rsc_hbm; }
+        s.where = (unsigned long long)((f.lslot > 0 ? f.lslot : 0) * slot_bytes) |
+                  (unsigned long long)((f.rslot > 0 ? f.rslot : 0) * slot_bytes) << 16 |
+                  (unsigned long long)((f.lslot > 0 ? f.lslot : 0) * count_bytes) << 32 |
+                  (unsigned long long)((f.rslot > 0 ? f.rslot : 0) * count_bytes) << 48;
+        srcs.push_back(s);
+      }
+    }
+    return 0;
+  };
+  memset(recs.data(), 0, recs.size() * sizeof(FusedRec));
+  if (look_ahead(recs[0], -2) || look_ahead(recs[1], -1)) return 1;
+  for (unsigned int pos = 0; pos < count; ++pos)
   {
-    recs[count + t] = recs[count - 1];
-    recs[count + t].dma_flags = 0;
-    recs[count + t].src = PLLHIP_FUSED_NONE;
+    const FusedOp & f = plan[pos];
+    FusedRec & r = recs[pos + 2];
+    r.flags = (unsigned int)f.kind & PLLHIP_FUSED_KIND_MASK;
+    if (f.pslot >= 0) r.flags |= PLLHIP_FUSED_HAS_PSLOT;
+    if (f.pscaler) r.flags |= PLLHIP_FUSED_SCALING;
+    if (f.kind == 0 && f.lsc_slot >= 0) r.flags |= PLLHIP_FUSED_LCNT;
+    if (f.kind != 2 && f.rsc_slot >= 0) r.flags |= PLLHIP_FUSED_RCNT;
+    r.parent = (unsigned long long)(uintptr_t)f.parent;
+    r.pscaler = (unsigned long long)(uintptr_t)f.pscaler;
+    r.lslot_b = (unsigned short)((f.lslot > 0 ? f.lslot : 0) * slot_bytes);
+    r.rslot_b = (unsigned short)((f.rslot > 0 ? f.rslot : 0) * slot_bytes);
+    r.pslot_b = (unsigned short)((f.pslot > 0 ? f.pslot : 0) * slot_bytes);
+    r.lcnt_b = (unsigned short)((f.lsc_slot > 0 ? f.lsc_slot : 0) * count_bytes);
+    r.rcnt_b = (unsigned short)((f.rsc_slot > 0 ? f.rsc_slot : 0) * count_bytes);
+    r.pcnt_b = (unsigned short)((f.pslot > 0 ? f.pslot : 0) * count_bytes);
+    r.list_pos = (unsigned short)f.list_pos;
+    if (look_ahead(r, (long)pos)) return 1;
   }
+  recs[count + 2] = recs[count + 1]; // (loaded by the last op, never used)
+  recs[count + 2].flags &= ~PLLHIP_FUSED_RELOAD_NEXT;
+
   const size_t rec_bytes = recs.size() * sizeof(FusedRec);
-  const size_t bytes = rec_bytes + (srcs.size() + 1) * sizeof(FusedSrc);
+  const size_t src_bytes = (srcs.size() + 1) * sizeof(FusedSrc);
+  const size_t job_bytes = (jobs.size() + 1) * sizeof(FusedPairJob);
+  const size_t bytes = rec_bytes + src_bytes + job_bytes;
   if (c->plan_cap < bytes)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1061,15 +1112,18 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   const int b = c->plan_next;
   c->plan_next ^= 1;
   if (c->plan_pending[b]) HIP_TRY(hipEventSynchronize(c->plan_done[b]));
-  memcpy(c->h_plan[b], recs.data(), rec_bytes);
-  if (!srcs.empty()) memcpy(static_cast<char *>(c->h_plan[b]) + rec_bytes, srcs.data(), srcs.size() * sizeof(FusedSrc));
+  char * stage = static_cast<char *>(c->h_plan[b]);
+  memcpy(stage, recs.data(), rec_bytes);
+  if (!srcs.empty()) memcpy(stage + rec_bytes, srcs.data(), srcs.size() * sizeof(FusedSrc));
+  if (!jobs.empty()) memcpy(stage + rec_bytes + src_bytes, jobs.data(), jobs.size() * sizeof(FusedPairJob));
   HIP_TRY(hipMemcpyAsync(c->d_plan, c->h_plan[b], bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 80 * sizeof(double2))); // 1280 B per wave
   if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, sizeof(unsigned int)));
   // what a repeated call with the same op list needs (pllhip_relaunch_fused)
-  c->fused_last_entries = (unsigned int)recs.size();
+  c->fused_last_jobs_offset = rec_bytes + src_bytes;
+  c->fused_last_jobs = (unsigned int)jobs.size();
   c->fused_last_count = count;
   c->fused_last_nslots = nslots;
   c->fused_last_mode = mode;
@@ -1078,22 +1132,26 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
 }
 
 // The device copy of the plan is still that of the previous call (same op list: the plan
-// holds buffer indices, not values -- P-matrices, tip characters and CLVs are read when the
+// holds buffer addresses, not values -- P-matrices, tip characters and CLVs are read when the
 // kernels run): tip tables and the list kernel again, no planning, no upload.
 int pllhip_relaunch_fused(pllhip_ctx * c)
 {
-  const unsigned int entries = c->fused_last_entries, count = c->fused_last_count, nslots = c->fused_last_nslots;
+  const unsigned int count = c->fused_last_count, nslots = c->fused_last_nslots, njobs = c->fused_last_jobs;
   const int mode = c->fused_last_mode;
   HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
   const FusedRec * d_plan = (const FusedRec *)c->d_plan;
-  const FusedBases bases = fused_bases(c);
-  switch (c->sh.rate_cats)
+  const FusedPairJob * d_jobs = (const FusedPairJob *)(static_cast<const char *>(c->d_plan) + c->fused_last_jobs_offset);
+  const FusedBases bases = {c->pmatrix, c->d_pairtab};
+  if (njobs)
   {
-    case 1: k_dna_pair_tables<1><<<entries, 256, 0, c->stream>>>(d_plan, entries, bases); break;
-    case 2: k_dna_pair_tables<2><<<entries, 256, 0, c->stream>>>(d_plan, entries, bases); break;
-    default: k_dna_pair_tables<4><<<entries, 256, 0, c->stream>>>(d_plan, entries, bases); break;
+    switch (c->sh.rate_cats)
+    {
+      case 1: k_dna_pair_tables<1><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
+      case 2: k_dna_pair_tables<2><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
+      default: k_dna_pair_tables<4><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
+    }
+    HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipGetLastError());
   switch (c->sh.rate_cats)
   {
     case 1: return launch_fused_rc<1>(c, d_plan, bases, count, nslots, mode);

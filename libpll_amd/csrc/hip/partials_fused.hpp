@@ -32,53 +32,66 @@ struct FusedOp
   const double * pair_tab;         // tip operands: [256 code pairs][rate][state] table, else nullptr
 };
 
-// The plan as the kernel reads it, through the scalar data cache: 32 bytes per op, indices
-// instead of pointers; the kernel rebuilds the addresses from FusedBases with scalar
-// arithmetic.  Every wave walks the whole plan once per tile, each at its own position, so the
-// plan should stay in the 16 KB scalar cache that neighbouring compute units share: the
-// 128-byte entries of round 1 did that for 62 ops (7.9 KB) but not for the 126 / 198 ops of
-// the 128- / 200-taxon lists (16 / 25 KB; now 4 / 6 KB).  Measured effect on this kernel:
-// none beyond noise (the look-ahead already hid the misses; what slows the long lists down is
-// the size of their CLVs, see launch_fused_rc) -- kept because it halves the plan upload, frees
-// SGPRs (114-125 VGPRs, no spills into them) and bounds the scalar-cache footprint for any list.
+// The plan as the kernel reads it, through the scalar data cache: ONE 64-byte record per op (one
+// scalar load, one cache line), holding everything the wave does WHILE that op runs, ready
+// to use -- absolute addresses and LDS byte offsets, no indices to multiply out:
+//   - what it requests for the op two ahead (tip rows, P-matrix offsets),
+//   - the pair table it gathers from for the op one ahead, what that op reloads and which of
+//     its matrices must be staged,
+//   - the op itself: parent, scale buffer, LDS places of operands, parent and counts.
+// Round 2 first had 32-byte records of 16-bit indices, decoded by the kernel; the counters say
+// a wave-op then cost 124 scalar + 124 vector instructions of which 30 were arithmetic, and that
+// the wave, not HBM, was the limit (tools/pmc_instmix.sh, tools/fused_timing.sh) -- so the
+// host now does the decoding once per list.  The records hold addresses: they are rebuilt when an
+// arena moves (layout_epoch).
 struct FusedRec
 {
-  // words 0, 1: what the look-ahead loads of an op need (read three ops ahead of it)
-  unsigned short ltip, rtip;       // tip index, 0xffff: none
-  unsigned short lmat, rmat;       // P-matrix index
-  unsigned int list_pos, pad1;
-  // words 4..7: what the op itself needs (read two ops ahead: the op before it looks at
-  // pair, dma_flags and the slots to gather from the pair table and to reload)
-  unsigned short parent, pscaler;  // CLV / scale-buffer index (pscaler 0xffff: no scaling)
-  unsigned short pair, src;        // pair-table number / FusedSrc number, 0xffff: none
-  signed char lslot, rslot, pslot, kind;
-  signed char lsc_slot, rsc_slot;
-  unsigned char dma_flags, pad0;
+  unsigned long long req_ltip, req_rtip; // tip rows of op + 2 (a row of zeros when it has none)
+  unsigned int req_lmat, req_rmat;       // byte offsets of its P-matrices in the matrix arena
+  unsigned int gather_off;               // byte offset of the pair table of op + 1 (0: the table of zeros)
+  unsigned int flags;                    // PLLHIP_FUSED_* below
+  unsigned long long parent;             // CLV the op writes
+  unsigned long long pscaler;            // its scale buffer (0: none)
+  unsigned short lslot_b, rslot_b;       // LDS byte offsets (within the wave's slots) of the operands,
+  unsigned short pslot_b, src;           //   of the parent; FusedSrc number of what op + 1 reloads
+  unsigned short lcnt_b, rcnt_b;         // LDS byte offsets (within the wave's counts) the inherited
+  unsigned short pcnt_b, list_pos;       //   counts are read from / the parent's are kept at
 };
-static_assert(sizeof(FusedRec) == 32, "eight words per op");
-#define PLLHIP_FUSED_NONE 0xffffu
-#define PLLHIP_FUSED_MAX_INDEX 0xfffeu /* lists with larger buffer indices run per level */
+static_assert(sizeof(FusedRec) == 64, "sixteen words per op");
+#define PLLHIP_FUSED_KIND_MASK 3u      /* 0 inner-inner, 1 tip-inner, 2 tip-tip */
+#define PLLHIP_FUSED_HAS_PSLOT 4u      /* the parent is kept in a slot */
+#define PLLHIP_FUSED_SCALING 8u        /* the op has a scale buffer */
+#define PLLHIP_FUSED_LCNT 16u          /* counts are inherited from the left / right operand's slot */
+#define PLLHIP_FUSED_RCNT 32u
+#define PLLHIP_FUSED_STAGE_SHIFT 6     /* two bits: matrices op + 1 needs (2 both, 1 right only, 0 none) */
+#define PLLHIP_FUSED_RELOAD_NEXT 256u  /* op + 1 reloads operands: FusedSrc number `src` */
+#define PLLHIP_FUSED_MAX_OPS 60000u    /* longer lists run per level */
 
-// sources of the operands an op reloads (few ops have any: kept out of the records)
+// sources and LDS destinations of the operands an op reloads (few ops have any: kept out of the records)
 struct FusedSrc
 {
   const double * left_hbm;
   const double * right_hbm;
   const unsigned int * lsc_hbm;
   const unsigned int * rsc_hbm;
+  unsigned long long where; // lslot_b | rslot_b << 16 | lcnt_b << 32 | rcnt_b << 48
+  unsigned long long pad;
 };
 
-// what the indices of a FusedRec are relative to (kernel argument; the FusedSrc entries follow
-// the records in the plan buffer)
+// one pair table to build (k_dna_pair_tables)
+struct FusedPairJob
+{
+  const double * lmat;
+  const double * rmat;
+  double * tab;
+  unsigned long long tip_tip;
+};
+
+// what the offsets of a FusedRec are relative to (kernel argument)
 struct FusedBases
 {
-  double * clv;                    // CLV of arena position i at clv + i * site_stride * (states * rate_cats)
-  unsigned int * scaler;           // scale buffer i at scaler + i * site_stride (* rate_cats with per-rate scalers)
-  const unsigned char * tips;      // tip i at tips + i * tip_stride
   const double * pmat;
-  double * pairtab;
-  unsigned int site_stride;        // sites + slack of every per-site buffer
-  unsigned int tip_stride;         // bytes
+  const double * pairtab;
 };
 
 // (The planner is host logic and needs no device: what it must know of the partition is here.)

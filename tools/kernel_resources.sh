@@ -6,5 +6,5 @@ f=$1; filt=${2:-.}
   -c "$f" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 | \
   grep -E "Function Name|SGPRs:|VGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* *//; s/ \[-Rpass.*//' | \
   paste - - - - - - | grep -E "$filt" | while IFS=$'\t' read -r n s v sc o l; do
-    echo "$(echo "$n" | sed 's/Function Name: //' | /opt/rocm/lib/llvm/bin/llvm-cxxfilt | cut -c1-90) | $s | $v | $sc | $o"
+    echo "$(echo "$n" | sed 's/Function Name: //' | c++filt | cut -c1-90) | $s | $v | $sc | $o"
   done
