@@ -380,23 +380,28 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     sink_stores();
     stage_rows(fb, (rec_flags(h1) >> PLLHIP_FUSED_STAGE_SHIFT) & 3u, pl, pr);
 
+#ifdef PLLHIP_FUSED_TIMING
+    // (tool build, tools/fused_timing.sh: where a wave's cycles go, printed by a few waves)
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+#define PLLHIP_TICK(n) { const unsigned long long t_now = __builtin_readcyclecounter(); seg[n] += t_now - t_last; t_last = t_now; }
+    unsigned long long t_last = __builtin_readcyclecounter();
+#else
+#define PLLHIP_TICK(n)
+#endif
     // One op.  r0: its record, r1: where the next one is loaded to; fu: the fetch of op i+1,
     // ff: where that of op i+2 goes; pu: its pair-table entries, pf: where those of op i+1 go.
     // The caller alternates the two of each, so that nothing loaded is ever copied (a copy
     // would have to wait for the load).
     auto step = [&](const Rec & r0, Rec & r1, const FusedFetch<J> & fu, FusedFetch<J> & ff, const double2 (&pu)[J],
                     double2 (&pf)[J], unsigned int i) __attribute__((always_inline)) {
+      // A wave is the limit of this kernel, not HBM: with twelve waves per CU nothing hides
+      // what a wave waits for itself (counters: ~2300 cycles per op of which ~500 issue
+      // vector and ~270 scalar instructions).  So the order below overlaps the wave's own
+      // latencies: operands are read from LDS FIRST and the look-ahead requests are
+      // computed and issued while they arrive; the next op's matrix rows go through LDS right
+      // after the arithmetic and arrive during the stores and the counts.
       r1 = rec_load(plan, i + 3);
       const unsigned int fl = rec_flags(r0);
-      // (rare, wave-uniform: the sources of the reload are read on the spot)
-      if (fl & PLLHIP_FUSED_RELOAD_NEXT) reload(rec_src(r0));
-      request(ff, r0);
-      // Everything requested one op ago has arrived once fu's characters are used -- and with
-      // it what that iteration's reload() copied into this op's slots (issued ahead of those
-      // requests; memory operations return in order).  No slot is read above this line.
-      asm volatile("" ::"v"(fu.codes_r[J - 1]) : "memory");
-      gather(pf, fu, r0);
-
       const unsigned int kind = fl & PLLHIP_FUSED_KIND_MASK;
       const bool has_slot = fl & PLLHIP_FUSED_HAS_PSLOT;
       const bool scaling = MODE != SCALE_NONE && (fl & PLLHIP_FUSED_SCALING);
@@ -404,23 +409,43 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       char * lds_l = reinterpret_cast<char *>(clv) + rec_lslot(r0) + lane16;
       char * lds_r = reinterpret_cast<char *>(clv) + rec_rslot(r0) + lane16;
       char * lds_p = reinterpret_cast<char *>(clv) + rec_pslot(r0) + lane16;
-      // the counts: entry t of the tile (a site, or a (site, rate) with per-rate scalers) is
-      // lane t's; what the operands bring along is read here, ahead of the arithmetic
       constexpr unsigned int GW = (MODE == SCALE_RATE) ? 2u : W; // lanes that share a count
       constexpr unsigned int EPS = 64u / GW, E = J * EPS;        // entries per sub-step / per tile
       static_assert(MODE == SCALE_NONE || CW == EPS, "one count word per entry of a sub-step");
       const unsigned int t = lane < E ? lane : 0u;
+
+      // Everything requested one op ago has arrived once fu's characters are used -- and with
+      // it what that iteration's reload() copied into this op's slots (issued ahead of those
+      // requests; memory operations return in order).  No slot is read above this line.
+      asm volatile("" ::"v"(fu.codes_r[J - 1]) : "memory");
+      // operands and the counts they bring along (entry t of the tile -- a site, or a (site, rate)
+      // with per-rate scalers -- is lane t's); every kind reads both operands (a tip-tip op reads
+      // slot 0 for nothing: no branch)
+      double2 lo[J], ro[J];
+#pragma unroll
+      for (unsigned int j = 0; j < J; ++j)
+      {
+        lo[j] = *reinterpret_cast<const double2 *>(lds_l + j * 1024u);
+        ro[j] = *reinterpret_cast<const double2 *>(lds_r + j * 1024u);
+      }
       unsigned int lc = 0u, rc = 0u;
-      if (MODE != SCALE_NONE && kind != 2)
+      if (MODE != SCALE_NONE)
       {
         lc = *reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + rec_lcnt(r0) + t * 4u);
         rc = *reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + rec_rcnt(r0) + t * 4u);
       }
+      asm volatile("" ::: "memory"); // (the reads above are issued before what follows)
+      // (rare, wave-uniform: the sources of the reload are read on the spot)
+      if (fl & PLLHIP_FUSED_RELOAD_NEXT) reload(rec_src(r0));
+      request(ff, r0);
+      gather(pf, fu, r0);
+      PLLHIP_TICK(0)
       // (every load is consumed on every path, needed or not: the registers of a load that
       // nobody waited for stay "pending" for the compiler, and it drains the queue -- this op's
       // predecessor's stores included -- when it next reuses them)
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j) asm volatile("" ::"v"(pu[j].x), "v"(pu[j].y));
+      PLLHIP_TICK(1)
       unsigned long long scaled[J];
       double p0[J], p1[J];
       if (kind == 2)
@@ -440,8 +465,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
 #pragma unroll
         for (unsigned int j = 0; j < J; ++j)
         {
-          const double2 ro = *reinterpret_cast<const double2 *>(lds_r + j * 1024u);
-          const double2 rp = make_double2(dpp_pair_swap(ro.x), dpp_pair_swap(ro.y));
+          const double2 rp = make_double2(dpp_pair_swap(ro[j].x), dpp_pair_swap(ro[j].y));
           double x0, x1;
           if (kind == 1)
           {
@@ -451,12 +475,11 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
           }
           else
           {
-            const double2 lo = *reinterpret_cast<const double2 *>(lds_l + j * 1024u);
-            const double2 lp = make_double2(dpp_pair_swap(lo.x), dpp_pair_swap(lo.y));
-            x0 = pl.dot(0, lo, lp);
-            x1 = pl.dot(1, lo, lp);
+            const double2 lp = make_double2(dpp_pair_swap(lo[j].x), dpp_pair_swap(lo[j].y));
+            x0 = pl.dot(0, lo[j], lp);
+            x1 = pl.dot(1, lo[j], lp);
           }
-          double q0 = x0 * pr.dot(0, ro, rp), q1 = x1 * pr.dot(1, ro, rp);
+          double q0 = x0 * pr.dot(0, ro[j], rp), q1 = x1 * pr.dot(1, ro[j], rp);
           // scaling rule of core_partials_avx.c:486-527: all entries of the site (of the rate,
           // with per-rate scalers) below the threshold; x * 1.0 is x
           scaled[j] = 0;
@@ -473,6 +496,12 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
           p1[j] = q1;
         }
       }
+      // (the arithmetic is done with pl, pr: their registers take the next op's rows, whose
+      // LDS round trip runs while the stores below are issued)
+      asm volatile("" ::"v"(p0[J - 1]), "v"(p1[J - 1]), "v"(fu.pm.x), "v"(fu.pm.y) : "memory");
+      PLLHIP_TICK(2)
+      stage_rows(fu, (fl >> PLLHIP_FUSED_STAGE_SHIFT) & 3u, pl, pr);
+      PLLHIP_TICK(5)
       // The stores are common to all kinds and under no branch: the compiler counts the memory
       // operations of the path with the FEWEST of them to decide how many may stay in flight at a
       // wait, and a path without this op's stores would make the next op wait for the stores of
@@ -483,6 +512,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
         st16g<NT>(out, j * 1024u + lane16, p0[j], p1[j]);
         if (has_slot) *reinterpret_cast<double2 *>(lds_p + j * 1024u) = make_double2(p0[j], p1[j]);
       }
+      PLLHIP_TICK(3)
       // The tile's counts, once per op: inherited counts plus one if the sub-step that held the
       // entry scaled its group; all of them leave in ONE store (64 contiguous bytes per tile
       // with per-site counts).  (An op without a scale buffer stores to the sink.)
@@ -502,10 +532,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
                                                  : (unsigned int PLL_GLOBAL *)((unsigned long long)(uintptr_t)sink_cnt + lane * 4u);
         *dst = count;
       }
-      // the next op's matrix rows replace this op's in the same registers: the block was
-      // requested an op ago, the LDS round trip overlaps the next op's scalar phase
-      asm volatile("" ::"v"(fu.pm.x), "v"(fu.pm.y));
-      stage_rows(fu, (fl >> PLLHIP_FUSED_STAGE_SHIFT) & 3u, pl, pr);
+      PLLHIP_TICK(4)
     };
     for (unsigned int i = 0;;)
     {
@@ -514,6 +541,11 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       step(rb, ra, fb, fa, ptb, pta, i);
       if (++i == nops) break;
     }
+#ifdef PLLHIP_FUSED_TIMING
+    if (lane == 0 && round == 3 && (wave == 0 || wave == 1001 || wave == 2002 || wave == 3003))
+      printf("wave %u ops %u: top (records, requests, characters arrive, gather) %llu pair entries arrive %llu arithmetic %llu stores %llu counts %llu stage %llu cycles per op\n",
+             (unsigned int)wave, nops, seg[0] / nops, seg[1] / nops, seg[2] / nops, seg[3] / nops, seg[4] / nops, seg[5] / nops);
+#endif
     if (++round < static_rounds)
     {
       tile += nwaves;
