@@ -607,7 +607,9 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     std::vector<FusedOp> fplan;
     unsigned int reloads = 0;
     const FusedGeom geom = {c->clv.size(), c->sh.scale_buffers, c->sh.tips, c->sh.pattern_tip != 0};
-    unsigned int nslots = pllhip_fused_slots(c, 3);
+    // (PLLHIP_FUSED_WGS=2: the 8-wave, 7-slot configuration at once -- tests run both)
+    const unsigned int first_wgs = getenv("PLLHIP_FUSED_WGS") && atoi(getenv("PLLHIP_FUSED_WGS")) == 2 ? 2u : 3u;
+    unsigned int nslots = pllhip_fused_slots(c, first_wgs);
     int rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, fplan, &reloads);
     if (rc > 0)
     {

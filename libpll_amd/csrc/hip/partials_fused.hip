@@ -400,7 +400,6 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       // latencies: operands are read from LDS FIRST and the look-ahead requests are
       // computed and issued while they arrive; the next op's matrix rows go through LDS right
       // after the arithmetic and arrive during the stores and the counts.
-      r1 = rec_load(plan, i + 3);
       const unsigned int fl = rec_flags(r0);
       const unsigned int kind = fl & PLLHIP_FUSED_KIND_MASK;
       const bool has_slot = fl & PLLHIP_FUSED_HAS_PSLOT;
@@ -408,7 +407,6 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       const unsigned long long out = rec_parent(r0) + clv_off; // (uniform)
       char * lds_l = reinterpret_cast<char *>(clv) + rec_lslot(r0) + lane16;
       char * lds_r = reinterpret_cast<char *>(clv) + rec_rslot(r0) + lane16;
-      char * lds_p = reinterpret_cast<char *>(clv) + rec_pslot(r0) + lane16;
       constexpr unsigned int GW = (MODE == SCALE_RATE) ? 2u : W; // lanes that share a count
       constexpr unsigned int EPS = 64u / GW, E = J * EPS;        // entries per sub-step / per tile
       static_assert(MODE == SCALE_NONE || CW == EPS, "one count word per entry of a sub-step");
@@ -500,17 +498,29 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       // LDS round trip runs while the stores below are issued)
       asm volatile("" ::"v"(p0[J - 1]), "v"(p1[J - 1]), "v"(fu.pm.x), "v"(fu.pm.y) : "memory");
       PLLHIP_TICK(2)
+      // the next record: a scalar load, and scalar loads return out of order -- while one is in
+      // flight every wait for an LDS read or an earlier record field becomes a wait for
+      // everything.  Here nothing of that kind is waited for until the next op begins.
+      r1 = rec_load(plan, i + 3);
       stage_rows(fu, (fl >> PLLHIP_FUSED_STAGE_SHIFT) & 3u, pl, pr);
       PLLHIP_TICK(5)
       // The stores are common to all kinds and under no branch: the compiler counts the memory
       // operations of the path with the FEWEST of them to decide how many may stay in flight at a
       // wait, and a path without this op's stores would make the next op wait for the stores of
       // the op before.
+      // (That goes for the parent's LDS slot too: `if (has_slot)` around its write made the
+      // compiler duplicate the store into both arms, and the structurizer's path through
+      // neither arm had one store less.  The write is masked through EXEC instead -- all lanes or
+      // none -- in assembly, so that there is no branch to reason about.)
+      const unsigned long long slot_mask = has_slot ? ~0ull : 0ull;
+      const unsigned int lds_p_b = clv_lds_b + rec_pslot(r0) + lane16;
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
         st16g<NT>(out, j * 1024u + lane16, p0[j], p1[j]);
-        if (has_slot) *reinterpret_cast<double2 *>(lds_p + j * 1024u) = make_double2(p0[j], p1[j]);
+        const pll_v2d v = {p0[j], p1[j]};
+        asm volatile("s_mov_b64 exec, %0\n\tds_write_b128 %1, %2 offset:%3\n\ts_mov_b64 exec, -1"
+                     :: "s"(slot_mask), "v"(lds_p_b), "v"(v), "n"(j * 1024u) : "memory");
       }
       PLLHIP_TICK(3)
       // The tile's counts, once per op: inherited counts plus one if the sub-step that held the
