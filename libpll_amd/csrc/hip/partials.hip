@@ -569,12 +569,12 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
 
   // 4 states, more than one op, no site repeats: the whole list in one site-blocked
   // launch (partials_fused.hip)
-  // (a wave takes the list op by op, ~1.5 us each: with fewer tiles than about one per wave
-  // of the 8-waves-per-CU configuration -- 33 k sites at 4 rate categories -- the per-level
-  // launches are faster; measured for 64 taxa: 20 k sites 108 vs 90 us, 35 k 125 vs 136,
-  // 50 k 165 vs 174, 100 k 244 vs 333; 200-taxon random tree: equal from 20 k to 50 k)
+  // (a wave takes the list op by op, ~1 us each: with fewer tiles than about one per SIMD --
+  // 16 k sites at 4 rate categories -- the per-level launches are faster; measured for 64 taxa,
+  // whole list vs per level: 8 k sites 74 vs 63 us, 16 k 78 vs 79, 24 k 84 vs 93, 33 k 100 vs 121,
+  // 50 k 118 vs 164.  A property of the device -- tiles against SIMDs -- not a tuned number.)
   const size_t fused_tile_sites = (size_t)PLLHIP_FUSED_J * 64 / (2 * c->sh.rate_cats);
-  const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 8 || c->force_fused;
+  const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 4 || c->force_fused;
   // (8 rate categories: a tile is 8 sites only and the variant spills -- 5.6 against 10.2 G/s
   // for the per-level launches at 500 k sites; not used)
   // (short lists -- the path to the root after one branch changed -- have little to keep on

@@ -97,7 +97,7 @@ def aa_mode(request, monkeypatch):
 @pytest.fixture(params=["fused", "fused-8-waves", "levels"])
 def dna_path(request, monkeypatch):
     """4-state CLV updates: the whole op list in one site-blocked launch (the default from
-    ~33 k sites on; forced here, PLLHIP_FUSED=2) or one launch per dependency level
+    ~16 k sites on; forced here, PLLHIP_FUSED=2) or one launch per dependency level
     (PLLHIP_FUSED=0); the whole-list kernel in its 12-wave (six LDS slots per wave) and 8-wave
     (seven slots) configurations.  All must give the same bits."""
     monkeypatch.setenv("PLLHIP_FUSED", "0" if request.param == "levels" else "2")

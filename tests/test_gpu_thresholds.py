@@ -31,7 +31,7 @@ def same(a, b):
     return a[0] == b[0] and bits_equal(a[1], b[1]) and bits_equal(a[2], b[2]) and (a[3] == b[3]).all()
 
 
-@pytest.mark.parametrize("sites", [32767, 32768, 32769, 40000])
+@pytest.mark.parametrize("sites", [16383, 16384, 16385, 32768, 40000])
 def test_whole_list_kernel_threshold(gpu, monkeypatch, sites):
     plan = W.balanced_tree(16, seed=3)
     seqs = W.random_alignment(16, sites, 4, seed=sites)
