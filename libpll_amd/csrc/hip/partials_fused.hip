@@ -986,13 +986,20 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
   unsigned int * tile_counter = getenv("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
-  // Address translations: the translation caches reach about 8 GB (4096 pages of 2 MB).  A
-  // partition whose CLVs exceed that is swept from end to end by every launch, so a launch
-  // that starts where the previous one started finds none of its pages cached (measured:
-  // every shape runs at 0.59-0.64 of the HBM peak up to 8 GB of CLVs and at 0.46-0.50 beyond,
-  // whatever the tree -- profiles/r2_footprint.txt).  Every other launch therefore walks the
-  // tiles backwards: it starts in the pages the previous launch touched last.
-  const unsigned int backwards = (c->fused_pingpong && c->clv_arena_bytes > ((size_t)6 << 30)) ? (c->fused_launches++ & 1u) : 0u;
+  // Address translations: the translation caches reach 8 GB (4096 pages of 2 MB).  A
+  // partition whose CLVs and scale buffers exceed that is swept from end to end by every launch,
+  // so a launch that starts where the previous one started finds none of its pages cached
+  // (measured: every shape runs at 0.59-0.64 of the HBM peak up to 8 GB and at 0.46-0.50
+  // beyond, whatever the tree -- profiles/r2_footprint.txt).  Every other launch of such a
+  // partition therefore walks the tiles backwards: it starts in the pages the previous launch
+  // touched last (128 taxa x 1 M sites, 16 GB: 0.51-0.56 -> 0.62; x 600 k sites, 9.7 GB: 0.55 ->
+  // 0.67).  Below the reach it must not: the 62-op list (8.2 GB) runs at 0.65 with alternating
+  // directions against 0.69-0.71 always forwards.  (Also measured: always forwards, each launch
+  // beginning where the previous one's still-cached pages begin and wrapping around -- the same
+  // reuse on paper; 16 GB equal, 9.7 GB 0.60 against 0.66, 133 GB 0.54 against 0.55.)
+  const size_t footprint = c->clv_arena_bytes + (size_t)c->sh.scale_buffers * c->scaler_stride * sizeof(unsigned int);
+  const bool beyond_reach = footprint > (size_t)4096 * ((size_t)2 << 20);
+  const unsigned int backwards = (beyond_reach && c->fused_pingpong == 1) || c->fused_pingpong == 2 ? (c->fused_launches++ & 1u) : 0u;
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                       : (count >= 32 ? 7u : 2u);
 #define LAUNCH_FUSED(MODEV, NTV)                                                                                  \
