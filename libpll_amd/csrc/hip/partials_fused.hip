@@ -30,11 +30,13 @@
 //   look-ahead  vector-memory loads and stores retire in ONE in-order queue, so a load
 //             issued after a store cannot be consumed before that store is acknowledged.
 //             Everything an op needs from memory (its two P-matrices, tip characters) is
-//             therefore requested at the top of the op two before it, ahead of that op's stores,
-//             with unconditional loads (absent operands read a zero block); the op itself
-//             contains LDS traffic and stores only.
-//   plan      32 bytes per op (indices, not pointers), read through the scalar data cache, a whole
-//             record three ops ahead: see FusedRec in partials_fused.hpp for why it is that small.
+//             therefore requested during the op two before it, ahead of that op's stores,
+//             with unconditional loads (an op without a tip reads a row of zeros), and its
+//             pair-table entries are gathered during the op before it.
+//   plan      one 64-byte record per op, read through the scalar data cache one op ahead: absolute
+//             addresses and LDS offsets, decoded by the host (FusedRec in partials_fused.hpp)
+//   limit     a wave's own serial path, not HBM: twelve waves per CU is all the slots allow, so
+//             the order within an op overlaps the wave's latencies with its own work (see step())
 //
 // The arithmetic per site is that of k_dna_partials, statement for statement (dot4 /
 // masksum4 order, scaling rule of core_partials_avx.c:486-527), so results are
@@ -42,7 +44,8 @@
 // tests run through this kernel.
 //
 // Roofline: HBM writes.  132 B per site-update (128 B CLV + 4 B scaler count) + 1 B per
-// tip character read; operands that are reloaded add 128 B each.
+// tip character read; operands that are reloaded add 128 B each.  Round 2: 0.65-0.72 of the
+// 8 TB/s peak on the 62-op list of the headline configuration.
 #include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
