@@ -339,7 +339,14 @@ def main():
             typical = sorted(ramp_steps)[len(ramp_steps) // 2]
             if stall_at is None and ramp_steps[-1] > 0.010 and ramp_steps[-1] > 8 * typical:
                 stall_at, stall_ms = now - t_ramp, ramp_steps[-1] * 1e3
-        if now - t_ramp >= 3.0 or (stall_at is not None and now - t_ramp >= max(0.3, stall_at + 0.2)):
+        done = now - t_ramp >= 3.0 or (stall_at is not None and now - t_ramp >= max(0.3, stall_at + 0.2))
+        if use_comm:
+            # (a step is a collective -- the all-reduce of lnL -- so all ranks must run the same number
+            # of them: they stop together, when the last one is past its stall)
+            flag = torch.tensor([1.0 if done else 0.0], dtype=torch.float32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(flag.item() >= 1.0)
+        if done:
             break
     ramp = {"seconds": round(time.perf_counter() - t_ramp, 2), "steps": len(ramp_steps),
             "stall_ms": round(stall_ms, 1), "stall_at_s": None if stall_at is None else round(stall_at, 2)}
