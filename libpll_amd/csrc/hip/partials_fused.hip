@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       constexpr unsigned int GW = (MODE == SCALE_RATE) ? 2u : W; // lanes that share a count
       constexpr unsigned int EPS = 64u / GW, E = J * EPS;        // entries per sub-step / per tile
       static_assert(MODE == SCALE_NONE || CW == EPS, "one count word per entry of a sub-step");
-      const unsigned int t = lane < E ? lane : 0u;
+      const unsigned int t = lane % E; // (lanes beyond the entries repeat them: same values to the same addresses)
 
       // Everything requested one op ago has arrived once fu's characters are used -- and with
       // it what that iteration's reload() copied into this op's slots (issued ahead of those
@@ -541,9 +541,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
         const unsigned int count = scaling ? lc + rc + bit : 0u;
         if (has_slot && lane < E) *reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + rec_pcnt(r0) + t * 4u) = count;
         const unsigned long long cdst = scaling ? rec_pscaler(r0) + cnt_off : (unsigned long long)(uintptr_t)sink_cnt; // (uniform)
-        unsigned int PLL_GLOBAL * dst = lane < E ? (unsigned int PLL_GLOBAL *)(cdst + lane * 4u)
-                                                 : (unsigned int PLL_GLOBAL *)((unsigned long long)(uintptr_t)sink_cnt + lane * 4u);
-        *dst = count;
+        *(unsigned int PLL_GLOBAL *)(cdst + t * 4u) = count;
       }
       PLLHIP_TICK(4)
     };
