@@ -144,7 +144,8 @@ struct pllhip_ctx
   struct pllhip_rep_work * rep_work = nullptr; // sort / scan buffers of repeats.hip
   size_t clv_arena_bytes = 0;            // all CLVs of the partition
   bool no_batch = false;                 // PLLHIP_NO_BATCH=1: one launch per op (measurements)
-  int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements)
+  int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements); 2: and the whole-list
+                                         // kernel's count stores, which follow the partition's size otherwise
   // 20 states: 1 = bit-exact vector kernels only (env PLLHIP_AA_EXACT=1);
   // 0 = matrix-core kernels where they exist (last-bit differences, see
   // partials_aa_mfma.hip)

@@ -154,13 +154,15 @@ __device__ __forceinline__ unsigned int group_and(unsigned int x)
 }
 
 // WPS: waves per SIMD the register budget is sized for (3 = 168 VGPRs: twelve waves per CU)
-template <int RC, int J, int MODE, bool NT, int WPS>
+// NTP: cache policy -- 0 plain stores, 1 the tiles non-temporal, 2 the counts as well
+template <int RC, int J, int MODE, int NTP, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan, FusedBases bases,
                                                         unsigned int nops, unsigned int sites, unsigned int nslots,
                                                         double2 * sink, unsigned int * next_tile, unsigned int backwards,
                                                         unsigned int dynamic_rounds)
 {
   static_assert(RC == 1 || RC == 2 || RC == 4, "lane groups of 2, 4 or 8");
+  constexpr bool NT = NTP != 0;
   constexpr unsigned int W = 2 * RC, SPS = 64 / W, TS = J * SPS;
   constexpr unsigned int MG = RC * 8;                   // 16-byte granules of one P-matrix
   extern __shared__ double2 lds_fused[];
@@ -541,7 +543,13 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
         const unsigned int count = scaling ? lc + rc + bit : 0u;
         if (has_slot && lane < E) *reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + rec_pcnt(r0) + t * 4u) = count;
         const unsigned long long cdst = scaling ? rec_pscaler(r0) + cnt_off : (unsigned long long)(uintptr_t)sink_cnt; // (uniform)
-        *(unsigned int PLL_GLOBAL *)(cdst + t * 4u) = count;
+        // (non-temporal like the tiles once the partition exceeds the translation caches' reach: as
+        // plain stores -- half a cache line each, which L2 completes by reading the other half --
+        // the counts cost the 126-op list of a 16 GB partition a fifth of its speed, 0.56 against
+        // 0.685 of the HBM peak on one box, the 198-op list 0.53 against 0.62; below the reach plain
+        // stores are the better ones by 0-3 %: neighbouring tiles' halves meet in L2)
+        if (NTP == 2) __builtin_nontemporal_store(count, (unsigned int PLL_GLOBAL *)(cdst + t * 4u));
+        else *(unsigned int PLL_GLOBAL *)(cdst + t * 4u) = count;
       }
       PLLHIP_TICK(4)
     };
@@ -1012,8 +1020,9 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
     else if (mode == SCALE_SITE) LAUNCH_FUSED(1, NTV);  \
     else LAUNCH_FUSED(2, NTV);                          \
   } while (0)
-  if (nt) LAUNCH_FUSED_MODE(true);
-  else LAUNCH_FUSED_MODE(false);
+  if (!nt) LAUNCH_FUSED_MODE(0);
+  else if (!beyond_reach && c->nt_override != 2) LAUNCH_FUSED_MODE(1);
+  else LAUNCH_FUSED_MODE(2);
 #undef LAUNCH_FUSED_MODE
 #undef LAUNCH_FUSED
   HIP_TRY(hipGetLastError());

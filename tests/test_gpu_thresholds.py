@@ -75,13 +75,13 @@ def test_cache_policy_threshold(gpu, monkeypatch, states, sites):
     plan = W.balanced_tree(16, seed=7)
     seqs = W.random_alignment(16, sites, states, seed=sites)
     res = {}
-    for mode in ("default", "0", "1"):
+    for mode in ("default", "0", "1", "2"):  # (2: the whole-list kernel's counts non-temporal too)
         if mode == "default":
             monkeypatch.delenv("PLLHIP_NT", raising=False)
         else:
             monkeypatch.setenv("PLLHIP_NT", mode)
         res[mode] = observe(gpu, plan, seqs, states)
-    assert same(res["default"], res["0"]) and same(res["default"], res["1"])
+    assert same(res["default"], res["0"]) and same(res["default"], res["1"]) and same(res["default"], res["2"])
 
 
 @pytest.mark.parametrize("taxa,sites", [(64, 20_000), (64, 26_000), (64, 40_000), (16, 90_000), (16, 120_000)])
