@@ -94,7 +94,6 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e); // 0 / 1; 2: the whole-list kernel's counts too
   if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
-  if (const char * e = getenv("PLLHIP_FUSED_PINGPONG")) c->fused_pingpong = atoi(e);
   if (const char * e = getenv("PLLHIP_FUSED"))
   {
     c->no_fused = atoi(e) == 0;

@@ -94,9 +94,6 @@ struct pllhip_ctx
   size_t plan_cap = 0;
   int plan_next = 0;
   bool no_fused = false; // env PLLHIP_FUSED=0: one launch per dependency level instead
-  int fused_pingpong = 1; // env PLLHIP_FUSED_PINGPONG: 0 every whole-list launch walks the tiles forwards, 1 every other one
-                          // backwards when the partition exceeds the translation caches' reach, 2 whatever its size
-  unsigned int fused_launches = 0;
   bool force_fused = false; // env PLLHIP_FUSED=2: also for partitions too small for it to pay (tests)
 
   // reductions: per-block partial sums, then a fixed-order final pass

@@ -158,8 +158,7 @@ __device__ __forceinline__ unsigned int group_and(unsigned int x)
 template <int RC, int J, int MODE, int NTP, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan, FusedBases bases,
                                                         unsigned int nops, unsigned int sites, unsigned int nslots,
-                                                        double2 * sink, unsigned int * next_tile, unsigned int backwards,
-                                                        unsigned int dynamic_rounds)
+                                                        double2 * sink, unsigned int * next_tile, unsigned int dynamic_rounds)
 {
   static_assert(RC == 1 || RC == 2 || RC == 4, "lane groups of 2, 4 or 8");
   constexpr bool NT = NTP != 0;
@@ -225,8 +224,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   size_t round = 0;
   for (size_t tile = wave; tile < tiles;)
   {
-    // (every other launch of a context walks the tiles from the far end: see pllhip_relaunch_fused)
-    const size_t site0 = (backwards ? tiles - 1 - tile : tile) * TS;
+    const size_t site0 = tile * TS;
     const size_t clv_off = site0 * (W * 16u);                             // bytes into a CLV
     const size_t cnt_off = site0 * ((MODE == SCALE_RATE) ? RC * 4u : 4u); // bytes into a scale buffer
 
@@ -995,25 +993,22 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
   unsigned int * tile_counter = getenv("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
-  // Address translations: the translation caches reach 8 GB (4096 pages of 2 MB).  A
-  // partition whose CLVs and scale buffers exceed that is swept from end to end by every launch,
-  // so a launch that starts where the previous one started finds none of its pages cached
-  // (measured: every shape runs at 0.59-0.64 of the HBM peak up to 8 GB and at 0.46-0.50
-  // beyond, whatever the tree -- profiles/r2_footprint.txt).  Every other launch of such a
-  // partition therefore walks the tiles backwards: it starts in the pages the previous launch
-  // touched last (128 taxa x 1 M sites, 16 GB: 0.51-0.56 -> 0.62; x 600 k sites, 9.7 GB: 0.55 ->
-  // 0.67).  Below the reach it must not: the 62-op list (8.2 GB) runs at 0.65 with alternating
-  // directions against 0.69-0.71 always forwards.  (Also measured: always forwards, each launch
-  // beginning where the previous one's still-cached pages begin and wrapping around -- the same
-  // reuse on paper; 16 GB equal, 9.7 GB 0.60 against 0.66, 133 GB 0.54 against 0.55.)
+  // Partitions beyond 8 GB (CLVs + scale buffers): the counts are stored non-temporally like the
+  // tiles (see the kernel).  8 GB is what the address-translation caches reach (4096 pages of
+  // 2 MB): every shape ran at 0.59-0.64 of the HBM peak up to there and at 0.46-0.50 beyond
+  // (profiles/r2_footprint.txt), which looked like the price of the page walks themselves -- and
+  // walking every other launch backwards, so that it began in the pages still cached, did recover
+  // part of it (0.51 -> 0.56-0.62).  The walks only hurt READS, though, and the one read this
+  // write stream had was L2 completing the half cache lines of the count stores.  With those
+  // non-temporal the same lists run at 0.69-0.75 and the direction makes no difference any more
+  // (0.747 / 0.746, 0.688 / 0.689): the alternating walk is gone.
   const size_t footprint = c->clv_arena_bytes + (size_t)c->sh.scale_buffers * c->scaler_stride * sizeof(unsigned int);
   const bool beyond_reach = footprint > (size_t)4096 * ((size_t)2 << 20);
-  const unsigned int backwards = (beyond_reach && c->fused_pingpong == 1) || c->fused_pingpong == 2 ? (c->fused_launches++ & 1u) : 0u;
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                       : (count >= 32 ? 7u : 2u);
 #define LAUNCH_FUSED(MODEV, NTV)                                                                                  \
   k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(                 \
-      d_plan, bases, count, sites, nslots, (double2 *)c->d_sink, tile_counter, backwards, dynamic_rounds)
+      d_plan, bases, count, sites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds)
 #define LAUNCH_FUSED_MODE(NTV)                         \
   do {                                                  \
     if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV);       \

@@ -100,26 +100,3 @@ def test_lookup_op_threshold(gpu, monkeypatch, taxa, sites):
             monkeypatch.setenv("PLLHIP_AA_CHERRY", mode)
         res[mode] = observe(gpu, plan, seqs, 20)
     assert same(res["default"], res["0"]) and same(res["default"], res["2"])
-
-
-def test_backward_launches_give_the_same_bits(gpu, monkeypatch):
-    """Partitions beyond the reach of the translation caches walk the tiles backwards in every other
-    whole-list launch; forced here on a small one (PLLHIP_FUSED_PINGPONG=2)."""
-    plan = W.balanced_tree(32, seed=5)
-    seqs = W.random_alignment(32, 20011, 4, seed=5)
-    monkeypatch.setenv("PLLHIP_FUSED", "2")
-    res = {}
-    for mode in ("0", "2"):
-        monkeypatch.setenv("PLLHIP_FUSED_PINGPONG", mode)
-        p = W.setup_partition(gpu, plan, seqs, 4, 4, ATTRIB_PATTERN_TIP)
-        outs = []
-        for _ in range(3):  # forwards, backwards, forwards
-            p.update_partials(plan.ops)
-            lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
-            top = plan.ops[-1]
-            outs.append((lnl, ps, p.get_clv(int(top["parent_clv_index"])), p.get_scaler(int(top["parent_scaler_index"]))))
-        p.destroy()
-        res[mode] = outs
-    for a, b in zip(res["0"], res["2"]):
-        assert same(a, b)
-    assert same(res["2"][0], res["2"][1])
