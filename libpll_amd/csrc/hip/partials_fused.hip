@@ -1004,8 +1004,13 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   // (0.747 / 0.746, 0.688 / 0.689): the alternating walk is gone.
   const size_t footprint = c->clv_arena_bytes + (size_t)c->sh.scale_buffers * c->scaler_stride * sizeof(unsigned int);
   const bool beyond_reach = footprint > (size_t)4096 * ((size_t)2 << 20);
+  // a third of a wave's rounds of tiles come from the counter (see the kernel: the XCDs' unequal
+  // write rates): seven of the ~21 rounds of 1 M sites (the measured optimum there), and in proportion
+  // for longer alignments (8 M sites x 128 taxa: 7 rounds 0.565, 30 0.584, 54 0.583 of the HBM peak;
+  // 2 M sites: 7 rounds 0.652, 14 0.672); short lists two, see the kernel
+  const size_t rounds = tiles / (grid * 4);
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
-                                      : (count >= 32 ? 7u : 2u);
+                                      : (count >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
 #define LAUNCH_FUSED(MODEV, NTV)                                                                                  \
   k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(                 \
       d_plan, bases, count, sites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds)
