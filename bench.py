@@ -436,8 +436,8 @@ def main():
                     "avg_op_us": round(launch_s * 1e6 / len(plan.ops), 2),
                     "note": "one launch runs the whole op list site-blocked and keeps children on chip: its "
                             "algorithmic bytes are one write per CLV entry and count + one read per tip character "
-                            "(algorithmic_bytes_per_site; traffic = PMC agrees), a write stream whose ceiling on "
-                            "this part is 5.6 TB/s.  Counting SURVEY 8(d)'s per-op bytes (396/265/134 B per "
+                            "(algorithmic_bytes_per_site; traffic = PMC agrees), a write stream (a bare one with the "
+                            "same addresses reaches 5.5-6.9 TB/s on this part).  Counting SURVEY 8(d)'s per-op bytes (396/265/134 B per "
                             "site-update, per_op_algorithm_bytes_per_site) the same launch is worth "
                             "per_op_algorithm_equivalent_GBs"}
     elif len(ii_ops):
