@@ -125,6 +125,90 @@ __device__ __forceinline__ void tile_matvec(const double * ptab_child, const dou
   for (int k = 0; k < RC; ++k) rate_matvec(ptab_child + (size_t)k * S20 * S20, b[k], lane, x[k]);
 }
 
+// ---- the same contraction in the REFERENCE's summation order (core_partials_avx2.c:632-750):
+// four accumulators strided by j mod 4, each a chain of fused multiply-adds over j = m, m+4,
+// ..., m+16 starting from zero, added as (a0+a1)+(a2+a3).  v_mfma_f64_4x4x4 adds its four
+// products to the accumulator as a chain of FMAs in k order, one rounding each (measured on
+// 1.28 M random outputs incl. denormals: tools/mfma_order_probe.hip,
+// profiles/r3_mfma_f64_accumulation_order.txt), so a contraction chunk made of the states
+// {m, m+4, m+8, m+12} IS the first four steps of chain m; the fifth (state 16+m) is a second
+// MFMA whose A operand is zero except in k-slot m (adding +0 products changes nothing).  Eight
+// MFMAs per four output rows instead of five, three VALU adds per output -- and the result is
+// the reference's bit for bit.
+//
+// B operands for that: lane (s, q) holds states 4q..4q+3 (b[k][0..3]) and 16+q (b[k][4])
+template <int RC>
+__device__ __forceinline__ void read_b_chain(const char * region, unsigned int s, unsigned int q,
+                                             double (&b)[RC][5])
+{
+  constexpr int ROW_B = aa_geom<RC>::ROW_G * 16;
+#pragma unroll
+  for (int k = 0; k < RC; ++k)
+  {
+    const char * p = region + s * ROW_B + k * 160;
+    const double2 v0 = *reinterpret_cast<const double2 *>(p + q * 32);
+    const double2 v1 = *reinterpret_cast<const double2 *>(p + q * 32 + 16);
+    b[k][0] = v0.x; b[k][1] = v0.y; b[k][2] = v1.x; b[k][3] = v1.y;
+    b[k][4] = *reinterpret_cast<const double *>(p + 128 + q * 8);
+  }
+}
+
+// o[g] = state 4g+q of  P . (column s of the tile), reference order.  The matrix is in LDS in its
+// natural layout; a14 / a5 are the lane's two addresses into matrix 0 -- row (lane & 3), columns
+// 4q..4q+3 / column 16+q -- made ONCE per kernel (chain_lane_bases): every operand is then one
+// of the two registers plus a constant.  (Spelled with indices the compiler kept a base
+// register per (rate, row group, child) alive across the tile loop and spilled 100 of them.)
+__device__ __forceinline__ void chain_lane_bases(const double * ptab, unsigned int lane, const char *& a14,
+                                                 const char *& a5)
+{
+  const unsigned int i = lane & 3u, q = lane >> 4;
+  a14 = reinterpret_cast<const char *>(ptab) + i * 160u + q * 32u;
+  a5 = reinterpret_cast<const char *>(ptab) + i * 160u + 128u + q * 8u;
+}
+
+template <int MAT_BYTE_OFFSET>
+__device__ __forceinline__ void rate_matvec_chain(const char * a14, const char * a5, const double (&bk)[5],
+                                                  unsigned int lane, double (&o)[5])
+{
+  const unsigned int q = lane >> 4;
+#pragma unroll
+  for (int g = 0; g < 5; ++g)
+  {
+    const double2 a01 = *reinterpret_cast<const double2 *>(a14 + MAT_BYTE_OFFSET + g * 640);
+    const double2 a23 = *reinterpret_cast<const double2 *>(a14 + MAT_BYTE_OFFSET + g * 640 + 16);
+    const double a4 = *reinterpret_cast<const double *>(a5 + MAT_BYTE_OFFSET + g * 640);
+    const double a1[4] = {a01.x, a01.y, a23.x, a23.y};
+    double acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[m], bk[m], 0.0, 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      acc[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(q == (unsigned int)m ? a4 : 0.0, bk[4], acc[m], 0, 0, 0);
+    o[g] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // The sum is wanted HERE: without a use at this point the optimiser sinks the three adds to
+    // where o[g] is consumed -- after the other child's products -- and keeps all four
+    // accumulators of every output alive until then (the kernel then spills 300-500 bytes per
+    // lane and takes 3.3 x the time).  And nothing moves across: left alone the scheduler
+    // fetches the A operands of several row groups ahead.
+    asm volatile("" : "+v"(o[g]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// x[k][g] for all rates of one child whose matrices start CHILD_BYTE_OFFSET bytes behind matrix 0
+template <int RC, int CHILD_BYTE_OFFSET>
+__device__ __forceinline__ void tile_matvec_chain(const char * a14, const char * a5, const double (&b)[RC][5],
+                                                  unsigned int lane, double (&x)[RC][5])
+{
+  if (RC >= 1) rate_matvec_chain<CHILD_BYTE_OFFSET>(a14, a5, b[0], lane, x[0]);
+  if (RC >= 2) rate_matvec_chain<CHILD_BYTE_OFFSET + 3200>(a14, a5, b[RC >= 2 ? 1 : 0], lane, x[RC >= 2 ? 1 : 0]);
+  if (RC >= 4)
+  {
+    rate_matvec_chain<CHILD_BYTE_OFFSET + 6400>(a14, a5, b[RC >= 4 ? 2 : 0], lane, x[RC >= 4 ? 2 : 0]);
+    rate_matvec_chain<CHILD_BYTE_OFFSET + 9600>(a14, a5, b[RC >= 4 ? 3 : 0], lane, x[RC >= 4 ? 3 : 0]);
+  }
+}
+
 // all 4 lanes of this lane's tile column (s, s+16, s+32, s+48) have the flag set
 __device__ __forceinline__ bool column_all(bool f, unsigned int s)
 {

@@ -87,6 +87,9 @@ struct pllhip_ctx
   unsigned char * cherry_codes = nullptr;
   unsigned int cherry_ms = 0; // maxstates the scratch was sized for
   unsigned char * cherry_zero = nullptr;     // [sites] zero characters (the absent second tip of a tip-inner lookup op)
+  double * cherry_pool_all = nullptr;        // the tables of ALL lookup ops of a list (partials_aa_fused.hip)
+  unsigned int cherry_pool_all_ops = 0;      // lookup ops it has room for
+  struct pllhip_aa_fused_cache * aa_fused = nullptr; // 20-state whole-list kernel: its kept plan
   size_t pairtab_elems = 0;
   void * h_plan[2] = {nullptr, nullptr};
   hipEvent_t plan_done[2] = {nullptr, nullptr};
@@ -313,3 +316,17 @@ bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode);
 bool pllhip_aa_cherry_pays(const pllhip_ctx * c, unsigned int lookups, unsigned int levels);
 int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
                               const PartialsArgs * kid2, unsigned int count, int mode);
+// the tables of a list's lookup ops, all at once: what each op's parent is the product of
+struct AaLookupTables
+{
+  const double * tl, * tr;                    // [pair][rate][state]
+  const unsigned char * t1, * t2, * t3, * t4; // characters: pair 1 = (t1, t2), pair 2 = (t3, t4)
+};
+int pllhip_aa_lookup_tables(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
+                            const PartialsArgs * kid2, unsigned int count, AaLookupTables * out);
+// partials_aa_fused.hip: a 20-state op list in one site-blocked launch; returns 1 if the list (or
+// the partition) is not one it takes -- the caller then launches per level
+int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count);
+// partials.hip: one op resolved into kernel arguments (kind 0 inner-inner, 1 tip-inner, 2 tip-tip)
+int pllhip_resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, int & kind, int & mode);
+void pllhip_aa_fused_free(pllhip_ctx * c);

@@ -534,6 +534,11 @@ static int resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, 
   return 0;
 }
 
+int pllhip_resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, int & kind, int & mode)
+{
+  return resolve_op(c, op, a, kind, mode);
+}
+
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_update_partials(s, ops, count)); // (enqueued on every device; nothing waits)
@@ -625,6 +630,17 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       if (rc <= 0) return rc;
     }
     // (a list shape the kernel does not take: per-level launches below)
+  }
+
+  // 20 states, 4 rate categories: the whole list in one site-blocked launch on the matrix cores
+  // (partials_aa_fused.hip); from one workgroup tile (32 sites) per workgroup slot of the device on
+  if (aa_fast && c->sh.rate_cats == 4 && !c->no_fused && count >= 2 &&
+      ((size_t)c->sh.sites / 32 >= (size_t)c->num_cus * 2 || c->force_fused))
+  {
+    pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
+    const int rc = pllhip_aa_fused_update(c, ops, count);
+    if (rc <= 0) return rc;
+    // (a list or a partition it does not take: per-level launches below)
   }
 
   // The plan of the previous per-level call is kept: an identical op list (the usual case

@@ -49,6 +49,8 @@
 #include "ctx.hpp"
 #include "numerics.hpp"
 
+#include <type_traits>
+
 #include "aa_mfma.hpp"
 
 // KIND 0: inner-inner.  KIND 1: tip-inner -- the left factor is not a mat-vec but
@@ -72,6 +74,10 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned int s = lane & 15u, q = lane >> 4;
+  // the lane's A-operand addresses: into the left matrices (inner-inner) and the right ones
+  const char * la14, * la5, * ra14, * ra5;
+  chain_lane_bases(ptab, lane, la14, la5);
+  chain_lane_bases(ptab_r, lane, ra14, ra5);
   char * region = reinterpret_cast<char *>(ptab_r + RC * 400) + wave * G::REGION_B;
   constexpr int ROW_B = G::ROW_G * 16;
 
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 
     // ---- first operand tile of this iteration has been requested earlier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    read_b_operands<RC>(region, s, q, b);
+    read_b_chain<RC>(region, s, q, b);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // what came in with it is taken out of the registers the next requests overwrite
     unsigned int csc[RC], code = code_next, srow = srow_next;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
       }
       if (GATHER) dma_tile_rows<RC, NT>(a.right, srow, toff, region);
       else dma_tile<RC, NT>(a.right, site0, toff, region);
-      tile_matvec<RC>(ptab, b, lane, xl); // overlaps the right child's DMA and the stores
+      tile_matvec_chain<RC, 0>(la14, la5, b, lane, xl); // overlaps the right child's DMA and the stores
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int k = 0; k < RC; ++k)
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
         csc[k] += ssc[k];
         asm volatile("" : "+v"(csc[k]));
       }
-      read_b_operands<RC>(region, s, q, b);
+      read_b_chain<RC>(region, s, q, b);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // ---- next tile's first operand: in flight while this tile is finished; behind it the
@@ -263,20 +269,25 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     // ---- right products, product + scaling (core_partials_avx2.c:752-800), a rate at a time
     bool small_site = true;
     bool small_rate[RC];
-#pragma unroll
-    for (int k = 0; k < RC; ++k)
-    {
+    auto right_rate = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      if (k >= RC) return;
+      constexpr int kk = k < RC ? k : 0;
       double yk[5];
-      rate_matvec(ptab_r + (size_t)k * S20 * S20, b[k], lane, yk);
-      small_rate[k] = true;
+      rate_matvec_chain<kk * 3200>(ra14, ra5, b[kk], lane, yk);
+      small_rate[kk] = true;
 #pragma unroll
       for (int g = 0; g < 5; ++g)
       {
-        x[k][g] = xl[k][g] * yk[g];
-        small_rate[k] = small_rate[k] && (x[k][g] < PLLHIP_SCALE_THRESHOLD);
+        x[kk][g] = xl[kk][g] * yk[g];
+        small_rate[kk] = small_rate[kk] && (x[kk][g] < PLLHIP_SCALE_THRESHOLD);
       }
-      small_site = small_site && small_rate[k];
-    }
+      small_site = small_site && small_rate[kk];
+    };
+    right_rate(std::integral_constant<int, 0>{});
+    right_rate(std::integral_constant<int, 1>{});
+    right_rate(std::integral_constant<int, 2>{});
+    right_rate(std::integral_constant<int, 3>{});
     if (MODE == SCALE_SITE)
     {
       const bool scale = column_all(small_site, s);
@@ -679,22 +690,23 @@ static __global__ void k_aa_tiprow_tables(CherryBatch batch, TipMats lmats,
   }
 }
 
-int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
-                              const PartialsArgs * kid2, unsigned int count, int mode)
+// scratch shared by every lookup-table build of a context: the characters of all pairs, a CLV
+// of ones, identity matrices, a row of zero characters
+static int cherry_scratch(pllhip_ctx * c, size_t rows, size_t row_elems, unsigned int chunk)
 {
   const unsigned int R = c->sh.rate_cats, ms = c->maxstates;
-  const size_t pairs = (size_t)ms * ms;
-  const size_t rows = pairs + PLLHIP_TAIL_SITES; // the kernels load whole tiles
-  const size_t row_elems = (size_t)R * 20;
-  const unsigned int chunk = PLLHIP_BATCH_MAX / 2; // two table ops per lookup op and launch
   if (c->cherry_pool && c->cherry_ms != ms)
   {
     // (the character map was replaced by one with another number of codes)
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(c->cherry_pool));
     HIP_TRY(hipFree(c->cherry_codes));
+    if (c->cherry_pool_all) HIP_TRY(hipFree(c->cherry_pool_all));
     c->cherry_pool = nullptr;
     c->cherry_codes = nullptr;
+    c->cherry_pool_all = nullptr;
+    c->cherry_pool_all_ops = 0;
+    ++c->layout_epoch;
   }
   if (!c->cherry_pool)
   {
@@ -714,83 +726,109 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
         c->cherry_codes, c->cherry_codes + rows, ones, ones + rows * row_elems, ms, (unsigned int)rows, R);
     HIP_TRY(hipGetLastError());
   }
+  return 0;
+}
+
+// The tables of n <= PLLHIP_BATCH_MAX / 2 lookup ops (ops / kid1 / kid2 [0..n)), built in `pool`
+// (n x 4 x rows x row_elems doubles); ch.op[i] describes op i for k_aa_cherry_rounds.
+static int cherry_tables(pllhip_ctx * c, double * pool, const PartialsArgs * ops, const PartialsArgs * kid1,
+                         const PartialsArgs * kid2, unsigned int n, CherryBatch & ch)
+{
+  const unsigned int R = c->sh.rate_cats, ms = c->maxstates;
+  const size_t pairs = (size_t)ms * ms;
+  const size_t rows = pairs + PLLHIP_TAIL_SITES; // the kernels load whole tiles
+  const size_t row_elems = (size_t)R * 20;
+  const unsigned int chunk = PLLHIP_BATCH_MAX / 2;
   const size_t per_op = 4 * rows * row_elems;
   double * ones = c->cherry_pool + chunk * per_op;
   double * ident = ones + rows * row_elems;
-  const bool nt = pllhip_use_nt(c);
+  PartialsBatch tt, ii;
+  unsigned int ntab = 0;
+  TipMats h_lmats;
+  memset(&h_lmats, 0, sizeof(h_lmats));
+  bool any_tip_left = false;
+  for (unsigned int i = 0; i < n; ++i)
+  {
+    const PartialsArgs & op = ops[i];
+    double * base = pool + i * per_op;
+    double * pair_clv[2] = {base, base + rows * row_elems};
+    double * table[2] = {base + 2 * rows * row_elems, base + 3 * rows * row_elems};
+    const PartialsArgs * kid[2] = {&kid1[i], &kid2[i]};
+    // tip-inner lookup op (kid 1 is a dummy): the left factor is the tip's own table
+    const bool tip_left = kid[0]->lmat == nullptr;
+    h_lmats.m[i] = tip_left ? op.lmat : nullptr;
+    for (int s = 0; s < 2; ++s)
+    {
+      if (s == 0 && tip_left) continue;
+      // the child over all character pairs, by the tip-tip kernel and the child op's matrices
+      PartialsArgs & t = tt.op[ntab];
+      memset(&t, 0, sizeof(t));
+      t.parent = pair_clv[s];
+      t.ltip = c->cherry_codes;
+      t.rtip = c->cherry_codes + rows;
+      t.lmat = kid[s]->lmat;
+      t.rmat = kid[s]->rmat;
+      t.tipmap = c->tipmap;
+      t.zero = c->d_zero;
+      t.sites = (unsigned int)pairs;
+      t.rate_cats = R;
+      t.states = 20;
+      t.maxstates = ms;
+      // P x child by the inner-inner kernel; the other factor is identity x ones = 1
+      PartialsArgs & u = ii.op[ntab++];
+      memset(&u, 0, sizeof(u));
+      u.parent = table[s];
+      u.left = pair_clv[s];
+      u.right = ones;
+      u.lmat = s == 0 ? op.lmat : op.rmat;
+      u.rmat = ident;
+      u.tipmap = c->tipmap;
+      u.zero = c->d_zero;
+      u.sites = (unsigned int)pairs;
+      u.rate_cats = R;
+      u.states = 20;
+      u.maxstates = ms;
+    }
+    CherryArgs & k = ch.op[i];
+    k.tl = table[0];
+    k.tr = table[1];
+    k.t1 = tip_left ? op.ltip : kid[0]->ltip;
+    k.t2 = tip_left ? c->cherry_zero : kid[0]->rtip;
+    k.t3 = kid[1]->ltip;
+    k.t4 = kid[1]->rtip;
+    k.parent = op.parent;
+    k.pscaler = op.pscaler;
+    k.sites = op.sites;
+    k.maxstates = ms;
+  }
+  int rc = pllhip_launch_aa_batch(c, tt, ntab, 2, SCALE_NONE);
+  if (rc) return rc;
+  rc = pllhip_launch_aa_batch(c, ii, ntab, 0, SCALE_NONE);
+  if (rc) return rc;
+  for (unsigned int i = 0; i < n; ++i) any_tip_left = any_tip_left || h_lmats.m[i];
+  if (any_tip_left)
+  {
+    k_aa_tiprow_tables<<<dim3(4, n), 256, 0, c->stream>>>(ch, h_lmats, c->tipmap, ms, R);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
+                              const PartialsArgs * kid2, unsigned int count, int mode)
+{
+  const unsigned int R = c->sh.rate_cats, ms = c->maxstates;
+  const size_t rows = (size_t)ms * ms + PLLHIP_TAIL_SITES;
+  const size_t row_elems = (size_t)R * 20;
+  const unsigned int chunk = PLLHIP_BATCH_MAX / 2; // two table ops per lookup op and launch
+  int rc = cherry_scratch(c, rows, row_elems, chunk);
+  if (rc) return rc;
   for (unsigned int first = 0; first < count; first += chunk)
   {
     const unsigned int n = (count - first < chunk) ? count - first : chunk;
-    PartialsBatch tt, ii;
     CherryBatch ch;
-    unsigned int ntab = 0;
-    TipMats h_lmats;
-    memset(&h_lmats, 0, sizeof(h_lmats));
-    bool any_tip_left = false;
-    for (unsigned int i = 0; i < n; ++i)
-    {
-      const PartialsArgs & op = ops[first + i];
-      double * base = c->cherry_pool + i * per_op;
-      double * pair_clv[2] = {base, base + rows * row_elems};
-      double * table[2] = {base + 2 * rows * row_elems, base + 3 * rows * row_elems};
-      const PartialsArgs * kid[2] = {&kid1[first + i], &kid2[first + i]};
-      // tip-inner lookup op (kid 1 is a dummy): the left factor is the tip's own table
-      const bool tip_left = kid[0]->lmat == nullptr;
-      h_lmats.m[i] = tip_left ? op.lmat : nullptr;
-      for (int s = 0; s < 2; ++s)
-      {
-        if (s == 0 && tip_left) continue;
-        // the child over all character pairs, by the tip-tip kernel and the child op's matrices
-        PartialsArgs & t = tt.op[ntab];
-        memset(&t, 0, sizeof(t));
-        t.parent = pair_clv[s];
-        t.ltip = c->cherry_codes;
-        t.rtip = c->cherry_codes + rows;
-        t.lmat = kid[s]->lmat;
-        t.rmat = kid[s]->rmat;
-        t.tipmap = c->tipmap;
-        t.zero = c->d_zero;
-        t.sites = (unsigned int)pairs;
-        t.rate_cats = R;
-        t.states = 20;
-        t.maxstates = ms;
-        // P x child by the inner-inner kernel; the other factor is identity x ones = 1
-        PartialsArgs & u = ii.op[ntab++];
-        memset(&u, 0, sizeof(u));
-        u.parent = table[s];
-        u.left = pair_clv[s];
-        u.right = ones;
-        u.lmat = s == 0 ? op.lmat : op.rmat;
-        u.rmat = ident;
-        u.tipmap = c->tipmap;
-        u.zero = c->d_zero;
-        u.sites = (unsigned int)pairs;
-        u.rate_cats = R;
-        u.states = 20;
-        u.maxstates = ms;
-      }
-      CherryArgs & k = ch.op[i];
-      k.tl = table[0];
-      k.tr = table[1];
-      k.t1 = tip_left ? op.ltip : kid[0]->ltip;
-      k.t2 = tip_left ? c->cherry_zero : kid[0]->rtip;
-      k.t3 = kid[1]->ltip;
-      k.t4 = kid[1]->rtip;
-      k.parent = op.parent;
-      k.pscaler = op.pscaler;
-      k.sites = op.sites;
-      k.maxstates = ms;
-    }
-    int rc = pllhip_launch_aa_batch(c, tt, ntab, 2, SCALE_NONE);
+    rc = cherry_tables(c, c->cherry_pool, ops + first, kid1 + first, kid2 + first, n, ch);
     if (rc) return rc;
-    rc = pllhip_launch_aa_batch(c, ii, ntab, 0, SCALE_NONE);
-    if (rc) return rc;
-    for (unsigned int i = 0; i < n; ++i) any_tip_left = any_tip_left || h_lmats.m[i];
-    if (any_tip_left)
-    {
-      k_aa_tiprow_tables<<<dim3(4, n), 256, 0, c->stream>>>(ch, h_lmats, c->tipmap, ms, R);
-      HIP_TRY(hipGetLastError());
-    }
     const size_t rounds = ((size_t)c->sh.sites + 63) / 64;
     size_t blocks = (rounds + 3) / 4;
     const size_t cap = (size_t)c->num_cus * 8;
@@ -809,7 +847,42 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
     }
 #undef CHERRY_LAUNCH
     HIP_TRY(hipGetLastError());
-    (void)nt;
+  }
+  return 0;
+}
+
+// The tables of ALL `count` lookup ops of a list at once (the whole-list kernel,
+// partials_aa_fused.hip, walks a tile of sites through every op): same builders, a pool of
+// their own that grows with the list.
+int pllhip_aa_lookup_tables(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
+                            const PartialsArgs * kid2, unsigned int count, AaLookupTables * out)
+{
+  const unsigned int R = c->sh.rate_cats, ms = c->maxstates;
+  const size_t rows = (size_t)ms * ms + PLLHIP_TAIL_SITES;
+  const size_t row_elems = (size_t)R * 20;
+  const size_t per_op = 4 * rows * row_elems;
+  const unsigned int chunk = PLLHIP_BATCH_MAX / 2;
+  int rc = cherry_scratch(c, rows, row_elems, chunk);
+  if (rc) return rc;
+  if (c->cherry_pool_all_ops < count)
+  {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->cherry_pool_all) HIP_TRY(hipFree(c->cherry_pool_all));
+    c->cherry_pool_all = nullptr;
+    c->cherry_pool_all_ops = 0;
+    const size_t n = ((size_t)count + 15) & ~(size_t)15;
+    HIP_TRY(hipMalloc((void **)&c->cherry_pool_all, n * per_op * sizeof(double)));
+    c->cherry_pool_all_ops = (unsigned int)n;
+    ++c->layout_epoch;
+  }
+  for (unsigned int first = 0; first < count; first += chunk)
+  {
+    const unsigned int n = (count - first < chunk) ? count - first : chunk;
+    CherryBatch ch;
+    rc = cherry_tables(c, c->cherry_pool_all + (size_t)first * per_op, ops + first, kid1 + first, kid2 + first, n, ch);
+    if (rc) return rc;
+    for (unsigned int i = 0; i < n; ++i)
+      out[first + i] = AaLookupTables{ch.op[i].tl, ch.op[i].tr, ch.op[i].t1, ch.op[i].t2, ch.op[i].t3, ch.op[i].t4};
   }
   return 0;
 }
