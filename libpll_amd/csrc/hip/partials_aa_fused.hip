@@ -46,6 +46,7 @@
 // about 0.6 of the time the stores need.  DESIGN.md 2.2c has the budget and the measurements.
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 #include "ctx.hpp"
@@ -144,31 +145,45 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
 
 // ---- device helpers
 typedef const unsigned int __attribute__((address_space(4))) * af_words;
-struct AfR
+// words [FIRST, FIRST + N) of record i, through the scalar cache
+template <int FIRST, int N>
+struct AfW
 {
-  unsigned int w[32];
+  unsigned int w[N];
+  __device__ __forceinline__ unsigned int operator[](int t) const { return w[t - FIRST]; }
+  __device__ __forceinline__ unsigned long long quad(int t) const
+  {
+    return (unsigned long long)w[t - FIRST] | ((unsigned long long)w[t - FIRST + 1] << 32);
+  }
 };
-__device__ __forceinline__ AfR af_load(const AaRec * plan, unsigned int i)
+template <int FIRST, int N>
+__device__ __forceinline__ AfW<FIRST, N> af_load(const AaRec * plan, unsigned int i)
 {
-  const af_words p = (af_words)(unsigned long long)(plan + i);
-  AfR r;
+  const af_words p = (af_words)(unsigned long long)(plan + i) + FIRST;
+  AfW<FIRST, N> r;
 #pragma unroll
-  for (int t = 0; t < 32; ++t) r.w[t] = p[t];
+  for (int t = 0; t < N; ++t) r.w[t] = p[t];
   return r;
 }
-__device__ __forceinline__ unsigned long long af_quad(const AfR & r, int t)
+
+// Every global access of the kernel is "wave-uniform 64-bit base (SGPRs) + 32-bit lane offset": one
+// VGPR per address instead of two, and nothing per-lane to keep (or spill) across the op loop.
+typedef char PLL_GLOBAL * af_gptr;
+__device__ __forceinline__ af_gptr af_base(unsigned long long uniform_address)
 {
-  return (unsigned long long)r.w[t] | ((unsigned long long)r.w[t + 1] << 32);
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)uniform_address);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(uniform_address >> 32));
+  return (af_gptr)(((unsigned long long)hi << 32) | lo);
 }
 
 // 64 lanes x 16 bytes from global memory straight into LDS (lane l lands at lds_b + 16 l).  Inline
 // assembly on purpose: the compiler neither counts it nor waits for it; the waits are ours.
-__device__ __forceinline__ void af_dma16(unsigned int lds_b, unsigned long long gaddr)
+__device__ __forceinline__ void af_dma16(unsigned int lds_b, unsigned long long uniform_src, unsigned int lane16)
 {
   unsigned int m0_saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                : "=&s"(m0_saved)
-               : "s"(lds_b), "v"(gaddr)
+               : "s"(lds_b), "v"(lane16), "s"(uniform_src)
                : "memory");
 }
 
@@ -177,21 +192,12 @@ struct AfSlot
   double v[AF_J][5];
   unsigned int c[AF_J];
 };
-// (element by element: a struct assignment is a memcpy, and the slots must never be memory)
-__device__ __forceinline__ void af_copy(AfSlot & d, const AfSlot & s)
-{
-#pragma unroll
-  for (int j = 0; j < AF_J; ++j)
-  {
-#pragma unroll
-    for (int t = 0; t < 5; ++t) d.v[j][t] = s.v[j][t];
-    d.c[j] = s.c[j];
-  }
-}
 
-// out[j][t] = (P . column)[state 4q + t | 16 + q], reference order; `mat`: the block in LDS
+// x[j][t] = (MUL ? x[j][t] : 1) * (P . column)[state 4q + t | 16 + q], reference order;
+// mat_lane: the block in LDS (operand order) + 8 lane
+template <bool MUL>
 __device__ __forceinline__ void af_matvec(const char * mat_lane, unsigned int q, const double (&b)[AF_J][5],
-                                          double (&out)[AF_J][5])
+                                          double (&x)[AF_J][5])
 {
 #pragma unroll
   for (int t = 0; t < 5; ++t)
@@ -215,9 +221,10 @@ __device__ __forceinline__ void af_matvec(const char * mat_lane, unsigned int q,
 #pragma unroll
     for (int j = 0; j < AF_J; ++j)
     {
-      out[j][t] = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
-      // (the sum is wanted here, see rate_matvec_chain in aa_mfma.hpp)
-      asm volatile("" : "+v"(out[j][t]));
+      const double sum = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+      x[j][t] = MUL ? x[j][t] * sum : sum;
+      // (the value is wanted here, see rate_matvec_chain in aa_mfma.hpp)
+      asm volatile("" : "+v"(x[j][t]));
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -236,15 +243,62 @@ __device__ __forceinline__ void af_read_tile(const char * stage_lane, const char
   }
 }
 
-#define AF_SLOT_DO(idx, S, ...)                           \
-  switch (idx)                                            \
-  {                                                       \
-    case 0: { AfSlot & S = s0; __VA_ARGS__; } break;      \
-    case 1: { AfSlot & S = s1; __VA_ARGS__; } break;      \
-    case 2: { AfSlot & S = s2; __VA_ARGS__; } break;      \
-    case 3: { AfSlot & S = s3; __VA_ARGS__; } break;      \
-    default: { AfSlot & S = s4; __VA_ARGS__; } break;     \
+// The five slots are sixty scalar variables that never move.  Three things it took:
+//  - a slot is read and written by INLINE ASSEMBLY that compares the (wave-uniform) slot number and
+//    branches over a dozen moves.  Written as a C++ switch the optimiser first merged the arms into
+//    one access through a pointer that depends on the slot number (the slots became 448 bytes of
+//    scratch per lane); with scalars instead of structs it kept them in registers but threaded all
+//    sixty values through every arm of every switch as phi nodes, and the register allocator answered
+//    with 1150 moves and a slot in scratch.  Behind the asm there is no control flow to see.
+//  - every asm names the PHYSICAL registers of the slot it touches (v146..v255): left to itself the
+//    allocator gave the same slot different registers in different parts of the op loop and copied
+//    all fifty pairs from one set to the other on the way (45 v_mov_b64 in a row).
+//  - no lambda may touch them: a reference capture takes their address, and they would be memory.
+#define AF_SLOT_VARS(N)                                                                                           \
+  double N##_00 = 0.0, N##_01 = 0.0, N##_02 = 0.0, N##_03 = 0.0, N##_04 = 0.0, N##_10 = 0.0, N##_11 = 0.0,        \
+         N##_12 = 0.0, N##_13 = 0.0, N##_14 = 0.0;                                                                \
+  unsigned int N##_c0 = 0u, N##_c1 = 0u;
+#define AF_MOVE6_ASM(K)                                                                                           \
+  "s_cmp_lg_u32 %12, " #K "\n\ts_cbranch_scc1 .Laf_skip_%=\n\t"                                                   \
+  "v_mov_b64 %0, %6\n\tv_mov_b64 %1, %7\n\tv_mov_b64 %2, %8\n\tv_mov_b64 %3, %9\n\t"                              \
+  "v_mov_b64 %4, %10\n\tv_mov_b32 %5, %11\n.Laf_skip_%=:"
+
+#define AF_PUT_0_0(idx, L) asm volatile(AF_MOVE6_ASM(0) : "+{v[146:147]}"(s0_00), "+{v[148:149]}"(s0_01), "+{v[150:151]}"(s0_02), "+{v[152:153]}"(s0_03), "+{v[154:155]}"(s0_04), "+{v166}"(s0_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
+#define AF_GET_0_0(idx, L) asm volatile(AF_MOVE6_ASM(0) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[146:147]}"(s0_00), "{v[148:149]}"(s0_01), "{v[150:151]}"(s0_02), "{v[152:153]}"(s0_03), "{v[154:155]}"(s0_04), "{v166}"(s0_c0), "s"(idx) : "scc");
+#define AF_PUT_0_1(idx, L) asm volatile(AF_MOVE6_ASM(0) : "+{v[156:157]}"(s0_10), "+{v[158:159]}"(s0_11), "+{v[160:161]}"(s0_12), "+{v[162:163]}"(s0_13), "+{v[164:165]}"(s0_14), "+{v167}"(s0_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
+#define AF_GET_0_1(idx, L) asm volatile(AF_MOVE6_ASM(0) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[156:157]}"(s0_10), "{v[158:159]}"(s0_11), "{v[160:161]}"(s0_12), "{v[162:163]}"(s0_13), "{v[164:165]}"(s0_14), "{v167}"(s0_c1), "s"(idx) : "scc");
+#define AF_PUT_1_0(idx, L) asm volatile(AF_MOVE6_ASM(1) : "+{v[168:169]}"(s1_00), "+{v[170:171]}"(s1_01), "+{v[172:173]}"(s1_02), "+{v[174:175]}"(s1_03), "+{v[176:177]}"(s1_04), "+{v188}"(s1_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
+#define AF_GET_1_0(idx, L) asm volatile(AF_MOVE6_ASM(1) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[168:169]}"(s1_00), "{v[170:171]}"(s1_01), "{v[172:173]}"(s1_02), "{v[174:175]}"(s1_03), "{v[176:177]}"(s1_04), "{v188}"(s1_c0), "s"(idx) : "scc");
+#define AF_PUT_1_1(idx, L) asm volatile(AF_MOVE6_ASM(1) : "+{v[178:179]}"(s1_10), "+{v[180:181]}"(s1_11), "+{v[182:183]}"(s1_12), "+{v[184:185]}"(s1_13), "+{v[186:187]}"(s1_14), "+{v189}"(s1_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
+#define AF_GET_1_1(idx, L) asm volatile(AF_MOVE6_ASM(1) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[178:179]}"(s1_10), "{v[180:181]}"(s1_11), "{v[182:183]}"(s1_12), "{v[184:185]}"(s1_13), "{v[186:187]}"(s1_14), "{v189}"(s1_c1), "s"(idx) : "scc");
+#define AF_PUT_2_0(idx, L) asm volatile(AF_MOVE6_ASM(2) : "+{v[190:191]}"(s2_00), "+{v[192:193]}"(s2_01), "+{v[194:195]}"(s2_02), "+{v[196:197]}"(s2_03), "+{v[198:199]}"(s2_04), "+{v210}"(s2_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
+#define AF_GET_2_0(idx, L) asm volatile(AF_MOVE6_ASM(2) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[190:191]}"(s2_00), "{v[192:193]}"(s2_01), "{v[194:195]}"(s2_02), "{v[196:197]}"(s2_03), "{v[198:199]}"(s2_04), "{v210}"(s2_c0), "s"(idx) : "scc");
+#define AF_PUT_2_1(idx, L) asm volatile(AF_MOVE6_ASM(2) : "+{v[200:201]}"(s2_10), "+{v[202:203]}"(s2_11), "+{v[204:205]}"(s2_12), "+{v[206:207]}"(s2_13), "+{v[208:209]}"(s2_14), "+{v211}"(s2_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
+#define AF_GET_2_1(idx, L) asm volatile(AF_MOVE6_ASM(2) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[200:201]}"(s2_10), "{v[202:203]}"(s2_11), "{v[204:205]}"(s2_12), "{v[206:207]}"(s2_13), "{v[208:209]}"(s2_14), "{v211}"(s2_c1), "s"(idx) : "scc");
+#define AF_PUT_3_0(idx, L) asm volatile(AF_MOVE6_ASM(3) : "+{v[212:213]}"(s3_00), "+{v[214:215]}"(s3_01), "+{v[216:217]}"(s3_02), "+{v[218:219]}"(s3_03), "+{v[220:221]}"(s3_04), "+{v232}"(s3_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
+#define AF_GET_3_0(idx, L) asm volatile(AF_MOVE6_ASM(3) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[212:213]}"(s3_00), "{v[214:215]}"(s3_01), "{v[216:217]}"(s3_02), "{v[218:219]}"(s3_03), "{v[220:221]}"(s3_04), "{v232}"(s3_c0), "s"(idx) : "scc");
+#define AF_PUT_3_1(idx, L) asm volatile(AF_MOVE6_ASM(3) : "+{v[222:223]}"(s3_10), "+{v[224:225]}"(s3_11), "+{v[226:227]}"(s3_12), "+{v[228:229]}"(s3_13), "+{v[230:231]}"(s3_14), "+{v233}"(s3_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
+#define AF_GET_3_1(idx, L) asm volatile(AF_MOVE6_ASM(3) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[222:223]}"(s3_10), "{v[224:225]}"(s3_11), "{v[226:227]}"(s3_12), "{v[228:229]}"(s3_13), "{v[230:231]}"(s3_14), "{v233}"(s3_c1), "s"(idx) : "scc");
+#define AF_PUT_4_0(idx, L) asm volatile(AF_MOVE6_ASM(4) : "+{v[234:235]}"(s4_00), "+{v[236:237]}"(s4_01), "+{v[238:239]}"(s4_02), "+{v[240:241]}"(s4_03), "+{v[242:243]}"(s4_04), "+{v254}"(s4_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
+#define AF_GET_4_0(idx, L) asm volatile(AF_MOVE6_ASM(4) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[234:235]}"(s4_00), "{v[236:237]}"(s4_01), "{v[238:239]}"(s4_02), "{v[240:241]}"(s4_03), "{v[242:243]}"(s4_04), "{v254}"(s4_c0), "s"(idx) : "scc");
+#define AF_PUT_4_1(idx, L) asm volatile(AF_MOVE6_ASM(4) : "+{v[244:245]}"(s4_10), "+{v[246:247]}"(s4_11), "+{v[248:249]}"(s4_12), "+{v[250:251]}"(s4_13), "+{v[252:253]}"(s4_14), "+{v255}"(s4_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
+#define AF_GET_4_1(idx, L) asm volatile(AF_MOVE6_ASM(4) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[244:245]}"(s4_10), "{v[246:247]}"(s4_11), "{v[248:249]}"(s4_12), "{v[250:251]}"(s4_13), "{v[252:253]}"(s4_14), "{v255}"(s4_c1), "s"(idx) : "scc");
+#define AF_SLOT_READ(idx_expr, L)                                                                                 \
+  {                                                                                                               \
+    const unsigned int idx_ = __builtin_amdgcn_readfirstlane(idx_expr);                                           \
+    L.v[0][0] = s0_00; L.v[0][1] = s0_01; L.v[0][2] = s0_02; L.v[0][3] = s0_03; L.v[0][4] = s0_04;                \
+    L.v[1][0] = s0_10; L.v[1][1] = s0_11; L.v[1][2] = s0_12; L.v[1][3] = s0_13; L.v[1][4] = s0_14;                \
+    L.c[0] = s0_c0; L.c[1] = s0_c1;                                                                               \
+    AF_GET_1_0(idx_, L) AF_GET_1_1(idx_, L) AF_GET_2_0(idx_, L) AF_GET_2_1(idx_, L)                               \
+    AF_GET_3_0(idx_, L) AF_GET_3_1(idx_, L) AF_GET_4_0(idx_, L) AF_GET_4_1(idx_, L)                               \
   }
+#define AF_SLOT_WRITE(idx_expr, L)                                                                                \
+  {                                                                                                               \
+    const unsigned int idx_ = __builtin_amdgcn_readfirstlane(idx_expr);                                           \
+    AF_PUT_0_0(idx_, L) AF_PUT_0_1(idx_, L) AF_PUT_1_0(idx_, L) AF_PUT_1_1(idx_, L) AF_PUT_2_0(idx_, L)           \
+    AF_PUT_2_1(idx_, L) AF_PUT_3_0(idx_, L) AF_PUT_3_1(idx_, L) AF_PUT_4_0(idx_, L) AF_PUT_4_1(idx_, L)           \
+  }
+static_assert(AF_J == 2 && AF_NSLOT == 5, "the slot macros spell out two sub-tiles and five slots");
 
 // MODE: SCALE_NONE (no op of the list has a scale buffer) or SCALE_SITE
 template <int MODE, bool NT>
@@ -264,38 +318,35 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   char * outs = lds + 2 * AF_MAT_B + wave * 2 * AF_TILE_B;
   char * ins = outs + AF_TILE_B;
   unsigned int * tile_word = reinterpret_cast<unsigned int *>(lds + 2 * AF_MAT_B + 8 * AF_TILE_B);
-  // what never changes for a lane
+  // what never changes for a lane (five registers)
   const unsigned int lane16 = lane * 16u;
   const unsigned int boff = n * 640u + rate * 160u + q * 32u;        // its four states 4q.. of sub-tile 0 in a stage
   const unsigned int boff5 = n * 640u + rate * 160u + 128u + q * 8u; // state 16 + q
   const char * xlane = lds + lane * 8u, * ylane = lds + AF_MAT_B + lane * 8u;
-  sink += ((size_t)blockIdx.x * 4u + wave) * 4u;
+  const unsigned long long sink_a = (unsigned long long)(uintptr_t)(sink + ((size_t)blockIdx.x * 4u + wave) * 4u);
+  const unsigned long long aorder_a = (unsigned long long)(uintptr_t)aorder;
 
-  AfSlot s0, s1, s2, s3, s4;
-#pragma unroll
-  for (int j = 0; j < AF_J; ++j)
-  {
-#pragma unroll
-    for (int t = 0; t < 5; ++t) s0.v[j][t] = s1.v[j][t] = s2.v[j][t] = s3.v[j][t] = s4.v[j][t] = 0.0;
-    s0.c[j] = s1.c[j] = s2.c[j] = s3.c[j] = s4.c[j] = 0u;
-  }
+  AF_SLOT_VARS(s0)
+  AF_SLOT_VARS(s1)
+  AF_SLOT_VARS(s2)
+  AF_SLOT_VARS(s3)
+  AF_SLOT_VARS(s4)
 
   // a matrix block into LDS: 13 pieces of 1 KB dealt to the four waves
   auto stage_matrix = [&](unsigned int buf_b, unsigned int off) __attribute__((always_inline)) {
-    const unsigned long long src = (unsigned long long)(uintptr_t)aorder + off + lane16;
 #pragma unroll
     for (unsigned int r = 0; r < 4; ++r)
     {
       const unsigned int piece = r * 4u + wave;
-      if (piece < (unsigned int)AF_MAT_PIECES) af_dma16(buf_b + piece * 1024u, src + piece * 1024u);
+      if (piece < (unsigned int)AF_MAT_PIECES) af_dma16(buf_b + piece * 1024u, aorder_a + off + piece * 1024u, lane16);
     }
   };
 
   const size_t tiles = ((size_t)sites + AF_WGS - 1) / AF_WGS;
   // the first op's left block (later tiles: requested by the last op of the tile before)
   {
-    const AfR r1 = af_load(plan, 1);
-    if ((r1.w[18] & AF_KIND_MASK) == 0u) stage_matrix(xbuf_b, r1.w[16]);
+    const AfW<16, 3> r1 = af_load<16, 3>(plan, 1);
+    if ((r1[18] & AF_KIND_MASK) == 0u) stage_matrix(xbuf_b, r1[16]);
   }
   for (size_t round = 0;; ++round)
   {
@@ -308,71 +359,72 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     {
       if (threadIdx.x == 0) *tile_word = atomicAdd(next_tile, 1u);
       __syncthreads();
-      tile = (size_t)static_rounds * gridDim.x + *tile_word;
+      tile = (size_t)static_rounds * gridDim.x + (unsigned int)__builtin_amdgcn_readfirstlane((int)*tile_word);
     }
     if (tile >= tiles) break;
     const size_t site0 = tile * AF_WGS + (size_t)wave * AF_WS;
     const unsigned long long clv_off = (unsigned long long)site0 * 640u;
     const unsigned long long cnt_off = (unsigned long long)site0 * 4u;
 
-    // an operand without a slot: from HBM through the wave's in stage into slot `slot`
+    // an operand without a slot: from HBM through the wave's in stage into a slot (AF_RELOAD_TAKE)
     auto reload_issue = [&](unsigned long long src) __attribute__((always_inline)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the stage's last readers are done)
 #pragma unroll
-      for (unsigned int it = 0; it < 5; ++it) af_dma16(in_b + it * 1024u, src + clv_off + it * 1024u + lane16);
+      for (unsigned int it = 0; it < 5; ++it) af_dma16(in_b + it * 1024u, src + clv_off + it * 1024u, lane16);
     };
     auto reload_counts = [&](unsigned long long cnt, unsigned int (&cj)[AF_J]) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < AF_J; ++j)
       {
         cj[j] = 0u;
-        if (MODE != SCALE_NONE && cnt) cj[j] = ((const unsigned int PLL_GLOBAL *)(cnt + cnt_off))[4 * j + n];
+        if (MODE != SCALE_NONE && cnt) cj[j] = *(const unsigned int PLL_GLOBAL *)(af_base(cnt + cnt_off) + (4u * j + n) * 4u);
       }
     };
-    auto reload_take = [&](unsigned int slot, const unsigned int (&cj)[AF_J]) __attribute__((always_inline)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      AfSlot tmp;
-      af_read_tile(ins + boff, ins + boff5, tmp.v);
+    // (a macro, not a lambda: a lambda would capture the slot variables by reference, and
+    // variables whose address is taken anywhere stay in memory)
+#define AF_RELOAD_TAKE(slot, cj)                                   \
+  {                                                                \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
+    AfSlot tmp;                                                    \
+    af_read_tile(ins + boff, ins + boff5, tmp.v);                  \
+    tmp.c[0] = cj[0];                                              \
+    tmp.c[1] = cj[1];                                              \
+    AF_SLOT_WRITE(slot, tmp)                                       \
+  }
+    // the tip characters of an op (record words 8..15: four rows): lane l holds those of site l & 7
+    auto request_chars = [&](const AfW<8, 11> & r, unsigned int (&c)[4]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < AF_J; ++j) tmp.c[j] = cj[j];
-      AF_SLOT_DO(slot, S, af_copy(S, tmp))
-    };
-    // the tip characters of an op: lane l holds those of site l & 7 of the tile
-    auto request_chars = [&](const AfR & r, unsigned int (&c)[4]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) c[k] = ((const unsigned char PLL_GLOBAL *)(af_quad(r, 8 + 2 * k) + site0))[lane & 7u];
+      for (int k = 0; k < 4; ++k) c[k] = *(const unsigned char PLL_GLOBAL *)(af_base(r.quad(8 + 2 * k) + site0) + (lane & 7u));
     };
 
     // ---- prologue: what the op before op 0 would have done for it
     unsigned int ch[4];
     {
-      const AfR h = af_load(plan, 0);
-      const unsigned int hf = __builtin_amdgcn_readfirstlane(h.w[18]);
+      const AfW<16, 12> h = af_load<16, 12>(plan, 0);
+      const unsigned int hf = __builtin_amdgcn_readfirstlane(h[18]);
       if (hf & AF_RELOAD_A)
       {
         unsigned int cj[AF_J];
-        reload_issue(af_quad(h, 20));
-        reload_counts(af_quad(h, 22), cj);
-        reload_take((h.w[19] >> 12) & 15u, cj);
+        reload_issue(h.quad(20));
+        reload_counts(h.quad(22), cj);
+        AF_RELOAD_TAKE((h[19] >> 12) & 15u, cj)
       }
       if (hf & AF_RELOAD_B)
       {
         unsigned int cj[AF_J];
-        reload_issue(af_quad(h, 24));
-        reload_counts(af_quad(h, 26), cj);
-        reload_take((h.w[19] >> 16) & 15u, cj);
+        reload_issue(h.quad(24));
+        reload_counts(h.quad(26), cj);
+        AF_RELOAD_TAKE((h[19] >> 16) & 15u, cj)
       }
+      request_chars(af_load<8, 11>(plan, 1), ch);
     }
-    AfR rc = af_load(plan, 1);
-    request_chars(rc, ch);
+    AfW<0, 28> rc = af_load<0, 28>(plan, 1);
 
     for (unsigned int i = 0; i < nops; ++i)
     {
-      // (the record behind the last op's is a copy of op 0's: the next tile begins with it)
-      const AfR rn = af_load(plan, i + 2);
-      const unsigned int fl = __builtin_amdgcn_readfirstlane(rc.w[18]);
+      const unsigned int fl = __builtin_amdgcn_readfirstlane(rc[18]);
       const unsigned int kind = fl & AF_KIND_MASK;
-      const unsigned int slots = __builtin_amdgcn_readfirstlane(rc.w[19]);
+      const unsigned int slots = __builtin_amdgcn_readfirstlane(rc[19]);
       const bool scaling = MODE != SCALE_NONE && (fl & AF_SCALING);
 
       // ---- barrier 1: the left block has landed everywhere, everybody is done with op i - 1.
@@ -381,72 +433,85 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kind <= 1u) stage_matrix(ybuf_b, rc.w[17]);
+      if (kind <= 1u) stage_matrix(ybuf_b, rc[17]);
       unsigned int ra_cj[AF_J], rb_cj[AF_J];
       if (fl & AF_RELOAD_A)
       {
-        reload_issue(af_quad(rc, 20));
-        reload_counts(af_quad(rc, 22), ra_cj);
+        reload_issue(rc.quad(20));
+        reload_counts(rc.quad(22), ra_cj);
       }
 
-      double xl[AF_J][5];        // the left factor
+      double x[AF_J][5];        // the left factor, then the product
       unsigned int lc[AF_J], rcn[AF_J];
 #pragma unroll
       for (int j = 0; j < AF_J; ++j) lc[j] = rcn[j] = 0u;
       if (kind == 0u)
       {
         AfSlot l;
-        AF_SLOT_DO(slots & 15u, S, af_copy(l, S))
+        AF_SLOT_READ(slots & 15u, l)
 #pragma unroll
         for (int j = 0; j < AF_J; ++j) lc[j] = l.c[j];
-        af_matvec(xlane, q, l.v, xl);
+        af_matvec<false>(xlane, q, l.v, x);
       }
       else if (kind == 1u)
       {
         // tip-inner: the tip's factor is a row of its table (requested now, used after the products)
-        const unsigned long long tab = af_quad(rc, 4);
+        const af_gptr tab = af_base(rc.quad(4));
 #pragma unroll
         for (int j = 0; j < AF_J; ++j)
         {
           unsigned int code = (unsigned int)__shfl((int)ch[0], 4 * j + (int)n, 64);
           if (code >= ms) code = 0;
-          const unsigned long long e = tab + ((unsigned long long)code * 4u + rate) * 160u;
-          const pll_v2d v0 = *(const pll_v2d PLL_GLOBAL *)(e + q * 32u);
-          const pll_v2d v1 = *(const pll_v2d PLL_GLOBAL *)(e + q * 32u + 16u);
-          xl[j][0] = v0.x; xl[j][1] = v0.y; xl[j][2] = v1.x; xl[j][3] = v1.y;
-          xl[j][4] = *(const double PLL_GLOBAL *)(e + 128u + q * 8u);
+          const unsigned int e = (code * 4u + rate) * 160u;
+          const pll_v2d v0 = *(const pll_v2d PLL_GLOBAL *)(tab + (e + q * 32u));
+          const pll_v2d v1 = *(const pll_v2d PLL_GLOBAL *)(tab + (e + q * 32u + 16u));
+          x[j][0] = v0.x; x[j][1] = v0.y; x[j][2] = v1.x; x[j][3] = v1.y;
+          x[j][4] = *(const double PLL_GLOBAL *)(tab + (e + 128u + q * 8u));
         }
       }
-      if (fl & AF_RELOAD_A) reload_take((slots >> 12) & 15u, ra_cj);
+      if (fl & AF_RELOAD_A) AF_RELOAD_TAKE((slots >> 12) & 15u, ra_cj)
 
       // ---- barrier 2: the right block has landed, everybody is done with the left one
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       // what the next op needs: its characters, its left block (the six stores of this op
-      // follow: barrier 1 of the next op lets exactly those stay in flight)
+      // follow: barrier 1 of the next op lets exactly those stay in flight).  (The record behind
+      // the last op's is a copy of op 0's: the next tile begins with it.)
       unsigned int nch[4];
-      request_chars(rn, nch);
-      asm volatile("" ::: "memory");
-      if ((rn.w[18] & AF_KIND_MASK) == 0u) stage_matrix(xbuf_b, rn.w[16]);
+      {
+        const AfW<8, 11> rn = af_load<8, 11>(plan, i + 2);
+        request_chars(rn, nch);
+        asm volatile("" ::: "memory");
+        if ((rn[18] & AF_KIND_MASK) == 0u) stage_matrix(xbuf_b, rn[16]);
+      }
       if (fl & AF_RELOAD_B)
       {
-        reload_issue(af_quad(rc, 24));
-        reload_counts(af_quad(rc, 26), rb_cj);
+        reload_issue(rc.quad(24));
+        reload_counts(rc.quad(26), rb_cj);
       }
 
       double2 g[5];            // the finished tile, 16 bytes per lane: granule it * 64 + lane
       unsigned int pc[AF_J];   // the parent's counts, lane's own site of each sub-tile
 #pragma unroll
       for (int j = 0; j < AF_J; ++j) pc[j] = 0u;
+      AfSlot p;                // the parent in the operand layout (what its slot takes)
+#pragma unroll
+      for (int j = 0; j < AF_J; ++j)
+      {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) p.v[j][t] = 0.0;
+        p.c[j] = 0u;
+      }
       if (kind <= 1u)
       {
-        AfSlot r;
-        AF_SLOT_DO((slots >> 4) & 15u, S, af_copy(r, S))
+        {
+          AfSlot r;
+          AF_SLOT_READ((slots >> 4) & 15u, r)
 #pragma unroll
-        for (int j = 0; j < AF_J; ++j) rcn[j] = r.c[j];
-        AfSlot p;
-        af_matvec(ylane, q, r.v, p.v);
+          for (int j = 0; j < AF_J; ++j) rcn[j] = r.c[j];
+          af_matvec<true>(ylane, q, r.v, x);
+        }
 #pragma unroll
         for (int j = 0; j < AF_J; ++j)
         {
@@ -454,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
 #pragma unroll
           for (int t = 0; t < 5; ++t)
           {
-            p.v[j][t] = xl[j][t] * p.v[j][t];
+            p.v[j][t] = x[j][t];
             small = small && (p.v[j][t] < PLLHIP_SCALE_THRESHOLD);
           }
           // scaling rule of core_partials_avx2.c:752-800: every entry of the site below the threshold
@@ -473,7 +538,6 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
           pc[j] = scaling ? ((fl & AF_LCNT) ? lc[j] : 0u) + ((fl & AF_RCNT) ? rcn[j] : 0u) + scaled : 0u;
           p.c[j] = pc[j];
         }
-        if (fl & AF_HAS_PSLOT) { AF_SLOT_DO((slots >> 8) & 15u, S, af_copy(S, p)) }
         // through the wave's out stage into the layout of the stores
 #pragma unroll
         for (int j = 0; j < AF_J; ++j)
@@ -490,50 +554,71 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
       else
       {
         // lookup: parent = TL[pair 1] (.) TR[pair 2] (k_aa_cherry_rounds, partials_aa_mfma.hip)
+        // (the lane number through an empty asm: what is derived from it below -- site and column
+        // of five granules -- is recomputed here instead of living in ten registers all along)
+        unsigned int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
         unsigned int c1 = ch[0], c2 = ch[1], c3 = ch[2], c4 = ch[3];
         if (c1 >= ms) c1 = 0;
         if (c2 >= ms) c2 = 0;
         if (c3 >= ms) c3 = 0;
         if (c4 >= ms) c4 = 0;
         const unsigned int p1 = c1 * ms + c2, p2 = c3 * ms + c4;
-        const unsigned long long tl = af_quad(rc, 4), tr = af_quad(rc, 6);
+        const af_gptr tl = af_base(rc.quad(4)), tr = af_base(rc.quad(6));
         unsigned long long bal[5];
+        // in two halves the scheduler may not mix (it would keep all five iterations' indices,
+        // addresses and operands alive at once, on top of the slots): where, fetch, multiply
+        auto lookup_part = [&](auto first_c, auto count_c) __attribute__((always_inline)) {
+          constexpr unsigned int FIRST = decltype(first_c)::value, COUNT = decltype(count_c)::value;
+          unsigned int o1[COUNT], o2[COUNT];
 #pragma unroll
-        for (unsigned int it = 0; it < 5; ++it)
-        {
-          const unsigned int gi = it * 64u + lane, sl = gi / 40u, rr = gi - 40u * sl;
-          const unsigned int q1 = (unsigned int)__shfl((int)p1, (int)sl, 64);
-          const unsigned int q2 = (unsigned int)__shfl((int)p2, (int)sl, 64);
-          const pll_v2d x = *(const pll_v2d PLL_GLOBAL *)(tl + ((unsigned long long)q1 * 40u + rr) * 16u);
-          const pll_v2d y = *(const pll_v2d PLL_GLOBAL *)(tr + ((unsigned long long)q2 * 40u + rr) * 16u);
-          g[it] = make_double2(x.x * y.x, x.y * y.y);
-          bal[it] = __ballot((g[it].x < PLLHIP_SCALE_THRESHOLD) & (g[it].y < PLLHIP_SCALE_THRESHOLD));
-        }
-        unsigned int scaled = 0u; // bit s: every entry of site s of the tile below the threshold
-        if (scaling)
+          for (unsigned int u = 0; u < COUNT; ++u)
+          {
+            const unsigned int gi = (FIRST + u) * 64u + lane_l, sl = gi / 40u, rr = gi - 40u * sl;
+            const unsigned int q1 = (unsigned int)__shfl((int)p1, (int)sl, 64);
+            const unsigned int q2 = (unsigned int)__shfl((int)p2, (int)sl, 64);
+            o1[u] = (q1 * 40u + rr) * 16u;
+            o2[u] = (q2 * 40u + rr) * 16u;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          pll_v2d a[COUNT], b[COUNT];
+#pragma unroll
+          for (unsigned int u = 0; u < COUNT; ++u)
+          {
+            a[u] = *(const pll_v2d PLL_GLOBAL *)(tl + o1[u]);
+            b[u] = *(const pll_v2d PLL_GLOBAL *)(tr + o2[u]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (unsigned int u = 0; u < COUNT; ++u)
+          {
+            g[FIRST + u] = make_double2(a[u].x * b[u].x, a[u].y * b[u].y);
+            bal[FIRST + u] = __ballot((g[FIRST + u].x < PLLHIP_SCALE_THRESHOLD) & (g[FIRST + u].y < PLLHIP_SCALE_THRESHOLD));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        lookup_part(std::integral_constant<unsigned int, 0>{}, std::integral_constant<unsigned int, 3>{});
+        lookup_part(std::integral_constant<unsigned int, 3>{}, std::integral_constant<unsigned int, 2>{});
+        // bit s: every entry of site s of the tile below the threshold.  The 320 flags of the tile
+        // are five wave masks; site s owns bits [40 s, 40 s + 40).  (Nearly always no flag is set.)
+        unsigned int scaled = 0u;
+        if (scaling && (bal[0] | bal[1] | bal[2] | bal[3] | bal[4]) != 0ull)
         {
 #pragma unroll
           for (int s = 0; s < AF_WS; ++s)
           {
-            bool all = true;
-#pragma unroll
-            for (int it = 0; it < 5; ++it)
-            {
-              const int a = 40 * s - 64 * it < 0 ? 0 : 40 * s - 64 * it;
-              const int b = 40 * s + 40 - 64 * it > 64 ? 64 : 40 * s + 40 - 64 * it;
-              if (a < b)
-              {
-                const unsigned long long m = (b - a == 64 ? ~0ull : ((1ull << (b - a)) - 1ull)) << a;
-                all = all && ((bal[it] & m) == m);
-              }
-            }
-            scaled |= all ? 1u << s : 0u;
+            constexpr unsigned long long F40 = (1ull << 40) - 1ull;
+            const int w = (40 * s) / 64, off = (40 * s) % 64;
+            unsigned long long field = bal[w] >> off;
+            if (off > 24) field |= bal[w + 1 < 5 ? w + 1 : 4] << (64 - off);
+            scaled |= ((field & F40) == F40) ? 1u << s : 0u;
           }
+          scaled = __builtin_amdgcn_readfirstlane(scaled);
           if (scaled)
 #pragma unroll
             for (unsigned int it = 0; it < 5; ++it)
             {
-              const unsigned int sl = (it * 64u + lane) / 40u;
+              const unsigned int sl = (it * 64u + lane_l) / 40u;
               const double f = ((scaled >> sl) & 1u) ? PLLHIP_SCALE_FACTOR : 1.0;
               g[it].x *= f;
               g[it].y *= f;
@@ -546,30 +631,30 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
 #pragma unroll
           for (int it = 0; it < 5; ++it) *reinterpret_cast<double2 *>(outs + it * 1024 + lane16) = g[it];
           asm volatile("" ::: "memory");
-          AfSlot p;
           af_read_tile(outs + boff, outs + boff5, p.v);
           asm volatile("" ::: "memory");
 #pragma unroll
           for (int j = 0; j < AF_J; ++j) p.c[j] = pc[j];
-          AF_SLOT_DO((slots >> 8) & 15u, S, af_copy(S, p))
         }
       }
-      if (fl & AF_RELOAD_B) reload_take((slots >> 16) & 15u, rb_cj);
+      // the parent's slot (ONE place for both kinds, and no branch around it: slot 15 is nobody's)
+      AF_SLOT_WRITE((fl & AF_HAS_PSLOT) ? (slots >> 8) & 15u : 15u, p)
+      if (fl & AF_RELOAD_B) AF_RELOAD_TAKE((slots >> 16) & 15u, rb_cj)
 
       // ---- the six stores (always six: barrier 1 of the next op counts on it): the counts --
       // to the wave's sink when the op has no scale buffer --, then the tile, 5 KB contiguous
       {
         const unsigned int mine = (lane & 4u) ? pc[1] : pc[0];
-        const unsigned long long cdst = scaling ? af_quad(rc, 2) + cnt_off : (unsigned long long)(uintptr_t)sink;
+        const af_gptr cdst = af_base(scaling ? rc.quad(2) + cnt_off : sink_a);
         asm volatile("" ::: "memory");
         if (lane < (unsigned int)AF_WS) *(unsigned int PLL_GLOBAL *)(cdst + lane * 4u) = mine;
         asm volatile("" ::: "memory");
-        const unsigned long long out = af_quad(rc, 0) + clv_off + lane16;
+        const af_gptr out = af_base(rc.quad(0) + clv_off);
 #pragma unroll
         for (unsigned int it = 0; it < 5; ++it)
         {
           const pll_v2d v = {g[it].x, g[it].y};
-          pll_v2d PLL_GLOBAL * dst = (pll_v2d PLL_GLOBAL *)(out + it * 1024u);
+          pll_v2d PLL_GLOBAL * dst = (pll_v2d PLL_GLOBAL *)(out + (lane16 + it * 1024u));
           if (NT) __builtin_nontemporal_store(v, dst);
           else *dst = v;
           asm volatile("" ::: "memory");
@@ -577,7 +662,8 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) ch[k] = nch[k];
-      rc = rn;
+      // the next op's record: on its way during barrier 1
+      rc = af_load<0, 28>(plan, i + 2);
     }
   }
 }
