@@ -30,8 +30,14 @@ $(BUILD):
 $(BUILD)/host_%.o: libpll_amd/csrc/host/%.c include/pll_amd.h include/pllhip.h libpll_amd/csrc/host/internal.h | $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(BUILD)/hip_%.o: libpll_amd/csrc/hip/%.hip include/pllhip.h $(wildcard libpll_amd/csrc/hip/*.hpp) | $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(BUILD)/hip_%.o: libpll_amd/csrc/hip/%.hip include/pllhip.h $(wildcard libpll_amd/csrc/hip/*.hpp) $(wildcard libpll_amd/csrc/hip/*.inc) | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_$*) -c $< -o $@
+
+# partials_aa_fused.hip keeps its values in the accumulation registers a0..a109 behind the compiler's
+# back (inline assembly): the matrix-core instructions must then keep THEIR accumulators in ordinary
+# registers, or the compiler parks them in a0.. between two assembly blocks (seen).  tools/check_agprs.py
+# (run by tests/test_host.py) verifies on the generated code that nothing but the slot assembly touches them.
+HIPFLAGS_partials_aa_fused := -mllvm -amdgpu-mfma-vgpr-form
 
 $(OUT): $(HOST_OBJ) $(HIP_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -Wl,-soname,libpll_amd.so -Wl,-rpath,/opt/rocm/lib \

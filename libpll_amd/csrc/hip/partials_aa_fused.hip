@@ -45,6 +45,7 @@
 // characters; the matrix cores run 80 MFMAs per 16 columns and child (16 cycles each):
 // about 0.6 of the time the stores need.  DESIGN.md 2.2c has the budget and the measurements.
 #include <algorithm>
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 #include <vector>
@@ -65,7 +66,7 @@ constexpr int AF_TILE_B = AF_WS * 640;     // bytes of a wave's tile of a CLV
 constexpr int AF_NSLOT = 5;                // values a wave keeps in registers
 constexpr int AF_MAT_PIECES = 13;          // 1 KB pieces of a matrix block in operand order (12.5, padded)
 constexpr int AF_MAT_B = AF_MAT_PIECES * 1024;
-constexpr int AF_LDS_B = 2 * AF_MAT_B + 4 * 2 * AF_TILE_B + 16;
+constexpr int AF_LDS_B = 3 * AF_MAT_B + 4 * 2 * AF_TILE_B + 16; // two workgroups per CU: 158 of its 160 KB
 
 // One record per op, read through the scalar cache: everything the wave needs while the op runs.
 struct AaRec
@@ -74,9 +75,9 @@ struct AaRec
   unsigned long long pscaler;     // its scale buffer (0: none)
   unsigned long long tab_l;       // lookup: table of pair 1; tip-inner: the tip's table [code][rate][state]
   unsigned long long tab_r;       // lookup: table of pair 2
-  unsigned long long row[4];      // tip rows: lookup (t1, t2), (t3, t4); tip-inner row[0]; else rows of zeros
-  unsigned int xoff, yoff;        // byte offsets of the op's left / right matrix blocks (operand order)
-  unsigned int flags;             // AF_* below
+  unsigned long long row[4];      // tip rows OF THE NEXT OP: lookup (t1, t2), (t3, t4); tip-inner row[0]; else rows of zeros
+  unsigned int xoff, yoff;        // byte offsets (operand order): left block OF THE NEXT OP, right block of this op
+  unsigned int flags;             // AF_* below; bits 8-9: kind of the next op
   unsigned int slots;             // lslot | rslot << 4 | pslot << 8 | ra_slot << 12 | rb_slot << 16
   unsigned long long ra_src, ra_cnt; // reload A: done during this op for the NEXT op's left operand
   unsigned long long rb_src, rb_cnt; // reload B: the next op's right operand
@@ -243,64 +244,101 @@ __device__ __forceinline__ void af_read_tile(const char * stage_lane, const char
   }
 }
 
-// The five slots are sixty scalar variables that never move.  Three things it took:
-//  - a slot is read and written by INLINE ASSEMBLY that compares the (wave-uniform) slot number and
-//    branches over a dozen moves.  Written as a C++ switch the optimiser first merged the arms into
-//    one access through a pointer that depends on the slot number (the slots became 448 bytes of
-//    scratch per lane); with scalars instead of structs it kept them in registers but threaded all
-//    sixty values through every arm of every switch as phi nodes, and the register allocator answered
-//    with 1150 moves and a slot in scratch.  Behind the asm there is no control flow to see.
-//  - every asm names the PHYSICAL registers of the slot it touches (v146..v255): left to itself the
-//    allocator gave the same slot different registers in different parts of the op loop and copied
-//    all fifty pairs from one set to the other on the way (45 v_mov_b64 in a row).
-//  - no lambda may touch them: a reference capture takes their address, and they would be memory.
-#define AF_SLOT_VARS(N)                                                                                           \
-  double N##_00 = 0.0, N##_01 = 0.0, N##_02 = 0.0, N##_03 = 0.0, N##_04 = 0.0, N##_10 = 0.0, N##_11 = 0.0,        \
-         N##_12 = 0.0, N##_13 = 0.0, N##_14 = 0.0;                                                                \
-  unsigned int N##_c0 = 0u, N##_c1 = 0u;
-#define AF_MOVE6_ASM(K)                                                                                           \
-  "s_cmp_lg_u32 %12, " #K "\n\ts_cbranch_scc1 .Laf_skip_%=\n\t"                                                   \
-  "v_mov_b64 %0, %6\n\tv_mov_b64 %1, %7\n\tv_mov_b64 %2, %8\n\tv_mov_b64 %3, %9\n\t"                              \
-  "v_mov_b64 %4, %10\n\tv_mov_b32 %5, %11\n.Laf_skip_%=:"
+// The five slots live in the ACCUMULATION registers a0..a109 and are touched by inline assembly
+// only: slot K, sub-tile j, word w (five doubles as lo/hi words, then the count) is a[22 K + 11 j + w].
+// The compiler never sees a slot: it learns from the clobber lists that these registers are taken
+// (it then splits the wave's 256 registers into 128 + 128) and keeps everything of its own in v0..v127.
+//
+// How it came to this (each step was built and looked at in the ISA):
+//  - slots as structs selected by a C++ switch: the optimiser merged the arms into one access through
+//    a pointer that depends on the slot number -- the slots became 448 bytes of scratch per lane;
+//  - sixty scalar variables and switches: all sixty values threaded through every arm of every switch
+//    as phi nodes, 1150 register moves, one slot in scratch;
+//  - the switches hidden in inline asm, slot variables as "+v" operands, then pinned to v146..v255:
+//    the register allocator treats a pinned operand as pinned AT the asm only, copied the slots to
+//    other registers in between and spilled them wholesale (590 spills) once the op body was there
+//    twice (the loop is unrolled by two so that no loaded value is ever copied).
+// A slot number of 15 matches no slot: "no slot" needs no branch around the access.
 
-#define AF_PUT_0_0(idx, L) asm volatile(AF_MOVE6_ASM(0) : "+{v[146:147]}"(s0_00), "+{v[148:149]}"(s0_01), "+{v[150:151]}"(s0_02), "+{v[152:153]}"(s0_03), "+{v[154:155]}"(s0_04), "+{v166}"(s0_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
-#define AF_GET_0_0(idx, L) asm volatile(AF_MOVE6_ASM(0) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[146:147]}"(s0_00), "{v[148:149]}"(s0_01), "{v[150:151]}"(s0_02), "{v[152:153]}"(s0_03), "{v[154:155]}"(s0_04), "{v166}"(s0_c0), "s"(idx) : "scc");
-#define AF_PUT_0_1(idx, L) asm volatile(AF_MOVE6_ASM(0) : "+{v[156:157]}"(s0_10), "+{v[158:159]}"(s0_11), "+{v[160:161]}"(s0_12), "+{v[162:163]}"(s0_13), "+{v[164:165]}"(s0_14), "+{v167}"(s0_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
-#define AF_GET_0_1(idx, L) asm volatile(AF_MOVE6_ASM(0) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[156:157]}"(s0_10), "{v[158:159]}"(s0_11), "{v[160:161]}"(s0_12), "{v[162:163]}"(s0_13), "{v[164:165]}"(s0_14), "{v167}"(s0_c1), "s"(idx) : "scc");
-#define AF_PUT_1_0(idx, L) asm volatile(AF_MOVE6_ASM(1) : "+{v[168:169]}"(s1_00), "+{v[170:171]}"(s1_01), "+{v[172:173]}"(s1_02), "+{v[174:175]}"(s1_03), "+{v[176:177]}"(s1_04), "+{v188}"(s1_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
-#define AF_GET_1_0(idx, L) asm volatile(AF_MOVE6_ASM(1) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[168:169]}"(s1_00), "{v[170:171]}"(s1_01), "{v[172:173]}"(s1_02), "{v[174:175]}"(s1_03), "{v[176:177]}"(s1_04), "{v188}"(s1_c0), "s"(idx) : "scc");
-#define AF_PUT_1_1(idx, L) asm volatile(AF_MOVE6_ASM(1) : "+{v[178:179]}"(s1_10), "+{v[180:181]}"(s1_11), "+{v[182:183]}"(s1_12), "+{v[184:185]}"(s1_13), "+{v[186:187]}"(s1_14), "+{v189}"(s1_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
-#define AF_GET_1_1(idx, L) asm volatile(AF_MOVE6_ASM(1) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[178:179]}"(s1_10), "{v[180:181]}"(s1_11), "{v[182:183]}"(s1_12), "{v[184:185]}"(s1_13), "{v[186:187]}"(s1_14), "{v189}"(s1_c1), "s"(idx) : "scc");
-#define AF_PUT_2_0(idx, L) asm volatile(AF_MOVE6_ASM(2) : "+{v[190:191]}"(s2_00), "+{v[192:193]}"(s2_01), "+{v[194:195]}"(s2_02), "+{v[196:197]}"(s2_03), "+{v[198:199]}"(s2_04), "+{v210}"(s2_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
-#define AF_GET_2_0(idx, L) asm volatile(AF_MOVE6_ASM(2) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[190:191]}"(s2_00), "{v[192:193]}"(s2_01), "{v[194:195]}"(s2_02), "{v[196:197]}"(s2_03), "{v[198:199]}"(s2_04), "{v210}"(s2_c0), "s"(idx) : "scc");
-#define AF_PUT_2_1(idx, L) asm volatile(AF_MOVE6_ASM(2) : "+{v[200:201]}"(s2_10), "+{v[202:203]}"(s2_11), "+{v[204:205]}"(s2_12), "+{v[206:207]}"(s2_13), "+{v[208:209]}"(s2_14), "+{v211}"(s2_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
-#define AF_GET_2_1(idx, L) asm volatile(AF_MOVE6_ASM(2) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[200:201]}"(s2_10), "{v[202:203]}"(s2_11), "{v[204:205]}"(s2_12), "{v[206:207]}"(s2_13), "{v[208:209]}"(s2_14), "{v211}"(s2_c1), "s"(idx) : "scc");
-#define AF_PUT_3_0(idx, L) asm volatile(AF_MOVE6_ASM(3) : "+{v[212:213]}"(s3_00), "+{v[214:215]}"(s3_01), "+{v[216:217]}"(s3_02), "+{v[218:219]}"(s3_03), "+{v[220:221]}"(s3_04), "+{v232}"(s3_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
-#define AF_GET_3_0(idx, L) asm volatile(AF_MOVE6_ASM(3) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[212:213]}"(s3_00), "{v[214:215]}"(s3_01), "{v[216:217]}"(s3_02), "{v[218:219]}"(s3_03), "{v[220:221]}"(s3_04), "{v232}"(s3_c0), "s"(idx) : "scc");
-#define AF_PUT_3_1(idx, L) asm volatile(AF_MOVE6_ASM(3) : "+{v[222:223]}"(s3_10), "+{v[224:225]}"(s3_11), "+{v[226:227]}"(s3_12), "+{v[228:229]}"(s3_13), "+{v[230:231]}"(s3_14), "+{v233}"(s3_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
-#define AF_GET_3_1(idx, L) asm volatile(AF_MOVE6_ASM(3) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[222:223]}"(s3_10), "{v[224:225]}"(s3_11), "{v[226:227]}"(s3_12), "{v[228:229]}"(s3_13), "{v[230:231]}"(s3_14), "{v233}"(s3_c1), "s"(idx) : "scc");
-#define AF_PUT_4_0(idx, L) asm volatile(AF_MOVE6_ASM(4) : "+{v[234:235]}"(s4_00), "+{v[236:237]}"(s4_01), "+{v[238:239]}"(s4_02), "+{v[240:241]}"(s4_03), "+{v[242:243]}"(s4_04), "+{v254}"(s4_c0) : "v"(L.v[0][0]), "v"(L.v[0][1]), "v"(L.v[0][2]), "v"(L.v[0][3]), "v"(L.v[0][4]), "v"(L.c[0]), "s"(idx) : "scc");
-#define AF_GET_4_0(idx, L) asm volatile(AF_MOVE6_ASM(4) : "+v"(L.v[0][0]), "+v"(L.v[0][1]), "+v"(L.v[0][2]), "+v"(L.v[0][3]), "+v"(L.v[0][4]), "+v"(L.c[0]) : "{v[234:235]}"(s4_00), "{v[236:237]}"(s4_01), "{v[238:239]}"(s4_02), "{v[240:241]}"(s4_03), "{v[242:243]}"(s4_04), "{v254}"(s4_c0), "s"(idx) : "scc");
-#define AF_PUT_4_1(idx, L) asm volatile(AF_MOVE6_ASM(4) : "+{v[244:245]}"(s4_10), "+{v[246:247]}"(s4_11), "+{v[248:249]}"(s4_12), "+{v[250:251]}"(s4_13), "+{v[252:253]}"(s4_14), "+{v255}"(s4_c1) : "v"(L.v[1][0]), "v"(L.v[1][1]), "v"(L.v[1][2]), "v"(L.v[1][3]), "v"(L.v[1][4]), "v"(L.c[1]), "s"(idx) : "scc");
-#define AF_GET_4_1(idx, L) asm volatile(AF_MOVE6_ASM(4) : "+v"(L.v[1][0]), "+v"(L.v[1][1]), "+v"(L.v[1][2]), "+v"(L.v[1][3]), "+v"(L.v[1][4]), "+v"(L.c[1]) : "{v[244:245]}"(s4_10), "{v[246:247]}"(s4_11), "{v[248:249]}"(s4_12), "{v[250:251]}"(s4_13), "{v[252:253]}"(s4_14), "{v255}"(s4_c1), "s"(idx) : "scc");
-#define AF_SLOT_READ(idx_expr, L)                                                                                 \
-  {                                                                                                               \
-    const unsigned int idx_ = __builtin_amdgcn_readfirstlane(idx_expr);                                           \
-    L.v[0][0] = s0_00; L.v[0][1] = s0_01; L.v[0][2] = s0_02; L.v[0][3] = s0_03; L.v[0][4] = s0_04;                \
-    L.v[1][0] = s0_10; L.v[1][1] = s0_11; L.v[1][2] = s0_12; L.v[1][3] = s0_13; L.v[1][4] = s0_14;                \
-    L.c[0] = s0_c0; L.c[1] = s0_c1;                                                                               \
-    AF_GET_1_0(idx_, L) AF_GET_1_1(idx_, L) AF_GET_2_0(idx_, L) AF_GET_2_1(idx_, L)                               \
-    AF_GET_3_0(idx_, L) AF_GET_3_1(idx_, L) AF_GET_4_0(idx_, L) AF_GET_4_1(idx_, L)                               \
+#define AF_SLOT_READ_ASM_0 \
+  "s_cmp_eq_u32 %11, 0\n\ts_cbranch_scc1 .Laf_r0_%=\n\t" \
+  "s_cmp_eq_u32 %11, 1\n\ts_cbranch_scc1 .Laf_r1_%=\n\t" \
+  "s_cmp_eq_u32 %11, 2\n\ts_cbranch_scc1 .Laf_r2_%=\n\t" \
+  "s_cmp_eq_u32 %11, 3\n\ts_cbranch_scc1 .Laf_r3_%=\n\t" \
+  ".Laf_r4_%=:\n\tv_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\tv_accvgpr_read_b32 %2, a90\n\tv_accvgpr_read_b32 %3, a91\n\tv_accvgpr_read_b32 %4, a92\n\tv_accvgpr_read_b32 %5, a93\n\tv_accvgpr_read_b32 %6, a94\n\tv_accvgpr_read_b32 %7, a95\n\tv_accvgpr_read_b32 %8, a96\n\tv_accvgpr_read_b32 %9, a97\n\tv_accvgpr_read_b32 %10, a98\n\ts_branch .Laf_re_%=\n" \
+  ".Laf_r3_%=:\n\tv_accvgpr_read_b32 %0, a66\n\tv_accvgpr_read_b32 %1, a67\n\tv_accvgpr_read_b32 %2, a68\n\tv_accvgpr_read_b32 %3, a69\n\tv_accvgpr_read_b32 %4, a70\n\tv_accvgpr_read_b32 %5, a71\n\tv_accvgpr_read_b32 %6, a72\n\tv_accvgpr_read_b32 %7, a73\n\tv_accvgpr_read_b32 %8, a74\n\tv_accvgpr_read_b32 %9, a75\n\tv_accvgpr_read_b32 %10, a76\n\ts_branch .Laf_re_%=\n" \
+  ".Laf_r2_%=:\n\tv_accvgpr_read_b32 %0, a44\n\tv_accvgpr_read_b32 %1, a45\n\tv_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a47\n\tv_accvgpr_read_b32 %4, a48\n\tv_accvgpr_read_b32 %5, a49\n\tv_accvgpr_read_b32 %6, a50\n\tv_accvgpr_read_b32 %7, a51\n\tv_accvgpr_read_b32 %8, a52\n\tv_accvgpr_read_b32 %9, a53\n\tv_accvgpr_read_b32 %10, a54\n\ts_branch .Laf_re_%=\n" \
+  ".Laf_r1_%=:\n\tv_accvgpr_read_b32 %0, a22\n\tv_accvgpr_read_b32 %1, a23\n\tv_accvgpr_read_b32 %2, a24\n\tv_accvgpr_read_b32 %3, a25\n\tv_accvgpr_read_b32 %4, a26\n\tv_accvgpr_read_b32 %5, a27\n\tv_accvgpr_read_b32 %6, a28\n\tv_accvgpr_read_b32 %7, a29\n\tv_accvgpr_read_b32 %8, a30\n\tv_accvgpr_read_b32 %9, a31\n\tv_accvgpr_read_b32 %10, a32\n\ts_branch .Laf_re_%=\n" \
+  ".Laf_r0_%=:\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\tv_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\t" \
+  ".Laf_re_%=:"
+#define AF_SLOT_WRITE_ASM_0 \
+  "s_cmp_lg_u32 %11, 0\n\ts_cbranch_scc1 .Laf_w0_%=\n\tv_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3\n\tv_accvgpr_write_b32 a4, %4\n\tv_accvgpr_write_b32 a5, %5\n\tv_accvgpr_write_b32 a6, %6\n\tv_accvgpr_write_b32 a7, %7\n\tv_accvgpr_write_b32 a8, %8\n\tv_accvgpr_write_b32 a9, %9\n\tv_accvgpr_write_b32 a10, %10\n\t.Laf_w0_%=:\n\t" \
+  "s_cmp_lg_u32 %11, 1\n\ts_cbranch_scc1 .Laf_w1_%=\n\tv_accvgpr_write_b32 a22, %0\n\tv_accvgpr_write_b32 a23, %1\n\tv_accvgpr_write_b32 a24, %2\n\tv_accvgpr_write_b32 a25, %3\n\tv_accvgpr_write_b32 a26, %4\n\tv_accvgpr_write_b32 a27, %5\n\tv_accvgpr_write_b32 a28, %6\n\tv_accvgpr_write_b32 a29, %7\n\tv_accvgpr_write_b32 a30, %8\n\tv_accvgpr_write_b32 a31, %9\n\tv_accvgpr_write_b32 a32, %10\n\t.Laf_w1_%=:\n\t" \
+  "s_cmp_lg_u32 %11, 2\n\ts_cbranch_scc1 .Laf_w2_%=\n\tv_accvgpr_write_b32 a44, %0\n\tv_accvgpr_write_b32 a45, %1\n\tv_accvgpr_write_b32 a46, %2\n\tv_accvgpr_write_b32 a47, %3\n\tv_accvgpr_write_b32 a48, %4\n\tv_accvgpr_write_b32 a49, %5\n\tv_accvgpr_write_b32 a50, %6\n\tv_accvgpr_write_b32 a51, %7\n\tv_accvgpr_write_b32 a52, %8\n\tv_accvgpr_write_b32 a53, %9\n\tv_accvgpr_write_b32 a54, %10\n\t.Laf_w2_%=:\n\t" \
+  "s_cmp_lg_u32 %11, 3\n\ts_cbranch_scc1 .Laf_w3_%=\n\tv_accvgpr_write_b32 a66, %0\n\tv_accvgpr_write_b32 a67, %1\n\tv_accvgpr_write_b32 a68, %2\n\tv_accvgpr_write_b32 a69, %3\n\tv_accvgpr_write_b32 a70, %4\n\tv_accvgpr_write_b32 a71, %5\n\tv_accvgpr_write_b32 a72, %6\n\tv_accvgpr_write_b32 a73, %7\n\tv_accvgpr_write_b32 a74, %8\n\tv_accvgpr_write_b32 a75, %9\n\tv_accvgpr_write_b32 a76, %10\n\t.Laf_w3_%=:\n\t" \
+  "s_cmp_lg_u32 %11, 4\n\ts_cbranch_scc1 .Laf_w4_%=\n\tv_accvgpr_write_b32 a88, %0\n\tv_accvgpr_write_b32 a89, %1\n\tv_accvgpr_write_b32 a90, %2\n\tv_accvgpr_write_b32 a91, %3\n\tv_accvgpr_write_b32 a92, %4\n\tv_accvgpr_write_b32 a93, %5\n\tv_accvgpr_write_b32 a94, %6\n\tv_accvgpr_write_b32 a95, %7\n\tv_accvgpr_write_b32 a96, %8\n\tv_accvgpr_write_b32 a97, %9\n\tv_accvgpr_write_b32 a98, %10\n\t.Laf_w4_%=:\n\t"
+#define AF_SLOT_CLOBBER_0 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98"
+#define AF_SLOT_READ_ASM_1 \
+  "s_cmp_eq_u32 %11, 0\n\ts_cbranch_scc1 .Laf_r0_%=\n\t" \
+  "s_cmp_eq_u32 %11, 1\n\ts_cbranch_scc1 .Laf_r1_%=\n\t" \
+  "s_cmp_eq_u32 %11, 2\n\ts_cbranch_scc1 .Laf_r2_%=\n\t" \
+  "s_cmp_eq_u32 %11, 3\n\ts_cbranch_scc1 .Laf_r3_%=\n\t" \
+  ".Laf_r4_%=:\n\tv_accvgpr_read_b32 %0, a99\n\tv_accvgpr_read_b32 %1, a100\n\tv_accvgpr_read_b32 %2, a101\n\tv_accvgpr_read_b32 %3, a102\n\tv_accvgpr_read_b32 %4, a103\n\tv_accvgpr_read_b32 %5, a104\n\tv_accvgpr_read_b32 %6, a105\n\tv_accvgpr_read_b32 %7, a106\n\tv_accvgpr_read_b32 %8, a107\n\tv_accvgpr_read_b32 %9, a108\n\tv_accvgpr_read_b32 %10, a109\n\ts_branch .Laf_re_%=\n" \
+  ".Laf_r3_%=:\n\tv_accvgpr_read_b32 %0, a77\n\tv_accvgpr_read_b32 %1, a78\n\tv_accvgpr_read_b32 %2, a79\n\tv_accvgpr_read_b32 %3, a80\n\tv_accvgpr_read_b32 %4, a81\n\tv_accvgpr_read_b32 %5, a82\n\tv_accvgpr_read_b32 %6, a83\n\tv_accvgpr_read_b32 %7, a84\n\tv_accvgpr_read_b32 %8, a85\n\tv_accvgpr_read_b32 %9, a86\n\tv_accvgpr_read_b32 %10, a87\n\ts_branch .Laf_re_%=\n" \
+  ".Laf_r2_%=:\n\tv_accvgpr_read_b32 %0, a55\n\tv_accvgpr_read_b32 %1, a56\n\tv_accvgpr_read_b32 %2, a57\n\tv_accvgpr_read_b32 %3, a58\n\tv_accvgpr_read_b32 %4, a59\n\tv_accvgpr_read_b32 %5, a60\n\tv_accvgpr_read_b32 %6, a61\n\tv_accvgpr_read_b32 %7, a62\n\tv_accvgpr_read_b32 %8, a63\n\tv_accvgpr_read_b32 %9, a64\n\tv_accvgpr_read_b32 %10, a65\n\ts_branch .Laf_re_%=\n" \
+  ".Laf_r1_%=:\n\tv_accvgpr_read_b32 %0, a33\n\tv_accvgpr_read_b32 %1, a34\n\tv_accvgpr_read_b32 %2, a35\n\tv_accvgpr_read_b32 %3, a36\n\tv_accvgpr_read_b32 %4, a37\n\tv_accvgpr_read_b32 %5, a38\n\tv_accvgpr_read_b32 %6, a39\n\tv_accvgpr_read_b32 %7, a40\n\tv_accvgpr_read_b32 %8, a41\n\tv_accvgpr_read_b32 %9, a42\n\tv_accvgpr_read_b32 %10, a43\n\ts_branch .Laf_re_%=\n" \
+  ".Laf_r0_%=:\n\tv_accvgpr_read_b32 %0, a11\n\tv_accvgpr_read_b32 %1, a12\n\tv_accvgpr_read_b32 %2, a13\n\tv_accvgpr_read_b32 %3, a14\n\tv_accvgpr_read_b32 %4, a15\n\tv_accvgpr_read_b32 %5, a16\n\tv_accvgpr_read_b32 %6, a17\n\tv_accvgpr_read_b32 %7, a18\n\tv_accvgpr_read_b32 %8, a19\n\tv_accvgpr_read_b32 %9, a20\n\tv_accvgpr_read_b32 %10, a21\n\t" \
+  ".Laf_re_%=:"
+#define AF_SLOT_WRITE_ASM_1 \
+  "s_cmp_lg_u32 %11, 0\n\ts_cbranch_scc1 .Laf_w0_%=\n\tv_accvgpr_write_b32 a11, %0\n\tv_accvgpr_write_b32 a12, %1\n\tv_accvgpr_write_b32 a13, %2\n\tv_accvgpr_write_b32 a14, %3\n\tv_accvgpr_write_b32 a15, %4\n\tv_accvgpr_write_b32 a16, %5\n\tv_accvgpr_write_b32 a17, %6\n\tv_accvgpr_write_b32 a18, %7\n\tv_accvgpr_write_b32 a19, %8\n\tv_accvgpr_write_b32 a20, %9\n\tv_accvgpr_write_b32 a21, %10\n\t.Laf_w0_%=:\n\t" \
+  "s_cmp_lg_u32 %11, 1\n\ts_cbranch_scc1 .Laf_w1_%=\n\tv_accvgpr_write_b32 a33, %0\n\tv_accvgpr_write_b32 a34, %1\n\tv_accvgpr_write_b32 a35, %2\n\tv_accvgpr_write_b32 a36, %3\n\tv_accvgpr_write_b32 a37, %4\n\tv_accvgpr_write_b32 a38, %5\n\tv_accvgpr_write_b32 a39, %6\n\tv_accvgpr_write_b32 a40, %7\n\tv_accvgpr_write_b32 a41, %8\n\tv_accvgpr_write_b32 a42, %9\n\tv_accvgpr_write_b32 a43, %10\n\t.Laf_w1_%=:\n\t" \
+  "s_cmp_lg_u32 %11, 2\n\ts_cbranch_scc1 .Laf_w2_%=\n\tv_accvgpr_write_b32 a55, %0\n\tv_accvgpr_write_b32 a56, %1\n\tv_accvgpr_write_b32 a57, %2\n\tv_accvgpr_write_b32 a58, %3\n\tv_accvgpr_write_b32 a59, %4\n\tv_accvgpr_write_b32 a60, %5\n\tv_accvgpr_write_b32 a61, %6\n\tv_accvgpr_write_b32 a62, %7\n\tv_accvgpr_write_b32 a63, %8\n\tv_accvgpr_write_b32 a64, %9\n\tv_accvgpr_write_b32 a65, %10\n\t.Laf_w2_%=:\n\t" \
+  "s_cmp_lg_u32 %11, 3\n\ts_cbranch_scc1 .Laf_w3_%=\n\tv_accvgpr_write_b32 a77, %0\n\tv_accvgpr_write_b32 a78, %1\n\tv_accvgpr_write_b32 a79, %2\n\tv_accvgpr_write_b32 a80, %3\n\tv_accvgpr_write_b32 a81, %4\n\tv_accvgpr_write_b32 a82, %5\n\tv_accvgpr_write_b32 a83, %6\n\tv_accvgpr_write_b32 a84, %7\n\tv_accvgpr_write_b32 a85, %8\n\tv_accvgpr_write_b32 a86, %9\n\tv_accvgpr_write_b32 a87, %10\n\t.Laf_w3_%=:\n\t" \
+  "s_cmp_lg_u32 %11, 4\n\ts_cbranch_scc1 .Laf_w4_%=\n\tv_accvgpr_write_b32 a99, %0\n\tv_accvgpr_write_b32 a100, %1\n\tv_accvgpr_write_b32 a101, %2\n\tv_accvgpr_write_b32 a102, %3\n\tv_accvgpr_write_b32 a103, %4\n\tv_accvgpr_write_b32 a104, %5\n\tv_accvgpr_write_b32 a105, %6\n\tv_accvgpr_write_b32 a106, %7\n\tv_accvgpr_write_b32 a107, %8\n\tv_accvgpr_write_b32 a108, %9\n\tv_accvgpr_write_b32 a109, %10\n\t.Laf_w4_%=:\n\t"
+#define AF_SLOT_CLOBBER_1 "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109"
+
+struct AfWords { unsigned int w[11]; };
+#define AF_SLOT_READ_J(J, idx_, L)                                                                                    \
+  {                                                                                                                   \
+    AfWords u_;                                                                                                       \
+    asm volatile(AF_SLOT_READ_ASM_##J                                                                                 \
+                 : "=&v"(u_.w[0]), "=&v"(u_.w[1]), "=&v"(u_.w[2]), "=&v"(u_.w[3]), "=&v"(u_.w[4]), "=&v"(u_.w[5]),    \
+                   "=&v"(u_.w[6]), "=&v"(u_.w[7]), "=&v"(u_.w[8]), "=&v"(u_.w[9]), "=&v"(u_.w[10])                    \
+                 : "s"(idx_)                                                                                          \
+                 : "scc");                                                                                            \
+    _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) L.v[J][t_] = __hiloint2double((int)u_.w[2 * t_ + 1], (int)u_.w[2 * t_]); \
+    L.c[J] = u_.w[10];                                                                                                \
   }
-#define AF_SLOT_WRITE(idx_expr, L)                                                                                \
-  {                                                                                                               \
-    const unsigned int idx_ = __builtin_amdgcn_readfirstlane(idx_expr);                                           \
-    AF_PUT_0_0(idx_, L) AF_PUT_0_1(idx_, L) AF_PUT_1_0(idx_, L) AF_PUT_1_1(idx_, L) AF_PUT_2_0(idx_, L)           \
-    AF_PUT_2_1(idx_, L) AF_PUT_3_0(idx_, L) AF_PUT_3_1(idx_, L) AF_PUT_4_0(idx_, L) AF_PUT_4_1(idx_, L)           \
+#define AF_SLOT_WRITE_J(J, idx_, L)                                                                                   \
+  {                                                                                                                   \
+    AfWords u_;                                                                                                       \
+    _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_)                                                                  \
+    {                                                                                                                 \
+      u_.w[2 * t_] = (unsigned int)__double2loint(L.v[J][t_]);                                                        \
+      u_.w[2 * t_ + 1] = (unsigned int)__double2hiint(L.v[J][t_]);                                                    \
+    }                                                                                                                 \
+    u_.w[10] = L.c[J];                                                                                                \
+    asm volatile(AF_SLOT_WRITE_ASM_##J                                                                                \
+                 :                                                                                                    \
+                 : "v"(u_.w[0]), "v"(u_.w[1]), "v"(u_.w[2]), "v"(u_.w[3]), "v"(u_.w[4]), "v"(u_.w[5]), "v"(u_.w[6]),  \
+                   "v"(u_.w[7]), "v"(u_.w[8]), "v"(u_.w[9]), "v"(u_.w[10]), "s"(idx_)                                 \
+                 : "scc", AF_SLOT_CLOBBER_##J);                                                                       \
+  }
+// (slot numbers above 4 read slot 4 / write nothing)
+#define AF_SLOT_READ(idx_expr, L)                                                                                     \
+  {                                                                                                                   \
+    const unsigned int idx_ = __builtin_amdgcn_readfirstlane(idx_expr);                                               \
+    AF_SLOT_READ_J(0, idx_, L)                                                                                        \
+    AF_SLOT_READ_J(1, idx_, L)                                                                                        \
+  }
+#define AF_SLOT_WRITE(idx_expr, L)                                                                                    \
+  {                                                                                                                   \
+    const unsigned int idx_ = __builtin_amdgcn_readfirstlane(idx_expr);                                               \
+    AF_SLOT_WRITE_J(0, idx_, L)                                                                                       \
+    AF_SLOT_WRITE_J(1, idx_, L)                                                                                       \
   }
 static_assert(AF_J == 2 && AF_NSLOT == 5, "the slot macros spell out two sub-tiles and five slots");
 
-// MODE: SCALE_NONE (no op of the list has a scale buffer) or SCALE_SITE
 template <int MODE, bool NT>
 __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ plan, unsigned int nops, unsigned int sites,
                                                      const char * aorder, unsigned int ms, double2 * sink,
@@ -310,27 +348,22 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned int q = lane >> 4, rate = (lane >> 2) & 3u, n = lane & 3u;
-  // LDS: [left block][right block][per wave: out stage, in stage][tile word]
+  // LDS: [left block 0][left block 1][right block][per wave: stage 0, stage 1][tile word]
   char * lds = reinterpret_cast<char *>(lds_af);
   const unsigned int lds_b = __builtin_amdgcn_readfirstlane((unsigned int)(uintptr_t)(PLL_LDS char *)lds_af);
-  const unsigned int xbuf_b = lds_b, ybuf_b = lds_b + AF_MAT_B;
-  const unsigned int in_b = lds_b + 2 * AF_MAT_B + wave * 2 * AF_TILE_B + AF_TILE_B;
-  char * outs = lds + 2 * AF_MAT_B + wave * 2 * AF_TILE_B;
-  char * ins = outs + AF_TILE_B;
-  unsigned int * tile_word = reinterpret_cast<unsigned int *>(lds + 2 * AF_MAT_B + 8 * AF_TILE_B);
-  // what never changes for a lane (five registers)
+  const unsigned int x0buf_b = lds_b, x1buf_b = lds_b + AF_MAT_B, ybuf_b = lds_b + 2 * AF_MAT_B;
+  const unsigned int st0_b = lds_b + 3 * AF_MAT_B + wave * 2 * AF_TILE_B, st1_b = st0_b + AF_TILE_B;
+  char * st0 = lds + 3 * AF_MAT_B + wave * 2 * AF_TILE_B;
+  char * st1 = st0 + AF_TILE_B;
+  unsigned int * tile_word = reinterpret_cast<unsigned int *>(lds + 3 * AF_MAT_B + 8 * AF_TILE_B);
+  // what never changes for a lane
   const unsigned int lane16 = lane * 16u;
   const unsigned int boff = n * 640u + rate * 160u + q * 32u;        // its four states 4q.. of sub-tile 0 in a stage
   const unsigned int boff5 = n * 640u + rate * 160u + 128u + q * 8u; // state 16 + q
-  const char * xlane = lds + lane * 8u, * ylane = lds + AF_MAT_B + lane * 8u;
+  const char * x0lane = lds + lane * 8u, * x1lane = lds + AF_MAT_B + lane * 8u, * ylane = lds + 2 * AF_MAT_B + lane * 8u;
   const unsigned long long sink_a = (unsigned long long)(uintptr_t)(sink + ((size_t)blockIdx.x * 4u + wave) * 4u);
   const unsigned long long aorder_a = (unsigned long long)(uintptr_t)aorder;
 
-  AF_SLOT_VARS(s0)
-  AF_SLOT_VARS(s1)
-  AF_SLOT_VARS(s2)
-  AF_SLOT_VARS(s3)
-  AF_SLOT_VARS(s4)
 
   // a matrix block into LDS: 13 pieces of 1 KB dealt to the four waves
   auto stage_matrix = [&](unsigned int buf_b, unsigned int off) __attribute__((always_inline)) {
@@ -343,11 +376,15 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   };
 
   const size_t tiles = ((size_t)sites + AF_WGS - 1) / AF_WGS;
-  // the first op's left block (later tiles: requested by the last op of the tile before)
+  unsigned int xpar = 0u; // which left buffer the current op multiplies by
+  // the first two ops' blocks (from then on every op requests those of the ops ahead, cyclically)
   {
-    const AfW<16, 3> r1 = af_load<16, 3>(plan, 1);
-    if ((r1[18] & AF_KIND_MASK) == 0u) stage_matrix(xbuf_b, r1[16]);
+    const AfW<16, 3> h = af_load<16, 3>(plan, 0), r1 = af_load<16, 3>(plan, 1);
+    if (((h[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x0buf_b, h[16]);
+    if ((r1[18] & AF_KIND_MASK) <= 1u) stage_matrix(ybuf_b, r1[17]);
+    if (((r1[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x1buf_b, r1[16]);
   }
+  unsigned int ch[4];  // tip characters of the op after next: lane l holds those of site l & 7 of the tile
   for (size_t round = 0;; ++round)
   {
     // a workgroup's first tiles are its own by a fixed stride, the last rounds' worth come from a
@@ -366,18 +403,20 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     const unsigned long long clv_off = (unsigned long long)site0 * 640u;
     const unsigned long long cnt_off = (unsigned long long)site0 * 4u;
 
-    // an operand without a slot: from HBM through the wave's in stage into a slot (AF_RELOAD_TAKE)
+    // an operand without a slot: from HBM through stage 1 into a slot (AF_RELOAD_TAKE)
     auto reload_issue = [&](unsigned long long src) __attribute__((always_inline)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the stage's last readers are done)
 #pragma unroll
-      for (unsigned int it = 0; it < 5; ++it) af_dma16(in_b + it * 1024u, src + clv_off + it * 1024u, lane16);
+      for (unsigned int it = 0; it < 5; ++it) af_dma16(st1_b + it * 1024u, src + clv_off + it * 1024u, lane16);
     };
     auto reload_counts = [&](unsigned long long cnt, unsigned int (&cj)[AF_J]) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < AF_J; ++j)
       {
         cj[j] = 0u;
-        if (MODE != SCALE_NONE && cnt) cj[j] = *(const unsigned int PLL_GLOBAL *)(af_base(cnt + cnt_off) + (4u * j + n) * 4u);
+        unsigned int o = (4u * j + n) * 4u;
+        asm volatile("" : "+v"(o));
+        if (MODE != SCALE_NONE && cnt) cj[j] = *(const unsigned int PLL_GLOBAL *)(af_base(cnt + cnt_off) + o);
       }
     };
     // (a macro, not a lambda: a lambda would capture the slot variables by reference, and
@@ -386,22 +425,67 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   {                                                                \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
     AfSlot tmp;                                                    \
-    af_read_tile(ins + boff, ins + boff5, tmp.v);                  \
+    af_read_tile(st1 + boff, st1 + boff5, tmp.v);                  \
     tmp.c[0] = cj[0];                                              \
     tmp.c[1] = cj[1];                                              \
     AF_SLOT_WRITE(slot, tmp)                                       \
   }
-    // the tip characters of an op (record words 8..15: four rows): lane l holds those of site l & 7
-    auto request_chars = [&](const AfW<8, 11> & r, unsigned int (&c)[4]) __attribute__((always_inline)) {
+    // the tip characters of the op BEHIND record r (words 8..15: its four rows)
+    auto request_chars = [&](const AfW<0, 28> & r, unsigned int (&c)[4]) __attribute__((always_inline)) {
+      unsigned int l7 = lane & 7u;
+      asm volatile("" : "+v"(l7)); // (see the stores: keeps the address "scalar base + lane offset")
 #pragma unroll
-      for (int k = 0; k < 4; ++k) c[k] = *(const unsigned char PLL_GLOBAL *)(af_base(r.quad(8 + 2 * k) + site0) + (lane & 7u));
+      for (int k = 0; k < 4; ++k) c[k] = *(const unsigned char PLL_GLOBAL *)(af_base(r.quad(8 + 2 * k) + site0) + l7);
+    };
+    // what an op of kind `nkind` gathers an op ahead, with its characters (in ch): a lookup its
+    // table entries -- LDS-DMA with one address per lane, straight into the two stages in the
+    // layout of the stores --, a tip-inner op the tip's factor (a row of its table per site, into stage 0)
+    auto next_gathers = [&](unsigned int nkind, unsigned long long tab_l, unsigned long long tab_r) __attribute__((always_inline)) {
+      if (nkind == 2u)
+      {
+        unsigned int lane_l = lane;
+        asm volatile("" : "+v"(lane_l)); // (site and column of five granules: recomputed, not kept)
+        unsigned int c1 = ch[0], c2 = ch[1], c3 = ch[2], c4 = ch[3];
+        if (c1 >= ms) c1 = 0;
+        if (c2 >= ms) c2 = 0;
+        if (c3 >= ms) c3 = 0;
+        if (c4 >= ms) c4 = 0;
+        const unsigned int p1 = c1 * ms + c2, p2 = c3 * ms + c4;
+#pragma unroll
+        for (unsigned int it = 0; it < 5; ++it)
+        {
+          const unsigned int gi = it * 64u + lane_l, sl = gi / 40u, rr = gi - 40u * sl;
+          const unsigned int q1 = (unsigned int)__shfl((int)p1, (int)sl, 64);
+          const unsigned int q2 = (unsigned int)__shfl((int)p2, (int)sl, 64);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          af_dma16(st0_b + it * 1024u, tab_l, (q1 * 40u + rr) * 16u);
+          af_dma16(st1_b + it * 1024u, tab_r, (q2 * 40u + rr) * 16u);
+        }
+      }
+      else if (nkind == 1u)
+      {
+        // the tip's factor: row `code` of its table is 640 bytes laid out like a site of a CLV
+        unsigned int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        unsigned int c1 = ch[0];
+        if (c1 >= ms) c1 = 0;
+#pragma unroll
+        for (unsigned int it = 0; it < 5; ++it)
+        {
+          const unsigned int gi = it * 64u + lane_l, sl = gi / 40u, rr = gi - 40u * sl;
+          const unsigned int q1 = (unsigned int)__shfl((int)c1, (int)sl, 64);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          af_dma16(st0_b + it * 1024u, tab_l, (q1 * 40u + rr) * 16u);
+        }
+      }
     };
 
-    // ---- prologue: what the op before op 0 would have done for it
-    unsigned int ch[4];
+    // ---- prologue: what the ops before op 0 would have done for it (reloads, characters, gathers)
+    AfW<0, 28> rc_a = af_load<0, 28>(plan, 1), rc_b;
     {
-      const AfW<16, 12> h = af_load<16, 12>(plan, 0);
+      const AfW<0, 28> h = af_load<0, 28>(plan, 0);
       const unsigned int hf = __builtin_amdgcn_readfirstlane(h[18]);
+      // (the stages' last readers -- the tile before -- are done)
       if (hf & AF_RELOAD_A)
       {
         unsigned int cj[AF_J];
@@ -416,255 +500,49 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
         reload_counts(h.quad(26), cj);
         AF_RELOAD_TAKE((h[19] >> 16) & 15u, cj)
       }
-      request_chars(af_load<8, 11>(plan, 1), ch);
+      request_chars(h, ch); // op 0's
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      next_gathers(__builtin_amdgcn_readfirstlane(rc_a[18]) & AF_KIND_MASK, rc_a.quad(4), rc_a.quad(6));
+      request_chars(rc_a, ch); // op 1's
     }
-    AfW<0, 28> rc = af_load<0, 28>(plan, 1);
+    // (the first tile's blocks were requested without a barrier behind them; a tile's last stores
+    // are waited for here too: once per tile)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
-    for (unsigned int i = 0; i < nops; ++i)
+#ifdef PLLHIP_AF_TIMING
+    // (tool build, tools/aa_fused_timing.sh: where a wave's cycles go, by op kind and phase)
+    unsigned long long seg[3][6] = {};
+    unsigned int nkind_ops[3] = {};
+    unsigned long long t_last = __builtin_readcyclecounter();
+#define AF_TICK(ph) { const unsigned long long t_now = __builtin_readcyclecounter(); seg[kind][ph] += t_now - t_last; t_last = t_now; }
+#else
+#define AF_TICK(ph)
+#endif
+    for (unsigned int i = 0;;)
     {
-      const unsigned int fl = __builtin_amdgcn_readfirstlane(rc[18]);
-      const unsigned int kind = fl & AF_KIND_MASK;
-      const unsigned int slots = __builtin_amdgcn_readfirstlane(rc[19]);
-      const bool scaling = MODE != SCALE_NONE && (fl & AF_SCALING);
-
-      // ---- barrier 1: the left block has landed everywhere, everybody is done with op i - 1.
-      // The block was requested BEFORE the previous op's six stores: they may stay in flight.
-      if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kind <= 1u) stage_matrix(ybuf_b, rc[17]);
-      unsigned int ra_cj[AF_J], rb_cj[AF_J];
-      if (fl & AF_RELOAD_A)
-      {
-        reload_issue(rc.quad(20));
-        reload_counts(rc.quad(22), ra_cj);
-      }
-
-      double x[AF_J][5];        // the left factor, then the product
-      unsigned int lc[AF_J], rcn[AF_J];
-#pragma unroll
-      for (int j = 0; j < AF_J; ++j) lc[j] = rcn[j] = 0u;
-      if (kind == 0u)
-      {
-        AfSlot l;
-        AF_SLOT_READ(slots & 15u, l)
-#pragma unroll
-        for (int j = 0; j < AF_J; ++j) lc[j] = l.c[j];
-        af_matvec<false>(xlane, q, l.v, x);
-      }
-      else if (kind == 1u)
-      {
-        // tip-inner: the tip's factor is a row of its table (requested now, used after the products)
-        const af_gptr tab = af_base(rc.quad(4));
-#pragma unroll
-        for (int j = 0; j < AF_J; ++j)
-        {
-          unsigned int code = (unsigned int)__shfl((int)ch[0], 4 * j + (int)n, 64);
-          if (code >= ms) code = 0;
-          const unsigned int e = (code * 4u + rate) * 160u;
-          const pll_v2d v0 = *(const pll_v2d PLL_GLOBAL *)(tab + (e + q * 32u));
-          const pll_v2d v1 = *(const pll_v2d PLL_GLOBAL *)(tab + (e + q * 32u + 16u));
-          x[j][0] = v0.x; x[j][1] = v0.y; x[j][2] = v1.x; x[j][3] = v1.y;
-          x[j][4] = *(const double PLL_GLOBAL *)(tab + (e + 128u + q * 8u));
-        }
-      }
-      if (fl & AF_RELOAD_A) AF_RELOAD_TAKE((slots >> 12) & 15u, ra_cj)
-
-      // ---- barrier 2: the right block has landed, everybody is done with the left one
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      // what the next op needs: its characters, its left block (the six stores of this op
-      // follow: barrier 1 of the next op lets exactly those stay in flight).  (The record behind
-      // the last op's is a copy of op 0's: the next tile begins with it.)
-      unsigned int nch[4];
-      {
-        const AfW<8, 11> rn = af_load<8, 11>(plan, i + 2);
-        request_chars(rn, nch);
-        asm volatile("" ::: "memory");
-        if ((rn[18] & AF_KIND_MASK) == 0u) stage_matrix(xbuf_b, rn[16]);
-      }
-      if (fl & AF_RELOAD_B)
-      {
-        reload_issue(rc.quad(24));
-        reload_counts(rc.quad(26), rb_cj);
-      }
-
-      double2 g[5];            // the finished tile, 16 bytes per lane: granule it * 64 + lane
-      unsigned int pc[AF_J];   // the parent's counts, lane's own site of each sub-tile
-#pragma unroll
-      for (int j = 0; j < AF_J; ++j) pc[j] = 0u;
-      AfSlot p;                // the parent in the operand layout (what its slot takes)
-#pragma unroll
-      for (int j = 0; j < AF_J; ++j)
-      {
-#pragma unroll
-        for (int t = 0; t < 5; ++t) p.v[j][t] = 0.0;
-        p.c[j] = 0u;
-      }
-      if (kind <= 1u)
-      {
-        {
-          AfSlot r;
-          AF_SLOT_READ((slots >> 4) & 15u, r)
-#pragma unroll
-          for (int j = 0; j < AF_J; ++j) rcn[j] = r.c[j];
-          af_matvec<true>(ylane, q, r.v, x);
-        }
-#pragma unroll
-        for (int j = 0; j < AF_J; ++j)
-        {
-          bool small = true;
-#pragma unroll
-          for (int t = 0; t < 5; ++t)
-          {
-            p.v[j][t] = x[j][t];
-            small = small && (p.v[j][t] < PLLHIP_SCALE_THRESHOLD);
-          }
-          // scaling rule of core_partials_avx2.c:752-800: every entry of the site below the threshold
-          unsigned int scaled = 0u;
-          if (scaling)
-          {
-            const unsigned long long bal = __ballot(small), m = 0x1111111111111111ull << n;
-            scaled = (bal & m) == m ? 1u : 0u;
-            if (__ballot(scaled != 0u))
-            {
-              const double f = scaled ? PLLHIP_SCALE_FACTOR : 1.0;
-#pragma unroll
-              for (int t = 0; t < 5; ++t) p.v[j][t] *= f;
-            }
-          }
-          pc[j] = scaling ? ((fl & AF_LCNT) ? lc[j] : 0u) + ((fl & AF_RCNT) ? rcn[j] : 0u) + scaled : 0u;
-          p.c[j] = pc[j];
-        }
-        // through the wave's out stage into the layout of the stores
-#pragma unroll
-        for (int j = 0; j < AF_J; ++j)
-        {
-          *reinterpret_cast<double2 *>(outs + boff + j * 2560) = make_double2(p.v[j][0], p.v[j][1]);
-          *reinterpret_cast<double2 *>(outs + boff + j * 2560 + 16) = make_double2(p.v[j][2], p.v[j][3]);
-          *reinterpret_cast<double *>(outs + boff5 + j * 2560) = p.v[j][4];
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 5; ++it) g[it] = *reinterpret_cast<const double2 *>(outs + it * 1024 + lane16);
-        asm volatile("" ::: "memory");
-      }
-      else
-      {
-        // lookup: parent = TL[pair 1] (.) TR[pair 2] (k_aa_cherry_rounds, partials_aa_mfma.hip)
-        // (the lane number through an empty asm: what is derived from it below -- site and column
-        // of five granules -- is recomputed here instead of living in ten registers all along)
-        unsigned int lane_l = lane;
-        asm volatile("" : "+v"(lane_l));
-        unsigned int c1 = ch[0], c2 = ch[1], c3 = ch[2], c4 = ch[3];
-        if (c1 >= ms) c1 = 0;
-        if (c2 >= ms) c2 = 0;
-        if (c3 >= ms) c3 = 0;
-        if (c4 >= ms) c4 = 0;
-        const unsigned int p1 = c1 * ms + c2, p2 = c3 * ms + c4;
-        const af_gptr tl = af_base(rc.quad(4)), tr = af_base(rc.quad(6));
-        unsigned long long bal[5];
-        // in two halves the scheduler may not mix (it would keep all five iterations' indices,
-        // addresses and operands alive at once, on top of the slots): where, fetch, multiply
-        auto lookup_part = [&](auto first_c, auto count_c) __attribute__((always_inline)) {
-          constexpr unsigned int FIRST = decltype(first_c)::value, COUNT = decltype(count_c)::value;
-          unsigned int o1[COUNT], o2[COUNT];
-#pragma unroll
-          for (unsigned int u = 0; u < COUNT; ++u)
-          {
-            const unsigned int gi = (FIRST + u) * 64u + lane_l, sl = gi / 40u, rr = gi - 40u * sl;
-            const unsigned int q1 = (unsigned int)__shfl((int)p1, (int)sl, 64);
-            const unsigned int q2 = (unsigned int)__shfl((int)p2, (int)sl, 64);
-            o1[u] = (q1 * 40u + rr) * 16u;
-            o2[u] = (q2 * 40u + rr) * 16u;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          pll_v2d a[COUNT], b[COUNT];
-#pragma unroll
-          for (unsigned int u = 0; u < COUNT; ++u)
-          {
-            a[u] = *(const pll_v2d PLL_GLOBAL *)(tl + o1[u]);
-            b[u] = *(const pll_v2d PLL_GLOBAL *)(tr + o2[u]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (unsigned int u = 0; u < COUNT; ++u)
-          {
-            g[FIRST + u] = make_double2(a[u].x * b[u].x, a[u].y * b[u].y);
-            bal[FIRST + u] = __ballot((g[FIRST + u].x < PLLHIP_SCALE_THRESHOLD) & (g[FIRST + u].y < PLLHIP_SCALE_THRESHOLD));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        };
-        lookup_part(std::integral_constant<unsigned int, 0>{}, std::integral_constant<unsigned int, 3>{});
-        lookup_part(std::integral_constant<unsigned int, 3>{}, std::integral_constant<unsigned int, 2>{});
-        // bit s: every entry of site s of the tile below the threshold.  The 320 flags of the tile
-        // are five wave masks; site s owns bits [40 s, 40 s + 40).  (Nearly always no flag is set.)
-        unsigned int scaled = 0u;
-        if (scaling && (bal[0] | bal[1] | bal[2] | bal[3] | bal[4]) != 0ull)
-        {
-#pragma unroll
-          for (int s = 0; s < AF_WS; ++s)
-          {
-            constexpr unsigned long long F40 = (1ull << 40) - 1ull;
-            const int w = (40 * s) / 64, off = (40 * s) % 64;
-            unsigned long long field = bal[w] >> off;
-            if (off > 24) field |= bal[w + 1 < 5 ? w + 1 : 4] << (64 - off);
-            scaled |= ((field & F40) == F40) ? 1u << s : 0u;
-          }
-          scaled = __builtin_amdgcn_readfirstlane(scaled);
-          if (scaled)
-#pragma unroll
-            for (unsigned int it = 0; it < 5; ++it)
-            {
-              const unsigned int sl = (it * 64u + lane_l) / 40u;
-              const double f = ((scaled >> sl) & 1u) ? PLLHIP_SCALE_FACTOR : 1.0;
-              g[it].x *= f;
-              g[it].y *= f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < AF_J; ++j) pc[j] = (scaled >> (4 * j + n)) & 1u; // (both children are tip-tip results: nothing to inherit)
-        if (fl & AF_HAS_PSLOT)
-        {
-#pragma unroll
-          for (int it = 0; it < 5; ++it) *reinterpret_cast<double2 *>(outs + it * 1024 + lane16) = g[it];
-          asm volatile("" ::: "memory");
-          af_read_tile(outs + boff, outs + boff5, p.v);
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int j = 0; j < AF_J; ++j) p.c[j] = pc[j];
-        }
-      }
-      // the parent's slot (ONE place for both kinds, and no branch around it: slot 15 is nobody's)
-      AF_SLOT_WRITE((fl & AF_HAS_PSLOT) ? (slots >> 8) & 15u : 15u, p)
-      if (fl & AF_RELOAD_B) AF_RELOAD_TAKE((slots >> 16) & 15u, rb_cj)
-
-      // ---- the six stores (always six: barrier 1 of the next op counts on it): the counts --
-      // to the wave's sink when the op has no scale buffer --, then the tile, 5 KB contiguous
-      {
-        const unsigned int mine = (lane & 4u) ? pc[1] : pc[0];
-        const af_gptr cdst = af_base(scaling ? rc.quad(2) + cnt_off : sink_a);
-        asm volatile("" ::: "memory");
-        if (lane < (unsigned int)AF_WS) *(unsigned int PLL_GLOBAL *)(cdst + lane * 4u) = mine;
-        asm volatile("" ::: "memory");
-        const af_gptr out = af_base(rc.quad(0) + clv_off);
-#pragma unroll
-        for (unsigned int it = 0; it < 5; ++it)
-        {
-          const pll_v2d v = {g[it].x, g[it].y};
-          pll_v2d PLL_GLOBAL * dst = (pll_v2d PLL_GLOBAL *)(out + (lane16 + it * 1024u));
-          if (NT) __builtin_nontemporal_store(v, dst);
-          else *dst = v;
-          asm volatile("" ::: "memory");
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) ch[k] = nch[k];
-      // the next op's record: on its way during barrier 1
-      rc = af_load<0, 28>(plan, i + 2);
+#define AF_RC rc_a
+#define AF_RN rc_b
+#include "partials_aa_fused_op.inc"
+#undef AF_RC
+#undef AF_RN
+      if (++i == nops) break;
+#define AF_RC rc_b
+#define AF_RN rc_a
+#include "partials_aa_fused_op.inc"
+#undef AF_RC
+#undef AF_RN
+      if (++i == nops) break;
     }
+#ifdef PLLHIP_AF_TIMING
+    if (lane == 0 && round == 2 && wave == 1 && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == 202 || blockIdx.x == 303))
+      for (int kd = 0; kd < 3; ++kd)
+        if (nkind_ops[kd])
+          printf("kind %d: %u ops: first half %llu, wait A %llu, barrier A %llu, second half %llu, barrier B %llu, end %llu cycles per op\n",
+                 kd, nkind_ops[kd], seg[kd][0] / nkind_ops[kd], seg[kd][1] / nkind_ops[kd], seg[kd][2] / nkind_ops[kd],
+                 seg[kd][3] / nkind_ops[kd], seg[kd][4] / nkind_ops[kd], seg[kd][5] / nkind_ops[kd]);
+#endif
   }
 }
 } // namespace
@@ -913,25 +791,31 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     }
   };
   reloads_of(recs[0], fplan[0]);
+  // what each op brings along itself: its rows, its left block, its kind -- recorded with the op BEFORE
+  // it (the header for op 0; the last op names op 0 again: the list is walked tile after tile)
+  std::vector<AaRec> own(n);
+  memset(own.data(), 0, n * sizeof(AaRec));
   for (unsigned int pos = 0; pos < n; ++pos)
   {
     const FusedOp & f = fplan[pos];
     const int oi = orig[f.list_pos];
     const int kind = kinds[oi] == 3 ? 2 : kinds[oi];
     AaRec & r = recs[pos + 1];
+    AaRec & o = own[pos];
     r.parent = (unsigned long long)(uintptr_t)f.parent;
     r.pscaler = (unsigned long long)(uintptr_t)f.pscaler;
     r.flags = (unsigned int)kind;
+    o.flags = (unsigned int)kind;
     if (f.pslot >= 0) r.flags |= AF_HAS_PSLOT;
     if (f.pscaler) r.flags |= AF_SCALING;
     if (kind == 0 && f.lsc_slot >= 0) r.flags |= AF_LCNT;
     if (kind <= 1 && f.rsc_slot >= 0) r.flags |= AF_RCNT;
     r.slots = slot4(f.lslot) | slot4(f.rslot) << 4 | slot4(f.pslot) << 8;
-    for (int t = 0; t < 4; ++t) r.row[t] = zero_row;
+    for (int t = 0; t < 4; ++t) o.row[t] = zero_row;
     if (kind == 0)
     {
-      r.xoff = (unsigned int)(mj.size() * AF_MAT_B);
-      mj.push_back(AfMatJob{f.lmat, (unsigned long long)r.xoff});
+      o.xoff = (unsigned int)(mj.size() * AF_MAT_B);
+      mj.push_back(AfMatJob{f.lmat, (unsigned long long)o.xoff});
     }
     if (kind <= 1)
     {
@@ -940,7 +824,7 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     }
     if (kind == 1)
     {
-      r.row[0] = (unsigned long long)(uintptr_t)f.ltip;
+      o.row[0] = (unsigned long long)(uintptr_t)f.ltip;
       r.tab_l = (unsigned long long)(tj.size() * tip_tab_b); // (made absolute below)
       tj.push_back(AfTipJob{f.lmat, (unsigned long long)(tj.size() * tip_tab_b)});
     }
@@ -949,12 +833,21 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       const AaLookupTables & t = tabs[lk_index[pos]];
       r.tab_l = (unsigned long long)(uintptr_t)t.tl;
       r.tab_r = (unsigned long long)(uintptr_t)t.tr;
-      r.row[0] = (unsigned long long)(uintptr_t)t.t1;
-      r.row[1] = (unsigned long long)(uintptr_t)t.t2;
-      r.row[2] = (unsigned long long)(uintptr_t)t.t3;
-      r.row[3] = (unsigned long long)(uintptr_t)t.t4;
+      o.row[0] = (unsigned long long)(uintptr_t)t.t1;
+      o.row[1] = (unsigned long long)(uintptr_t)t.t2;
+      o.row[2] = (unsigned long long)(uintptr_t)t.t3;
+      o.row[3] = (unsigned long long)(uintptr_t)t.t4;
     }
     if (pos + 1 < n) reloads_of(r, fplan[pos + 1]);
+  }
+  for (unsigned int pos = 0; pos <= n; ++pos)
+  {
+    // recs[pos] is the record before op `pos` (recs[0]: the header; recs[n] names op 0 again)
+    const AaRec & o = own[pos == n ? 0 : pos];
+    AaRec & r = recs[pos];
+    for (int t = 0; t < 4; ++t) r.row[t] = o.row[t];
+    r.xoff = o.xoff;
+    r.flags |= (o.flags & AF_KIND_MASK) << 8;
   }
   if ((mj.size() + 1) * (size_t)AF_MAT_B > 0xffffffffull) return 1;
   // buffers: matrices in operand order, tip tables
@@ -976,8 +869,6 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   }
   for (unsigned int pos = 0; pos < n; ++pos)
     if ((recs[pos + 1].flags & AF_KIND_MASK) == 1u) recs[pos + 1].tab_l += (unsigned long long)(uintptr_t)k.d_titab;
-  recs[n + 1] = recs[1]; // (the next tile begins with op 0: its left block is requested by the last op)
-  recs[n + 1].flags &= ~(AF_RELOAD_A | AF_RELOAD_B);
 
   const size_t rec_b = recs.size() * sizeof(AaRec), mat_b = (mj.size() + 1) * sizeof(AfMatJob),
                tip_b = (tj.size() + 1) * sizeof(AfTipJob);
