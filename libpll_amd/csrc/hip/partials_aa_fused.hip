@@ -75,7 +75,7 @@ struct AaRec
   unsigned long long pscaler;     // its scale buffer (0: none)
   unsigned long long tab_l;       // lookup: table of pair 1; tip-inner: the tip's table [code][rate][state]
   unsigned long long tab_r;       // lookup: table of pair 2
-  unsigned long long row[4];      // tip rows OF THE NEXT OP: lookup (t1, t2), (t3, t4); tip-inner row[0]; else rows of zeros
+  unsigned long long row[4];      // tip rows OF THE OP AFTER NEXT: lookup (t1, t2), (t3, t4); tip-inner row[0]; else rows of zeros
   unsigned int xoff, yoff;        // byte offsets (operand order): left block OF THE NEXT OP, right block of this op
   unsigned int flags;             // AF_* below; bits 8-9: kind of the next op
   unsigned int slots;             // lslot | rslot << 4 | pslot << 8 | ra_slot << 12 | rb_slot << 16
@@ -144,6 +144,15 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
   }
 }
 
+#ifdef PLLHIP_AF_TIMING
+// (tool build: PLLHIP_AF_EXP=mask switches parts of the kernel off -- wrong results, for timing only:
+// 1 no matrix-core products, 2 no stores, 4 no gathers, 8 no block staging, 16 no barriers)
+__device__ unsigned int af_exp_mask;
+#define AF_EXP(bit) (exp_mask & (bit))
+#else
+#define AF_EXP(bit) false
+#endif
+
 // ---- device helpers
 typedef const unsigned int __attribute__((address_space(4))) * af_words;
 // words [FIRST, FIRST + N) of record i, through the scalar cache
@@ -178,14 +187,34 @@ __device__ __forceinline__ af_gptr af_base(unsigned long long uniform_address)
 }
 
 // 64 lanes x 16 bytes from global memory straight into LDS (lane l lands at lds_b + 16 l).  Inline
-// assembly on purpose: the compiler neither counts it nor waits for it; the waits are ours.
-__device__ __forceinline__ void af_dma16(unsigned int lds_b, unsigned long long uniform_src, unsigned int lane16)
+// assembly on purpose: the compiler neither counts it nor waits for it; the waits are ours.  The
+// instruction's immediate offset moves BOTH addresses (tools/dma_offset_probe.hip), so N consecutive
+// KiB cost one M0 and N instructions.
+template <int N>
+__device__ __forceinline__ void af_dma_run(unsigned int lds_b, unsigned long long uniform_src, unsigned int lane16)
 {
-  unsigned int m0_saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(m0_saved)
-               : "s"(lds_b), "v"(lane16), "s"(uniform_src)
-               : "memory");
+  static_assert(N >= 1 && N <= 4, "immediate offsets reach 4095");
+  if (N == 1)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory", "m0");
+  else if (N == 4)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
+                 :: "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory", "m0");
+  else
+    static_assert(N == 1 || N == 4, "");
+}
+// a gather: five KiB of LDS from five lane offsets each (voff[it] relative to table); the first four
+// share an M0 -- the immediate offset that advances the LDS address advances the global one as well,
+// which a base moved back by 3 KiB and lane offsets moved forward by (3 - it) KiB undo
+__device__ __forceinline__ void af_dma_gather5(unsigned int lds_b, unsigned long long table, const unsigned int (&voff)[5])
+{
+  const unsigned int v0 = voff[0] + 3072u, v1 = voff[1] + 2048u, v2 = voff[2] + 1024u;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+               "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072"
+               :: "s"(lds_b), "v"(v0), "v"(v1), "v"(v2), "v"(voff[3]), "s"(table - 3072ull) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds_b + 4096u), "v"(voff[4]), "s"(table) : "memory", "m0");
 }
 
 struct AfSlot
@@ -195,40 +224,74 @@ struct AfSlot
 };
 
 // x[j][t] = (MUL ? x[j][t] : 1) * (P . column)[state 4q + t | 16 + q], reference order;
-// mat_lane: the block in LDS (operand order) + 8 lane
+// mat_lane: the block in LDS (operand order) + 8 lane.  Software-pipelined by hand: the A operands of
+// row group t + 1 are fetched before the sixteen MFMAs of group t are issued, and the three adds of
+// group t wait until those of group t + 1 are in the pipe -- a wave has nobody to hide its LDS and
+// matrix-core latencies behind but itself (two waves per SIMD).
+struct AfAops
+{
+  double a1[4], a4;
+};
+__device__ __forceinline__ void af_fetch_a(const char * mat_lane, int t, AfAops & a)
+{
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a.a1[m] = *reinterpret_cast<const double *>(mat_lane + (t * 5 + m) * 512);
+  a.a4 = *reinterpret_cast<const double *>(mat_lane + (t * 5 + 4) * 512);
+}
+__device__ __forceinline__ void af_group(const AfAops & a, unsigned int q, const double (&b)[AF_J][5], double (&acc)[AF_J][4])
+{
+#pragma unroll
+  for (int j = 0; j < AF_J; ++j)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[j][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.a1[m], b[j][m], 0.0, 0, 0, 0);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+  {
+    const double am = (q == (unsigned int)m) ? a.a4 : 0.0;
+#pragma unroll
+    for (int j = 0; j < AF_J; ++j) acc[j][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, b[j][4], acc[j][m], 0, 0, 0);
+  }
+}
+template <bool MUL>
+__device__ __forceinline__ void af_sum(const double (&acc)[AF_J][4], int t, double (&x)[AF_J][5])
+{
+#pragma unroll
+  for (int j = 0; j < AF_J; ++j)
+  {
+    const double sum = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+    x[j][t] = MUL ? x[j][t] * sum : sum;
+    // (the value is wanted here, see rate_matvec_chain in aa_mfma.hpp)
+    asm volatile("" : "+v"(x[j][t]));
+  }
+}
 template <bool MUL>
 __device__ __forceinline__ void af_matvec(const char * mat_lane, unsigned int q, const double (&b)[AF_J][5],
                                           double (&x)[AF_J][5])
 {
-#pragma unroll
-  for (int t = 0; t < 5; ++t)
-  {
-    double a1[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) a1[m] = *reinterpret_cast<const double *>(mat_lane + (t * 5 + m) * 512);
-    const double a4 = *reinterpret_cast<const double *>(mat_lane + (t * 5 + 4) * 512);
-    double acc[AF_J][4];
-#pragma unroll
-    for (int j = 0; j < AF_J; ++j)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) acc[j][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[m], b[j][m], 0.0, 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-    {
-      const double am = (q == (unsigned int)m) ? a4 : 0.0;
-#pragma unroll
-      for (int j = 0; j < AF_J; ++j) acc[j][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, b[j][4], acc[j][m], 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < AF_J; ++j)
-    {
-      const double sum = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
-      x[j][t] = MUL ? x[j][t] * sum : sum;
-      // (the value is wanted here, see rate_matvec_chain in aa_mfma.hpp)
-      asm volatile("" : "+v"(x[j][t]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  AfAops a0, a1;
+  double acc0[AF_J][4], acc1[AF_J][4];
+  af_fetch_a(mat_lane, 0, a0);
+  __builtin_amdgcn_sched_barrier(0);
+  af_fetch_a(mat_lane, 1, a1);
+  af_group(a0, q, b, acc0);
+  __builtin_amdgcn_sched_barrier(0);
+  af_fetch_a(mat_lane, 2, a0);
+  af_group(a1, q, b, acc1);
+  af_sum<MUL>(acc0, 0, x);
+  __builtin_amdgcn_sched_barrier(0);
+  af_fetch_a(mat_lane, 3, a1);
+  af_group(a0, q, b, acc0);
+  af_sum<MUL>(acc1, 1, x);
+  __builtin_amdgcn_sched_barrier(0);
+  af_fetch_a(mat_lane, 4, a0);
+  af_group(a1, q, b, acc1);
+  af_sum<MUL>(acc0, 2, x);
+  __builtin_amdgcn_sched_barrier(0);
+  af_group(a0, q, b, acc0);
+  af_sum<MUL>(acc1, 3, x);
+  __builtin_amdgcn_sched_barrier(0);
+  af_sum<MUL>(acc0, 4, x);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // a tile in the lane layout of the MFMA operands, out of a stage in LDS
@@ -365,14 +428,16 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   const unsigned long long aorder_a = (unsigned long long)(uintptr_t)aorder;
 
 
-  // a matrix block into LDS: 13 pieces of 1 KB dealt to the four waves
+#ifdef PLLHIP_AF_TIMING
+  const unsigned int exp_mask = __builtin_amdgcn_readfirstlane(af_exp_mask);
+#endif
+  // a matrix block into LDS: 13 pieces of 1 KB over the four waves
   auto stage_matrix = [&](unsigned int buf_b, unsigned int off) __attribute__((always_inline)) {
-#pragma unroll
-    for (unsigned int r = 0; r < 4; ++r)
-    {
-      const unsigned int piece = r * 4u + wave;
-      if (piece < (unsigned int)AF_MAT_PIECES) af_dma16(buf_b + piece * 1024u, aorder_a + off + piece * 1024u, lane16);
-    }
+    if (AF_EXP(8u)) return;
+    // (waves 0..2 four consecutive pieces each, wave 3 the thirteenth)
+    const unsigned int w4 = wave * 4096u;
+    if (wave < 3u) af_dma_run<4>(buf_b + w4, aorder_a + off + w4, lane16);
+    else af_dma_run<1>(buf_b + 12288u, aorder_a + off + 12288u, lane16);
   };
 
   const size_t tiles = ((size_t)sites + AF_WGS - 1) / AF_WGS;
@@ -384,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     if ((r1[18] & AF_KIND_MASK) <= 1u) stage_matrix(ybuf_b, r1[17]);
     if (((r1[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x1buf_b, r1[16]);
   }
-  unsigned int ch[4];  // tip characters of the op after next: lane l holds those of site l & 7 of the tile
+  unsigned int ch_p[4], ch_q[4]; // tip characters of the next op / the op after next, in turn: lane l holds those of site l & 7
   for (size_t round = 0;; ++round)
   {
     // a workgroup's first tiles are its own by a fixed stride, the last rounds' worth come from a
@@ -406,8 +471,8 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     // an operand without a slot: from HBM through stage 1 into a slot (AF_RELOAD_TAKE)
     auto reload_issue = [&](unsigned long long src) __attribute__((always_inline)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the stage's last readers are done)
-#pragma unroll
-      for (unsigned int it = 0; it < 5; ++it) af_dma16(st1_b + it * 1024u, src + clv_off + it * 1024u, lane16);
+      af_dma_run<4>(st1_b, src + clv_off, lane16);
+      af_dma_run<1>(st1_b + 4096u, src + clv_off + 4096u, lane16);
     };
     auto reload_counts = [&](unsigned long long cnt, unsigned int (&cj)[AF_J]) __attribute__((always_inline)) {
 #pragma unroll
@@ -440,7 +505,8 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     // what an op of kind `nkind` gathers an op ahead, with its characters (in ch): a lookup its
     // table entries -- LDS-DMA with one address per lane, straight into the two stages in the
     // layout of the stores --, a tip-inner op the tip's factor (a row of its table per site, into stage 0)
-    auto next_gathers = [&](unsigned int nkind, unsigned long long tab_l, unsigned long long tab_r) __attribute__((always_inline)) {
+    auto next_gathers = [&](unsigned int nkind, unsigned long long tab_l, unsigned long long tab_r, const unsigned int (&ch)[4]) __attribute__((always_inline)) {
+      if (AF_EXP(4u)) return;
       if (nkind == 2u)
       {
         unsigned int lane_l = lane;
@@ -451,16 +517,18 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
         if (c3 >= ms) c3 = 0;
         if (c4 >= ms) c4 = 0;
         const unsigned int p1 = c1 * ms + c2, p2 = c3 * ms + c4;
+        unsigned int o1[5], o2[5];
 #pragma unroll
         for (unsigned int it = 0; it < 5; ++it)
         {
           const unsigned int gi = it * 64u + lane_l, sl = gi / 40u, rr = gi - 40u * sl;
           const unsigned int q1 = (unsigned int)__shfl((int)p1, (int)sl, 64);
           const unsigned int q2 = (unsigned int)__shfl((int)p2, (int)sl, 64);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          af_dma16(st0_b + it * 1024u, tab_l, (q1 * 40u + rr) * 16u);
-          af_dma16(st1_b + it * 1024u, tab_r, (q2 * 40u + rr) * 16u);
+          o1[it] = (q1 * 40u + rr) * 16u;
+          o2[it] = (q2 * 40u + rr) * 16u;
         }
+        af_dma_gather5(st0_b, tab_l, o1);
+        af_dma_gather5(st1_b, tab_r, o2);
       }
       else if (nkind == 1u)
       {
@@ -469,14 +537,15 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
         asm volatile("" : "+v"(lane_l));
         unsigned int c1 = ch[0];
         if (c1 >= ms) c1 = 0;
+        unsigned int o1[5];
 #pragma unroll
         for (unsigned int it = 0; it < 5; ++it)
         {
           const unsigned int gi = it * 64u + lane_l, sl = gi / 40u, rr = gi - 40u * sl;
           const unsigned int q1 = (unsigned int)__shfl((int)c1, (int)sl, 64);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          af_dma16(st0_b + it * 1024u, tab_l, (q1 * 40u + rr) * 16u);
+          o1[it] = (q1 * 40u + rr) * 16u;
         }
+        af_dma_gather5(st0_b, tab_l, o1);
       }
     };
 
@@ -500,10 +569,15 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
         reload_counts(h.quad(26), cj);
         AF_RELOAD_TAKE((h[19] >> 16) & 15u, cj)
       }
-      request_chars(h, ch); // op 0's
+      request_chars(h, ch_p); // op 0's
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      next_gathers(__builtin_amdgcn_readfirstlane(rc_a[18]) & AF_KIND_MASK, rc_a.quad(4), rc_a.quad(6));
-      request_chars(rc_a, ch); // op 1's
+      next_gathers(__builtin_amdgcn_readfirstlane(rc_a[18]) & AF_KIND_MASK, rc_a.quad(4), rc_a.quad(6), ch_p);
+      // op 1's (used at the end of op 0): a record names the rows of the op after next, the last op's those of op 1
+      const AfW<8, 8> r1 = af_load<8, 8>(plan, nops);
+      AfW<0, 28> rows1 = rc_a;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) rows1.w[8 + t] = r1[8 + t];
+      request_chars(rows1, ch_q);
     }
     // (the first tile's blocks were requested without a barrier behind them; a tile's last stores
     // are waited for here too: once per tile)
@@ -513,10 +587,14 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
 
 #ifdef PLLHIP_AF_TIMING
     // (tool build, tools/aa_fused_timing.sh: where a wave's cycles go, by op kind and phase)
-    unsigned long long seg[3][6] = {};
+    unsigned long long seg[3][11] = {};
     unsigned int nkind_ops[3] = {};
     unsigned long long t_last = __builtin_readcyclecounter();
+#ifdef PLLHIP_AF_NOTICKS
+#define AF_TICK(ph)
+#else
 #define AF_TICK(ph) { const unsigned long long t_now = __builtin_readcyclecounter(); seg[kind][ph] += t_now - t_last; t_last = t_now; }
+#endif
 #else
 #define AF_TICK(ph)
 #endif
@@ -524,24 +602,34 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     {
 #define AF_RC rc_a
 #define AF_RN rc_b
+#define AF_CH_REQ ch_p
+#define AF_CH_USE ch_q
 #include "partials_aa_fused_op.inc"
 #undef AF_RC
 #undef AF_RN
+#undef AF_CH_REQ
+#undef AF_CH_USE
       if (++i == nops) break;
 #define AF_RC rc_b
 #define AF_RN rc_a
+#define AF_CH_REQ ch_q
+#define AF_CH_USE ch_p
 #include "partials_aa_fused_op.inc"
 #undef AF_RC
 #undef AF_RN
+#undef AF_CH_REQ
+#undef AF_CH_USE
       if (++i == nops) break;
     }
-#ifdef PLLHIP_AF_TIMING
+#if defined(PLLHIP_AF_TIMING) && !defined(PLLHIP_AF_NOTICKS)
     if (lane == 0 && round == 2 && wave == 1 && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == 202 || blockIdx.x == 303))
       for (int kd = 0; kd < 3; ++kd)
         if (nkind_ops[kd])
-          printf("kind %d: %u ops: first half %llu, wait A %llu, barrier A %llu, second half %llu, barrier B %llu, end %llu cycles per op\n",
+          printf("kind %d: %u ops: first half %llu, wait A %llu, barrier A %llu, [slot read %llu, products %llu] rest of second half %llu, barrier B %llu, "
+                 "[lds wait %llu, blocks %llu, gathers %llu] characters + stores %llu cycles per op\n",
                  kd, nkind_ops[kd], seg[kd][0] / nkind_ops[kd], seg[kd][1] / nkind_ops[kd], seg[kd][2] / nkind_ops[kd],
-                 seg[kd][3] / nkind_ops[kd], seg[kd][4] / nkind_ops[kd], seg[kd][5] / nkind_ops[kd]);
+                 seg[kd][6] / nkind_ops[kd], seg[kd][7] / nkind_ops[kd], seg[kd][3] / nkind_ops[kd], seg[kd][4] / nkind_ops[kd],
+                 seg[kd][8] / nkind_ops[kd], seg[kd][9] / nkind_ops[kd], seg[kd][10] / nkind_ops[kd], seg[kd][5] / nkind_ops[kd]);
 #endif
   }
 }
@@ -624,6 +712,12 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
   const unsigned int static_rounds = rounds > dynamic_rounds ? (unsigned int)(rounds - dynamic_rounds) : 1u;
   unsigned int * counter = getenv("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
   HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+#ifdef PLLHIP_AF_TIMING
+  {
+    const unsigned int m = getenv("PLLHIP_AF_EXP") ? (unsigned int)atoi(getenv("PLLHIP_AF_EXP")) : 0u;
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(af_exp_mask), &m, sizeof(m), 0, hipMemcpyHostToDevice, c->stream));
+  }
+#endif
   const bool nt = pllhip_use_nt(c);
 #define AF_LAUNCH(MODEV, NTV)                                                                                          \
   do {                                                                                                                 \
@@ -845,9 +939,11 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     // recs[pos] is the record before op `pos` (recs[0]: the header; recs[n] names op 0 again)
     const AaRec & o = own[pos == n ? 0 : pos];
     AaRec & r = recs[pos];
-    for (int t = 0; t < 4; ++t) r.row[t] = o.row[t];
     r.xoff = o.xoff;
     r.flags |= (o.flags & AF_KIND_MASK) << 8;
+    // (rows: those of the op after next -- the header names op 0's)
+    const AaRec & o2 = pos == 0 ? own[0] : own[(pos + 1) % n];
+    for (int t = 0; t < 4; ++t) r.row[t] = o2.row[t];
   }
   if ((mj.size() + 1) * (size_t)AF_MAT_B > 0xffffffffull) return 1;
   // buffers: matrices in operand order, tip tables

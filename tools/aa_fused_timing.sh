@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   make -s -j8 BUILD=build/aftiming OUT=$lib EXTRA_HIPFLAGS=-DPLLHIP_AF_TIMING lib
   exit $?
 fi
-for cfg in "c3 --states 20 --taxa 64 --sites 200000" "c3_tipclv --states 20 --taxa 64 --sites 100000 --tip-clv" "c3_random --states 20 --taxa 64 --sites 200000 --tree random"; do
+for cfg in "c3 --states 20 --taxa 64 --sites 200000" "c3_random --states 20 --taxa 64 --sites 200000 --tree random"; do
   set -- $cfg; tag=$1; shift
   echo "== $tag"
   PLL_AMD_LIB=$lib python3 bench.py --steps 2 --warmup 1 --cpu-sites 0 --no-c4 "$@" 2>/dev/null | grep -v '^{' | sort -k2,2n -s | awk '{c[$2]++; if (c[$2] <= 3) print}'
