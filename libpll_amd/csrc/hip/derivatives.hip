@@ -648,7 +648,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     const size_t tiles = ((size_t)a.sites + 15) / 16;
     size_t blocks = (tiles + 3) / 4;
-    const size_t cap = (size_t)c->num_cus * 3; // 47 KB of LDS per workgroup
+    const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 3; // 47 KB of LDS per workgroup (env: tests)
     if (blocks > cap) blocks = cap;
     grid = (unsigned int)blocks;
     a.reduce = pllhip_reduce_out(c, grid);

@@ -14,6 +14,8 @@
 // Numerics: one fused chain per row (as the CLV kernel), then lane sums in a
 // fixed order; per-site lnL agrees with the reference to ~1e-15 relative.
 // PLLHIP_AA_EXACT=1 selects the bit-exact vector kernel (likelihood.hip).
+#include <stdlib.h>
+
 #include "aa_mfma.hpp"
 #include "lnl_common.hpp"
 
@@ -247,7 +249,7 @@ static int launch_lnl_rc(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * g
   using G = aa_geom<RC>;
   const size_t tiles = ((size_t)a.sites + 15) / 16;
   size_t blocks = (tiles + 3) / 4;
-  const size_t cap = (size_t)c->num_cus * 2;
+  const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per wave)
   if (blocks > cap) blocks = cap;
   const size_t head = (kind == EDGE_II) ? (size_t)RC * 400
                                         : (kind == EDGE_TI ? (size_t)a.maxstates * RC * 20 : 0);

@@ -704,7 +704,7 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
   }
   const size_t tiles = ((size_t)c->sh.sites + AF_WGS - 1) / AF_WGS;
   size_t grid = tiles;
-  const size_t cap = (size_t)c->num_cus * 2;
+  const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per workgroup)
   if (grid > cap) grid = cap;
   const size_t rounds = tiles / grid;
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))

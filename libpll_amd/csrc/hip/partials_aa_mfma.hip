@@ -255,7 +255,13 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
         frow_next2 = row_of(first_idx, next + nwaves < tiles ? next + nwaves : next);
       }
       else
+      {
         srow_next = (unsigned int)(next * 16 + s);
+        // (round 3: this line was missing -- from a wave's THIRD tile on the first operand's scaler
+        // counts were read at the second tile's sites.  Invisible until sites, taxa and scaling
+        // events came together: 100,000 sites x 200 taxa; found by the whole-list kernel disagreeing)
+        frow_next2 = (unsigned int)((next + nwaves < tiles ? next + nwaves : next) * 16 + s);
+      }
     }
     if (KIND == 1)
     {
@@ -410,7 +416,8 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   const unsigned int wpb = 4u;
   size_t blocks = (tiles + wpb - 1) / wpb;
   // the P-matrix staging per workgroup is amortised over several tiles per wave
-  const size_t cap = (size_t)c->num_cus * 2;
+  // (PLLHIP_AA_GRID_CAP: tests make every wave walk many tiles of a small partition)
+  const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2;
   if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned int)blocks, count), block(64 * wpb);
   const size_t lds = fixed + wpb * (size_t)G::REGION_B;

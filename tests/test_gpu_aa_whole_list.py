@@ -1,0 +1,156 @@
+"""20-state data: the whole-list kernel (partials_aa_fused.hip) and the reference-order matrix-core
+products (round 3), through the C-ABI against the oracle and against the per-level launches.
+
+What is asserted:
+  * an inner-inner CLV update on the DEFAULT path (matrix cores) equals the oracle bit for bit --
+    core_partials_avx2.c:632-750's four FMA chains and pairwise tree, reproduced with the MFMA's own
+    accumulation order (tools/mfma_order_probe.hip); scaler counts equal everywhere;
+  * the whole-list kernel (PLLHIP_FUSED=2) and the per-level launches (PLLHIP_FUSED=0) give the same
+    bits for every CLV and scale buffer: full traversals, partial traversals on top of them (operands
+    from earlier calls), tips as characters and as CLVs, trees that need evictions, ragged site
+    counts, lists without scale buffers;
+  * waves that walk many tiles (PLLHIP_AA_GRID_CAP) on trees deep enough to scale: the regression
+    test of a round-2 bug (from a wave's third tile on, inherited scaler counts were read at the
+    second tile's sites) that no test saw because no test had sites x depth x scaling together.
+"""
+import numpy as np
+import pytest
+
+from helpers import make_case, build_partition, oracle_run, bits_equal
+from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, SCALE_BUFFER_NONE
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(gpu, shape, tips, sites, seed=11):
+    case = make_case(20, shape, tips, sites, seed=seed)
+    case["rates"], case["freqs"] = gpu.aa_model("lg")
+    return case
+
+
+def _kinds(plan, tips, attrs):
+    out = []
+    for op in plan.ops:
+        t1 = bool(attrs & ATTRIB_PATTERN_TIP) and int(op["child1_clv_index"]) < tips
+        t2 = bool(attrs & ATTRIB_PATTERN_TIP) and int(op["child2_clv_index"]) < tips
+        out.append("tt" if (t1 and t2) else "ti" if (t1 or t2) else "ii")
+    return out
+
+
+def _evaluate(gpu, case, attrs, monkeypatch, fused, partial=True):
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "0")
+    monkeypatch.setenv("PLLHIP_AA_CHERRY", "2")
+    monkeypatch.setenv("PLLHIP_FUSED", fused)
+    plan = case["plan"]
+    p = build_partition(gpu, case, attrs)
+    p.update_partials(plan.ops)
+    if partial:
+        # partial traversals on top: the last few ops again, their operands written by the call before
+        p.update_partials(plan.ops[-3:])
+        p.update_partials(plan.ops[-1:])
+    clvs = [p.get_clv(int(op["parent_clv_index"])) for op in plan.ops]
+    scs = [p.get_scaler(int(op["parent_scaler_index"])) for op in plan.ops]
+    lnl = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4)
+    return p, clvs, scs, lnl
+
+
+@pytest.mark.parametrize("shape,tips,sites", [
+    ("balanced", 16, 333), ("balanced", 64, 1000), ("random", 12, 500), ("caterpillar", 40, 100),
+    ("random", 50, 97), ("balanced", 128, 64), ("random", 30, 1), ("random", 200, 40), ("balanced", 8, 40000)])
+@pytest.mark.parametrize("attrs", [ATTRIB_PATTERN_TIP, 0])
+def test_whole_list_equals_per_level_and_oracle(gpu, orc, monkeypatch, shape, tips, sites, attrs):
+    case = _case(gpu, shape, tips, sites)
+    plan = case["plan"]
+    pf, cf, sf, lf = _evaluate(gpu, case, attrs, monkeypatch, "2")
+    pf.destroy()
+    pl, cl, sl, ll = _evaluate(gpu, case, attrs, monkeypatch, "0")
+    o = oracle_run(orc, gpu, pl, case, attrs)
+    o.update_partials()
+    pl.destroy()
+    kinds = _kinds(plan, tips, attrs)
+    tainted = set()  # (a tip-inner op is not bit-exact, and nothing above one is)
+    for op, kind, a, b, x, y in zip(plan.ops, kinds, cf, cl, sf, sl):
+        node = int(op["parent_clv_index"])
+        assert bits_equal(a, b), "CLV %d: whole list != per level" % node
+        assert (x == y).all(), "scale buffer of CLV %d: whole list != per level" % node
+        assert (x == o.scalers[int(op["parent_scaler_index"])]).all(), "scaler counts of CLV %d != oracle" % node
+        if kind == "ti" or int(op["child1_clv_index"]) in tainted or int(op["child2_clv_index"]) in tainted:
+            tainted.add(node)
+        else:
+            assert bits_equal(a, o.clv[node]), "CLV %d (%s, no tip-inner op below it) != oracle" % (node, kind)
+    assert lf == ll
+    ref = o.edge_loglikelihood(*plan.root_edge)
+    assert abs(lf - ref) <= 1e-11 * abs(ref)
+
+
+def test_whole_list_without_scale_buffers(gpu, orc, monkeypatch):
+    case = _case(gpu, "balanced", 32, 700)
+    plan = case["plan"]
+    ops = plan.ops.copy()
+    for f in ("parent_scaler_index", "child1_scaler_index", "child2_scaler_index"):
+        ops[f] = SCALE_BUFFER_NONE
+    res = {}
+    for fused in ("2", "0"):
+        monkeypatch.setenv("PLLHIP_AA_EXACT", "0")
+        monkeypatch.setenv("PLLHIP_AA_CHERRY", "2")
+        monkeypatch.setenv("PLLHIP_FUSED", fused)
+        p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+        p.update_partials(ops)
+        res[fused] = [p.get_clv(int(op["parent_clv_index"])) for op in ops]
+        p.destroy()
+    for a, b in zip(res["2"], res["0"]):
+        assert bits_equal(a, b)
+
+
+@pytest.mark.parametrize("attrs", [ATTRIB_PATTERN_TIP, 0])
+@pytest.mark.parametrize("fused", ["0", "2"])
+def test_many_tiles_per_wave_on_a_tree_that_scales(gpu, orc, monkeypatch, attrs, fused):
+    """One workgroup walks the whole partition (PLLHIP_AA_GRID_CAP=1: 4+ tiles per wave) on a
+    300-tip caterpillar, whose scaler counts reach 4: every count must equal the oracle's -- the
+    per-level kernel read a wave's third and later tiles' inherited counts at the wrong sites until
+    round 3 -- and every inner-inner CLV its bits."""
+    monkeypatch.setenv("PLLHIP_AA_GRID_CAP", "1")
+    case = _case(gpu, "caterpillar", 300, 300, seed=5)
+    plan = case["plan"]
+    p, clvs, scs, lnl = _evaluate(gpu, case, attrs, monkeypatch, fused, partial=False)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    o.update_partials()
+    p.destroy()
+    top = 0
+    kinds = _kinds(plan, 300, attrs)
+    for op, kind, a, x in zip(plan.ops, kinds, clvs, scs):
+        sc = o.scalers[int(op["parent_scaler_index"])]
+        assert (x == sc).all(), "scaler counts of CLV %d" % int(op["parent_clv_index"])
+        top = max(top, int(sc.max()))
+        if attrs == 0:
+            assert bits_equal(a, o.clv[int(op["parent_clv_index"])])
+    assert top >= 3, "the tree was meant to scale (highest count %d)" % top
+    ref = o.edge_loglikelihood(*plan.root_edge)
+    assert abs(lnl - ref) <= 1e-11 * abs(ref)
+
+
+def test_default_path_against_the_bit_exact_kernels_at_size(gpu, monkeypatch):
+    """100,000 sites x 200 taxa (a random tree: tip-inner ops, evictions, three tiles per wave of the
+    per-level kernel, scaling events near the root): scaler counts of the default path, whole list and
+    per level, equal those of the bit-exact vector kernels; lnL within the stated tolerance."""
+    from libpll_amd import workload as W
+    T, sites, R = 200, 100_000, 4
+    plan = W.random_tree(T, seed=42)
+    rates, freqs = gpu.aa_model("lg")
+    seqs = W.simulated_alignment(plan, sites, rates, freqs, gpu.compute_gamma_cats(W.GAMMA_ALPHA, R), seed=42)
+    out = {}
+    for name, env in (("whole list", {"PLLHIP_FUSED": "1", "PLLHIP_AA_EXACT": "0"}),
+                      ("per level", {"PLLHIP_FUSED": "0", "PLLHIP_AA_EXACT": "0"}),
+                      ("bit-exact", {"PLLHIP_FUSED": "0", "PLLHIP_AA_EXACT": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP)
+        p.update_partials(plan.ops)
+        lnl = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+        out[name] = (lnl, [p.get_scaler(int(op["parent_scaler_index"])) for op in plan.ops[-12:]])
+        p.destroy()
+    assert max(int(s.max()) for s in out["bit-exact"][1]) >= 1, "no scaling event: the test has lost its point"
+    for name in ("whole list", "per level"):
+        for a, b in zip(out[name][1], out["bit-exact"][1]):
+            assert (a == b).all(), name
+        assert abs(out[name][0] - out["bit-exact"][0]) <= 1e-11 * abs(out["bit-exact"][0]), name

@@ -18,9 +18,10 @@ lib = libpll_amd.load()
 orc = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
 bad = 0
 cases = [("balanced", 16, 333), ("balanced", 64, 1000), ("random", 12, 500), ("caterpillar", 40, 100),
-         ("random", 50, 97), ("balanced", 128, 64), ("random", 30, 1), ("balanced", 8, 40000)]
+         ("random", 50, 97), ("balanced", 128, 64), ("random", 30, 1), ("balanced", 8, 40000), ("random", 200, 40),
+         ("caterpillar", 120, 33), ("random", 200, 20000)]
 if len(sys.argv) > 1:
-    cases = cases[:int(sys.argv[1])]
+    cases = cases[:int(sys.argv[1])] if int(sys.argv[1]) > 0 else cases[int(sys.argv[1]):]
 for shape, tips, sites in cases:
     for attrs in (ATTRIB_PATTERN_TIP, 0):
         case = make_case(20, shape, tips, sites, seed=11)

@@ -10,7 +10,7 @@ pass() { # tag, counters...
   local tag=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d $out/$tag -- python3 $root/bench.py --steps 4 --warmup 1 --cpu-sites 0 --no-c4 $ARGS > /dev/null 2> $out/$tag.err
   python3 $root/tools/summarize_rocprof.py pmc $out/$tag $out/$tag.csv 2>/dev/null
-  grep k_dna_fused $out/$tag.csv | sed 's/^"[^"]*"/fused/'
+  grep "${KERNEL:-k_dna_fused}" $out/$tag.csv | sed "s/^\"[^\"]*\"/fused/"
   rm -rf $out/$tag
 }
 ARGS="$*"
