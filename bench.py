@@ -162,7 +162,11 @@ def main():
     ap.add_argument("--devices", default="",
                     help="with --in-process: the device list (default 0..N-1; an ordinal may repeat, e.g. 0,0)")
     ap.add_argument("--no-c4", action="store_true", help="N>1: skip the BASELINE config 4 strong-scaling section")
+    ap.add_argument("--no-vary", action="store_true", help="skip the leg with op lists that change from call to call")
     ap.add_argument("--force-c4", action="store_true", help="diagnostic: run that section with one GPU as well")
+    ap.add_argument("--no-c4-one-gpu", action="store_true",
+                    help="N>1: do not measure the one-GPU time of config 4 in this run (133 GB on rank 0's GPU); "
+                         "the speed-up then uses the recorded figure, labelled as such")
     ap.add_argument("--tree", default="balanced", choices=("balanced", "random", "caterpillar"))
     ap.add_argument("--newton", type=int, default=0,
                     help="also time pll_update_sumtable + N x pll_compute_likelihood_derivatives "
@@ -373,6 +377,7 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed
     if use_comm:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -380,6 +385,36 @@ def main():
 
     site_updates = float(ops_per_eval) * total_sites * args.steps
     value = site_updates / elapsed / 1e6
+    untimed_steps = 1 + len(ramp_steps) + args.warmup   # what really ran before the timed region
+
+    # ---- the spread the K-step region cannot show (boxes of the pool differ by 10-20 %, processes on one
+    # box by several per cent): every step synchronised and timed on its own, for at least 20 steps
+    # and half a second.  (Each step then pays its own launch + completion latency: the median reads
+    # a little above ms_per_step.)
+    per_step = []
+    t_spread = time.perf_counter()
+    while len(per_step) < 20 or time.perf_counter() - t_spread < 0.5:
+        t1 = time.perf_counter()
+        step()
+        sync()
+        per_step.append((time.perf_counter() - t1) * 1e3)
+        if use_comm:
+            # (a step is a collective: every rank runs the same number of them)
+            flag = torch.tensor([1.0 if (len(per_step) >= 20 and time.perf_counter() - t_spread >= 0.5) else 0.0],
+                                dtype=torch.float32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() >= 1.0:
+                break
+    ps = sorted(per_step)
+    per_step_ms = {"steps": len(ps), "median": round(ps[len(ps) // 2], 4), "p10": round(ps[len(ps) // 10], 4),
+                   "p90": round(ps[(9 * len(ps)) // 10], 4), "min": round(ps[0], 4), "max": round(ps[-1], 4)}
+    per_rank_ms = None
+    if use_comm:
+        # one figure per rank, so that a straggler GPU is visible
+        mine = torch.tensor([elapsed_own / args.steps * 1e3], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(x.item()), 4) for x in every]
 
     # ---- roofline leg, for the dominant kernel (the inner-inner CLV update):
     # HIP events on the partition's own stream around back-to-back launches of
@@ -401,7 +436,7 @@ def main():
     prof_full = part.profile_read()
     part.profile_enable(False)
     full_launches = sum(v[0] for k, v in prof_full.items() if k.startswith("partials"))
-    if S == 4 and full_launches == 1 and len(plan.ops) > 1:
+    if S in (4, 20) and full_launches == 1 and len(plan.ops) > 1:
         n_ii = int((c1 & c2).sum()) if not args.tip_clv else len(plan.ops)
         n_tt = 0 if args.tip_clv else int((~c1 & ~c2).sum())
         n_ti = len(plan.ops) - n_ii - n_tt
@@ -424,8 +459,11 @@ def main():
                           tip_clv=bool(args.tip_clv), rate_scalers=bool(args.rate_scalers),
                           kernel_class="whole-list") if inproc == 1 else None
         traffic = pmc["bytes_per_launch"] if pmc else None
-        roofline = {"bound": "hbm", "kernel": "k_dna_fused: pll_update_partials, %d ops in one launch "
-                                              "(%d inner-inner, %d tip-inner, %d tip-tip)" % (len(plan.ops), n_ii, n_ti, n_tt),
+        roofline = {"bound": "hbm", "kernel": ("k_dna_fused: pll_update_partials, %d ops in one launch "
+                                               "(%d inner-inner, %d tip-inner, %d tip-tip)" if S == 4 else
+                                               "pll_update_partials, %d ops site-blocked (20 states: the tip-tip ops and the "
+                                               "lookup tables ahead, then k_aa_fused; timed as one) "
+                                               "(%d inner-inner, %d tip-inner, %d tip-tip)") % (len(plan.ops), n_ii, n_ti, n_tt),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": pmc["source"] if pmc else None,
@@ -501,6 +539,84 @@ def main():
     api = {"update_partials_ms_hip_events": spread(ev_up), "update_partials_ms_wall": spread(wall_up),
            "edge_loglikelihood_ms_wall": spread(wall_lnl)}
 
+    # ---- op lists that CHANGE from call to call: what the reference's real callers do (tree search:
+    # test/src/partial-traversal.c:17-58 re-roots and prunes; examples/newton).  Every figure above
+    # replays one list, which the library recognises (memcmp) and relaunches from its kept plan; here
+    # each call hands pll_update_partials a list it has not just seen -- full traversals directed at five
+    # different edges, and after each of them partial traversals of about 3, 7 and 15 ops that follow
+    # branch-length changes (pll_update_prob_matrices for the changed branches is in the step) -- so
+    # ordering the list, assigning slots, encoding and uploading the plan are inside the timed steps.
+    varying = None
+    if not args.no_vary and not args.site_repeats:
+        view = W.UnrootedView(plan, use_scalers=not args.no_scalers)
+        rng = W.SplitMix64(777)
+        all_edges = view.edges()
+        inner_edges = [e for e in all_edges if e[0] >= T and e[1] >= T]
+        roots = [view.root] + [inner_edges[rng.below(len(inner_edges))] for _ in range(4)]
+        length_of = {int(m): float(b) for m, b in zip(plan.matrix_indices, plan.branch_lengths)}
+        sched = []
+        for r in roots:
+            ops_r, edge_r = view.traversal(r)
+            sched.append(("full traversal", ops_r, edge_r, []))
+            for want in (3, 7, 15):
+                changed, part_ops = [], ops_r[:0]
+                for _ in range(400):
+                    if len(part_ops) >= want:
+                        break
+                    e = all_edges[rng.below(len(all_edges))]
+                    cand = view.partial(ops_r, changed + [e], r)
+                    if len(part_ops) < len(cand) <= want:
+                        changed, part_ops = changed + [e], cand
+                if len(part_ops):
+                    sched.append(("partial traversal, about %d ops" % want, part_ops, edge_r, changed))
+
+        def vary_step(entry, scale):
+            _, ops_e, edge_e, changed = entry
+            if changed:
+                mi = [view.matrix[frozenset(e)] for e in changed]
+                part.update_prob_matrices(fi, mi, [length_of[int(m)] * scale for m in mi])
+            part.update_partials(ops_e)
+            return part.compute_edge_loglikelihood(*edge_e, fi)
+
+        for entry in sched:                      # once untimed: buffers that grow on first use
+            vary_step(entry, 1.0)
+        sync()
+        times = {}
+        n_sched, t_v, updates = 0, time.perf_counter(), 0
+        while n_sched < 2 or time.perf_counter() - t_v < 0.4:
+            for k, entry in enumerate(sched):
+                t1 = time.perf_counter()
+                v_lnl = vary_step(entry, 1.0 + 0.001 * ((n_sched + k) % 5))
+                sync()
+                times.setdefault(entry[0], []).append((time.perf_counter() - t1) * 1e3)
+                updates += len(entry[1])
+            n_sched += 1
+            if use_comm:
+                flag = torch.tensor([1.0 if (n_sched >= 2 and time.perf_counter() - t_v >= 0.4) else 0.0],
+                                    dtype=torch.float32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() >= 1.0:
+                    break
+        t_vary = time.perf_counter() - t_v
+        # the partial traversals must have kept every CLV right: a from-scratch evaluation of the final
+        # state (same branch lengths) gives the same lnL
+        ops_l, edge_l = sched[-1][1], sched[-1][2]
+        full_l = [e for e in sched if e[0] == "full traversal" and e[2] == edge_l][0]
+        part.update_partials(full_l[1])
+        scratch_lnl = part.compute_edge_loglikelihood(*edge_l, fi)
+        # (back to the benchmark's own branch lengths and list for what follows)
+        part.update_prob_matrices(fi, plan.matrix_indices, plan.branch_lengths)
+        part.update_partials(plan.ops)
+        varying = {"what": "every call gets a list it has not just seen: 5 full traversals directed at different edges, each "
+                           "followed by partial traversals after branch-length changes (pll_update_prob_matrices + "
+                           "pll_update_partials + pll_compute_edge_loglikelihood per step, each step synchronised)",
+                   "steps": sum(len(v) for v in times.values()),
+                   "ms_per_step": {k: {"median": round(sorted(v)[len(v) // 2], 4), "min": round(min(v), 4), "ops": int(np.median(
+                       [len(e[1]) for e in sched if e[0] == k]))} for k, v in times.items()},
+                   "replayed_list_ms_per_step": per_step_ms["median"],
+                   "value": round(updates * float(total_sites) / t_vary / 1e6, 2), "unit": "M CLV-site-updates/s over the mix",
+                   "lnl_after_partials_vs_from_scratch_rel": abs(v_lnl - scratch_lnl) / abs(scratch_lnl)}
+
     # per-class averages with one event pair per launch (diagnostic; each pair
     # adds ~2 us, so these read high)
     part.profile_enable(True)
@@ -555,15 +671,76 @@ def main():
     if (world * inproc > 1 or args.force_c4) and not args.no_c4 and S == 4:
         part.destroy()
         part = None
-        try:
-            c4_sites, c4_taxa = 8_000_000, 128
-            plan4 = W.balanced_tree(c4_taxa, seed=42)
-            lo4, hi4 = W.shard_bounds(c4_sites, world)[rank:rank + 2]
-            # a 250,000-site block simulated down the tree, repeated to the shard's length
-            block = W.simulated_alignment(plan4, 250_000, W.GTR_RATES, W.GTR_FREQS, cat_rates, seed=4242 + rank)
+        c4_sites, c4_taxa = 8_000_000, 128
+        plan4 = W.balanced_tree(c4_taxa, seed=42)
+
+        def c4_alignment(lo4, hi4, seed):
+            # a 250,000-site block simulated down the tree, repeated to the range's length
+            block = W.simulated_alignment(plan4, 250_000, W.GTR_RATES, W.GTR_FREQS, cat_rates, seed=seed)
             reps4 = -(-(hi4 - lo4) // 250_000)
-            seqs4 = [(b * reps4)[:hi4 - lo4] for b in block]
-            p4 = W.setup_partition(amd, plan4, seqs4, 4, R, ATTRIB_PATTERN_TIP)
+            return [(b * reps4)[:hi4 - lo4] for b in block]
+
+        def c4_time(p4, steps4, collective):
+            lnl4 = None
+            for _ in range(2):
+                p4.update_partials(plan4.ops)
+                lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
+            p4.wait()
+            torch.cuda.synchronize()
+            if collective:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(steps4):
+                p4.update_partials(plan4.ops)
+                lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
+            p4.wait()
+            torch.cuda.synchronize()
+            own = time.perf_counter() - t1
+            if collective:
+                dist.barrier()
+            return time.perf_counter() - t1, own, lnl4
+
+        steps4 = max(3, min(args.steps, 10))
+        # (1) the denominator of the speed-up, measured HERE: the whole alignment on ONE GPU of this node
+        # (rank 0's; 133 GB), in this run, before the sharded section -- boxes differ by 10-20 %, a
+        # constant recorded elsewhere is kept as a labelled fallback only.  The other ranks wait.
+        one_ms, one_err, one_lnl = None, None, None
+        if rank == 0 and not args.no_c4_one_gpu:
+            try:
+                devs1 = None
+                if inproc > 1:
+                    import ctypes
+                    devs1 = [int(args.devices.split(",")[0])] if args.devices else [0]
+                    amd.lib.pll_amd_set_devices((ctypes.c_int * 1)(*devs1), 1)
+                p1 = W.setup_partition(amd, plan4, c4_alignment(0, c4_sites, 4242), 4, R, ATTRIB_PATTERN_TIP)
+                t_all, _, one_lnl = c4_time(p1, steps4, False)
+                one_ms = t_all / steps4 * 1e3
+                p1.destroy()
+                if inproc > 1:
+                    devs = [int(x) for x in args.devices.split(",")] if args.devices else list(range(inproc))
+                    amd.lib.pll_amd_set_devices((ctypes.c_int * len(devs))(*devs), len(devs))
+            except Exception as exc:
+                one_err = "%s: %s" % (type(exc).__name__, exc)
+        if use_comm:
+            dist.barrier()
+        # (2) the same alignment divided over the GPUs.  A rank that fails must not leave the others in
+        # a collective: every rank works inside try, then all agree on success BEFORE the next collective
+        err, p4 = None, None
+        try:
+            lo4, hi4 = W.shard_bounds(c4_sites, world)[rank:rank + 2]
+            p4 = W.setup_partition(amd, plan4, c4_alignment(lo4, hi4, 4242 + rank), 4, R, ATTRIB_PATTERN_TIP)
+        except Exception as exc:
+            err = "%s: %s" % (type(exc).__name__, exc)
+        ok = err is None
+        if use_comm:
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() >= 1.0)
+        if not ok:
+            c4 = {"error": err or "another rank failed to set its shard up"}
+            if p4 is not None:
+                p4.destroy()
+        else:
             if use_comm:
                 uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
                 if rank == 0:
@@ -574,55 +751,48 @@ def main():
                     uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
                 dist.broadcast(uid, src=0)
                 p4.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-            steps4 = max(3, min(args.steps, 10))
-            lnl4 = None
-            for _ in range(2):
-                p4.update_partials(plan4.ops)
-                lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
-            p4.wait()
-            torch.cuda.synchronize()
-            if use_comm:
-                dist.barrier()
-            t1 = time.perf_counter()
-            for _ in range(steps4):
-                p4.update_partials(plan4.ops)
-                lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
-            p4.wait()
-            torch.cuda.synchronize()
-            if use_comm:
-                dist.barrier()
-            t4 = time.perf_counter() - t1
+            t4, own4, lnl4 = c4_time(p4, steps4, use_comm)
+            per_rank4 = None
             if use_comm:
                 t = torch.tensor([t4], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 t4 = float(t.item())
+                mine = torch.tensor([own4 / steps4 * 1e3], dtype=torch.float64, device="cuda")
+                every = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                per_rank4 = [round(float(x.item()), 4) for x in every]
+            elif inproc > 1:
+                per_rank4 = p4.shard_step_ms() if hasattr(p4, "shard_step_ms") else None
             p4.destroy()
-            one = None
+            recorded = None
             try:
-                one = json.load(open(os.path.join(root, "profiles", "r2_bench_c4_one_gpu.json")))
+                recorded = json.load(open(os.path.join(root, "profiles", "r2_bench_c4_one_gpu.json")))
             except (OSError, ValueError):
                 pass
             ms4 = t4 / steps4 * 1e3
+            base_ms = one_ms if one_ms else (recorded["ms_per_step"] if recorded else None)
             c4 = {"workload": "BASELINE config 4: 4-state GTR, 4 rates, %d sites, %d-taxon balanced tree, PATTERN_TIP, "
                               "divided over %d GPUs (%s)" % (c4_sites, c4_taxa, world * inproc,
                                                              "one process, library-sharded partition" if inproc > 1
                                                              else "one process per GPU, RCCL lnL all-reduce"),
                   "scaling": "strong", "n_gpus": world * inproc, "steps": steps4,
                   "value": round((c4_taxa - 2) * c4_sites * steps4 / t4 / 1e6, 2), "unit": "M CLV-site-updates/s",
-                  "ms_per_step": round(ms4, 4), "lnl": lnl4,
-                  "one_gpu_ms_per_step": one["ms_per_step"] if one else None,
-                  "one_gpu_source": "profiles/r2_bench_c4_one_gpu.json (recorded: python bench.py --total-sites "
-                                    "8000000 --taxa 128 --cpu-sites 0)" if one else None,
-                  "speedup_vs_one_gpu": round(one["ms_per_step"] / ms4, 3) if one else None}
-        except Exception as exc:  # the headline line must survive a failure of this extra section
-            c4 = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                  "ms_per_step": round(ms4, 4), "lnl": lnl4, "per_rank_ms_per_step": per_rank4,
+                  "one_gpu_ms_per_step": round(base_ms, 4) if base_ms else None,
+                  "one_gpu_source": ("measured in this run on this node: the whole alignment on rank 0's GPU, %d steps"
+                                     % steps4) if one_ms else
+                                    ("FALLBACK, another box: profiles/r2_bench_c4_one_gpu.json" +
+                                     (" (the one-GPU leg failed here: %s)" % one_err if one_err else "")) if recorded else None,
+                  "one_gpu_lnl": one_lnl,
+                  "speedup_vs_one_gpu": round(base_ms / ms4, 3) if base_ms else None}
     if rank == 0:
         tt, ti, ii = plan.op_kinds() if not args.tip_clv else (0, 0, ops_per_eval)
         out = {
             "metric": "M CLV-site-updates/s (%dx%d states x rates)" % (S, R),
             "value": round(value, 2), "unit": "M CLV-site-updates/s",
-            "n_gpus": world * inproc, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world * inproc, "steps": args.steps, "warmup": untimed_steps, "warmup_flag": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "per_step_ms": per_step_ms, "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (%s alignment, seed 42)" % args.alignment,
@@ -643,7 +813,7 @@ def main():
             "first_evaluation_ms": round(first_ms, 2),
             "ramp": ramp,
             "roofline": roofline, "api_calls": api, "kernels": per_kernel, "cpu_baseline": cpu,
-            "newton": newton, "c4_strong": c4,
+            "varying_lists": varying, "newton": newton, "c4_strong": c4,
         }
         print(json.dumps(out))
     if part is not None:

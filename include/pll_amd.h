@@ -609,8 +609,9 @@ PLL_EXPORT void pll_amd_core_release(void);
 
 /* ---- additions of this library (no reference counterpart) ---- */
 
-/* Device the NEXT pll_partition_create binds to (default: env
- * PLL_AMD_DEVICE, else LOCAL_RANK, else 0). */
+/* Device the NEXT pll_partition_create OF THE CALLING THREAD binds to (default: env
+ * PLL_AMD_DEVICE, else LOCAL_RANK, else 0).  Per thread, like pll_errno (pll.c:24-25): distinct
+ * threads may create distinct partitions concurrently, as with the reference. */
 PLL_EXPORT int pll_amd_set_device(int device);
 PLL_EXPORT int pll_amd_device_count(void);
 /* One partition over several GPUs of this process: the NEXT pll_partition_create splits its
@@ -619,7 +620,9 @@ PLL_EXPORT int pll_amd_device_count(void);
  * the client: pll_update_partials runs every range's op list on its device,
  * pll_compute_edge_loglikelihood / pll_compute_likelihood_derivatives return the sum over the
  * ranges (added on the host in range order: deterministic), the pll_amd_sync_* mirrors and
- * persite_lnl are gathered.  Not combined with PLL_ATTRIB_SITE_REPEATS or pll_amd_comm_init. */
+ * persite_lnl are gathered.  Not combined with PLL_ATTRIB_SITE_REPEATS or pll_amd_comm_init.  The
+ * list belongs to the calling thread; calls on such a partition leave the caller's current HIP
+ * device as they found it. */
 PLL_EXPORT int pll_amd_set_devices(const int * devices, unsigned int count);
 /* shards of a partition (1 = one device) */
 PLL_EXPORT unsigned int pll_amd_shard_count(const pll_partition_t * partition);
@@ -648,6 +651,10 @@ PLL_EXPORT int pll_amd_wait(pll_partition_t * partition);
 PLL_EXPORT int pll_amd_comm_unique_id(void * unique_id_128bytes);
 PLL_EXPORT int pll_amd_comm_init(pll_partition_t * partition, int rank, int nranks,
                                  const void * unique_id_128bytes);
+/* Which RCCL the process runs on: the file the collective symbols were bound to and how -- the
+ * copy the host program had already mapped (PyTorch ships its own librccl.so) is used if there is
+ * one, so that the process never holds two instances; "" before the first pll_amd_comm_* call. */
+PLL_EXPORT const char * pll_amd_rccl_path(void);
 
 /* The host eigen solver behind pll_update_eigen, callable without a partition
  * (and without a GPU): eigen system of the reversible rate matrix given by the

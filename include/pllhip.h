@@ -240,6 +240,10 @@ PLLHIP_EXPORT int pllhip_get_site_id(pllhip_ctx_t * ctx, unsigned int clv_index,
 
 /* ---- multi-GPU: one process per GPU, RCCL sum of the scalar results ---- */
 PLLHIP_EXPORT int pllhip_comm_unique_id(void * id128);
+/* which RCCL the process uses: the file the collective symbols were bound to -- the copy already
+ * mapped by the host program (e.g. PyTorch's) if there is one, else the system's; "" before the
+ * first pllhip_comm_* call */
+PLLHIP_EXPORT const char * pllhip_rccl_path(void);
 PLLHIP_EXPORT int pllhip_comm_init(pllhip_ctx_t * ctx, int rank, int nranks,
                                    const void * id128);
 

@@ -186,11 +186,28 @@ struct rccl_api
 };
 static rccl_api g_rccl;
 
+// ONE RCCL per process.  A host program that has already mapped an RCCL -- PyTorch brings its own
+// copy, torch/lib/librccl.so, which is not the one of /opt/rocm/lib -- must not get a second instance
+// next to it (two copies keep two sets of device state and transports): the copy ALREADY in the process
+// is bound first (RTLD_NOLOAD does not load anything), and only a process without one loads the
+// system's.  pllhip_rccl_path() says which file it was (bench.py prints it).
+static char g_rccl_path[512] = "";
+extern "C" const char * pllhip_rccl_path(void) { return g_rccl_path; }
+
 static int rccl_load()
 {
   if (g_rccl.handle) return 0;
-  void * h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  static const char * names[] = {"librccl.so.1", "librccl.so"};
+  void * h = nullptr;
+  const char * how = "already in the process";
+  for (const char * n : names)
+    if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+  if (!h)
+  {
+    how = "loaded by libpll_amd";
+    for (const char * n : names)
+      if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  }
   if (!h)
   {
     pllhip_set_error("cannot load librccl: %s", dlerror());
@@ -207,6 +224,12 @@ static int rccl_load()
     dlclose(h);
     return -1;
   }
+  Dl_info info;
+  if (dladdr((void *)g_rccl.AllReduce, &info) && info.dli_fname)
+    snprintf(g_rccl_path, sizeof(g_rccl_path), "%s (%s)", info.dli_fname, how);
+  else
+    snprintf(g_rccl_path, sizeof(g_rccl_path), "? (%s)", how);
+  if (getenv("PLLHIP_RCCL_DEBUG")) fprintf(stderr, "pllhip: RCCL bound to %s\n", g_rccl_path);
   g_rccl.handle = h;
   return 0;
 }

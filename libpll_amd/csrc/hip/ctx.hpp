@@ -173,9 +173,18 @@ void pllhip_set_error(const char * fmt, ...);
 
 // Run `expr` on every shard of a group context and return (inside `expr`: s = the shard, lo =
 // its first site within the group); falls through for an ordinary context.
+// (A call on a group visits every device of the group; the caller's current device is put back
+// when it returns -- a client that works with devices of its own must not find it changed.)
+struct pllhip_device_guard
+{
+  int prev = -1;
+  pllhip_device_guard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~pllhip_device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 #define PLLHIP_ALL_SHARDS(c, expr)                              \
   do {                                                          \
     if (!(c)->shards.empty()) {                                 \
+      pllhip_device_guard guard_;                               \
       for (size_t si_ = 0; si_ < (c)->shards.size(); ++si_) {   \
         pllhip_ctx * s = (c)->shards[si_];                      \
         const size_t lo = (c)->shard_lo[si_];                   \

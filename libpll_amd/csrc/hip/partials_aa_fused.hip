@@ -193,16 +193,16 @@ __device__ __forceinline__ af_gptr af_base(unsigned long long uniform_address)
 template <int N>
 __device__ __forceinline__ void af_dma_run(unsigned int lds_b, unsigned long long uniform_src, unsigned int lane16)
 {
-  static_assert(N >= 1 && N <= 4, "immediate offsets reach 4095");
+  static_assert(N == 1 || N == 4, "immediate offsets reach 4095");
+  unsigned int m0_saved; // (M0 is the compiler's: put back, not declared clobbered)
   if (N == 1)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :: "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory", "m0");
-  else if (N == 4)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
-                 :: "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory", "m0");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory");
   else
-    static_assert(N == 1 || N == 4, "");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "global_load_lds_dwordx4 %2, %3 offset:1024\n\tglobal_load_lds_dwordx4 %2, %3 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %2, %3 offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory");
 }
 // a gather: five KiB of LDS from five lane offsets each (voff[it] relative to table); the first four
 // share an M0 -- the immediate offset that advances the LDS address advances the global one as well,
@@ -210,11 +210,14 @@ __device__ __forceinline__ void af_dma_run(unsigned int lds_b, unsigned long lon
 __device__ __forceinline__ void af_dma_gather5(unsigned int lds_b, unsigned long long table, const unsigned int (&voff)[5])
 {
   const unsigned int v0 = voff[0] + 3072u, v1 = voff[1] + 2048u, v2 = voff[2] + 1024u;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
-               "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072"
-               :: "s"(lds_b), "v"(v0), "v"(v1), "v"(v2), "v"(voff[3]), "s"(table - 3072ull) : "memory", "m0");
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-               :: "s"(lds_b + 4096u), "v"(voff[4]), "s"(table) : "memory", "m0");
+  unsigned int m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %8\n\t"
+               "global_load_lds_dwordx4 %4, %8 offset:1024\n\tglobal_load_lds_dwordx4 %5, %8 offset:2048\n\t"
+               "global_load_lds_dwordx4 %6, %8 offset:3072\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %7, %9\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved)
+               : "s"(lds_b), "s"(lds_b + 4096u), "v"(v0), "v"(v1), "v"(v2), "v"(voff[3]), "v"(voff[4]), "s"(table - 3072ull), "s"(table)
+               : "memory");
 }
 
 struct AfSlot

@@ -64,6 +64,7 @@ extern "C" int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int
 
 void pllhip_group_destroy(pllhip_ctx * g)
 {
+  pllhip_device_guard guard;
   for (pllhip_ctx * s : g->shards) pllhip_ctx_destroy(s);
   g->shards.clear();
   delete g;
@@ -94,6 +95,7 @@ namespace
 template <typename Enqueue>
 int fan_out_and_sum(pllhip_ctx * g, unsigned int ncomp, double * sums, Enqueue enqueue)
 {
+  pllhip_device_guard guard; // (the caller's current device is put back on return)
   int rc = 0;
   for (size_t i = 0; i < g->shards.size() && !rc; ++i)
   {

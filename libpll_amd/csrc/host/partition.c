@@ -17,7 +17,8 @@ __thread int pll_errno;
 __thread char pll_errmsg[200] = {0};
 
 int pll_amd_mirror_mode = 0;
-static int g_device = -1;
+/* (per thread, like pll_errno: distinct threads may create distinct partitions concurrently) */
+static __thread int g_device = -1;
 
 void pll_amd_set_error(int code, const char * fmt, ...)
 {
@@ -65,8 +66,8 @@ unsigned int pll_amd_shard_count(const pll_partition_t * p) { return pllhip_shar
  * PLL_AMD_DEVICES = "0-7" / "0,1,2" / "all"; an ordinal may repeat).  One entry or none: the
  * partition lives on one device as before. */
 #define PLL_AMD_MAX_DEVICES 64
-static int g_devices[PLL_AMD_MAX_DEVICES];
-static int g_ndevices = -1; /* -1: not set by the API, look at the environment */
+static __thread int g_devices[PLL_AMD_MAX_DEVICES];
+static __thread int g_ndevices = -1; /* -1: not set by the API, look at the environment */
 
 int pll_amd_set_devices(const int * devices, unsigned int count)
 {
@@ -712,6 +713,8 @@ int pll_amd_wait(pll_partition_t * p)
   if (rc) return pll_amd_fail_hip(rc, "stream synchronize");
   return PLL_SUCCESS;
 }
+
+const char * pll_amd_rccl_path(void) { return pllhip_rccl_path(); }
 
 int pll_amd_comm_unique_id(void * id)
 {

@@ -157,6 +157,85 @@ def random_tree(tips, seed=42, use_scalers=True, branch=None):
     return _assemble(tips, joins, (u, v), rng, "random", use_scalers, branch)
 
 
+# ---- op lists that change: what a tree search hands pll_update_partials ------------------------
+class UnrootedView:
+    """The tree of a TreePlan as an unrooted tree: every inner node has one CLV / scale buffer (its
+    node number, as in TreePlan) that holds the node's partial towards WHICHEVER neighbour the last
+    traversal was directed at -- the way libpll's unrooted trees share a clv_index among the three
+    directions of a node (pll.h:312-324; test/src/partial-traversal.c:17-58 re-orients them)."""
+
+    def __init__(self, plan, use_scalers=True):
+        self.tips = plan.tips
+        self.use_scalers = use_scalers
+        self.adj = {}
+        self.matrix = {}
+        u, _, v, _, m = plan.root_edge
+        for child, parent in plan.parent_of.items():
+            if child == v and parent == u:
+                continue
+            self._edge(child, parent, child)      # an edge's matrix slot is its child's number
+        self._edge(u, v, m)
+        self.root = (u, v)
+
+    def _edge(self, a, b, m):
+        self.adj.setdefault(a, []).append(b)
+        self.adj.setdefault(b, []).append(a)
+        self.matrix[frozenset((a, b))] = m
+
+    def edges(self):
+        return [tuple(sorted(e)) for e in self.matrix]
+
+    def traversal(self, root):
+        """Post-order op list of the whole tree directed at the edge `root` = (a, b), and the
+        arguments of pll_compute_edge_loglikelihood at that edge."""
+        a, b = root
+        ops = []
+        for top, away in ((a, b), (b, a)):
+            stack = [(top, away, False)]
+            while stack:
+                x, frm, done = stack.pop()
+                if x < self.tips:
+                    continue
+                kids = [y for y in self.adj[x] if y != frm]
+                if not done:
+                    stack.append((x, frm, True))
+                    for y in kids:
+                        stack.append((y, x, False))
+                else:
+                    c1, c2 = kids
+                    ops.append((x, _scaler_of(x, self.tips, self.use_scalers),
+                                c1, self.matrix[frozenset((x, c1))], _scaler_of(c1, self.tips, self.use_scalers),
+                                c2, self.matrix[frozenset((x, c2))], _scaler_of(c2, self.tips, self.use_scalers)))
+        arr = np.zeros(len(ops), dtype=OPS_DTYPE)
+        for i, o in enumerate(ops):
+            arr[i] = o
+        # (a tip may only be the "child" side of the call: the inner node first)
+        if a < self.tips:
+            a, b = b, a
+        edge = (a, _scaler_of(a, self.tips, self.use_scalers), b, _scaler_of(b, self.tips, self.use_scalers),
+                self.matrix[frozenset((a, b))])
+        return arr, edge
+
+    def partial(self, full_ops, changed_edges, root):
+        """The ops of `full_ops` (a traversal directed at `root`) that a change of the branches
+        `changed_edges` invalidates: the nodes between each branch and the root edge."""
+        parent = {}
+        for op in full_ops:
+            p = int(op["parent_clv_index"])
+            parent[int(op["child1_clv_index"])] = p
+            parent[int(op["child2_clv_index"])] = p
+        dirty = set()
+        for x, y in changed_edges:
+            # (the branch hangs below y if y is x's parent in this orientation, below x the other way
+            # round; the root edge itself invalidates no CLV)
+            node = y if parent.get(x) == y else x if parent.get(y) == x else None
+            while node is not None:
+                dirty.add(node)
+                node = parent.get(node)
+        keep = np.array([int(op["parent_clv_index"]) in dirty for op in full_ops], dtype=bool)
+        return full_ops[keep]
+
+
 # ---- models ---------------------------------------------------------------------
 
 def q_matrix(rates, freqs):
