@@ -504,10 +504,15 @@ PLL_EXPORT void pll_show_clv(const pll_partition_t * partition,
  * operand is a host array.  Each call stages its operands into a per-thread scratch device
  * context, runs the kernels the partition-level calls run, and copies the results back
  * (PCIe-bound by construction: keep data in a partition where speed matters).  Arrays are
- * unpadded (states_padded == states) whatever ISA bit `attrib` carries; of `attrib` only
- * PLL_ATTRIB_RATE_SCALERS is looked at.  Errors: pll_errno / pll_errmsg (PLL_ERROR_HIP_*),
- * -INFINITY from the double functions, PLL_FAILURE from the int functions.
- * pll_amd_core_release frees the calling thread's scratch context. */
+ * unpadded (states_padded == states).  The reference pads rows of states under its SIMD flags
+ * (pll.c:437-451): a call that carries PLL_ATTRIB_ARCH_SSE / _AVX / _AVX2 with a state count that
+ * flag would pad (5 or 7 states under AVX ...) fails with PLL_ERROR_PARAM_INVALID -- the caller's
+ * arrays have another stride -- instead of being misread; where the padding is none (4, 8, 20
+ * states) the flag is accepted and ignored.  Otherwise of `attrib` only PLL_ATTRIB_RATE_SCALERS
+ * is looked at.  Errors: pll_errno / pll_errmsg (PLL_ERROR_HIP_*), -INFINITY from the double
+ * functions, PLL_FAILURE from the int functions.
+ * The calling thread keeps a few scratch contexts (one per recent shape); pll_amd_core_release
+ * frees them -- call it before a thread that used pll_core_* exits. */
 PLL_EXPORT void pll_core_create_lookup(unsigned int states, unsigned int rate_cats, double * lookup,
                                        const double * left_matrix, const double * right_matrix,
                                        const unsigned int * tipmap, unsigned int tipmap_size,

@@ -92,6 +92,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   HIP_TRY(hipGetDeviceProperties(&prop, shape->device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
+  if (const char * e = getenv("PLLHIP_SPIN")) c->no_spin = atoi(e) == 0;
   if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e); // 0 / 1; 2: the whole-list kernel's counts too
   if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_FUSED"))
@@ -149,7 +150,9 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   if ((rc = dev_alloc(&c->d_zero, (size_t)64, true, c->stream))) goto fail; // a zero word; 16-byte dummy loads read it too
   HIP_TRY(hipHostMalloc((void **)&c->h_result, 4 * sizeof(double), hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void **)&c->h_result_dev, c->h_result, 0));
-  if ((rc = dev_alloc(&c->d_counter, (size_t)4, true, c->stream))) goto fail;
+  memset(c->h_result, 0, 4 * sizeof(double));
+  // (arrival tickets of the reducing kernels: one word per group of 64 workgroups + one)
+  if ((rc = dev_alloc(&c->d_counter, (size_t)(PLLHIP_REDUCE_BLOCKS / 64 + 4) * sizeof(unsigned int), true, c->stream))) goto fail;
 
   // (the sumtable's two matrix sets are built in the device half: 2 x one P-matrix set)
   c->stage_bytes = 64 * 1024 + (size_t)shape->prob_matrices * 16 +

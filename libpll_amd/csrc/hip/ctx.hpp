@@ -105,7 +105,9 @@ struct pllhip_ctx
   unsigned int * d_zero = nullptr;     // [4] zeros
   double * d_tiptab = nullptr;         // 20 states: [2][maxstates][rate_cats][20] tip row sums of the current op
   size_t tiptab_elems = 0;
-  double * h_result = nullptr;         // pinned, host-mapped [4]
+  double * h_result = nullptr;         // pinned, host-mapped [4]: [0..2] results, [3] the sequence word the host spins on
+  unsigned long long result_seq = 0;   // number of the last result-returning launch
+  bool no_spin = false;                // env PLLHIP_SPIN=0: wait for the stream instead (A/B measurements)
   double * h_result_dev = nullptr;     // device address of h_result
   unsigned int * d_counter = nullptr;  // arrival counter of the reducing kernels
   double * d_persite = nullptr;        // [sites], lazily allocated

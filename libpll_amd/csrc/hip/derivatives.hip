@@ -628,8 +628,21 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     grid = pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    // (a Newton iteration is a 17 us kernel: fewer, longer workgroups -- two per CU -- leave the final
+    // sum 512 values instead of 1954 and the launch less to dispatch: 33.9 -> 28.8 us per call at
+    // 500 k sites; PLLHIP_DERIV_GRID for measurements)
+    {
+      const char * e = getenv("PLLHIP_DERIV_GRID");
+      const unsigned int cap = e && atoi(e) > 0 ? (unsigned int)atoi(e) : (unsigned int)c->num_cus * 2;
+      if (grid > cap) grid = cap;
+    }
     a.reduce = pllhip_reduce_out(c, grid);
-    const bool nt = pllhip_use_nt(c);
+    // A table that fits the 256 MiB Infinity Cache with room to spare is re-read by every Newton
+    // iteration from there: no streaming hint on its loads (the hint is for CLV-sized streams that
+    // nothing will touch again)
+    const size_t table_bytes = (size_t)c->sh.sites * R * S * sizeof(double);
+    bool nt = pllhip_use_nt(c) && table_bytes > ((size_t)128 << 20);
+    if (const char * e = getenv("PLLHIP_DERIV_NT")) nt = atoi(e) != 0; // (measurements)
 #define DERIV_DNA(RCV)                                                        \
     do {                                                                      \
       if (nt) k_derivatives_dna<RCV, true><<<grid, 256, 0, c->stream>>>(a);   \
@@ -704,7 +717,10 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
                            c->stream));
   }
   if (c->defer) return 0; // a shard of a group: the group waits for all of them
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  {
+    int rc = pllhip_result_wait_host(c, a.reduce, c->comm != nullptr);
+    if (rc) return rc;
+  }
   *h_d_f = c->h_result[0];
   *h_dd_f = c->h_result[1];
   return 0;

@@ -17,17 +17,19 @@
 // unless persite_lnl is asked for.
 //
 // Site sum: per-lane running sums -> wave __shfl_down tree -> LDS -> one double
-// per workgroup -> fixed-order final sum, fused into the same launch for grids of
-// up to 512 workgroups (last-arriving workgroup), a one-workgroup k_final_sum
-// launch otherwise (lnl_common.hpp).  Reproducible run to run; the reference adds
+// per workgroup -> fixed-order final sum: by the last-arriving workgroup of the same launch
+// for small grids (tickets in two levels, lnl_common.hpp), by a one-workgroup k_final_sum launch
+// otherwise (measured: pllhip_reduce_out).  The host then spins on a host-mapped word instead of
+// waiting for the stream (pllhip_result_wait_host).  Reproducible run to run; the reference adds
 // sites sequentially, agreement is ~1e-16*sqrt(sites) relative.  The final step
 // also adds the ascertainment-bias correction when one is set (asc_bias.hip).
+#include <stdlib.h>
+
 #include "ctx.hpp"
 #include "numerics.hpp"
 
 #include "lnl_common.hpp"
 
-#define PLLHIP_FUSE_MAX_GRID 512
 
 ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid)
 {
@@ -36,9 +38,22 @@ ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid)
   r.counter = c->d_counter;
   r.result = c->d_result;
   r.host_result = c->comm ? nullptr : c->h_result_dev;
+  // (the word the host spins on: h_result[3]; not with a communicator -- the collective follows -- and
+  // not for a shard of a group, whose results the group collects after enqueueing everywhere)
+  r.host_seq = (c->comm || c->defer || c->no_spin) ? nullptr : reinterpret_cast<unsigned long long *>(c->h_result_dev + 3);
+  r.seq = ++c->result_seq;
   r.extra = c->pending_extra; // set by the caller for exactly one launch
   c->pending_extra = nullptr;
-  r.fused = grid <= PLLHIP_FUSE_MAX_GRID ? 1 : 0;
+  // The last-arriving workgroup finishes the sum in the same launch only for small grids
+  // (PLLHIP_FUSE_MAX_GRID workgroups, default 128; PLLHIP_FUSE_REDUCE=0/1 forces either way).  Measured
+  // in round 3 with two levels of tickets (64 workgroups per counter, so that no counter serialises
+  // thousands of atomics): every workgroup still ends with a write-through store, a wait for it and an
+  // atomic round trip, and the finisher reads all partials past the L2 -- 45.8 us per derivative call
+  // at 1954 workgroups against 33.9 us with the separate 6 us launch, 31.3 against 28.8 at 512
+  // (tools/call_floor_ab.sh).  Small grids are latency-bound and save the launch.
+  static const int forced = getenv("PLLHIP_FUSE_REDUCE") ? atoi(getenv("PLLHIP_FUSE_REDUCE")) : -1;
+  static const unsigned int max_grid = getenv("PLLHIP_FUSE_MAX_GRID") ? (unsigned int)atoi(getenv("PLLHIP_FUSE_MAX_GRID")) : 128u;
+  r.fused = forced >= 0 ? (forced ? 1 : 0) : (grid <= max_grid ? 1 : 0);
   return r;
 }
 
@@ -65,6 +80,30 @@ __global__ __launch_bounds__(256) void k_final_sum(ReduceOut ro, unsigned int np
     }
     __syncthreads();
   }
+  if (threadIdx.x == 0) pllhip_publish_seq(ro);
+}
+
+// Bounded spin on the host-mapped word; beyond ~2 ms (a long kernel, a profiler in between, memory that is
+// not coherent after all) the stream's own completion is waited for, as before round 3.
+int pllhip_result_wait_host(pllhip_ctx * c, const ReduceOut & ro, bool stream_work_follows)
+{
+  if (!ro.host_seq || stream_work_follows)
+  {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  const volatile unsigned long long * word = reinterpret_cast<const volatile unsigned long long *>(c->h_result + 3);
+  for (unsigned int spins = 0; spins < 400000u; ++spins)
+  {
+    if (*word == ro.seq)
+    {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return 0;
+    }
+    __builtin_ia32_pause();
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp)
@@ -908,7 +947,10 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
     HIP_TRY(hipMemcpyAsync(h_persite, c->d_persite, (size_t)a.sites * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
   if (c->defer) return 0; // a shard of a group: the group waits for all of them (pllhip_result_wait)
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  {
+    int rc = pllhip_result_wait_host(c, a.reduce, c->comm != nullptr || h_persite != nullptr);
+    if (rc) return rc;
+  }
   *h_lnl = c->h_result[0];
   return 0;
 }

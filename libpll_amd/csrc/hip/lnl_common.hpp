@@ -4,18 +4,21 @@
 #include "ctx.hpp"
 #include "numerics.hpp"
 
+#define PLLHIP_TICKET_GROUP 64u
+
 // Reduction target shared by the reducing kernels: per-workgroup partial sums,
 // an arrival counter, and where the final value goes.
 struct ReduceOut
 {
   double * partials;       // [NCOMP][gridDim.x]
-  unsigned int * counter;  // arrival ticket, zero between launches
+  unsigned int * counter;  // arrival tickets, zero between launches: [0] the groups', [1 + g] group g's workgroups'
   double * result;         // device result [NCOMP] (input of the RCCL all-reduce)
   double * host_result;    // host-mapped copy (nullptr when an all-reduce follows)
+  unsigned long long * host_seq; // host-mapped word that takes `seq` once host_result is complete (nullptr: nobody spins)
+  unsigned long long seq;
   const double * extra;    // [NCOMP] added to the finished sums (asc-bias correction) or nullptr
-  int fused;               // 1: the last-arriving workgroup finishes the sum in this launch;
-                           // 0: a one-workgroup k_final_sum launch follows (large grids: the
-                           // per-workgroup ticket costs more than a launch there, measured)
+  int fused;               // 1: the last-arriving workgroup finishes the sum in this launch (small grids);
+                           // 0: a one-workgroup k_final_sum launch follows (measured: pllhip_reduce_out)
 };
 
 struct LnlArgs
@@ -56,6 +59,16 @@ enum { EDGE_II = 0, EDGE_TI = 1, ROOT = 2 };
 __device__ __forceinline__ double scale_minlh(unsigned int d)
 {
   return d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
+}
+
+// The host does not wait for the STREAM to report the launch complete (10-20 us of runtime and
+// interrupt latency per result-returning call -- the floor of a Newton loop): it spins
+// on a word of host-mapped memory that the finishing workgroup writes after the result, system scope.
+__device__ __forceinline__ void pllhip_publish_seq(const ReduceOut & ro)
+{
+  if (!ro.host_seq) return;
+  __threadfence_system(); // the result before the word
+  __hip_atomic_store(ro.host_seq, ro.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Sum `v[0..NCOMP)` over the whole grid, reproducibly: lane sums -> wave
@@ -99,9 +112,16 @@ __device__ __forceinline__ void grid_sum(const double (&v_in)[NCOMP], const Redu
     s_last = false;
     if (ro.fused)
     {
+      // Tickets in two levels: groups of PLLHIP_TICKET_GROUP consecutive workgroups share a counter,
+      // the last of a group takes a ticket of the top counter, the last of those finishes the sum.
+      // One counter for everybody serialises its atomics (~30 ns each across the XCDs: +125 us on a
+      // 3907-workgroup grid, which is why grids above 512 workgroups used to launch k_final_sum
+      // instead); with 64 per counter the longest chain is 64 + grid / 64 atomics.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores have left before the ticket
-      const unsigned int ticket = atomicAdd(ro.counter, 1u);
-      s_last = (ticket == nparts - 1);
+      const unsigned int g = blockIdx.x / PLLHIP_TICKET_GROUP, ngroups = (nparts + PLLHIP_TICKET_GROUP - 1) / PLLHIP_TICKET_GROUP;
+      const unsigned int gsize = (g + 1 == ngroups) ? nparts - g * PLLHIP_TICKET_GROUP : PLLHIP_TICKET_GROUP;
+      if (atomicAdd(ro.counter + 1 + g, 1u) == gsize - 1)
+        s_last = (atomicAdd(ro.counter, 1u) == ngroups - 1);
     }
   }
   __syncthreads();
@@ -133,8 +153,10 @@ __device__ __forceinline__ void grid_sum(const double (&v_in)[NCOMP], const Redu
       ro.result[cidx] = total;
       if (ro.host_result) ro.host_result[cidx] = total;
     }
-    *ro.counter = 0u; // ready for the next launch (stream order separates launches)
+    pllhip_publish_seq(ro);
   }
+  // ready for the next launch (stream order separates launches)
+  for (unsigned int i = threadIdx.x; i <= (nparts + PLLHIP_TICKET_GROUP - 1) / PLLHIP_TICKET_GROUP; i += blockDim.x) ro.counter[i] = 0u;
 }
 
 __device__ __forceinline__ void block_sum_to_partials(double v, const ReduceOut & ro)
@@ -177,6 +199,9 @@ __device__ __forceinline__ double site_loglk(const LnlArgs & a, double terma, si
 // pllhip_finish_reduce launches the final pass when the kernel did not fuse it
 ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid);
 int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp);
+// after the launches of a result-returning call: wait until h_result holds this call's values
+// (`stream_work_follows`: copies or a collective were enqueued behind the kernel -- wait for the stream)
+int pllhip_result_wait_host(pllhip_ctx * c, const ReduceOut & ro, bool stream_work_follows);
 
 // asc_bias.hip: launch the correction kernel (if a correction type is set) ahead of the
 // site kernel; *extra = what that kernel's final sum must add

@@ -158,7 +158,8 @@ __device__ __forceinline__ unsigned int group_and(unsigned int x)
 template <int RC, int J, int MODE, int NTP, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan, FusedBases bases,
                                                         unsigned int nops, unsigned int sites, unsigned int nslots,
-                                                        double2 * sink, unsigned int * next_tile, unsigned int dynamic_rounds)
+                                                        double2 * sink, unsigned int * next_tile, unsigned int dynamic_rounds,
+                                                        unsigned int site_base)
 {
   static_assert(RC == 1 || RC == 2 || RC == 4, "lane groups of 2, 4 or 8");
   constexpr bool NT = NTP != 0;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   size_t round = 0;
   for (size_t tile = wave; tile < tiles;)
   {
-    const size_t site0 = tile * TS;
+    const size_t site0 = (size_t)site_base + tile * TS; // (site_base: this launch's block of the alignment)
     const size_t clv_off = site0 * (W * 16u);                             // bytes into a CLV
     const size_t cnt_off = site0 * ((MODE == SCALE_RATE) ? RC * 4u : 4u); // bytes into a scale buffer
 
@@ -1008,12 +1009,35 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   // write rates): seven of the ~21 rounds of 1 M sites (the measured optimum there), and in proportion
   // for longer alignments (8 M sites x 128 taxa: 7 rounds 0.565, 30 0.584, 54 0.583 of the HBM peak;
   // 2 M sites: 7 rounds 0.652, 14 0.672); short lists two, see the kernel
-  const size_t rounds = tiles / (grid * 4);
+  // Alignments whose CLVs do not fit ~32 GB at once are walked in BLOCKS of sites, one launch each
+  // (every launch takes its block through the whole list): a launch then writes a set of pages the
+  // translation caches and the memory system have seen work well (profiles/r3_footprint_blocks.txt;
+  // PLLHIP_FUSED_BLOCK_SITES sets the block, 0 = one launch).
+  size_t block_sites = sites;
+  {
+    const char * e = getenv("PLLHIP_FUSED_BLOCK_SITES");
+    if (e) block_sites = atoi(e) > 0 ? (size_t)atoi(e) : sites;
+    else if (footprint > ((size_t)32 << 30))
+    {
+      const size_t nblocks = (footprint + ((size_t)16 << 30) - 1) / ((size_t)16 << 30);
+      block_sites = (sites + nblocks - 1) / nblocks;
+    }
+    block_sites = (block_sites + 255) / 256 * 256; // (whole tiles, whole rounds)
+    if (block_sites > sites) block_sites = sites;
+  }
+  for (size_t base = 0; base < sites; base += block_sites)
+  {
+  const unsigned int bsites = (unsigned int)(sites - base < block_sites ? sites - base : block_sites);
+  const size_t btiles = (bsites + tile_sites - 1) / tile_sites;
+  size_t bgrid = (btiles + 3) / 4;
+  if (bgrid > cap) bgrid = cap;
+  if (base) HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+  const size_t rounds = btiles / (bgrid * 4);
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                       : (count >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
 #define LAUNCH_FUSED(MODEV, NTV)                                                                                  \
-  k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<(unsigned int)grid, 256, lds, c->stream>>>(                 \
-      d_plan, bases, count, sites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds)
+  k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<(unsigned int)bgrid, 256, lds, c->stream>>>(                \
+      d_plan, bases, count, bsites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds, (unsigned int)base)
 #define LAUNCH_FUSED_MODE(NTV)                         \
   do {                                                  \
     if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV);       \
@@ -1025,6 +1049,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   else LAUNCH_FUSED_MODE(2);
 #undef LAUNCH_FUSED_MODE
 #undef LAUNCH_FUSED
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -7,7 +7,9 @@
  * construction; a client that cares about speed keeps its data in a partition.
  *
  * Layout: arrays are UNPADDED (states_padded == states, as everywhere in this library,
- * include/pll_amd.h) whatever ISA bit `attrib` carries; of `attrib` only
+ * include/pll_amd.h).  An ISA bit in `attrib` is accepted where the reference's padding for it is
+ * none (4, 8, 20 states ...) and refused with PLL_ERROR_PARAM_INVALID where the reference would
+ * expect padded rows (5 or 7 states under AVX: core_layout_ok below); otherwise of `attrib` only
  * PLL_ATTRIB_RATE_SCALERS matters.  Arithmetic order is the AVX2-flag path's for 4 and 20
  * states and the plain C kernels' otherwise -- see numerics.hpp.
  *
@@ -20,20 +22,48 @@
 
 #include "internal.h"
 
-/* ---- the scratch context of the calling thread ---------------------------------------- */
-
-static __thread pllhip_ctx_t * t_ctx;
-static __thread pllhip_shape_t t_shape;
-static __thread int t_shape_valid;
+/* ---- the scratch contexts of the calling thread ----------------------------------------
+ * A traversal through pll_core_update_partial_tt / _ti / _ii changes shape on almost every call (tips,
+ * CLVs, scale buffers differ), so ONE kept context would be torn down and rebuilt -- stream, arenas,
+ * pinned buffers -- call after call.  A few are kept, least recently used out first.
+ * They live until pll_amd_core_release(), which a thread that used pll_core_* should call before it
+ * exits (thread-local storage has no destructor in C). */
+#define CORE_CTX_KEPT 6
+static __thread struct
+{
+  pllhip_ctx_t * ctx;
+  pllhip_shape_t shape;
+  unsigned long long stamp;
+} t_kept[CORE_CTX_KEPT];
+static __thread unsigned long long t_clock;
 
 void pll_amd_core_release(void)
 {
-  if (t_ctx) pllhip_ctx_destroy(t_ctx);
-  t_ctx = NULL;
-  t_shape_valid = 0;
+  int i;
+  for (i = 0; i < CORE_CTX_KEPT; ++i)
+  {
+    if (t_kept[i].ctx) pllhip_ctx_destroy(t_kept[i].ctx);
+    t_kept[i].ctx = NULL;
+  }
 }
 
 extern int pll_amd_core_device(void); /* partition.c: the device a new partition would bind to */
+
+/* The arrays of pll_core_* are UNPADDED here.  The reference pads every row of states to
+ * states_padded under its SIMD flags (pll.c:437-451: even for SSE, a multiple of 4 for AVX / AVX2):
+ * a client that passes such a flag with a state count the flag would pad has laid its arrays out
+ * differently -- refused, rather than read with the wrong stride. */
+static int core_layout_ok(unsigned int states, unsigned int attrib)
+{
+  unsigned int padded = states;
+  if (attrib & PLL_ATTRIB_ARCH_SSE) padded = (states + 1u) & ~1u;
+  if (attrib & (PLL_ATTRIB_ARCH_AVX | PLL_ATTRIB_ARCH_AVX2 | PLL_ATTRIB_ARCH_AVX512)) padded = (states + 3u) & ~3u;
+  if (padded == states) return 1;
+  pll_amd_set_error(PLL_ERROR_PARAM_INVALID,
+                    "pll_core_*: %u states under a SIMD attribute mean arrays padded to %u per row in the "
+                    "reference; this library takes unpadded arrays: pass PLL_ATTRIB_ARCH_CPU", states, padded);
+  return 0;
+}
 
 static pllhip_ctx_t * scratch(unsigned int states, unsigned int sites, unsigned int rate_cats,
                               unsigned int tips, unsigned int clv_buffers, unsigned int rate_matrices,
@@ -41,7 +71,8 @@ static pllhip_ctx_t * scratch(unsigned int states, unsigned int sites, unsigned 
                               unsigned int attrib)
 {
   pllhip_shape_t sh;
-  int rc;
+  int rc, i, victim = 0;
+  if (!core_layout_ok(states, attrib)) return NULL;
   memset(&sh, 0, sizeof(sh));
   sh.device = pll_amd_core_device();
   sh.states = states;
@@ -54,18 +85,27 @@ static pllhip_ctx_t * scratch(unsigned int states, unsigned int sites, unsigned 
   sh.scale_buffers = scale_buffers;
   sh.pattern_tip = pattern_tip;
   sh.rate_scalers = (attrib & PLL_ATTRIB_RATE_SCALERS) ? 1 : 0;
-  if (t_ctx && t_shape_valid && !memcmp(&sh, &t_shape, sizeof(sh))) return t_ctx;
-  pll_amd_core_release();
-  if ((rc = pllhip_ctx_create(&sh, &t_ctx)))
+  for (i = 0; i < CORE_CTX_KEPT; ++i)
+    if (t_kept[i].ctx && !memcmp(&sh, &t_kept[i].shape, sizeof(sh)))
+    {
+      t_kept[i].stamp = ++t_clock;
+      return t_kept[i].ctx;
+    }
+  /* an empty place, else the least recently used one */
+  for (i = 1; i < CORE_CTX_KEPT; ++i)
+    if (t_kept[victim].ctx && (!t_kept[i].ctx || t_kept[i].stamp < t_kept[victim].stamp)) victim = i;
+  if (t_kept[victim].ctx) pllhip_ctx_destroy(t_kept[victim].ctx);
+  t_kept[victim].ctx = NULL;
+  if ((rc = pllhip_ctx_create(&sh, &t_kept[victim].ctx)))
   {
     pll_amd_set_error(rc == -1 ? PLL_ERROR_HIP_UNSUPPORTED : PLL_ERROR_HIP_RUNTIME,
                       "pll_core_*: cannot create the scratch device context: %s", pllhip_last_error());
-    t_ctx = NULL;
+    t_kept[victim].ctx = NULL;
     return NULL;
   }
-  t_shape = sh;
-  t_shape_valid = 1;
-  return t_ctx;
+  t_kept[victim].shape = sh;
+  t_kept[victim].stamp = ++t_clock;
+  return t_kept[victim].ctx;
 }
 
 #define TRY(call, what)                  \
@@ -185,9 +225,19 @@ void pll_core_create_lookup(unsigned int states, unsigned int rate_cats, double 
       pllhip_update_partials(c, &op, 1) || pllhip_get_clv(c, 2, rows))
     pll_amd_fail_hip(-1, "pll_core_create_lookup");
   else
+  {
+    /* (4 states: the rows of character 0 exist in the caller's 256-row table and are zero in the
+       reference, core_partials.c:665-723; pll_core_update_partial_tt uploads all 256) */
+    if (states == 4)
+      for (j = 0; j < 16; ++j)
+      {
+        memset(lookup + ((size_t)j << 4) * span, 0, span * sizeof(double));
+        memset(lookup + (size_t)j * span, 0, span * sizeof(double));
+      }
     for (n = 0, j = first; j < codes; ++j)
       for (k = first; k < codes; ++k, ++n)
         memcpy(lookup + (((size_t)j << shift) + k) * span, rows + (size_t)n * span, span * sizeof(double));
+  }
   free(c1);
   free(rows);
 }

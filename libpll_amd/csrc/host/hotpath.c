@@ -101,30 +101,53 @@ static int slot_of(pll_amd_partition_t * q, const double * key)
 static int was_evicted(const pll_amd_partition_t * q, const double * key)
 {
   unsigned int i;
-  for (i = 0; i < PLL_AMD_EVICTED_KEYS; ++i)
+  for (i = 0; i < q->sumtable_evicted_n; ++i)
     if (key && q->sumtable_evicted[i] == key) return 1;
   return 0;
+}
+
+static void evicted_remove(pll_amd_partition_t * q, const double * key)
+{
+  unsigned int i;
+  for (i = 0; i < q->sumtable_evicted_n; ++i)
+    if (q->sumtable_evicted[i] == key) q->sumtable_evicted[i--] = q->sumtable_evicted[--q->sumtable_evicted_n];
+}
+
+static void evicted_add(pll_amd_partition_t * q, const double * key)
+{
+  if (was_evicted(q, key)) return;
+  if (q->sumtable_evicted_n == q->sumtable_evicted_cap)
+  {
+    const unsigned int cap = q->sumtable_evicted_cap ? 2 * q->sumtable_evicted_cap : 64;
+    const double ** grown = (const double **)realloc((void *)q->sumtable_evicted, cap * sizeof(*grown));
+    if (!grown) return; /* (out of memory: the guard loses a key, nothing else) */
+    q->sumtable_evicted = grown;
+    q->sumtable_evicted_cap = cap;
+  }
+  q->sumtable_evicted[q->sumtable_evicted_n++] = key;
 }
 
 /* a slot for a table that has none yet */
 static int slot_assign(pll_amd_partition_t * q, const double * key)
 {
   unsigned int s, i;
+  int freed = -1;
   if (!q->sumtable_cap) q->sumtable_cap = pllhip_sumtable_budget(q->ctx);
-  for (i = 0; i < PLL_AMD_EVICTED_KEYS; ++i)
-    if (q->sumtable_evicted[i] == key) q->sumtable_evicted[i] = NULL; /* it is alive again */
-  if (q->sumtable_used < q->sumtable_cap)
+  evicted_remove(q, key); /* it is alive again */
+  /* a slot the client gave back (pll_amd_forget_sumtable) before a new one: its device buffer is
+     there already (allocate / forget / free in a loop grew device memory up to the budget) */
+  for (i = 0; i < q->sumtable_used && freed < 0; ++i)
+    if (!q->sumtable_key[i]) freed = (int)i;
+  if (freed >= 0)
+    s = (unsigned int)freed;
+  else if (q->sumtable_used < q->sumtable_cap)
     s = q->sumtable_used++;
   else
   {
     s = 0;
     for (i = 1; i < q->sumtable_used; ++i)
       if (q->sumtable_stamp[i] < q->sumtable_stamp[s]) s = i;
-    if (q->sumtable_key[s])
-    {
-      q->sumtable_evicted[q->sumtable_evicted_next] = q->sumtable_key[s];
-      q->sumtable_evicted_next = (q->sumtable_evicted_next + 1) % PLL_AMD_EVICTED_KEYS;
-    }
+    if (q->sumtable_key[s]) evicted_add(q, q->sumtable_key[s]);
   }
   q->sumtable_key[s] = key;
   q->sumtable_stamp[s] = ++q->sumtable_clock;
@@ -137,10 +160,8 @@ static int slot_assign(pll_amd_partition_t * q, const double * key)
 int pll_amd_forget_sumtable(pll_partition_t * p, const double * sumtable)
 {
   pll_amd_partition_t * q = pll_amd_priv(p);
-  unsigned int i;
   int slot = slot_of(q, sumtable);
-  for (i = 0; i < PLL_AMD_EVICTED_KEYS; ++i)
-    if (q->sumtable_evicted[i] == sumtable) q->sumtable_evicted[i] = NULL;
+  evicted_remove(q, sumtable);
   if (slot < 0) return PLL_FAILURE;
   q->sumtable_key[slot] = NULL;
   q->sumtable_stamp[slot] = 0; /* first to be reused */

@@ -12,7 +12,6 @@
 #include "pll_amd.h"
 #include "pllhip.h"
 
-#define PLL_AMD_EVICTED_KEYS 64
 #define PLL_AMD_MAX_RATE_CATS 64 /* = PLLHIP_MAX_RATE_CATS of the shim */
 #define PLL_AMD_MAGIC 0x504c4c414d443031ull /* "PLLAMD01" */
 
@@ -45,8 +44,11 @@ typedef struct pll_amd_partition
   unsigned long long sumtable_stamp[PLLHIP_SUMTABLE_MAX_SLOTS];
   unsigned int sumtable_used, sumtable_cap;
   unsigned long long sumtable_clock;
-  const double * sumtable_evicted[PLL_AMD_EVICTED_KEYS];
-  unsigned int sumtable_evicted_next;
+  /* every key whose device table was recycled and that has not been produced or forgotten since:
+     a growable set (a ring of 64 let older keys drop out, and a later use of such a buffer
+     uploaded host memory nobody had written) */
+  const double ** sumtable_evicted;
+  unsigned int sumtable_evicted_n, sumtable_evicted_cap;
   /* PLL_ATTRIB_SITE_REPEATS: per CLV slot, and which CLV each scale buffer belongs to */
   pll_amd_node_repeats_t * rep;
   int * scaler_owner;

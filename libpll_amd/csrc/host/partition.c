@@ -155,6 +155,7 @@ void pll_partition_destroy(pll_partition_t * p)
   if (!p) return;
   nodes = p->tips + p->clv_buffers;
   if (q->ctx) pllhip_ctx_destroy(q->ctx);
+  free((void *)q->sumtable_evicted);
   free_ptr_array((void **)p->clv, nodes);
   if (p->pmatrix)
   {

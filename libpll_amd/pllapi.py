@@ -17,6 +17,7 @@ import numpy as np
 
 SCALE_BUFFER_NONE = -1
 ATTRIB_ARCH_CPU = 0
+ERROR_PARAM_INVALID = 113   # pll.h:159
 ATTRIB_ARCH_SSE = 1 << 0
 ATTRIB_ARCH_AVX = 1 << 1
 ATTRIB_ARCH_AVX2 = 1 << 2
@@ -160,6 +161,9 @@ class PllLibrary:
     # -- library-level helpers -------------------------------------------------
     def errno(self):
         return C.c_int.in_dll(self.lib, "pll_errno").value
+
+    def clear_error(self):
+        C.c_int.in_dll(self.lib, "pll_errno").value = 0
 
     def errmsg(self):
         return C.string_at(C.addressof((C.c_char * 200).in_dll(self.lib, "pll_errmsg"))).decode()

@@ -84,6 +84,92 @@ def test_site_sharding_two_ranks_gloo(tmp_path, orc, amd):
     assert "SHARDED_OK" in out.stdout
 
 
+# ---------------------------------------------------------------- the product's HOST logic per rank
+
+HOST_WORKER = r'''
+import ctypes as C
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from libpll_amd import workload as W
+from libpll_amd.pllapi import PllLibrary
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+amd = PllLibrary(os.path.join(sys.argv[1], "libpll_amd", "libpll_amd.so"))
+
+# (1) the site ranges every rank derives for itself: contiguous, on multiples of 256, none empty,
+# the same on every rank -- and the last one is where the ascertainment-bias sites go
+total = 10_000
+b = W.shard_bounds(total, world)
+assert b[0] == 0 and b[-1] == total and all(x < y for x, y in zip(b, b[1:]))
+assert all(x % 256 == 0 for x in b[1:-1])
+mine = torch.tensor(b, dtype=torch.int64)
+every = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(every, mine)
+assert all(bool((e == mine).all()) for e in every)
+carries_extra_sites = rank == world - 1
+# too few sites for the ranks: refused identically everywhere, before any collective could hang
+try:
+    W.shard_bounds(100, 4)
+    refused = False
+except ValueError:
+    refused = True
+assert refused
+
+# (2) the PRODUCT's planner (pllhip_fused_plan_dry: pure host logic) on the op list every rank is
+# handed: the same order, slots and reloads on every rank -- the ranks then launch the same kernels
+plan = W.random_tree(40, seed=5)
+ops = np.ascontiguousarray(plan.ops)
+n = len(ops)
+order = (C.c_uint * n)(); slots = (C.c_int * (6 * n))(); hbm = C.c_uint()
+rc = amd.lib.pllhip_fused_plan_dry(C.c_uint(40), C.c_uint(38), C.c_uint(38), C.c_int(1), ops.ctypes.data_as(C.c_void_p),
+                                   C.c_uint(n), C.c_uint(6), order, C.byref(hbm), slots)
+assert rc == 0, amd.errmsg()
+sig = torch.tensor(list(order) + list(slots) + [hbm.value], dtype=torch.int64)
+sigs = [torch.zeros_like(sig) for _ in range(world)]
+dist.all_gather(sigs, sig)
+assert all(bool((x == sig).all()) for x in sigs)
+assert sorted(order) == list(range(n))
+
+# (3) the rest of the host pipeline in front of the path, per rank on its own columns: pattern
+# compression of the rank's slice (weights sum to the slice's length), the tree builders' op list
+seqs = W.random_alignment(40, total, 4, seed=9)
+lo, hi = b[rank], b[rank + 1]
+rows = [s[lo:hi] for s in seqs]
+arr = (C.c_char_p * 40)(*rows)
+length = C.c_int(hi - lo)
+amd.lib.pll_compress_site_patterns.restype = C.POINTER(C.c_uint)
+w = amd.lib.pll_compress_site_patterns(arr, (C.c_uint * 256).in_dll(amd.lib, "pll_map_nt"), 40, C.byref(length))
+assert bool(w), amd.errmsg()
+weights = np.ctypeslib.as_array(w, shape=(length.value,))
+assert int(weights.sum()) == hi - lo and 0 < length.value <= hi - lo
+counts = torch.tensor([hi - lo, int(weights.sum())], dtype=torch.int64)
+dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+assert counts.tolist() == [total, total]
+if rank == 0:
+    print("HOST_OK bounds=%s reloads=%d patterns(rank 0)=%d" % (b, hbm.value, length.value))
+dist.destroy_process_group()
+'''
+
+
+def test_product_host_logic_two_ranks_gloo(tmp_path, amd):
+    """What each rank of the one-process-per-GPU mode does on the HOST, with the product library (no
+    device needed): its site range, the op-list planner's dry run (identical plans on all ranks),
+    pattern compression of its own columns."""
+    script = tmp_path / "host_worker.py"
+    script.write_text(HOST_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(free_port()), str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "HOST_OK" in out.stdout
+
+
 # ---------------------------------------------------------------- the product, one rank per GPU
 
 PRODUCT_WORKER = r'''

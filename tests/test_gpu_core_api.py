@@ -65,7 +65,9 @@ def test_tree_through_core_api(gpu, orc, monkeypatch, states, shape, tips, sites
         case = odd_state_case(states, tips=tips, sites=sites, seed=9, shape=shape)
     plan, S, R = case["plan"], states, case["rate_cats"]
     attrs = (ATTRIB_PATTERN_TIP if pattern_tip else 0) | (ATTRIB_RATE_SCALERS if rate_scalers else 0)
-    attrib = attrs | ATTRIB_ARCH_AVX2          # (the ISA bit is accepted and ignored)
+    # (an ISA bit is accepted and ignored where the reference's padding for it is none; 5 states under AVX2
+    # would mean rows padded to 8 in the reference: refused, test_padded_layouts_are_refused)
+    attrib = attrs | (ATTRIB_ARCH_AVX2 if states % 4 == 0 else 0)
     # a partition only to get the encoded tips and the host eigen system, and the oracle beside it
     p = build_partition(gpu, case, attrs)
     o = oracle_run(orc, gpu, p, case, attrs)
@@ -177,4 +179,70 @@ def test_tree_through_core_api(gpu, orc, monkeypatch, states, shape, tips, sites
                                                  per_cat(vals), d(st), C.byref(df), C.byref(ddf), attrib) == 1
         assert rel_err(np.array([df.value, ddf.value]), np.array(o.derivatives(want_st, t))) < 1e-10
     p.destroy()
+    L.pll_amd_core_release()
+
+
+@pytest.mark.parametrize("states,flag,padded", [(5, "avx", 8), (7, "avx2", 8), (5, "sse", 6), (7, "sse", 8), (61, "avx2", 64)])
+def test_padded_layouts_are_refused(gpu, states, flag, padded):
+    """The reference pads rows of states under its SIMD flags (pll.c:437-451); this library takes
+    unpadded arrays.  A call that carries such a flag with a state count the flag would pad is
+    refused with PLL_ERROR_PARAM_INVALID instead of being read with the wrong stride; without the
+    flag the same call works."""
+    from libpll_amd.pllapi import ATTRIB_ARCH_AVX, ATTRIB_ARCH_SSE, ERROR_PARAM_INVALID
+    L = bind(gpu)
+    bit = {"avx": ATTRIB_ARCH_AVX, "avx2": ATTRIB_ARCH_AVX2, "sse": ATTRIB_ARCH_SSE}[flag]
+    sites, R = 17, 2
+    rng = np.random.default_rng(3)
+    left, right = rng.random((sites, R, states)), rng.random((sites, R, states))
+    pm = rng.random((2, R, states, states))
+    parent = np.full((sites, R, states), -1.0)
+    gpu.clear_error()
+    L.pll_core_update_partial_ii(states, sites, R, d(parent), None, d(left), d(right), d(pm[0]), d(pm[1]), None, None, bit)
+    assert gpu.errno() == ERROR_PARAM_INVALID and str(padded) in gpu.errmsg()
+    assert (parent == -1.0).all(), "nothing may have been written"
+    gpu.clear_error()
+    L.pll_core_update_partial_ii(states, sites, R, d(parent), None, d(left), d(right), d(pm[0]), d(pm[1]), None, None, 0)
+    assert gpu.errno() == 0, gpu.errmsg()
+    want = np.einsum("kij,nkj->nki", pm[0], left) * np.einsum("kij,nkj->nki", pm[1], right)
+    assert np.allclose(parent, want, rtol=1e-13)
+    L.pll_amd_core_release()
+
+
+def test_lookup_rows_of_character_zero_are_zero(gpu):
+    """pll_core_create_lookup for 4 states fills all 256 rows of the caller's table: those of
+    character 0, which no sequence contains, with zeros (core_partials.c:665-723) -- they used to
+    be left as they were, and pll_core_update_partial_tt uploads all 256."""
+    L = bind(gpu)
+    R = 4
+    rng = np.random.default_rng(5)
+    pm = rng.random((2, R, 4, 4))
+    lookup = np.full(256 * 4 * R, np.nan)
+    L.pll_core_create_lookup(4, R, d(lookup), d(pm[0]), d(pm[1]), None, 0, 0)
+    t = lookup.reshape(16, 16, R * 4)
+    assert (t[0] == 0.0).all() and (t[:, 0] == 0.0).all()
+    assert np.isfinite(t[1:, 1:]).all() and (t[1:, 1:] > 0).all()
+    L.pll_amd_core_release()
+
+
+def test_core_api_keeps_a_context_per_recent_shape(gpu):
+    """Alternating shapes (what a traversal through pll_core_update_partial_tt/ti/ii does) must not
+    rebuild the scratch context call after call: the second round of the same shapes is much faster
+    than the first."""
+    import time
+    L = bind(gpu)
+    L.pll_amd_core_release()
+    rng = np.random.default_rng(1)
+    shapes = [(4, 100, 4), (20, 60, 2), (4, 300, 1)]
+    data = []
+    for S, sites, R in shapes:
+        data.append((rng.random((sites, R, S)), rng.random((sites, R, S)), rng.random((2, R, S, S)), np.zeros((sites, R, S))))
+
+    def round_():
+        t0 = time.perf_counter()
+        for (S, sites, R), (l, r, pm, par) in zip(shapes, data):
+            L.pll_core_update_partial_ii(S, sites, R, d(par), None, d(l), d(r), d(pm[0]), d(pm[1]), None, None, 0)
+        return time.perf_counter() - t0
+    first = round_()
+    later = min(round_() for _ in range(3))
+    assert later < 0.5 * first, (first, later)
     L.pll_amd_core_release()

@@ -331,3 +331,19 @@ def test_fused_planner_on_random_op_sequences(amd):
     bad = W.balanced_tree(8).ops.copy()
     bad[0]["child1_clv_index"] = 1000
     assert _plan_dry(amd, bad, 8, 6, 6, 1, 5)[0] == -1
+
+
+def test_whole_list_kernel_keeps_out_of_the_slot_registers():
+    """partials_aa_fused.hip keeps its values in the accumulation registers a0..a109 behind the
+    compiler's back (inline assembly).  The generated code is checked: no instruction outside that
+    assembly may touch them (without -mllvm -amdgpu-mfma-vgpr-form the compiler parks the matrix cores'
+    accumulators there: seen in round 3)."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_agprs.py")], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "4 kernels checked, 0 instructions" in out.stdout

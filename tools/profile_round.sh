@@ -6,7 +6,7 @@
 # gpurun_out/<tag>/summary/ (what gets copied into profiles/) and writes the index bench.py reads
 # `roofline.traffic` from.
 set -u
-tag=${1:-r2}
+tag=${1:-r3}
 root=$(pwd)
 out=$root/gpurun_out/$tag
 sum=$out/summary
@@ -38,6 +38,8 @@ run() { # name, [ENV=VAL ...] -- bench args...
 run c2 --
 run c2_per_level PLLHIP_FUSED=0 --
 run c3 -- --states 20 --sites 200000
+run c3_per_level PLLHIP_FUSED=0 -- --states 20 --sites 200000
+run c3_random_200 -- --states 20 --sites 100000 --taxa 200 --tree random
 run c4_shard -- --taxa 128
 run c5_shape -- --sites 500000 --taxa 200 --tree random --newton 5
 run c2_tip_clv -- --tip-clv
@@ -63,8 +65,11 @@ cat > "$sum/pmc_spec.json" <<EOF
  {"csv": "${tag}_pmc_hbm_traffic_c2_per_level.csv", "kernel_match": "k_dna_partials<4, 1, true, 0", "kernel_class": "inner-inner",
   "bench_json": "${tag}_bench_c2_per_level_under_rocprof.json",
   "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
- {"csv": "${tag}_pmc_hbm_traffic_c3.csv", "kernel_match": "k_aa_ii_mfma<4, 1", "kernel_class": "inner-inner",
-  "bench_json": "${tag}_bench_c3_under_rocprof.json",
+ {"csv": "${tag}_pmc_hbm_traffic_c3.csv", "kernel_match": "k_aa_fused", "kernel_class": "whole-list", "sum_call": true,
+  "exclude": ["k_lnl", "k_update_pmatrix", "fillBuffer", "copyBuffer", "k_final_sum"],
+  "workload": {"states": 20, "rate_cats": 4, "sites": 200000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
+ {"csv": "${tag}_pmc_hbm_traffic_c3_per_level.csv", "kernel_match": "k_aa_ii_mfma<4, 1", "kernel_class": "inner-inner",
+  "bench_json": "${tag}_bench_c3_per_level_under_rocprof.json",
   "workload": {"states": 20, "rate_cats": 4, "sites": 200000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}}
 ]
 EOF

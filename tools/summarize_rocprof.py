@@ -109,8 +109,17 @@ def cmd_index(spec_path, out):
                 best = r
         if best is None:
             continue
-        entry = {"workload": dict(e["workload"], kernel_class=e["kernel_class"]), "kernel": best[0],
-                 "dispatches": int(best[1]), "hbm_MB_per_launch": float(best[4]),
+        mb = float(best[4])
+        name = best[0]
+        if e.get("sum_call"):
+            # a call that is several launches (20 states: tip-tip ops and tables ahead of the list kernel):
+            # everything the call launches, per launch of the kernel that runs once per call
+            calls = int(best[1])
+            skip = e.get("exclude", [])
+            mb = sum(float(r[4]) * int(r[1]) for r in rows[1:] if not any(x in r[0] for x in skip)) / calls
+            name = "every launch of the call (per launch of %s)" % best[0][:60]
+        entry = {"workload": dict(e["workload"], kernel_class=e["kernel_class"]), "kernel": name,
+                 "dispatches": int(best[1]), "hbm_MB_per_launch": mb,
                  "source": "profiles/" + os.path.basename(path)}
         bj = e.get("bench_json")
         if bj:
