@@ -75,6 +75,7 @@ struct pllhip_ctx
   struct pllhip_level_cache * level_cache = nullptr; // the same for the per-level path (partials.hip)
   unsigned int fused_last_jobs = 0, fused_last_count = 0, fused_last_nslots = 0;
   size_t fused_last_jobs_offset = 0; // pair-table jobs within d_plan
+  size_t fused_last_rowtab_offset = 0;     // ... and of the tip-character row table (partials_fused.hip)
   unsigned char * fused_zero_row = nullptr; // [sites + slack] zeros: the "tip" of an op without one
   int fused_last_mode = 0;
   // Kept plans (the whole-list kernel's records, the per-level path's arguments) hold device

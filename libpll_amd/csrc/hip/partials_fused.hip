@@ -86,8 +86,7 @@ __device__ __forceinline__ Rec rec_load(const FusedRec * plan, unsigned int i)
   return r;
 }
 __device__ __forceinline__ unsigned long long rec_quad(const Rec & r, int t) { return (unsigned long long)r.w[t] | ((unsigned long long)r.w[t + 1] << 32); }
-__device__ __forceinline__ unsigned long long rec_req_ltip(const Rec & r) { return rec_quad(r, 0); }
-__device__ __forceinline__ unsigned long long rec_req_rtip(const Rec & r) { return rec_quad(r, 2); }
+__device__ __forceinline__ unsigned int rec_chars(const Rec & r) { return r.w[0]; }
 __device__ __forceinline__ unsigned int rec_req_lmat(const Rec & r) { return r.w[4]; }
 __device__ __forceinline__ unsigned int rec_req_rmat(const Rec & r) { return r.w[5]; }
 __device__ __forceinline__ unsigned int rec_gather(const Rec & r) { return r.w[6]; }
@@ -128,20 +127,10 @@ __global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedPairJob * __
 template <int J>
 struct FusedFetch
 {
-  double2 pm;                          // its 16 bytes of [P_l | P_r] (a coalesced block per wave)
-  unsigned int codes_l[J], codes_r[J]; // tip characters of the lane's own site in each sub-step
-  // element by element: a plain struct assignment of the arrays goes through scratch memory
-  __device__ __forceinline__ void take(const FusedFetch & o)
-  {
-    pm = o.pm;
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-    {
-      codes_l[j] = o.codes_l[j];
-      codes_r[j] = o.codes_r[j];
-    }
-  }
+  double2 pm; // its 16 bytes of [P_l | P_r] (a coalesced block per wave)
 };
+
+typedef unsigned int pll_v4u __attribute__((ext_vector_type(4)));
 
 // all lanes of a group of W (2, 4 or 8: a site's lanes, or a rate's) hold x != 0?  DPP, no ballot
 template <int W>
@@ -209,6 +198,9 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   // 62-op list but not behind a 5-op one)
   sink += wave * 80;
   unsigned int * sink_cnt = reinterpret_cast<unsigned int *>(sink + 64);
+  // where this lane's 16 bytes of tip characters of the first batch of rows begin (+ the tile's first site)
+  const unsigned long long row0 = bases.rowtab[lane];
+  static_assert(TS >= 16 && 1024 % TS == 0, "a tip row of a tile is a whole number of 16-byte lanes");
 
   // A wave's first tiles are its own by a fixed stride; the last `dynamic_rounds` rounds' worth come
   // from a counter.  Not only for the tail: the eight XCDs do not write at the same rate -- on
@@ -229,30 +221,56 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     const size_t clv_off = site0 * (W * 16u);                             // bytes into a CLV
     const size_t cnt_off = site0 * ((MODE == SCALE_RATE) ? RC * 4u : 4u); // bytes into a scale buffer
 
-    // What an op needs from memory is requested TWO ops ahead of it: its 16 bytes of [P_l | P_r]
-    // and its tip characters.  Every load is unconditional (an op without a tip reads a row of
-    // zeros): a load inside a branch makes the compiler wait for everything in flight.
+    // The tip characters.  Lane l holds 16 bytes -- this tile's sites -- of one tip row (of a TS / 16-th of
+    // one): the rows of up to 1024 / TS tip operands in the order the list uses them, ALL fetched by the one
+    // load below at the top of the tile.  (Until round 3 every op requested its own two rows two ops ahead:
+    // a few bytes from two pages of their own per op, whose address translations the write streams keep
+    // evicting -- with 8 M sites per row that cost the 133 GB partition a quarter of its speed; tool builds
+    // that read every row from the first row's pages: 0.56 -> 0.76 of the HBM peak, profiles/r3_footprint.txt.
+    // Sixty-four rows in one instruction wait for their translations together, long before they are used.)
+    pll_v4u cs = *(const pll_v4u PLL_GLOBAL *)(row0 + site0);
+    // What an op needs from memory besides is requested TWO ops ahead of it: its 16 bytes of [P_l | P_r].
     auto request = [&](FusedFetch<J> & f, const Rec & r) {
       const unsigned int off = (pm_left ? rec_req_lmat(r) : rec_req_rmat(r)) + pm_lane;
       f.pm = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(bases.pmat) + off);
-      const unsigned char PLL_GLOBAL * lt = (const unsigned char PLL_GLOBAL *)(rec_req_ltip(r) + site0); // (uniform)
-      const unsigned char PLL_GLOBAL * rt = (const unsigned char PLL_GLOBAL *)(rec_req_rtip(r) + site0);
-#pragma unroll
-      for (unsigned int j = 0; j < J; ++j)
-      {
-        f.codes_l[j] = lt[j * SPS + tip_lane];
-        f.codes_r[j] = rt[j * SPS + tip_lane];
-      }
     };
-    // ... and ONE op ahead its entries of the pair table are gathered with the characters that
-    // have arrived by then (table 0, all zeros, for an op without a tip)
-    auto gather = [&](double2 (&pt)[J], const FusedFetch<J> & f, const Rec & r) {
+    // A lane's characters of sub-step j of a row: byte j * SPS + tip_lane of the row's TS bytes, i.e. one of
+    // the SPS / 4 words that `readlane` brings from the lane(s) holding them (wave-uniform positions).
+    auto row_code = [&](unsigned int pos, unsigned int j) -> unsigned int {
+      unsigned int word = 0;
+#pragma unroll
+      for (unsigned int m = 0; m < SPS / 4; ++m)
+      {
+        const unsigned int w = j * (SPS / 4) + m; // word of the row
+        const unsigned int v = (w & 3u) == 0 ? cs.x : (w & 3u) == 1 ? cs.y : (w & 3u) == 2 ? cs.z : cs.w;
+        const unsigned int sw = (unsigned int)__builtin_amdgcn_readlane((int)v, (int)(pos + w / 4));
+        word = ((tip_lane >> 2) == m) ? sw : word;
+      }
+      return (word >> ((tip_lane & 3u) * 8u)) & 255u;
+    };
+    // ... and ONE op ahead its entries of the pair table are gathered (table 0, all zeros, for an op
+    // without a tip; an absent tip's character is 0)
+    auto gather = [&](double2 (&pt)[J], const Rec & r) {
+      const unsigned int ch = rec_chars(r);
+      const unsigned int lmask = (ch & PLLHIP_FUSED_CH_LTIP) ? 15u : 0u, rmask = (ch & PLLHIP_FUSED_CH_RTIP) ? 15u : 0u;
 #pragma unroll
       for (unsigned int j = 0; j < J; ++j)
       {
-        const unsigned int pair = ((f.codes_l[j] << 4) | f.codes_r[j]) & 255u;
+        const unsigned int pair = ((row_code(PLLHIP_FUSED_CH_LPOS(ch), j) & lmask) << 4) | (row_code(PLLHIP_FUSED_CH_RPOS(ch), j) & rmask);
         const unsigned int off = pair * (W * 16u) + gat_lane + rec_gather(r);
         pt[j] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(bases.pairtab) + off);
+      }
+      // the list moves on to rows this batch does not hold (rare: every 1024 / TS tip operands): the lanes'
+      // addresses of the next batch, then its rows.  Assembly, like reload(): the compiler counts no load
+      // here (a load inside a branch makes it wait for everything in flight on every path), the next op's
+      // first wait -- for a request issued after this -- covers it.
+      if (ch & PLLHIP_FUSED_CH_LOAD)
+      {
+        const unsigned long long tab = (unsigned long long)(bases.rowtab + (size_t)(ch >> 24) * 64u);
+        unsigned long long a;
+        asm volatile("global_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(lane * 8u), "s"(tab) : "memory");
+        a += site0;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(cs) : "v"(a) : "memory");
       }
     };
 
@@ -378,9 +396,9 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     request(fb, h0);
     sink_stores();
     if (rec_flags(h1) & PLLHIP_FUSED_RELOAD_NEXT) reload(rec_src(h1));
+    gather(pta, h1);
     request(fa, h1);
-    asm volatile("" ::"v"(fb.codes_r[J - 1]) : "memory");
-    gather(pta, fb, h1);
+    asm volatile("" ::"v"(fb.pm.x), "v"(fb.pm.y) : "memory");
     sink_stores();
     stage_rows(fb, (rec_flags(h1) >> PLLHIP_FUSED_STAGE_SHIFT) & 3u, pl, pr);
 
@@ -416,10 +434,10 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       static_assert(MODE == SCALE_NONE || CW == EPS, "one count word per entry of a sub-step");
       const unsigned int t = lane % E; // (lanes beyond the entries repeat them: same values to the same addresses)
 
-      // Everything requested one op ago has arrived once fu's characters are used -- and with
+      // Everything requested one op ago has arrived once fu's matrix block is used -- and with
       // it what that iteration's reload() copied into this op's slots (issued ahead of those
       // requests; memory operations return in order).  No slot is read above this line.
-      asm volatile("" ::"v"(fu.codes_r[J - 1]) : "memory");
+      asm volatile("" ::"v"(fu.pm.x), "v"(fu.pm.y) : "memory");
       // operands and the counts they bring along (entry t of the tile -- a site, or a (site, rate)
       // with per-rate scalers -- is lane t's); every kind reads both operands (a tip-tip op reads
       // slot 0 for nothing: no branch)
@@ -439,8 +457,9 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       asm volatile("" ::: "memory"); // (the reads above are issued before what follows)
       // (rare, wave-uniform: the sources of the reload are read on the spot)
       if (fl & PLLHIP_FUSED_RELOAD_NEXT) reload(rec_src(r0));
+      // (the request last: what the next op waits for first is the youngest operation in flight)
+      gather(pf, r0);
       request(ff, r0);
-      gather(pf, fu, r0);
       PLLHIP_TICK(0)
       // (every load is consumed on every path, needed or not: the registers of a load that
       // nobody waited for stay "pending" for the compiler, and it drains the queue -- this op's
@@ -1080,7 +1099,7 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
     c->pairtab_elems = ntab * per;
     ++c->layout_epoch;
   }
-  // the row of zeros an op without a tip reads its "characters" from
+  // the row of zeros that lanes without a tip row fetch their "characters" from
   if (!c->fused_zero_row)
   {
     const size_t bytes = (size_t)c->sh.sites + PLLHIP_TAIL_SITES + 256;
@@ -1096,6 +1115,37 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   std::vector<FusedRec> recs(count + 3);
   std::vector<FusedSrc> srcs;
   std::vector<FusedPairJob> jobs;
+  // Tip rows in the order the list uses them, in batches of what a wave's 64 x 16 bytes hold of a tile
+  // (64 rows at 4 rate categories); both rows of an op in one batch.  rowtab[batch][lane]: the address
+  // the lane fetches from (+ the tile's first site); lanes without a row fetch zeros.
+  const unsigned int lpr = J * sps / 16, rpb = 64 / lpr; // lanes per row, rows per batch
+  std::vector<unsigned int> chars_of(count, 0), batch_of(count, 0);
+  std::vector<unsigned long long> rowtab(64, (unsigned long long)(uintptr_t)c->fused_zero_row);
+  {
+    unsigned int batch = 0, q = 0;
+    for (unsigned int pos = 0; pos < count; ++pos)
+    {
+      const FusedOp & f = plan[pos];
+      const unsigned int n = (f.ltip ? 1u : 0u) + (f.rtip ? 1u : 0u);
+      if (q + n > rpb)
+      {
+        ++batch;
+        q = 0;
+        rowtab.resize((size_t)(batch + 1) * 64, (unsigned long long)(uintptr_t)c->fused_zero_row);
+      }
+      batch_of[pos] = batch;
+      const unsigned char * rows[2] = {f.ltip, f.rtip};
+      for (int o = 0; o < 2; ++o)
+      {
+        if (!rows[o]) continue;
+        chars_of[pos] |= (o == 0 ? PLLHIP_FUSED_CH_LTIP : PLLHIP_FUSED_CH_RTIP) | (q * lpr) << (o == 0 ? 0 : 8);
+        for (unsigned int l = 0; l < lpr; ++l)
+          rowtab[(size_t)batch * 64 + q * lpr + l] = (unsigned long long)(uintptr_t)rows[o] + l * 16u;
+        ++q;
+      }
+    }
+    if (batch > 254) return 1;
+  }
   std::vector<unsigned int> table_of(count, 0); // byte offset of each op's pair table (0: zeros)
   int mode = SCALE_NONE;
   for (unsigned int pos = 0; pos < count; ++pos)
@@ -1112,13 +1162,15 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   }
   // what record `r` says about the ops ahead of position `pos` (pos may be -2, -1: the headers)
   auto look_ahead = [&](FusedRec & r, long pos) -> int {
-    r.req_ltip = r.req_rtip = (unsigned long long)(uintptr_t)c->fused_zero_row;
+    r.chars = 0;
     r.req_lmat = r.req_rmat = 0;
+    if (pos + 1 >= 0 && pos + 1 < (long)count) r.chars = chars_of[pos + 1];
     if (pos + 2 < (long)count)
     {
       const FusedOp & f = plan[pos + 2];
-      if (f.ltip) r.req_ltip = (unsigned long long)(uintptr_t)f.ltip;
-      if (f.rtip) r.req_rtip = (unsigned long long)(uintptr_t)f.rtip;
+      // (the rows of op + 2 are fetched once op + 1's characters have been taken from the registers)
+      const unsigned int now = pos + 1 >= 0 ? batch_of[pos + 1] : 0u;
+      if (batch_of[pos + 2] != now) r.chars |= PLLHIP_FUSED_CH_LOAD | batch_of[pos + 2] << 24;
       r.req_lmat = (unsigned int)((f.lmat - c->pmatrix) * sizeof(double));
       r.req_rmat = (unsigned int)((f.rmat - c->pmatrix) * sizeof(double));
     }
@@ -1174,7 +1226,8 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   const size_t rec_bytes = recs.size() * sizeof(FusedRec);
   const size_t src_bytes = (srcs.size() + 1) * sizeof(FusedSrc);
   const size_t job_bytes = (jobs.size() + 1) * sizeof(FusedPairJob);
-  const size_t bytes = rec_bytes + src_bytes + job_bytes;
+  const size_t tab_bytes = rowtab.size() * sizeof(unsigned long long);
+  const size_t bytes = rec_bytes + src_bytes + job_bytes + tab_bytes;
   if (c->plan_cap < bytes)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1200,6 +1253,7 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   memcpy(stage, recs.data(), rec_bytes);
   if (!srcs.empty()) memcpy(stage + rec_bytes, srcs.data(), srcs.size() * sizeof(FusedSrc));
   if (!jobs.empty()) memcpy(stage + rec_bytes + src_bytes, jobs.data(), jobs.size() * sizeof(FusedPairJob));
+  memcpy(stage + rec_bytes + src_bytes + job_bytes, rowtab.data(), tab_bytes);
   HIP_TRY(hipMemcpyAsync(c->d_plan, c->h_plan[b], bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
@@ -1207,6 +1261,7 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, sizeof(unsigned int)));
   // what a repeated call with the same op list needs (pllhip_relaunch_fused)
   c->fused_last_jobs_offset = rec_bytes + src_bytes;
+  c->fused_last_rowtab_offset = rec_bytes + src_bytes + job_bytes;
   c->fused_last_jobs = (unsigned int)jobs.size();
   c->fused_last_count = count;
   c->fused_last_nslots = nslots;
@@ -1225,7 +1280,8 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
   HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
   const FusedRec * d_plan = (const FusedRec *)c->d_plan;
   const FusedPairJob * d_jobs = (const FusedPairJob *)(static_cast<const char *>(c->d_plan) + c->fused_last_jobs_offset);
-  const FusedBases bases = {c->pmatrix, c->d_pairtab};
+  const FusedBases bases = {c->pmatrix, c->d_pairtab,
+                            (const unsigned long long *)(static_cast<const char *>(c->d_plan) + c->fused_last_rowtab_offset)};
   if (njobs)
   {
     switch (c->sh.rate_cats)

@@ -35,9 +35,10 @@ struct FusedOp
 // The plan as the kernel reads it, through the scalar data cache: ONE 64-byte record per op (one
 // scalar load, one cache line), holding everything the wave does WHILE that op runs, ready
 // to use -- absolute addresses and LDS byte offsets, no indices to multiply out:
-//   - what it requests for the op two ahead (tip rows, P-matrix offsets),
-//   - the pair table it gathers from for the op one ahead, what that op reloads and which of
-//     its matrices must be staged,
+//   - what it requests for the op two ahead (P-matrix offsets),
+//   - the pair table it gathers from for the op one ahead and where that op's tip characters are
+//     (which lanes of the wave's character registers), what that op reloads and which of its
+//     matrices must be staged,
 //   - the op itself: parent, scale buffer, LDS places of operands, parent and counts.
 // Round 2 first had 32-byte records of 16-bit indices, decoded by the kernel; the counters say
 // a wave-op then cost 124 scalar + 124 vector instructions of which 30 were arithmetic, and that
@@ -46,7 +47,8 @@ struct FusedOp
 // arena moves (layout_epoch).
 struct FusedRec
 {
-  unsigned long long req_ltip, req_rtip; // tip rows of op + 2 (a row of zeros when it has none)
+  unsigned int chars;                    // tip characters of op + 1, PLLHIP_FUSED_CH_* below
+  unsigned int pad[3];
   unsigned int req_lmat, req_rmat;       // byte offsets of its P-matrices in the matrix arena
   unsigned int gather_off;               // byte offset of the pair table of op + 1 (0: the table of zeros)
   unsigned int flags;                    // PLLHIP_FUSED_* below
@@ -66,6 +68,14 @@ static_assert(sizeof(FusedRec) == 64, "sixteen words per op");
 #define PLLHIP_FUSED_STAGE_SHIFT 6     /* two bits: matrices op + 1 needs (2 both, 1 right only, 0 none) */
 #define PLLHIP_FUSED_RELOAD_NEXT 256u  /* op + 1 reloads operands: FusedSrc number `src` */
 #define PLLHIP_FUSED_MAX_OPS 60000u    /* longer lists run per level */
+// FusedRec::chars -- a wave holds the characters of up to 1024 / (tile sites) tip rows at its tile, 16 bytes per
+// lane, fetched with ONE load per tile (rows in the order the list uses them; lists with more tip operands fetch
+// the next batch of rows when they get there):
+#define PLLHIP_FUSED_CH_LPOS(x) ((x) & 0xffu)         /* first lane of the left tip's row (op + 1) */
+#define PLLHIP_FUSED_CH_RPOS(x) (((x) >> 8) & 0xffu)  /* ... of the right tip's */
+#define PLLHIP_FUSED_CH_LTIP (1u << 16)                /* op + 1 has a left / right tip */
+#define PLLHIP_FUSED_CH_RTIP (1u << 17)
+#define PLLHIP_FUSED_CH_LOAD (1u << 18)                /* op + 2's rows are in another batch: fetch batch (x >> 24) */
 
 // sources and LDS destinations of the operands an op reloads (few ops have any: kept out of the records)
 struct FusedSrc
@@ -92,6 +102,7 @@ struct FusedBases
 {
   const double * pmat;
   const double * pairtab;
+  const unsigned long long * rowtab; // [batch][64]: the address each lane fetches its 16 bytes of tip characters from (+ site)
 };
 
 // (The planner is host logic and needs no device: what it must know of the partition is here.)

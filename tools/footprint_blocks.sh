@@ -21,13 +21,13 @@ out=$root/gpurun_out/footprint
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-for b in 0 auto; do
-  if [ $b = auto ]; then unset PLLHIP_FUSED_BLOCK_SITES; else export PLLHIP_FUSED_BLOCK_SITES=$b; fi
-  for ctr in FETCH_SIZE WRITE_SIZE "TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT" "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE"; do
-    tag=$(echo $ctr | tr ' ' '_')_block_$b
-    rocprofv3 --pmc $ctr --output-format csv -d $out/$tag -- python3 $root/bench.py --total-sites 8000000 --taxa 128 --cpu-sites 0 --steps 3 --warmup 1 --no-vary > /dev/null 2> $out/$tag.err
-    python3 $root/tools/summarize_rocprof.py pmc $out/$tag $out/$tag.csv "PLLHIP_FUSED_BLOCK_SITES=$b python3 bench.py --total-sites 8000000 --taxa 128 --cpu-sites 0 --steps 3 --warmup 1 --no-vary" 2>/dev/null
-    grep -h "k_dna_fused" $out/$tag.csv | sed "s/^\"[^\"]*\"/block $b k_dna_fused/"
+# the 16 GB shard (1 M sites) beside the 133 GB whole (8 M sites): same list, same tiles per workgroup slot
+for shape in "--sites 1000000" "--total-sites 8000000"; do
+  for ctr in FETCH_SIZE WRITE_SIZE "TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT" "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE" "TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_sum" "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_GMI_CREDIT_STALL_sum" "TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum"; do
+    tag=$(echo $shape $ctr | tr ' ' '_' | tr -d '-')
+    rocprofv3 --pmc $ctr --output-format csv -d $out/$tag -- python3 $root/bench.py $shape --taxa 128 --cpu-sites 0 --steps 3 --warmup 1 --no-vary --no-c4 > /dev/null 2> $out/$tag.err
+    python3 $root/tools/summarize_rocprof.py pmc $out/$tag $out/$tag.csv "python3 bench.py $shape --taxa 128 --cpu-sites 0 --steps 3 --warmup 1 --no-vary" 2>/dev/null
+    grep -h "k_dna_fused" $out/$tag.csv | sed "s/^\"[^\"]*\"/$shape k_dna_fused/"
     rm -rf $out/$tag
   done
 done
