@@ -1,5 +1,5 @@
 /* LD_PRELOAD helper: print a backtrace on SIGSEGV / SIGBUS / SIGABRT (for crashes that happen once in many runs)
- *   gcc -shared -fPIC -O1 tools/segv_backtrace.c -o build/tools/segv_backtrace.so */
+ *   built by oracle/Makefile as oracle/segv_backtrace.so; tests/test_reference_programs.py preloads it into the client programs */
 #define _GNU_SOURCE
 #include <execinfo.h>
 #include <signal.h>

@@ -31,6 +31,9 @@ def test_reference_program_output(gpu, name, mode):
     if not os.path.exists(exe):
         pytest.skip("prebuilt reference test program missing (make -C oracle reftests)")
     env = dict(os.environ, PLLHIP_AA_EXACT="1")
+    helper = os.path.join(ROOT, "oracle", "segv_backtrace.so")  # (a crash then says where)
+    if os.path.exists(helper):
+        env["LD_PRELOAD"] = helper
     run = subprocess.run([exe] + mode, capture_output=True, text=True, timeout=600, env=env)
     assert run.returncode == 0, run.stderr[-2000:]
     got = run.stdout

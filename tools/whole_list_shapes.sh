@@ -1,5 +1,6 @@
 #!/bin/bash
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r3_gputests.txt 2>&1; echo rc=$?; tail -3 gpurun_out/r3_gputests.txt
+# On the GPU box: the 4-state whole-list launch across the partition shapes of BASELINE configs 2, 4 (shard and
+# whole), 5 and a 256-taxon list: launch time, rate on the launch's own bytes, fraction of the 8 TB/s peak.
 line() { python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
