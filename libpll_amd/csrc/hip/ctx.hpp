@@ -67,7 +67,8 @@ struct pllhip_ctx
   // whole-list kernel (partials_fused.hip): the plan's device copy and two pinned staging buffers
   void * d_plan = nullptr;
   void * d_sink = nullptr; // 1 KB that the stores of lanes past the last site go to
-  unsigned int * d_tile_counter = nullptr; // whole-list kernel: next tile to hand out
+  unsigned int * d_tile_counter = nullptr; // whole-list kernels: next tile to hand out (PLLHIP_TILE_COUNTER_BYTES: one per
+                                           // group of eight workgroups, 128 bytes apart -- partials_fused.hip)
   // the op list of the last whole-list launch (its plan is still on the device: an identical
   // list -- the usual case while branch lengths or model parameters are optimised -- is
   // launched again without planning or upload)
@@ -300,6 +301,7 @@ struct PartialsArgs
 // element, so that a wave working on the last (partial) round of 64 sites may load
 // unconditionally and unclamped; what it computes there is masked out of every result.
 #define PLLHIP_TAIL_SITES 64
+#define PLLHIP_TILE_COUNTER_BYTES (256 * 128)
 
 #define PLLHIP_BATCH_MAX 24
 struct PartialsBatch

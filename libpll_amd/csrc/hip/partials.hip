@@ -582,11 +582,12 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 4 || c->force_fused;
   // (8 rate categories: a tile is 8 sites only and the variant spills -- 5.6 against 10.2 G/s
   // for the per-level launches at 500 k sites; not used)
-  // (short lists -- the path to the root after one branch changed -- have little to keep on
-  // chip and pay the kernel's per-tile set-up: 1 M sites, 3 ops 267 vs 197 us, 5 ops 327 vs
-  // 282, 7 ops 239 vs 312, 15 ops 410 vs 663, 31 ops 802 vs 1387; tools/partial_traversal_timing.py)
-  if (dna_fast && c->sh.rate_cats <= 4 && !c->no_fused && fused_pays && c->rows.empty() &&
-      (count >= 7 || (c->force_fused && count >= 2)))
+  // (short lists -- the path to the root after one branch changed -- have little to keep on chip, but they
+  // are one launch instead of one per op, and half the bytes: 1 M sites, whole list vs per level, 2 ops 134 vs
+  // 134 us, 3 ops 180 vs 200, 5 ops 239 vs 282, 7 ops 192 vs 309, 15 ops 380 vs 662; 50 k sites 14 vs 17, 17 vs
+  // 26, 27 vs 38, 25 vs 27, 35 vs 47 (tools/partial_traversal_timing.py, profiles/r3_short_lists.txt).  Until
+  // round 3 they lost -- 3 ops 260 vs 200 us -- to the tile counter, not to their reloads: see the kernel.)
+  if (dna_fast && c->sh.rate_cats <= 4 && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
   {
     if (c->fused_last_ops.size() == count && !getenv("PLLHIP_FUSED_DEBUG") &&
         c->fused_last_epoch == c->layout_epoch &&

@@ -834,7 +834,7 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     HIP_TRY(hipMemsetAsync(c->fused_zero_row, 0, bytes, c->stream));
   }
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 80 * sizeof(double2)));
-  if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, sizeof(unsigned int)));
+  if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, PLLHIP_TILE_COUNTER_BYTES));
   k.lk_ops.clear();
   k.lk_k1.clear();
   k.lk_k2.clear();

@@ -148,7 +148,7 @@ template <int RC, int J, int MODE, int NTP, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan, FusedBases bases,
                                                         unsigned int nops, unsigned int sites, unsigned int nslots,
                                                         double2 * sink, unsigned int * next_tile, unsigned int dynamic_rounds,
-                                                        unsigned int site_base)
+                                                        unsigned int site_base, unsigned int tile_groups)
 {
   static_assert(RC == 1 || RC == 2 || RC == 4, "lane groups of 2, 4 or 8");
   constexpr bool NT = NTP != 0;
@@ -196,8 +196,19 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   // every wave has 1280 bytes of sink of its own: thousands of waves storing to ONE block
   // serialise on its cache lines (measured: ~0.7 ms per launch at 1 M sites, hidden behind a
   // 62-op list but not behind a 5-op one)
-  sink += wave * 80;
+  sink += wave * 96;
   unsigned int * sink_cnt = reinterpret_cast<unsigned int *>(sink + 64);
+  // Tiles of the last rounds come from `tile_groups` counters (eight): groups of eight consecutive workgroups --
+  // one on each XCD -- take the counters in turn, counter g hands out tiles g, g + 8, ... of that region.  (One
+  // counter for everybody serialised its atomics at ~12 ns: 37 us per round of 3072 waves, which a 62-op list
+  // hides and a 3-op list does not; a counter per group of eight workgroups balances too little -- the 62-op list
+  // lost 6 % -- eight counters cost nothing and balance like one: 2 / 3 / 5 ops at 1 M sites 225 / 261 / 311 us
+  // with one counter, 134 / 180 / 239 with eight; per-level launches 134 / 200 / 282.)  The tile after this one is
+  // asked for during the last-but-one op, so that nobody waits for the answer (no earlier: a wave would sit on a
+  // tile it only begins a whole list later); static rounds ask a word of the wave's own sink instead.
+  const unsigned int tile_group = (blockIdx.x / 8u) % tile_groups;
+  const unsigned long long my_counter = (unsigned long long)(uintptr_t)(next_tile + (size_t)tile_group * 32u);
+  const unsigned long long no_counter = (unsigned long long)(uintptr_t)(sink + 80);
   // where this lane's 16 bytes of tip characters of the first batch of rows begin (+ the tile's first site)
   const unsigned long long row0 = bases.rowtab[lane];
   static_assert(TS >= 16 && 1024 % TS == 0, "a tip row of a tile is a whole number of 16-byte lanes");
@@ -218,6 +229,11 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   for (size_t tile = wave; tile < tiles;)
   {
     const size_t site0 = (size_t)site_base + tile * TS; // (site_base: this launch's block of the alignment)
+#ifdef PLLHIP_FUSED_TIMING
+    const unsigned long long t_tile = __builtin_readcyclecounter();
+#endif
+    unsigned int next_ticket = 0;
+    const unsigned long long ticket_counter = (next_tile && round + 1 >= static_rounds) ? my_counter : no_counter;
     const size_t clv_off = site0 * (W * 16u);                             // bytes into a CLV
     const size_t cnt_off = site0 * ((MODE == SCALE_RATE) ? RC * 4u : 4u); // bytes into a scale buffer
 
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
 #define PLLHIP_TICK(n) { const unsigned long long t_now = __builtin_readcyclecounter(); seg[n] += t_now - t_last; t_last = t_now; }
     unsigned long long t_last = __builtin_readcyclecounter();
+    const unsigned long long t_prologue = t_last - t_tile;
 #else
 #define PLLHIP_TICK(n)
 #endif
@@ -457,6 +474,11 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       asm volatile("" ::: "memory"); // (the reads above are issued before what follows)
       // (rare, wave-uniform: the sources of the reload are read on the spot)
       if (fl & PLLHIP_FUSED_RELOAD_NEXT) reload(rec_src(r0));
+      // the ticket for the next tile (lane 0 only, through EXEC; assembly: the compiler sees no memory
+      // operation, and operations return in order -- the next op's first wait covers it)
+      if (i + 2 == nops)
+        asm volatile("s_mov_b64 exec, 1\n\tglobal_atomic_add %0, %1, %2, off sc0\n\ts_mov_b64 exec, -1"
+                     : "=&v"(next_ticket) : "v"(ticket_counter), "v"(1u) : "memory");
       // (the request last: what the next op waits for first is the youngest operation in flight)
       gather(pf, r0);
       request(ff, r0);
@@ -580,17 +602,17 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     }
 #ifdef PLLHIP_FUSED_TIMING
     if (lane == 0 && round == 3 && (wave == 0 || wave == 1001 || wave == 2002 || wave == 3003))
-      printf("wave %u ops %u: top (records, requests, characters arrive, gather) %llu pair entries arrive %llu arithmetic %llu stores %llu counts %llu stage %llu cycles per op\n",
-             (unsigned int)wave, nops, seg[0] / nops, seg[1] / nops, seg[2] / nops, seg[3] / nops, seg[4] / nops, seg[5] / nops);
+      printf("wave %u ops %u: tile %llu cycles, of which prologue %llu; per op: top (records, requests arrive, gather) %llu pair entries arrive %llu arithmetic %llu stores %llu counts %llu stage %llu\n",
+             (unsigned int)wave, nops, (unsigned long long)__builtin_readcyclecounter() - t_tile, t_prologue,
+             seg[0] / nops, seg[1] / nops, seg[2] / nops, seg[3] / nops, seg[4] / nops, seg[5] / nops);
 #endif
     if (++round < static_rounds)
     {
       tile += nwaves;
       continue;
     }
-    unsigned int nt = 0;
-    if (lane == 0) nt = atomicAdd(next_tile, 1u);
-    tile = static_rounds * nwaves + (unsigned int)__builtin_amdgcn_readfirstlane((int)nt);
+    asm volatile("" : "+v"(next_ticket));
+    tile = static_rounds * nwaves + tile_group + (size_t)tile_groups * (unsigned int)__builtin_amdgcn_readfirstlane((int)next_ticket);
   }
 }
 
@@ -617,6 +639,9 @@ unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int wgs)
   const size_t cw = c->sh.rate_scalers ? 32 : (sps < 4 ? 4 : sps);
   const size_t per_slot = (size_t)PLLHIP_FUSED_J * (64 * 16 + cw * 4);
   const size_t pmat = (size_t)R * 16 * sizeof(double); // one matrix at a time (stage_rows)
+  // (four workgroups -- 16 waves of 128 registers, four slots -- were measured for short lists in round 3 and are
+  // slower than three at every list length: 2 / 3 / 5 / 7 / 15 ops 257 / 286 / 335 / 282 / 421 us against 226 / 260 /
+  // 310 / 246 / 411; the variant spills seven registers)
   const size_t budget = PLLHIP_FUSED_J == 1 ? 9472 : (wgs >= 3 ? 13312 : 16384); // J = 1: four workgroups per CU
   return (unsigned int)((budget - pmat) / per_slot);
 }
@@ -1028,19 +1053,15 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   // write rates): seven of the ~21 rounds of 1 M sites (the measured optimum there), and in proportion
   // for longer alignments (8 M sites x 128 taxa: 7 rounds 0.565, 30 0.584, 54 0.583 of the HBM peak;
   // 2 M sites: 7 rounds 0.652, 14 0.672); short lists two, see the kernel
-  // Alignments whose CLVs do not fit ~32 GB at once are walked in BLOCKS of sites, one launch each
-  // (every launch takes its block through the whole list): a launch then writes a set of pages the
-  // translation caches and the memory system have seen work well (profiles/r3_footprint_blocks.txt;
-  // PLLHIP_FUSED_BLOCK_SITES sets the block, 0 = one launch).
+  // PLLHIP_FUSED_BLOCK_SITES (an experiment kept as a switch; default one launch): the alignment walked in
+  // BLOCKS of sites, one launch each, every launch taking its block through the whole list.  Measured on the
+  // 133 GB partition (8 M sites x 128 taxa) with blocks of 4 M ... 500 k sites: 0.557 / 0.558 / 0.554 / 0.547 of
+  // the HBM peak against 0.555 in one launch -- what that partition lost it lost on the reads of the tip
+  // characters, not on the footprint of a launch (profiles/r3_footprint.txt).
   size_t block_sites = sites;
   {
     const char * e = getenv("PLLHIP_FUSED_BLOCK_SITES");
     if (e) block_sites = atoi(e) > 0 ? (size_t)atoi(e) : sites;
-    else if (footprint > ((size_t)32 << 30))
-    {
-      const size_t nblocks = (footprint + ((size_t)16 << 30) - 1) / ((size_t)16 << 30);
-      block_sites = (sites + nblocks - 1) / nblocks;
-    }
     block_sites = (block_sites + 255) / 256 * 256; // (whole tiles, whole rounds)
     if (block_sites > sites) block_sites = sites;
   }
@@ -1050,13 +1071,15 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   const size_t btiles = (bsites + tile_sites - 1) / tile_sites;
   size_t bgrid = (btiles + 3) / 4;
   if (bgrid > cap) bgrid = cap;
-  if (base) HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+  if (base) HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, PLLHIP_TILE_COUNTER_BYTES, c->stream));
   const size_t rounds = btiles / (bgrid * 4);
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                       : (count >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
-#define LAUNCH_FUSED(MODEV, NTV)                                                                                  \
-  k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<(unsigned int)bgrid, 256, lds, c->stream>>>(                \
-      d_plan, bases, count, bsites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds, (unsigned int)base)
+  const unsigned int tile_groups = getenv("PLLHIP_FUSED_TILE_GROUPS") ? (unsigned int)std::max(1, atoi(getenv("PLLHIP_FUSED_TILE_GROUPS")))
+                                   : 8u;
+#define LAUNCH_FUSED_ARGS (unsigned int)bgrid, 256, lds, c->stream>>>( \
+      d_plan, bases, count, bsites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds, (unsigned int)base, tile_groups)
+#define LAUNCH_FUSED(MODEV, NTV) k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<LAUNCH_FUSED_ARGS
 #define LAUNCH_FUSED_MODE(NTV)                         \
   do {                                                  \
     if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV);       \
@@ -1068,6 +1091,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   else LAUNCH_FUSED_MODE(2);
 #undef LAUNCH_FUSED_MODE
 #undef LAUNCH_FUSED
+#undef LAUNCH_FUSED_ARGS
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1257,8 +1281,8 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   HIP_TRY(hipMemcpyAsync(c->d_plan, c->h_plan[b], bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
-  if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 80 * sizeof(double2))); // 1280 B per wave
-  if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, sizeof(unsigned int)));
+  if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 96 * sizeof(double2))); // 1536 B per wave
+  if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, PLLHIP_TILE_COUNTER_BYTES));
   // what a repeated call with the same op list needs (pllhip_relaunch_fused)
   c->fused_last_jobs_offset = rec_bytes + src_bytes;
   c->fused_last_rowtab_offset = rec_bytes + src_bytes + job_bytes;
@@ -1277,7 +1301,7 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
 {
   const unsigned int count = c->fused_last_count, nslots = c->fused_last_nslots, njobs = c->fused_last_jobs;
   const int mode = c->fused_last_mode;
-  HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, PLLHIP_TILE_COUNTER_BYTES, c->stream));
   const FusedRec * d_plan = (const FusedRec *)c->d_plan;
   const FusedPairJob * d_jobs = (const FusedPairJob *)(static_cast<const char *>(c->d_plan) + c->fused_last_jobs_offset);
   const FusedBases bases = {c->pmatrix, c->d_pairtab,

@@ -1,7 +1,7 @@
 """Every dispatch threshold has the same bits on both sides.
 
 The library picks kernels by partition size: the whole-list 4-state kernel from one tile per
-wave on (32,768 sites at 4 rate categories on 256 CUs) and for lists of seven ops or more,
+SIMD on (16,384 sites at 4 rate categories on 256 CUs) and for lists of two ops or more,
 non-temporal loads / stores once the CLVs exceed the 256 MB memory-side cache, the 20-state
 lookup ops once their saving is twice the cost of their tables (a model in partials.hip).
 Which side of a threshold a partition falls on must never show in a result: at sizes right
@@ -45,10 +45,11 @@ def test_whole_list_kernel_threshold(gpu, monkeypatch, sites):
     assert same(res["default"], res["0"]) and same(res["default"], res["2"])
 
 
-@pytest.mark.parametrize("nops", [6, 7, 8])
+@pytest.mark.parametrize("nops", [1, 2, 3, 4, 6, 7, 8])
 def test_short_list_threshold(gpu, monkeypatch, nops):
-    """Lists shorter than seven ops run per level also on large partitions: the last `nops` ops
-    of a traversal (a partial traversal towards the root) either way."""
+    """Single ops run per level also on large partitions, lists from two ops on in one launch (seven
+    until round 3): the last `nops` ops of a traversal (a partial traversal towards the root -- every
+    op reloads an operand an earlier call wrote) either way."""
     plan = W.caterpillar_tree(12, seed=5)
     seqs = W.random_alignment(12, 40_000, 4, seed=nops)
     res = {}

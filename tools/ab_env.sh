@@ -1,10 +1,15 @@
 #!/bin/bash
-# A/B of one environment switch on ONE box: bash tools/ab_env.sh VAR "v1 v2 ..." [bench args...]
+# On the GPU box: interleaved A/B of one environment variable's values on bench.py shapes
+#   bash tools/ab_env.sh PLLHIP_FUSED_TILE_GROUPS "1 8 96" "--sites 1000000 --taxa 64" ...
 var=$1; vals=$2; shift 2
-for rep in 1 2; do
-for v in $vals; do
-  env $var=$v python3 bench.py --cpu-sites 0 --steps 20 --warmup 3 --no-c4 "$@" 2>/dev/null | python3 -c "
+line() { python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('%-26s %-34s launch_us %8.1f frac %.3f value %8.1f lnl %.6f' % ('$var=$v', '$*', r['avg_launch_us'], r['frac'], d['value'], d['lnl']))"
-done; done
+print('%-44s %-28s step %7.3f ms  launch %8.3f ms  frac %.3f  value %.1f' % ('$1', '$2', d['ms_per_step'], r['avg_launch_us']/1e3, r['frac'], d['value']))"; }
+for shape in "$@"; do
+  for rep in 1 2; do
+    for v in $vals; do
+      env $var=$v python3 bench.py $shape --cpu-sites 0 --steps 20 --warmup 2 --no-vary --no-c4 2>/dev/null | line "$shape" "$var=$v"
+    done
+  done
+done

@@ -16,7 +16,10 @@ p.update_partials(plan.ops); p.wait()
 sub8 = [0, 1, 2, 3, 32, 33, 48]
 sub16 = list(range(8)) + [32, 33, 34, 35, 48, 49, 56]
 sub32 = list(range(16)) + list(range(32, 40)) + [48, 49, 50, 51, 56, 57, 60]
-for idx in ([60], [56, 60], [48, 56, 60], [0, 32, 48, 56, 60], sub8, sub16, sub32, list(range(32))):
+lists = ([60], [56, 60], [48, 56, 60], [0, 32, 48, 56, 60], sub8, sub16, sub32, list(range(32)))
+if len(sys.argv) > 2:  # one list only, e.g. 56,60 (for a profiler run)
+    lists = ([int(x) for x in sys.argv[2].split(",")],)
+for idx in lists:
     ops = plan.ops[idx]
     p.update_partials(ops); p.wait()
     t = time.perf_counter()

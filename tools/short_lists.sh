@@ -1,0 +1,6 @@
+#!/bin/bash
+# On the GPU box: short op lists (partial traversals) at 1 M sites x 64 taxa -- per level, whole list with
+# one launch
+sites=${1:-1000000}
+echo "== per level";                     PLLHIP_FUSED=0 python3 tools/partial_traversal_timing.py $sites
+echo "== whole list";                    PLLHIP_FUSED=2 python3 tools/partial_traversal_timing.py $sites
