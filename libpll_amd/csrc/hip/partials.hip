@@ -587,7 +587,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // 134 us, 3 ops 180 vs 200, 5 ops 239 vs 282, 7 ops 192 vs 309, 15 ops 380 vs 662; 50 k sites 14 vs 17, 17 vs
   // 26, 27 vs 38, 25 vs 27, 35 vs 47 (tools/partial_traversal_timing.py, profiles/r3_short_lists.txt).  Until
   // round 3 they lost -- 3 ops 260 vs 200 us -- to the tile counter, not to their reloads: see the kernel.)
-  if (dna_fast && c->sh.rate_cats <= 4 && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
+  if (dna_fast && (c->sh.rate_cats <= 4 || c->sh.rate_cats == 8) && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
   {
     if (c->fused_last_ops.size() == count && !getenv("PLLHIP_FUSED_DEBUG") &&
         c->fused_last_epoch == c->layout_epoch &&

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedPairJob * __
 template <int J>
 struct FusedFetch
 {
-  double2 pm; // its 16 bytes of [P_l | P_r] (a coalesced block per wave)
+  double2 pm;  // its 16 bytes of [P_l | P_r] (a coalesced block per wave)
+  double2 pm2; // 8 rate categories: a matrix is a whole 1 KB block -- pm of the left, pm2 of the right one
 };
 
 typedef unsigned int pll_v4u __attribute__((ext_vector_type(4)));
@@ -139,6 +140,7 @@ __device__ __forceinline__ unsigned int group_and(unsigned int x)
   x &= (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);                // lane ^ 1
   if (W >= 4) x &= (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);    // lane ^ 2
   if (W >= 8) x &= (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);   // lane <-> 7 - lane
+  if (W >= 16) x &= (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true);  // row_ror:8 = lane ^ 8
   return x;
 }
 
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
                                                         double2 * sink, unsigned int * next_tile, unsigned int dynamic_rounds,
                                                         unsigned int site_base, unsigned int tile_groups)
 {
-  static_assert(RC == 1 || RC == 2 || RC == 4, "lane groups of 2, 4 or 8");
+  static_assert(RC == 1 || RC == 2 || RC == 4 || RC == 8, "lane groups of 2, 4, 8 or 16");
   constexpr bool NT = NTP != 0;
   constexpr unsigned int W = 2 * RC, SPS = 64 / W, TS = J * SPS;
   constexpr unsigned int MG = RC * 8;                   // 16-byte granules of one P-matrix
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   const unsigned long long no_counter = (unsigned long long)(uintptr_t)(sink + 80);
   // where this lane's 16 bytes of tip characters of the first batch of rows begin (+ the tile's first site)
   const unsigned long long row0 = bases.rowtab[lane];
-  static_assert(TS >= 16 && 1024 % TS == 0, "a tip row of a tile is a whole number of 16-byte lanes");
+  // (8 rate categories: a tile is 8 sites -- a lane fetches 16 bytes all the same and uses the first 8)
+  static_assert((TS >= 16 || TS == 8) && 1024 % TS == 0, "a tip row of a tile is a whole number of 16-byte lanes, or half of one");
 
   // A wave's first tiles are its own by a fixed stride; the last `dynamic_rounds` rounds' worth come
   // from a counter.  Not only for the tail: the eight XCDs do not write at the same rate -- on
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     auto request = [&](FusedFetch<J> & f, const Rec & r) {
       const unsigned int off = (pm_left ? rec_req_lmat(r) : rec_req_rmat(r)) + pm_lane;
       f.pm = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(bases.pmat) + off);
+      if (RC == 8) f.pm2 = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(bases.pmat) + rec_req_rmat(r) + pm_lane);
     };
     // A lane's characters of sub-step j of a row: byte j * SPS + tip_lane of the row's TS bytes, i.e. one of
     // the SPS / 4 words that `readlane` brings from the lane(s) holding them (wave-uniform positions).
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       }
       if (need >= 1)
       {
-        if (lane >= MG && lane < 2 * MG) p[lane - MG] = f.pm;
+        if (RC == 8) p[lane] = f.pm2;
+        else if (lane >= MG && lane < 2 * MG) p[lane - MG] = f.pm;
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     gather(pta, h1);
     request(fa, h1);
     asm volatile("" ::"v"(fb.pm.x), "v"(fb.pm.y) : "memory");
+    if (RC == 8) asm volatile("" ::"v"(fb.pm2.x), "v"(fb.pm2.y) : "memory");
     sink_stores();
     stage_rows(fb, (rec_flags(h1) >> PLLHIP_FUSED_STAGE_SHIFT) & 3u, pl, pr);
 
@@ -455,6 +461,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
       // it what that iteration's reload() copied into this op's slots (issued ahead of those
       // requests; memory operations return in order).  No slot is read above this line.
       asm volatile("" ::"v"(fu.pm.x), "v"(fu.pm.y) : "memory");
+      if (RC == 8) asm volatile("" ::"v"(fu.pm2.x), "v"(fu.pm2.y) : "memory");
       // operands and the counts they bring along (entry t of the tile -- a site, or a (site, rate)
       // with per-rate scalers -- is lane t's); every kind reads both operands (a tip-tip op reads
       // slot 0 for nothing: no branch)
@@ -1142,7 +1149,7 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   // Tip rows in the order the list uses them, in batches of what a wave's 64 x 16 bytes hold of a tile
   // (64 rows at 4 rate categories); both rows of an op in one batch.  rowtab[batch][lane]: the address
   // the lane fetches from (+ the tile's first site); lanes without a row fetch zeros.
-  const unsigned int lpr = J * sps / 16, rpb = 64 / lpr; // lanes per row, rows per batch
+  const unsigned int lpr = J * sps >= 16 ? J * sps / 16 : 1, rpb = 64 / lpr; // lanes per row, rows per batch
   std::vector<unsigned int> chars_of(count, 0), batch_of(count, 0);
   std::vector<unsigned long long> rowtab(64, (unsigned long long)(uintptr_t)c->fused_zero_row);
   {
@@ -1312,6 +1319,7 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
     {
       case 1: k_dna_pair_tables<1><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
       case 2: k_dna_pair_tables<2><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
+      case 8: k_dna_pair_tables<8><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
       default: k_dna_pair_tables<4><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
     }
     HIP_TRY(hipGetLastError());
@@ -1320,6 +1328,7 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
   {
     case 1: return launch_fused_rc<1>(c, d_plan, bases, count, nslots, mode);
     case 2: return launch_fused_rc<2>(c, d_plan, bases, count, nslots, mode);
+    case 8: return launch_fused_rc<8>(c, d_plan, bases, count, nslots, mode);
     default: return launch_fused_rc<4>(c, d_plan, bases, count, nslots, mode);
   }
 }
