@@ -370,8 +370,12 @@ def main():
             trace.append(round((time.perf_counter() - t1) * 1e3, 3))
         print("step ms:", trace, file=sys.stderr)
     t0 = time.perf_counter()
+    if inproc > 1:
+        part.timer_start()   # (an event on every shard's own stream: per-device times, below)
     for _ in range(args.steps):
         lnl = step()
+    if inproc > 1:
+        part.timer_stop_ms()
     sync()
     if use_comm:
         dist.barrier()
@@ -415,6 +419,9 @@ def main():
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_ms = [round(float(x.item()), 4) for x in every]
+    elif inproc > 1:
+        # one process, library-sharded partition: HIP-event time of the K steps on each device's stream
+        per_rank_ms = [round(t / args.steps, 4) for t in part.shard_ms()]
 
     # ---- roofline leg, for the dominant kernel (the inner-inner CLV update):
     # HIP events on the partition's own stream around back-to-back launches of
@@ -690,9 +697,11 @@ def main():
             if collective:
                 dist.barrier()
             t1 = time.perf_counter()
+            p4.timer_start()   # (HIP events on every shard's own stream: which device is the slow one)
             for _ in range(steps4):
                 p4.update_partials(plan4.ops)
                 lnl4 = p4.compute_edge_loglikelihood(*plan4.root_edge, fi)
+            p4.timer_stop_ms()
             p4.wait()
             torch.cuda.synchronize()
             own = time.perf_counter() - t1
@@ -762,7 +771,7 @@ def main():
                 dist.all_gather(every, mine)
                 per_rank4 = [round(float(x.item()), 4) for x in every]
             elif inproc > 1:
-                per_rank4 = p4.shard_step_ms() if hasattr(p4, "shard_step_ms") else None
+                per_rank4 = [round(t / steps4, 4) for t in p4.shard_ms()]
             p4.destroy()
             recorded = None
             try:

@@ -673,6 +673,10 @@ PLL_EXPORT int pll_amd_eigen_decompose(unsigned int n, const double * subst_para
  * time of THIS stream; torch.cuda.Event only sees torch's own stream). */
 PLL_EXPORT int pll_amd_timer_start(pll_partition_t * partition);
 PLL_EXPORT int pll_amd_timer_stop_ms(pll_partition_t * partition, float * ms);
+/* A partition sharded over several devices (pll_amd_set_devices): what the last stop measured on each
+ * device's own stream -- the stopwatch reports the slowest, this shows which one it was.  Returns the
+ * number of shards (1 for an ordinary partition) and fills at most `cap` entries. */
+PLL_EXPORT unsigned int pll_amd_timer_shard_ms(pll_partition_t * partition, float * ms, unsigned int cap);
 
 /* Per-kernel-class launch timing (HIP events around every hot-kernel launch
  * while enabled).  Arrays have PLL_AMD_PROF_KINDS entries, indexed

@@ -250,6 +250,8 @@ PLLHIP_EXPORT int pllhip_comm_init(pllhip_ctx_t * ctx, int rank, int nranks,
 /* ---- HIP-event stopwatch on the context's stream ---- */
 PLLHIP_EXPORT int pllhip_timer_start(pllhip_ctx_t * ctx);
 PLLHIP_EXPORT int pllhip_timer_stop_ms(pllhip_ctx_t * ctx, float * ms);
+/* the last stop's time on every shard's own stream (returns the number of shards; fills at most `cap`) */
+PLLHIP_EXPORT unsigned int pllhip_timer_shard_ms(pllhip_ctx_t * ctx, float * ms, unsigned int cap);
 
 /* Per-launch kernel timing for bench.py's roofline figure: while enabled, every
  * launch of the hot kernels is bracketed by a HIP event pair on the context's

@@ -731,5 +731,24 @@ extern "C" int pllhip_timer_stop_ms(pllhip_ctx_t * c, float * ms)
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  c->last_timer_ms = *ms;
   return 0;
+}
+
+// what the last pllhip_timer_stop_ms measured on every shard's own stream (one value for an unsharded
+// context): a straggling device shows here, the stopwatch itself reports the slowest
+extern "C" unsigned int pllhip_timer_shard_ms(pllhip_ctx_t * c, float * ms, unsigned int cap)
+{
+  if (c->shards.empty())
+  {
+    if (cap) ms[0] = c->last_timer_ms;
+    return 1;
+  }
+  unsigned int n = 0;
+  for (pllhip_ctx * s : c->shards)
+  {
+    if (n < cap) ms[n] = s->last_timer_ms;
+    ++n;
+  }
+  return n;
 }

@@ -580,8 +580,9 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // 50 k 118 vs 164.  A property of the device -- tiles against SIMDs -- not a tuned number.)
   const size_t fused_tile_sites = (size_t)PLLHIP_FUSED_J * 64 / (2 * c->sh.rate_cats);
   const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 4 || c->force_fused;
-  // (8 rate categories: a tile is 8 sites only and the variant spills -- 5.6 against 10.2 G/s
-  // for the per-level launches at 500 k sites; not used)
+  // (8 rate categories: a tile is 8 sites, a P-matrix a whole 1 KB block per wave, a site's lanes a DPP row of 16.
+  // Round 1's first attempt spilled and lost -- 5.6 against 10.2 G site-updates/s per level; the rebuilt kernel
+  // needs 136-147 registers for it: 500 k sites x 64 taxa 1.49 ms against 3.07 per level, 20.9 against 10.1 G/s.)
   // (short lists -- the path to the root after one branch changed -- have little to keep on chip, but they
   // are one launch instead of one per op, and half the bytes: 1 M sites, whole list vs per level, 2 ops 134 vs
   // 134 us, 3 ops 180 vs 200, 5 ops 239 vs 282, 7 ops 192 vs 309, 15 ops 380 vs 662; 50 k sites 14 vs 17, 17 vs

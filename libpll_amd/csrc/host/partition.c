@@ -745,6 +745,11 @@ int pll_amd_timer_stop_ms(pll_partition_t * p, float * ms)
   return PLL_SUCCESS;
 }
 
+unsigned int pll_amd_timer_shard_ms(pll_partition_t * p, float * ms, unsigned int cap)
+{
+  return pllhip_timer_shard_ms(pll_amd_priv(p)->ctx, ms, cap);
+}
+
 int pll_amd_profile_enable(pll_partition_t * p, int on)
 {
   int rc = pllhip_profile_enable(pll_amd_priv(p)->ctx, on);

@@ -152,6 +152,8 @@ class PllLibrary:
             lib.pll_amd_shard_count.restype = C.c_uint
             lib.pll_amd_timer_start.argtypes = [_PP]
             lib.pll_amd_timer_stop_ms.argtypes = [_PP, C.POINTER(C.c_float)]
+            lib.pll_amd_timer_shard_ms.argtypes = [_PP, C.POINTER(C.c_float), C.c_uint]
+            lib.pll_amd_timer_shard_ms.restype = C.c_uint
             lib.pll_amd_comm_unique_id.argtypes = [C.c_void_p]
             lib.pll_amd_comm_init.argtypes = [_PP, C.c_int, C.c_int, C.c_void_p]
             lib.pll_amd_profile_enable.argtypes = [_PP, C.c_int]
@@ -378,6 +380,12 @@ class Partition:
         ms = C.c_float()
         self._check(self.lib.pll_amd_timer_stop_ms(self.ptr, C.byref(ms)), "pll_amd_timer_stop_ms")
         return ms.value
+
+    def shard_ms(self):
+        """what the last timer_stop_ms measured on each shard's own stream (one entry if unsharded)"""
+        buf = (C.c_float * 64)()
+        n = self.lib.pll_amd_timer_shard_ms(self.ptr, buf, 64)
+        return [float(buf[i]) for i in range(min(n, 64))]
 
     def profile_enable(self, on=True):
         self._check(self.lib.pll_amd_profile_enable(self.ptr, 1 if on else 0), "pll_amd_profile_enable")

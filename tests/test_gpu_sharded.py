@@ -133,6 +133,31 @@ def test_small_partitions_get_fewer_shards(gpu):
         q.destroy()
 
 
+def test_per_shard_stopwatch(gpu):
+    """pll_amd_timer_shard_ms: the stopwatch of a sharded partition reports the slowest shard; the per-shard
+    figures (what bench.py prints as per_rank_ms_per_step in --in-process mode) show every device's own time."""
+    case = make_case(4, "balanced", 16, 40_000, seed=3)
+    with devices(gpu, [0, 0, 0]):
+        p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    assert gpu.lib.pll_amd_shard_count(p.ptr) == 3
+    p.update_partials(case["plan"].ops)
+    p.wait()
+    p.timer_start()
+    for _ in range(5):
+        p.update_partials(case["plan"].ops)
+    slowest = p.timer_stop_ms()
+    per = p.shard_ms()
+    assert len(per) == 3 and all(t > 0.0 for t in per)
+    assert abs(max(per) - slowest) <= 1e-6 * slowest
+    p.destroy()
+    q = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    q.timer_start()
+    q.update_partials(case["plan"].ops)
+    t = q.timer_stop_ms()
+    assert q.shard_ms() == [pytest.approx(t)]
+    q.destroy()
+
+
 @pytest.mark.parametrize("kind", [ATTRIB_AB_LEWIS, ATTRIB_AB_STAMATAKIS])
 def test_sharded_ascertainment_bias(gpu, kind):
     """The per-state sites and their correction live on the last shard; the value is the same."""

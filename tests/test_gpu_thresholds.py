@@ -17,10 +17,10 @@ from libpll_amd.pllapi import ATTRIB_PATTERN_TIP
 pytestmark = pytest.mark.gpu
 
 
-def observe(gpu, plan, seqs, states, ops=None):
-    p = W.setup_partition(gpu, plan, seqs, states, 4, ATTRIB_PATTERN_TIP)
+def observe(gpu, plan, seqs, states, ops=None, rate_cats=4):
+    p = W.setup_partition(gpu, plan, seqs, states, rate_cats, ATTRIB_PATTERN_TIP)
     p.update_partials(plan.ops if ops is None else ops)
-    lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
+    lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, [0] * rate_cats, persite=True)
     top = plan.ops[-1]
     out = (lnl, ps, p.get_clv(int(top["parent_clv_index"])), p.get_scaler(int(top["parent_scaler_index"])))
     p.destroy()
@@ -42,6 +42,22 @@ def test_whole_list_kernel_threshold(gpu, monkeypatch, sites):
         else:
             monkeypatch.setenv("PLLHIP_FUSED", mode)
         res[mode] = observe(gpu, plan, seqs, 4)
+    assert same(res["default"], res["0"]) and same(res["default"], res["2"])
+
+
+@pytest.mark.parametrize("rate_cats,sites", [(1, 70_000), (2, 40_000), (8, 8_191), (8, 8_192), (8, 30_001)])
+def test_whole_list_kernel_rate_categories(gpu, monkeypatch, rate_cats, sites):
+    """The whole-list kernel's other tile shapes -- 64, 32 and (round 3) 8 sites per tile for 1, 2 and 8 rate
+    categories -- on both sides of their size threshold."""
+    plan = W.random_tree(24, seed=rate_cats)
+    seqs = W.random_alignment(24, sites, 4, seed=sites)
+    res = {}
+    for mode in ("default", "0", "2"):
+        if mode == "default":
+            monkeypatch.delenv("PLLHIP_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("PLLHIP_FUSED", mode)
+        res[mode] = observe(gpu, plan, seqs, 4, rate_cats=rate_cats)
     assert same(res["default"], res["0"]) and same(res["default"], res["2"])
 
 
