@@ -159,6 +159,14 @@ PLLHIP_EXPORT int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buff
                                         unsigned int nslots, unsigned int * order_out,
                                         unsigned int * reloads_out, int * slots_out);
 
+/* Host logic of the same planner, no device: where the 4-state whole-list kernel keeps each op's tip characters.
+ * tips[i]: bit 0 / 1 = op i (in the PLANNED order) has a left / right tip row.  chars_out[i]: bits 0-7 / 8-15 the
+ * first lane of the left / right row in the wave's character registers, bit 16 / 17 = has a left / right tip;
+ * batch_out[i]: the batch of 64 x 16 bytes the op's rows are fetched with.  Returns the number of batches. */
+PLLHIP_EXPORT unsigned int pllhip_fused_char_batches_dry(const unsigned int * tips, unsigned int count,
+                                                         unsigned int rate_cats, unsigned int * chars_out,
+                                                         unsigned int * batch_out);
+
 /* replaces pll_core_update_partial_tt proper (core_partials.c:82-200): the parent CLV of a tip-tip
  * node is, per site, row ((code1 << log2_maxstates) + code2) of the lookup table the caller built
  * with pll_core_create_lookup -- a gather on the device from the uploaded table (h_lookup:

@@ -1104,6 +1104,39 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   return 0;
 }
 
+// Where each op's tip characters sit in a wave's character registers.  A wave holds the characters of 64 / lpr tip
+// rows of its tile at a time (lpr lanes of 16 bytes per row); the rows are dealt in the order the list uses them,
+// both rows of an op into the same batch.  tips[pos]: bit 0 / 1 = the op has a left / right tip.  Out, per op:
+// chars (PLLHIP_FUSED_CH_LPOS / RPOS = first lane of the row, CH_LTIP / CH_RTIP) and the batch its rows are in
+// (an op without tips: the batch current at that point).  Returns the number of batches.  Pure host logic.
+unsigned int pllhip_fused_char_batches(const unsigned int * tips, unsigned int count, unsigned int lpr,
+                                       unsigned int * chars_out, unsigned int * batch_out)
+{
+  const unsigned int rpb = 64 / lpr; // rows per batch
+  unsigned int batch = 0, q = 0;
+  for (unsigned int pos = 0; pos < count; ++pos)
+  {
+    const unsigned int n = (tips[pos] & 1u) + ((tips[pos] >> 1) & 1u);
+    if (q + n > rpb)
+    {
+      ++batch;
+      q = 0;
+    }
+    batch_out[pos] = batch;
+    chars_out[pos] = 0;
+    if (tips[pos] & 1u) chars_out[pos] |= PLLHIP_FUSED_CH_LTIP | (q++ * lpr);
+    if (tips[pos] & 2u) chars_out[pos] |= PLLHIP_FUSED_CH_RTIP | (q++ * lpr) << 8;
+  }
+  return batch + 1;
+}
+
+extern "C" unsigned int pllhip_fused_char_batches_dry(const unsigned int * tips, unsigned int count, unsigned int rate_cats,
+                                                      unsigned int * chars_out, unsigned int * batch_out)
+{
+  const unsigned int ts = PLLHIP_FUSED_J * (64 / (2 * rate_cats));
+  return pllhip_fused_char_batches(tips, count, ts >= 16 ? ts / 16 : 1, chars_out, batch_out);
+}
+
 // Encode the plan for the device (FusedRec in partials_fused.hpp): two header records that
 // stand for ops -2 and -1, one record per op, one of padding (the last op's look-ahead load), the
 // reload sources, the pair-table jobs.  Returns 1 if the list is not one the kernel takes.
@@ -1147,35 +1180,25 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   std::vector<FusedSrc> srcs;
   std::vector<FusedPairJob> jobs;
   // Tip rows in the order the list uses them, in batches of what a wave's 64 x 16 bytes hold of a tile
-  // (64 rows at 4 rate categories); both rows of an op in one batch.  rowtab[batch][lane]: the address
-  // the lane fetches from (+ the tile's first site); lanes without a row fetch zeros.
-  const unsigned int lpr = J * sps >= 16 ? J * sps / 16 : 1, rpb = 64 / lpr; // lanes per row, rows per batch
+  // (pllhip_fused_char_batches).  rowtab[batch][lane]: the address the lane fetches from (+ the tile's first
+  // site); lanes without a row fetch zeros.
+  const unsigned int lpr = J * sps >= 16 ? J * sps / 16 : 1; // lanes per row
   std::vector<unsigned int> chars_of(count, 0), batch_of(count, 0);
-  std::vector<unsigned long long> rowtab(64, (unsigned long long)(uintptr_t)c->fused_zero_row);
+  std::vector<unsigned long long> rowtab;
   {
-    unsigned int batch = 0, q = 0;
+    std::vector<unsigned int> ntips(count);
+    for (unsigned int pos = 0; pos < count; ++pos) ntips[pos] = (plan[pos].ltip ? 1u : 0u) | (plan[pos].rtip ? 2u : 0u);
+    const unsigned int nbatches = pllhip_fused_char_batches(ntips.data(), count, lpr, chars_of.data(), batch_of.data());
+    if (nbatches > 255) return 1;
+    rowtab.assign((size_t)nbatches * 64, (unsigned long long)(uintptr_t)c->fused_zero_row);
     for (unsigned int pos = 0; pos < count; ++pos)
     {
-      const FusedOp & f = plan[pos];
-      const unsigned int n = (f.ltip ? 1u : 0u) + (f.rtip ? 1u : 0u);
-      if (q + n > rpb)
-      {
-        ++batch;
-        q = 0;
-        rowtab.resize((size_t)(batch + 1) * 64, (unsigned long long)(uintptr_t)c->fused_zero_row);
-      }
-      batch_of[pos] = batch;
-      const unsigned char * rows[2] = {f.ltip, f.rtip};
+      const unsigned char * rows[2] = {plan[pos].ltip, plan[pos].rtip};
+      const unsigned int lane0[2] = {PLLHIP_FUSED_CH_LPOS(chars_of[pos]), PLLHIP_FUSED_CH_RPOS(chars_of[pos])};
       for (int o = 0; o < 2; ++o)
-      {
-        if (!rows[o]) continue;
-        chars_of[pos] |= (o == 0 ? PLLHIP_FUSED_CH_LTIP : PLLHIP_FUSED_CH_RTIP) | (q * lpr) << (o == 0 ? 0 : 8);
-        for (unsigned int l = 0; l < lpr; ++l)
-          rowtab[(size_t)batch * 64 + q * lpr + l] = (unsigned long long)(uintptr_t)rows[o] + l * 16u;
-        ++q;
-      }
+        for (unsigned int l = 0; rows[o] && l < lpr; ++l)
+          rowtab[(size_t)batch_of[pos] * 64 + lane0[o] + l] = (unsigned long long)(uintptr_t)rows[o] + l * 16u;
     }
-    if (batch > 254) return 1;
   }
   std::vector<unsigned int> table_of(count, 0); // byte offset of each op's pair table (0: zeros)
   int mode = SCALE_NONE;

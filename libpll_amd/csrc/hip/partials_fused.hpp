@@ -97,6 +97,9 @@ struct FusedPairJob
   unsigned long long tip_tip;
 };
 
+unsigned int pllhip_fused_char_batches(const unsigned int * tips, unsigned int count, unsigned int lpr,
+                                       unsigned int * chars_out, unsigned int * batch_out);
+
 // what the offsets of a FusedRec are relative to (kernel argument)
 struct FusedBases
 {

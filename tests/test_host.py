@@ -333,6 +333,46 @@ def test_fused_planner_on_random_op_sequences(amd):
     assert _plan_dry(amd, bad, 8, 6, 6, 1, 5)[0] == -1
 
 
+@pytest.mark.parametrize("rate_cats", [1, 2, 4, 8])
+def test_tip_character_batches_of_the_whole_list_kernel(amd, rate_cats):
+    """pllhip_fused_char_batches (host logic of partials_fused.hip): a wave fetches the characters of its tile's
+    tip rows 64 lanes x 16 bytes at a time, in the order the list uses them.  For random lists: every tip row gets
+    lanes of its own inside its batch, both rows of an op lie in the same batch, batches never go backwards, an
+    op without tips takes no lanes, and the number of batches is what the rows need (no batch but the last may
+    leave more than one row's lanes unused)."""
+    rng = np.random.default_rng(rate_cats)
+    tile_sites = 2 * (64 // (2 * rate_cats))
+    lpr = max(1, tile_sites // 16)       # lanes per row
+    rpb = 64 // lpr                      # rows per batch
+    for count in (1, 2, 7, 62, 126, 198, 1000):
+        tips = rng.integers(0, 4, size=count).astype(np.uint32)
+        if count == 62:  # a balanced 64-taxon list as planned: 32 tip-tip ops among 30 inner ones
+            tips = np.array([3 if i % 2 == 0 and i < 64 else 0 for i in range(62)], dtype=np.uint32)
+        chars = (C.c_uint * count)()
+        batch = (C.c_uint * count)()
+        nb = amd.lib.pllhip_fused_char_batches_dry(tips.ctypes.data_as(C.POINTER(C.c_uint)), C.c_uint(count),
+                                                   C.c_uint(rate_cats), chars, batch)
+        taken = {}                        # batch -> set of lanes
+        rows_in = {}
+        last = 0
+        for i in range(count):
+            ch, b = int(chars[i]), int(batch[i])
+            assert b >= last and b < nb
+            last = b
+            assert bool(ch & (1 << 16)) == bool(tips[i] & 1) and bool(ch & (1 << 17)) == bool(tips[i] & 2)
+            for has, lane0 in ((tips[i] & 1, ch & 0xff), (tips[i] & 2, (ch >> 8) & 0xff)):
+                if not has:
+                    continue
+                lanes = set(range(lane0, lane0 + lpr))
+                assert lane0 % lpr == 0 and lane0 + lpr <= 64
+                assert not (lanes & taken.setdefault(b, set())), "two rows share a lane"
+                taken[b] |= lanes
+                rows_in[b] = rows_in.get(b, 0) + 1
+        assert nb == last + 1
+        for b in range(nb - 1):
+            assert rows_in.get(b, 0) >= rpb - 1, "a batch was closed with room for a whole op left"
+
+
 def test_whole_list_kernel_keeps_out_of_the_slot_registers():
     """partials_aa_fused.hip keeps its values in the accumulation registers a0..a109 behind the
     compiler's back (inline assembly).  The generated code is checked: no instruction outside that
