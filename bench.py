@@ -794,6 +794,11 @@ def main():
                                      (" (the one-GPU leg failed here: %s)" % one_err if one_err else "")) if recorded else None,
                   "one_gpu_lnl": one_lnl,
                   "speedup_vs_one_gpu": round(base_ms / ms4, 3) if base_ms else None}
+    rccl_path = None
+    if use_comm:
+        import ctypes
+        amd.lib.pll_amd_rccl_path.restype = ctypes.c_char_p
+        rccl_path = (amd.lib.pll_amd_rccl_path() or b"").decode() or None
     if rank == 0:
         tt, ti, ii = plan.op_kinds() if not args.tip_clv else (0, 0, ops_per_eval)
         out = {
@@ -823,12 +828,30 @@ def main():
             "ramp": ramp,
             "roofline": roofline, "api_calls": api, "kernels": per_kernel, "cpu_baseline": cpu,
             "varying_lists": varying, "newton": newton, "c4_strong": c4,
+            # which RCCL the library bound (the copy torch had mapped already, unless it says otherwise)
+            "rccl": rccl_path,
         }
-        print(json.dumps(out))
+    else:
+        out = None
     if part is not None:
         part.destroy()
     if use_comm:
         dist.destroy_process_group()
+    # The JSON line is the ONLY thing on stdout: libraries loaded along the way write to C's stdio (RCCL prints a
+    # version banner of five lines when it is initialised), which is fully buffered on a pipe and would otherwise
+    # land behind Python's line when the process exits.  Whatever is pending there goes to stderr instead.
+    sys.stdout.flush()
+    try:
+        import ctypes
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+    except Exception:
+        pass
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
