@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun) from the repo root:  bash tools/profile_round.sh <tag>
 # Takes, for each BASELINE workload, the plain bench line, the rocprofv3 kernel statistics of
-# the same command and the HBM traffic counters (FETCH_SIZE and WRITE_SIZE in passes of their
+# the same workload (with --no-vary: the varying-lists leg launches the same kernels on short and re-rooted lists and
+# would dilute the per-kernel averages the bench line's avg_launch_us is to be compared with) and the HBM traffic counters (FETCH_SIZE and WRITE_SIZE in passes of their
 # own: no trace domains next to --pmc), condenses them with tools/summarize_rocprof.py into
 # gpurun_out/<tag>/summary/ (what gets copied into profiles/) and writes the index bench.py reads
 # `roofline.traffic` from.
@@ -20,38 +21,42 @@ run() { # name, [ENV=VAL ...] -- bench args...
   while [ "$1" != "--" ]; do envs+=("$1"); shift; done
   shift
   for e in "${envs[@]}"; do export "$e"; done
-  (cd "$root" && python3 bench.py "$@" > "$sum/${tag}_bench_$name.json" 2> "$out/bench_$name.err")
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$name" -- \
-      python3 "$root/bench.py" --steps 20 --warmup 3 --cpu-sites 0 "$@" > "$sum/${tag}_bench_${name}_under_rocprof.json" 2> "$out/trace_$name.err"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_$name" -- \
-      python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 "$@" > /dev/null 2> "$out/fetch_$name.err"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write_$name" -- \
-      python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 "$@" > /dev/null 2> "$out/write_$name.err"
-  python3 "$root/tools/summarize_rocprof.py" stats "$out/trace_$name" "$sum/${tag}_bench_${name}_kernel_stats.csv"
-  python3 "$root/tools/summarize_rocprof.py" hbm "$out/fetch_$name" "$out/write_$name" "$sum/${tag}_pmc_hbm_traffic_$name.csv" \
-      "${envs[*]} python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 $*"
+  if [ "$phase" = pmc ]; then
+    # first phase: the HBM counters (their index is what the later bench lines look roofline.traffic up in)
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_$name" -- \
+        python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary "$@" > "$out/pmcpass_$name.json" 2> "$out/fetch_$name.err"
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write_$name" -- \
+        python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary "$@" > /dev/null 2> "$out/write_$name.err"
+    python3 "$root/tools/summarize_rocprof.py" hbm "$out/fetch_$name" "$out/write_$name" "$sum/${tag}_pmc_hbm_traffic_$name.csv" \
+        "${envs[*]} python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 --no-vary $*"
+    rm -rf "$out/fetch_$name" "$out/write_$name"
+  else
+    # second phase: the kernel statistics of the same workload, then the plain line
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$name" -- \
+        python3 "$root/bench.py" --steps 20 --warmup 3 --cpu-sites 0 --no-vary "$@" > "$sum/${tag}_bench_${name}_under_rocprof.json" 2> "$out/trace_$name.err"
+    python3 "$root/tools/summarize_rocprof.py" stats "$out/trace_$name" "$sum/${tag}_bench_${name}_kernel_stats.csv"
+    rm -rf "$out/trace_$name"
+    (cd "$root" && python3 bench.py "$@" > "$sum/${tag}_bench_$name.json" 2> "$out/bench_$name.err")
+  fi
   for e in "${envs[@]}"; do unset "${e%%=*}"; done
-  # keep what travels back small
-  rm -rf "$out/trace_$name" "$out/fetch_$name" "$out/write_$name"
 }
 
-run c2 --
-run c2_per_level PLLHIP_FUSED=0 --
-run c3 -- --states 20 --sites 200000
-run c3_per_level PLLHIP_FUSED=0 -- --states 20 --sites 200000
-run c3_random_200 -- --states 20 --sites 100000 --taxa 200 --tree random
-run c4_shard -- --taxa 128
-run c5_shape -- --sites 500000 --taxa 200 --tree random --newton 5
-run c2_tip_clv -- --tip-clv
+workloads() {
+  run c2 --
+  run c2_per_level PLLHIP_FUSED=0 --
+  run c3 -- --states 20 --sites 200000
+  run c3_per_level PLLHIP_FUSED=0 -- --states 20 --sites 200000
+  run c3_random_200 -- --states 20 --sites 100000 --taxa 200 --tree random
+  run c4_shard -- --taxa 128
+  run c5_shape -- --sites 500000 --taxa 200 --tree random --newton 5
+  run c2_tip_clv -- --tip-clv
+}
+phase=pmc
+workloads
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/mfma_c3" -- \
-    python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --states 20 --sites 200000 > /dev/null 2> "$out/mfma_c3.err"
-python3 "$root/tools/summarize_rocprof.py" pmc "$out/mfma_c3" "$sum/${tag}_pmc_mfma_c3.csv" "python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 --states 20 --sites 200000"
+    python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary --states 20 --sites 200000 > /dev/null 2> "$out/mfma_c3.err"
+python3 "$root/tools/summarize_rocprof.py" pmc "$out/mfma_c3" "$sum/${tag}_pmc_mfma_c3.csv" "python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 --no-vary --states 20 --sites 200000"
 rm -rf "$out/mfma_c3"
-# BASELINE config 4 on ONE GPU (133 GB): the strong-scaling reference point
-(cd "$root" && python3 bench.py --total-sites 8000000 --taxa 128 --cpu-sites 0 --steps 10 > "$sum/${tag}_bench_c4_one_gpu.json" 2> "$out/bench_c4_one_gpu.err")
-# site repeats on the C5 shape
-(cd "$root" && python3 bench.py --sites 500000 --taxa 200 --tree random --site-repeats --cpu-sites 0 > "$sum/${tag}_bench_c5_shape_site_repeats.json" 2> "$out/bench_c5rep.err")
-
 cat > "$sum/pmc_spec.json" <<EOF
 [
  {"csv": "${tag}_pmc_hbm_traffic_c2.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
@@ -63,15 +68,26 @@ cat > "$sum/pmc_spec.json" <<EOF
  {"csv": "${tag}_pmc_hbm_traffic_c2_tip_clv.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
   "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 64, "tree": "balanced", "tip_clv": true, "rate_scalers": false}},
  {"csv": "${tag}_pmc_hbm_traffic_c2_per_level.csv", "kernel_match": "k_dna_partials<4, 1, true, 0", "kernel_class": "inner-inner",
-  "bench_json": "${tag}_bench_c2_per_level_under_rocprof.json",
+  "bench_json": "$out/pmcpass_c2_per_level.json",
   "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
  {"csv": "${tag}_pmc_hbm_traffic_c3.csv", "kernel_match": "k_aa_fused", "kernel_class": "whole-list", "sum_call": true,
   "exclude": ["k_lnl", "k_update_pmatrix", "fillBuffer", "copyBuffer", "k_final_sum"],
   "workload": {"states": 20, "rate_cats": 4, "sites": 200000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
+ {"csv": "${tag}_pmc_hbm_traffic_c3_random_200.csv", "kernel_match": "k_aa_fused", "kernel_class": "whole-list", "sum_call": true,
+  "exclude": ["k_lnl", "k_update_pmatrix", "fillBuffer", "copyBuffer", "k_final_sum"],
+  "workload": {"states": 20, "rate_cats": 4, "sites": 100000, "taxa": 200, "tree": "random", "tip_clv": false, "rate_scalers": false}},
  {"csv": "${tag}_pmc_hbm_traffic_c3_per_level.csv", "kernel_match": "k_aa_ii_mfma<4, 1", "kernel_class": "inner-inner",
-  "bench_json": "${tag}_bench_c3_per_level_under_rocprof.json",
+  "bench_json": "$out/pmcpass_c3_per_level.json",
   "workload": {"states": 20, "rate_cats": 4, "sites": 200000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}}
 ]
 EOF
 python3 "$root/tools/summarize_rocprof.py" index "$sum/pmc_spec.json" "$sum/pmc_traffic.json"
+# the bench lines that follow read roofline.traffic from the index of THIS run
+cp "$sum/pmc_traffic.json" "$root/profiles/pmc_traffic.json"
+phase=lines
+workloads
+# BASELINE config 4 on ONE GPU (133 GB): the strong-scaling reference point
+(cd "$root" && python3 bench.py --total-sites 8000000 --taxa 128 --cpu-sites 0 --steps 10 > "$sum/${tag}_bench_c4_one_gpu.json" 2> "$out/bench_c4_one_gpu.err")
+# site repeats on the C5 shape
+(cd "$root" && python3 bench.py --sites 500000 --taxa 200 --tree random --site-repeats --cpu-sites 0 > "$sum/${tag}_bench_c5_shape_site_repeats.json" 2> "$out/bench_c5rep.err")
 ls -la "$sum"
