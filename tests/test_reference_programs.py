@@ -35,6 +35,13 @@ def test_reference_program_output(gpu, name, mode):
     if os.path.exists(helper):
         env["LD_PRELOAD"] = helper
     run = subprocess.run([exe] + mode, capture_output=True, text=True, timeout=600, env=env)
+    if run.returncode < 0:
+        # killed by a signal: seen ONCE in several thousand runs of these programs (round 3, a SIGSEGV of
+        # derivatives-oddstates that 500 repetitions under tools/crash_hunt.sh did not reproduce).  One more
+        # attempt, and the first one's backtrace (oracle/segv_backtrace.so) goes into the warnings either way.
+        import warnings
+        warnings.warn("%s %s died with signal %d: %s" % (name, mode, -run.returncode, run.stderr[-1500:]))
+        run = subprocess.run([exe] + mode, capture_output=True, text=True, timeout=600, env=env)
     assert run.returncode == 0, run.stderr[-2000:]
     got = run.stdout
     # (protein-models and the extra examples have no stored output in the reference: their
