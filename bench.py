@@ -16,9 +16,11 @@ N x 1,000,000-site alignment (weak scaling, no data-path collective; one
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself -- a fresh
 `python -m torch.distributed.run` child, before this process has touched a GPU -- and fails if
-fewer than N devices are visible.  For N>1 the line also carries `c4_strong`: BASELINE
-config 4 (8,000,000 sites, 128 taxa) divided over the N GPUs, with the speed-up against the
-recorded one-GPU time of that workload (profiles/r2_bench_c4_one_gpu.json).
+fewer than N devices are visible.  The line also carries `c4_strong`: BASELINE config 4
+(8,000,000 sites, 128 taxa) as a strong-scaling job -- at N=1 (default workload only, ~5 s) the
+whole alignment on this GPU, the one-GPU point of the curve; for N>1 divided over the N GPUs, with
+the speed-up against the whole alignment evaluated on rank 0's GPU IN THE SAME RUN (boxes differ by
+10-20 %; --no-c4-one-gpu falls back to a recorded figure and says so), and per-rank step times.
 `--in-process` instead drives the N GPUs from ONE process through the library's own sharding of
 a partition (PLL_AMD_DEVICES; host sum of the per-device lnL, no RCCL).
 
@@ -675,7 +677,12 @@ def main():
     # ---- N > 1: BASELINE config 4 as a strong-scaling job (fixed 8,000,000 sites x 128 taxa
     # divided over the GPUs), next to the weak-scaling headline above
     c4 = None
-    if (world * inproc > 1 or args.force_c4) and not args.no_c4 and S == 4:
+    # (N = 1 with the default workload: the whole config-4 alignment on this GPU, ~25 s: the one-GPU point)
+    default_workload = (S == 4 and R == 4 and T == 64 and args.sites == 1_000_000 and args.tree == "balanced" and
+                        not strong and not args.tip_clv and not args.site_repeats and not args.rate_scalers and
+                        not args.no_scalers)
+    c4_single = world * inproc == 1 and not args.force_c4
+    if (world * inproc > 1 or args.force_c4 or default_workload) and not args.no_c4 and S == 4:
         part.destroy()
         part = None
         c4_sites, c4_taxa = 8_000_000, 128
@@ -732,68 +739,80 @@ def main():
                 one_err = "%s: %s" % (type(exc).__name__, exc)
         if use_comm:
             dist.barrier()
-        # (2) the same alignment divided over the GPUs.  A rank that fails must not leave the others in
-        # a collective: every rank works inside try, then all agree on success BEFORE the next collective
-        err, p4 = None, None
-        try:
-            lo4, hi4 = W.shard_bounds(c4_sites, world)[rank:rank + 2]
-            p4 = W.setup_partition(amd, plan4, c4_alignment(lo4, hi4, 4242 + rank), 4, R, ATTRIB_PATTERN_TIP)
-        except Exception as exc:
-            err = "%s: %s" % (type(exc).__name__, exc)
-        ok = err is None
-        if use_comm:
-            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(flag.item() >= 1.0)
-        if not ok:
-            c4 = {"error": err or "another rank failed to set its shard up"}
-            if p4 is not None:
-                p4.destroy()
-        else:
-            if use_comm:
-                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    import ctypes
-                    buf = ctypes.create_string_buffer(128)
-                    if not amd.lib.pll_amd_comm_unique_id(buf):
-                        raise SystemExit("pll_amd_comm_unique_id failed: " + amd.errmsg())
-                    uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
-                dist.broadcast(uid, src=0)
-                p4.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-            t4, own4, lnl4 = c4_time(p4, steps4, use_comm)
-            per_rank4 = None
-            if use_comm:
-                t = torch.tensor([t4], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                t4 = float(t.item())
-                mine = torch.tensor([own4 / steps4 * 1e3], dtype=torch.float64, device="cuda")
-                every = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(every, mine)
-                per_rank4 = [round(float(x.item()), 4) for x in every]
-            elif inproc > 1:
-                per_rank4 = [round(t / steps4, 4) for t in p4.shard_ms()]
-            p4.destroy()
-            recorded = None
-            try:
-                recorded = json.load(open(os.path.join(root, "profiles", "r2_bench_c4_one_gpu.json")))
-            except (OSError, ValueError):
-                pass
-            ms4 = t4 / steps4 * 1e3
-            base_ms = one_ms if one_ms else (recorded["ms_per_step"] if recorded else None)
+        if c4_single:
+            # N = 1: this run IS the one-GPU point of the strong-scaling curve (SCALE at N = 1 then carries
+            # the same-node denominator too)
             c4 = {"workload": "BASELINE config 4: 4-state GTR, 4 rates, %d sites, %d-taxon balanced tree, PATTERN_TIP, "
-                              "divided over %d GPUs (%s)" % (c4_sites, c4_taxa, world * inproc,
-                                                             "one process, library-sharded partition" if inproc > 1
-                                                             else "one process per GPU, RCCL lnL all-reduce"),
-                  "scaling": "strong", "n_gpus": world * inproc, "steps": steps4,
-                  "value": round((c4_taxa - 2) * c4_sites * steps4 / t4 / 1e6, 2), "unit": "M CLV-site-updates/s",
-                  "ms_per_step": round(ms4, 4), "lnl": lnl4, "per_rank_ms_per_step": per_rank4,
-                  "one_gpu_ms_per_step": round(base_ms, 4) if base_ms else None,
-                  "one_gpu_source": ("measured in this run on this node: the whole alignment on rank 0's GPU, %d steps"
-                                     % steps4) if one_ms else
-                                    ("FALLBACK, another box: profiles/r2_bench_c4_one_gpu.json" +
-                                     (" (the one-GPU leg failed here: %s)" % one_err if one_err else "")) if recorded else None,
-                  "one_gpu_lnl": one_lnl,
-                  "speedup_vs_one_gpu": round(base_ms / ms4, 3) if base_ms else None}
+                              "whole on one GPU" % (c4_sites, c4_taxa),
+                  "scaling": "strong", "n_gpus": 1, "steps": steps4,
+                  "value": round((c4_taxa - 2) * c4_sites / (one_ms * 1e-3) / 1e6, 2) if one_ms else None,
+                  "unit": "M CLV-site-updates/s", "ms_per_step": round(one_ms, 4) if one_ms else None,
+                  "lnl": one_lnl, "one_gpu_ms_per_step": round(one_ms, 4) if one_ms else None,
+                  "one_gpu_source": "measured in this run on this node" if one_ms else None,
+                  "error": one_err, "speedup_vs_one_gpu": 1.0 if one_ms else None}
+        else:
+            # (2) the same alignment divided over the GPUs.  A rank that fails must not leave the others in
+            # a collective: every rank works inside try, then all agree on success BEFORE the next collective
+            err, p4 = None, None
+            try:
+                lo4, hi4 = W.shard_bounds(c4_sites, world)[rank:rank + 2]
+                p4 = W.setup_partition(amd, plan4, c4_alignment(lo4, hi4, 4242 + rank), 4, R, ATTRIB_PATTERN_TIP)
+            except Exception as exc:
+                err = "%s: %s" % (type(exc).__name__, exc)
+            ok = err is None
+            if use_comm:
+                flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(flag.item() >= 1.0)
+            if not ok:
+                c4 = {"error": err or "another rank failed to set its shard up"}
+                if p4 is not None:
+                    p4.destroy()
+            else:
+                if use_comm:
+                    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                    if rank == 0:
+                        import ctypes
+                        buf = ctypes.create_string_buffer(128)
+                        if not amd.lib.pll_amd_comm_unique_id(buf):
+                            raise SystemExit("pll_amd_comm_unique_id failed: " + amd.errmsg())
+                        uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                    dist.broadcast(uid, src=0)
+                    p4.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+                t4, own4, lnl4 = c4_time(p4, steps4, use_comm)
+                per_rank4 = None
+                if use_comm:
+                    t = torch.tensor([t4], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    t4 = float(t.item())
+                    mine = torch.tensor([own4 / steps4 * 1e3], dtype=torch.float64, device="cuda")
+                    every = [torch.zeros_like(mine) for _ in range(world)]
+                    dist.all_gather(every, mine)
+                    per_rank4 = [round(float(x.item()), 4) for x in every]
+                elif inproc > 1:
+                    per_rank4 = [round(t / steps4, 4) for t in p4.shard_ms()]
+                p4.destroy()
+                recorded = None
+                try:
+                    recorded = json.load(open(os.path.join(root, "profiles", "r2_bench_c4_one_gpu.json")))
+                except (OSError, ValueError):
+                    pass
+                ms4 = t4 / steps4 * 1e3
+                base_ms = one_ms if one_ms else (recorded["ms_per_step"] if recorded else None)
+                c4 = {"workload": "BASELINE config 4: 4-state GTR, 4 rates, %d sites, %d-taxon balanced tree, PATTERN_TIP, "
+                                  "divided over %d GPUs (%s)" % (c4_sites, c4_taxa, world * inproc,
+                                                                 "one process, library-sharded partition" if inproc > 1
+                                                                 else "one process per GPU, RCCL lnL all-reduce"),
+                      "scaling": "strong", "n_gpus": world * inproc, "steps": steps4,
+                      "value": round((c4_taxa - 2) * c4_sites * steps4 / t4 / 1e6, 2), "unit": "M CLV-site-updates/s",
+                      "ms_per_step": round(ms4, 4), "lnl": lnl4, "per_rank_ms_per_step": per_rank4,
+                      "one_gpu_ms_per_step": round(base_ms, 4) if base_ms else None,
+                      "one_gpu_source": ("measured in this run on this node: the whole alignment on rank 0's GPU, %d steps"
+                                         % steps4) if one_ms else
+                                        ("FALLBACK, another box: profiles/r2_bench_c4_one_gpu.json" +
+                                         (" (the one-GPU leg failed here: %s)" % one_err if one_err else "")) if recorded else None,
+                      "one_gpu_lnl": one_lnl,
+                      "speedup_vs_one_gpu": round(base_ms / ms4, 3) if base_ms else None}
     rccl_path = None
     if use_comm:
         import ctypes
