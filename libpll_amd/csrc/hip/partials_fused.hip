@@ -1,7 +1,8 @@
 // partials_fused.hip -- a whole op list of 4-state CLV updates in ONE kernel, site-blocked.
 //
 // Replaces the per-level launches of partials.hip for pll_update_partials
-// (partials.c:214-278 -> core_partials.c) when the list has more than one op.
+// (partials.c:214-278 -> core_partials.c) when the list has more than one op and the partition at
+// least one tile per SIMD.
 //
 // Observation.  A CLV update at site n needs the children's entries of site n only, so
 // the order "all sites of op 1, all sites of op 2, ..." of the reference is a choice, not
@@ -29,10 +30,14 @@
 //             (global_load_lds: no registers) at the top of the op BEFORE its reader.
 //   look-ahead  vector-memory loads and stores retire in ONE in-order queue, so a load
 //             issued after a store cannot be consumed before that store is acknowledged.
-//             Everything an op needs from memory (its two P-matrices, tip characters) is
-//             therefore requested during the op two before it, ahead of that op's stores,
-//             with unconditional loads (an op without a tip reads a row of zeros), and its
-//             pair-table entries are gathered during the op before it.
+//             Everything an op needs from memory (its two P-matrices) is therefore requested
+//             during the op two before it, ahead of that op's stores, with unconditional loads,
+//             and its pair-table entries are gathered during the op before it.
+//   characters  the tile's characters of up to 64 tip rows are fetched with ONE load at the top of
+//             the tile and kept in four registers; an op takes its own with v_readlane (round 3:
+//             per-op requests of two rows each were what held partitions beyond 33 GB at 0.5-0.57)
+//   tiles     a wave's first rounds by fixed stride, the last third from eight counters (the XCDs
+//             do not write at the same rate), the ticket requested two ops before it is needed
 //   plan      one 64-byte record per op, read through the scalar data cache one op ahead: absolute
 //             addresses and LDS offsets, decoded by the host (FusedRec in partials_fused.hpp)
 //   limit     a wave's own serial path, not HBM: twelve waves per CU is all the slots allow, so
@@ -44,8 +49,9 @@
 // tests run through this kernel.
 //
 // Roofline: HBM writes.  132 B per site-update (128 B CLV + 4 B scaler count) + 1 B per
-// tip character read; operands that are reloaded add 128 B each.  Round 2: 0.65-0.72 of the
-// 8 TB/s peak on the 62-op list of the headline configuration.
+// tip character read; operands that are reloaded add 128 B each.  Round 3: 0.69-0.75 of the
+// 8 TB/s peak on every shape from 8 to 133 GB, rate categories 1, 2, 4, 8, lists from two ops on
+// (DESIGN.md 2.0).
 #include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
