@@ -24,7 +24,7 @@ for seed in range(first, first + count):
     shape = ("random", "random", "balanced", "caterpillar")[seed % 4]
     tips = int(2 ** rng.integers(2, 8)) if shape == "balanced" else int(rng.integers(4, 140))
     sites = int(rng.integers(17, 400))
-    rate_cats = int((1, 2, 4, 4)[seed % 4 if seed % 3 else 3])
+    rate_cats = int((1, 2, 4, 8)[seed % 4 if seed % 3 else 2])
     attrs = (ATTRIB_PATTERN_TIP if rng.random() < 0.7 else 0) | (ATTRIB_RATE_SCALERS if rng.random() < 0.3 else 0)
     case = make_case(4, shape, tips, sites, rate_cats=rate_cats, seed=seed)
     plan, R = case["plan"], rate_cats
