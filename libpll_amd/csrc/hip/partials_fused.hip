@@ -1089,7 +1089,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                       : (count >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
   const unsigned int tile_groups = getenv("PLLHIP_FUSED_TILE_GROUPS") ? (unsigned int)std::max(1, atoi(getenv("PLLHIP_FUSED_TILE_GROUPS")))
-                                   : 8u;
+                                   : (unsigned int)std::min<size_t>(8, std::max<size_t>(1, bgrid / 8)); // (every counter has takers)
 #define LAUNCH_FUSED_ARGS (unsigned int)bgrid, 256, lds, c->stream>>>( \
       d_plan, bases, count, bsites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds, (unsigned int)base, tile_groups)
 #define LAUNCH_FUSED(MODEV, NTV) k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<LAUNCH_FUSED_ARGS
