@@ -1088,8 +1088,11 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   const size_t rounds = btiles / (bgrid * 4);
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                       : (count >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
-  const unsigned int tile_groups = getenv("PLLHIP_FUSED_TILE_GROUPS") ? (unsigned int)std::max(1, atoi(getenv("PLLHIP_FUSED_TILE_GROUPS")))
-                                   : (unsigned int)std::min<size_t>(8, std::max<size_t>(1, bgrid / 8)); // (every counter has takers)
+  // (eight counters, or what PLLHIP_FUSED_TILE_GROUPS says -- but never more than there are groups of eight
+  // workgroups, or a counter's tiles would have no takers; and no more than the counter buffer holds)
+  const size_t want_groups = getenv("PLLHIP_FUSED_TILE_GROUPS") ? (size_t)std::max(1, atoi(getenv("PLLHIP_FUSED_TILE_GROUPS"))) : 8;
+  const unsigned int tile_groups = (unsigned int)std::min<size_t>(std::min<size_t>(want_groups, PLLHIP_TILE_COUNTER_BYTES / 128),
+                                                                  std::max<size_t>(1, bgrid / 8));
 #define LAUNCH_FUSED_ARGS (unsigned int)bgrid, 256, lds, c->stream>>>( \
       d_plan, bases, count, bsites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds, (unsigned int)base, tile_groups)
 #define LAUNCH_FUSED(MODEV, NTV) k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<LAUNCH_FUSED_ARGS
