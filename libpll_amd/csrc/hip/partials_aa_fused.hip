@@ -91,6 +91,9 @@ constexpr unsigned int AF_LCNT = 16u;
 constexpr unsigned int AF_RCNT = 32u;
 constexpr unsigned int AF_RELOAD_A = 64u;
 constexpr unsigned int AF_RELOAD_B = 128u;
+constexpr unsigned int AF_SYNC_LEFT = 2048u;   // an inner-inner op behind a lookup: a barrier of its own ahead of the left products
+constexpr unsigned int AF_ZERO_COUNTS = 1024u; // (bits 8-9: the next op's kind) a tip-tip op inside the list: never
+                                               // scales, but clears its scale buffer (core_partials_avx.c:598-599)
 
 struct AfMatJob
 {
@@ -762,6 +765,12 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   std::vector<std::pair<int, int>> lk_kids(count, {-1, -1});
   bool any_scaler = false;
   const bool lookups_ok = pllhip_aa_cherry_covers(c, SCALE_SITE);
+  // Tip-tip ops INSIDE the list (kind 4 below): parent = tip table of the left matrix [character 1] (.) tip table of
+  // the right matrix [character 2] is what a lookup op does with two other tables, so a tip-tip op is a lookup op
+  // whose tables are the two tip tables k_af_prepare builds anyway and whose "pairs" are (0, character): no code of
+  // its own in the kernel.  Its stores then interleave with the matrix ops of the other workgroup on the CU
+  // instead of preceding the list as a launch of their own.  PLLHIP_AA_TT_INSIDE=0: ahead of the list as before.
+  const bool tt_inside = c->sh.pattern_tip && (!getenv("PLLHIP_AA_TT_INSIDE") || atoi(getenv("PLLHIP_AA_TT_INSIDE")) != 0);
   for (unsigned int i = 0; i < count; ++i)
   {
     const int rc = pllhip_resolve_op(c, ops[i], args[i], kinds[i], modes[i]);
@@ -800,17 +809,18 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   k.tt_modes.clear();
   for (int pass = 0; pass < 2; ++pass) // (tip-tip ops grouped by mode: without a scale buffer first)
     for (unsigned int i = 0; i < count; ++i)
-      if (kinds[i] == 2 && (modes[i] != SCALE_NONE) == (pass == 1))
+      if (kinds[i] == 2 && !tt_inside && (modes[i] != SCALE_NONE) == (pass == 1))
       {
         k.tt_ops.push_back(args[i]);
         k.tt_modes.push_back(modes[i]);
       }
   for (unsigned int i = 0; i < count; ++i)
-    if (kinds[i] != 2)
+    if (kinds[i] != 2 || tt_inside)
     {
+      if (kinds[i] == 2) kinds[i] = 4; // (a tip-tip op of the list)
       rops.push_back(ops[i]);
       rargs.push_back(args[i]);
-      rkinds.push_back(kinds[i] == 3 ? 2 : kinds[i]);
+      rkinds.push_back(kinds[i] >= 3 ? 2 : kinds[i]);
       orig.push_back((int)i);
     }
   const unsigned int n = (unsigned int)rops.size();
@@ -842,7 +852,7 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   for (unsigned int pos = 0; pos < n; ++pos)
   {
     const int ri = fplan[pos].list_pos, oi = orig[ri];
-    if (kinds[oi] != 3) continue;
+    if (kinds[oi] != 3) continue; // (a tip-tip op of the list needs no pair tables)
     lk_index[pos] = (int)k.lk_ops.size();
     k.lk_ops.push_back(args[oi]);
     if (lk_kids[oi].first >= 0) k.lk_k1.push_back(args[lk_kids[oi].first]);
@@ -891,12 +901,14 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   // what each op brings along itself: its rows, its left block, its kind -- recorded with the op BEFORE
   // it (the header for op 0; the last op names op 0 again: the list is walked tile after tile)
   std::vector<AaRec> own(n);
+  std::vector<unsigned int> tt_inside_pos;
   memset(own.data(), 0, n * sizeof(AaRec));
   for (unsigned int pos = 0; pos < n; ++pos)
   {
     const FusedOp & f = fplan[pos];
     const int oi = orig[f.list_pos];
-    const int kind = kinds[oi] == 3 ? 2 : kinds[oi];
+    const bool tt_op = kinds[oi] == 4;
+    const int kind = kinds[oi] >= 3 ? 2 : kinds[oi];
     AaRec & r = recs[pos + 1];
     AaRec & o = own[pos];
     r.parent = (unsigned long long)(uintptr_t)f.parent;
@@ -904,7 +916,7 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     r.flags = (unsigned int)kind;
     o.flags = (unsigned int)kind;
     if (f.pslot >= 0) r.flags |= AF_HAS_PSLOT;
-    if (f.pscaler) r.flags |= AF_SCALING;
+    if (f.pscaler) r.flags |= tt_op ? AF_ZERO_COUNTS : AF_SCALING;
     if (kind == 0 && f.lsc_slot >= 0) r.flags |= AF_LCNT;
     if (kind <= 1 && f.rsc_slot >= 0) r.flags |= AF_RCNT;
     r.slots = slot4(f.lslot) | slot4(f.rslot) << 4 | slot4(f.pslot) << 8;
@@ -925,7 +937,18 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       r.tab_l = (unsigned long long)(tj.size() * tip_tab_b); // (made absolute below)
       tj.push_back(AfTipJob{f.lmat, (unsigned long long)(tj.size() * tip_tab_b)});
     }
-    if (kind == 2)
+    if (tt_op)
+    {
+      // (offsets into the tip tables, made absolute below; "pair" (0, character) is row `character`)
+      r.tab_l = (unsigned long long)(tj.size() * tip_tab_b);
+      tj.push_back(AfTipJob{args[oi].lmat, (unsigned long long)(tj.size() * tip_tab_b)});
+      r.tab_r = (unsigned long long)(tj.size() * tip_tab_b);
+      tj.push_back(AfTipJob{args[oi].rmat, (unsigned long long)(tj.size() * tip_tab_b)});
+      o.row[1] = (unsigned long long)(uintptr_t)args[oi].ltip;
+      o.row[3] = (unsigned long long)(uintptr_t)args[oi].rtip;
+      tt_inside_pos.push_back(pos);
+    }
+    else if (kind == 2)
     {
       const AaLookupTables & t = tabs[lk_index[pos]];
       r.tab_l = (unsigned long long)(uintptr_t)t.tl;
@@ -937,6 +960,14 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     }
     if (pos + 1 < n) reloads_of(r, fplan[pos + 1]);
   }
+  // The left block of op i is staged by the four waves, a part each, while they run op i - 2, and the barrier that
+  // tells a wave that everybody's part has landed is barrier A of op i - 1 -- which a lookup does not have.  Until
+  // the tip-tip ops joined the list (runs of tens of barrier-free ops, over which the waves drift apart by whole
+  // ops) this went unnoticed: an inner-inner op behind a lookup then read its left block a few hundred cycles
+  // after the waves had last met.  Such an op now begins with a barrier of its own.
+  for (unsigned int pos = 0; pos < n; ++pos)
+    if ((own[pos].flags & AF_KIND_MASK) == 0u && (own[(pos + n - 1) % n].flags & AF_KIND_MASK) == 2u)
+      recs[pos + 1].flags |= AF_SYNC_LEFT;
   for (unsigned int pos = 0; pos <= n; ++pos)
   {
     // recs[pos] is the record before op `pos` (recs[0]: the header; recs[n] names op 0 again)
@@ -968,6 +999,11 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   }
   for (unsigned int pos = 0; pos < n; ++pos)
     if ((recs[pos + 1].flags & AF_KIND_MASK) == 1u) recs[pos + 1].tab_l += (unsigned long long)(uintptr_t)k.d_titab;
+  for (unsigned int pos : tt_inside_pos)
+  {
+    recs[pos + 1].tab_l += (unsigned long long)(uintptr_t)k.d_titab;
+    recs[pos + 1].tab_r += (unsigned long long)(uintptr_t)k.d_titab;
+  }
 
   const size_t rec_b = recs.size() * sizeof(AaRec), mat_b = (mj.size() + 1) * sizeof(AfMatJob),
                tip_b = (tj.size() + 1) * sizeof(AfTipJob);
