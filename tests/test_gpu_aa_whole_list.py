@@ -154,3 +154,29 @@ def test_default_path_against_the_bit_exact_kernels_at_size(gpu, monkeypatch):
         for a, b in zip(out[name][1], out["bit-exact"][1]):
             assert (a == b).all(), name
         assert abs(out[name][0] - out["bit-exact"][0]) <= 1e-11 * abs(out["bit-exact"][0]), name
+
+
+def test_whole_list_repeats_itself_at_size(gpu, monkeypatch):
+    """100,000 sites x 200 taxa, the whole-list kernel eight times on fresh and on used partitions: every evaluation's
+    per-site lnL equals the per-level launches' bit for bit.  (Round 3: an inner-inner op behind a run of barrier-free
+    lookups read its left matrix block before every wave of the workgroup had staged its part -- one wave's tile
+    wrong in one evaluation of six, and only at sizes where the waves have tiles enough to drift apart.)"""
+    from libpll_amd import workload as W
+    T, sites, R = 200, 100_000, 4
+    plan = W.random_tree(T, seed=42)
+    rates, freqs = gpu.aa_model("lg")
+    seqs = W.simulated_alignment(plan, sites, rates, freqs, gpu.compute_gamma_cats(W.GAMMA_ALPHA, R), seed=42)
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "0")
+    monkeypatch.setenv("PLLHIP_FUSED", "0")
+    p = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    ref = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+    p.destroy()
+    monkeypatch.setenv("PLLHIP_FUSED", "1")
+    for fresh in range(2):
+        p = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP)
+        for again in range(4):
+            p.update_partials(plan.ops)
+            got = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+            assert got[0] == ref[0] and bits_equal(got[1], ref[1]), "partition %d, evaluation %d" % (fresh, again)
+        p.destroy()
