@@ -45,6 +45,7 @@
 // characters; the matrix cores run 80 MFMAs per 16 columns and child (16 cycles each):
 // about 0.6 of the time the stores need.  DESIGN.md 2.2c has the budget and the measurements.
 #include <algorithm>
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -663,6 +664,7 @@ struct pllhip_aa_fused_cache
   size_t aorder_cap = 0;
   char * d_titab = nullptr;
   size_t titab_cap = 0;
+  bool tried_inside = false;          // the list in last_ops has been planned with its tip-tip ops inside (or found unfit for it)
 };
 
 void pllhip_aa_fused_free(pllhip_ctx * c)
@@ -742,7 +744,34 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
 
 // Returns 0 when the list has been enqueued, 1 when it is not one this path takes (the caller
 // launches per level), < 0 on error.
+static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count, bool tt_wanted);
+
+// A list seen for the first time is planned with its tip-tip ops AHEAD of the list kernel (the cheaper plan: 30
+// ops instead of 62 for BASELINE config 3, ~50 us of host time less, and what a list with reloads runs best with);
+// when the very same list comes again -- branch-length optimisation, repeated evaluations -- it is planned once
+// more with the tip-tip ops INSIDE the list (4-5 % faster from then on, kept).  Measured on C3's partition: new
+// full traversals 2.29 ms per step either way (2.50 with every new list planned inside), the repeated list 2.07
+// instead of 2.19.
 int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count)
+{
+  if (c->aa_fused)
+  {
+    pllhip_aa_fused_cache & k = *c->aa_fused;
+    const bool same = k.last_ops.size() == count && k.epoch == c->layout_epoch && k.maxstates == c->maxstates &&
+                      !getenv("PLLHIP_FUSED_DEBUG") && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0;
+    if (same && !k.tried_inside && !getenv("PLLHIP_AA_TT_INSIDE"))
+    {
+      k.last_ops.clear(); // (plan it again)
+      const int rc = aa_fused_update(c, ops, count, true);
+      if (c->aa_fused) c->aa_fused->tried_inside = true;
+      return rc;
+    }
+  }
+  const int rc = aa_fused_update(c, ops, count, false);
+  return rc;
+}
+
+static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count, bool tt_wanted)
 {
   if (c->sh.states != 20 || c->sh.rate_cats != 4 || c->sh.rate_scalers || c->sh.asc_states || !c->rows.empty() ||
       c->aa_exact || count > PLLHIP_FUSED_MAX_OPS)
@@ -750,10 +779,20 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   if (c->sh.pattern_tip && (c->maxstates < 1 || c->maxstates > 32)) return 1;
   if (!c->aa_fused) c->aa_fused = new pllhip_aa_fused_cache();
   pllhip_aa_fused_cache & k = *c->aa_fused;
+  // (PLLHIP_FUSED_DEBUG=3: where the host's time goes when a list is new)
+  const bool host_times = getenv("PLLHIP_FUSED_DEBUG") && atoi(getenv("PLLHIP_FUSED_DEBUG")) == 3;
+  auto t_host = std::chrono::steady_clock::now();
+  auto lap = [&](const char * what) {
+    if (!host_times) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "pllhip 20-state list, host: %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_host).count());
+    t_host = now;
+  };
   if (k.last_ops.size() == count && k.epoch == c->layout_epoch && k.maxstates == c->maxstates &&
       !getenv("PLLHIP_FUSED_DEBUG") && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
     return aa_fused_launch(c, false);
   k.last_ops.clear();
+  k.tried_inside = false;
 
   // ---- classify.  Tip-tip ops run ahead of the list: allowed only if nothing earlier in the list
   // wrote or read what they write (they read tips only).  An inner-inner op over two tip-tip
@@ -769,8 +808,12 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   // the right matrix [character 2] is what a lookup op does with two other tables, so a tip-tip op is a lookup op
   // whose tables are the two tip tables k_af_prepare builds anyway and whose "pairs" are (0, character): no code of
   // its own in the kernel.  Its stores then interleave with the matrix ops of the other workgroup on the CU
-  // instead of preceding the list as a launch of their own.  PLLHIP_AA_TT_INSIDE=0: ahead of the list as before.
-  const bool tt_inside = c->sh.pattern_tip && (!getenv("PLLHIP_AA_TT_INSIDE") || atoi(getenv("PLLHIP_AA_TT_INSIDE")) != 0);
+  // instead of preceding the list as a launch of their own.  Measured (C3's partition, lists directed at five
+  // edges): a list with no or one operand reloaded from HBM gains 4-5 % (2.09-2.11 against 2.19 ms), the two
+  // lists with three reloads lose 10 % (2.47 against 2.25) -- so a list with more than one reload is planned again
+  // with the tip-tip ops ahead of it (a rule from five lists, not a law).  PLLHIP_AA_TT_INSIDE=0 / 1: never / always.
+  const char * tt_env = getenv("PLLHIP_AA_TT_INSIDE");
+  const bool tt_inside = c->sh.pattern_tip && (tt_env ? atoi(tt_env) != 0 : tt_wanted);
   for (unsigned int i = 0; i < count; ++i)
   {
     const int rc = pllhip_resolve_op(c, ops[i], args[i], kinds[i], modes[i]);
@@ -800,6 +843,7 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     if (op.child2_scaler >= 0) sc_touched[op.child2_scaler] = 1;
   }
 
+  lap("resolve + classify");
   // ---- the list the kernel walks: everything but the tip-tip ops, ordered and given slots by the
   // planner of the 4-state kernel (a lookup has no inner operands: a "tip-tip" op to the planner)
   std::vector<pllhip_op_t> rops;
@@ -835,6 +879,8 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   const FusedGeom geom = {nclv, nsc, c->sh.tips, c->sh.pattern_tip != 0};
   int rc = pllhip_fused_plan(geom, rops.data(), rargs.data(), rkinds.data(), n, AF_NSLOT, fplan, &reloads);
   if (rc) return rc;
+  lap("plan (order, slots)");
+  if (tt_inside && !tt_env && reloads > 1) return aa_fused_update(c, ops, count, false);
 
   // ---- encode
   if (!c->fused_zero_row)
@@ -872,6 +918,7 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
                                  tabs.data());
     if (rc) return rc;
   }
+  lap("lookup tables (launches)");
   std::vector<AaRec> recs(n + 2);
   std::vector<AfMatJob> mj;
   std::vector<AfTipJob> tj;
@@ -1034,10 +1081,17 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   k.ntip = (unsigned int)tj.size();
   k.nops = n;
   if (getenv("PLLHIP_FUSED_DEBUG"))
-    fprintf(stderr, "pllhip 20-state list kernel: %u ops = %zu tip-tip ahead + %zu lookups + %u on the matrix cores, %u operands reloaded\n",
-            count, k.tt_ops.size(), k.lk_ops.size(), n - (unsigned int)k.lk_ops.size(), reloads);
+  {
+    unsigned int synced = 0;
+    for (unsigned int pos = 0; pos < n; ++pos) synced += (recs[pos + 1].flags & AF_SYNC_LEFT) ? 1u : 0u;
+    fprintf(stderr, "pllhip 20-state list kernel: %u ops = %zu tip-tip ahead + %zu tip-tip in the list + %zu lookups + %zu on the matrix cores "
+                    "(%u of them behind a lookup: a barrier more), %u operands reloaded\n",
+            count, k.tt_ops.size(), tt_inside_pos.size(), k.lk_ops.size(), (size_t)n - k.lk_ops.size() - tt_inside_pos.size(), synced, reloads);
+  }
+  lap("encode + upload");
   rc = aa_fused_launch(c, true);
   if (rc) return rc;
+  lap("launches");
   k.last_ops.assign(ops, ops + count);
   k.epoch = c->layout_epoch;
   k.maxstates = c->maxstates;

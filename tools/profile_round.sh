@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun) from the repo root:  bash tools/profile_round.sh <tag>
 # Takes, for each BASELINE workload, the plain bench line, the rocprofv3 kernel statistics of
 # the same workload (with --no-vary: the varying-lists leg launches the same kernels on short and re-rooted lists and
-# would dilute the per-kernel averages the bench line's avg_launch_us is to be compared with) and the HBM traffic counters (FETCH_SIZE and WRITE_SIZE in passes of their
+# (and --no-c4: the N = 1 line of the default workload also evaluates config 4 whole) would dilute the per-kernel averages the bench line's avg_launch_us is to be compared with) and the HBM traffic counters (FETCH_SIZE and WRITE_SIZE in passes of their
 # own: no trace domains next to --pmc), condenses them with tools/summarize_rocprof.py into
 # gpurun_out/<tag>/summary/ (what gets copied into profiles/) and writes the index bench.py reads
 # `roofline.traffic` from.
@@ -24,16 +24,16 @@ run() { # name, [ENV=VAL ...] -- bench args...
   if [ "$phase" = pmc ]; then
     # first phase: the HBM counters (their index is what the later bench lines look roofline.traffic up in)
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_$name" -- \
-        python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary "$@" > "$out/pmcpass_$name.json" 2> "$out/fetch_$name.err"
+        python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary --no-c4 "$@" > "$out/pmcpass_$name.json" 2> "$out/fetch_$name.err"
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write_$name" -- \
-        python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary "$@" > /dev/null 2> "$out/write_$name.err"
+        python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary --no-c4 "$@" > /dev/null 2> "$out/write_$name.err"
     python3 "$root/tools/summarize_rocprof.py" hbm "$out/fetch_$name" "$out/write_$name" "$sum/${tag}_pmc_hbm_traffic_$name.csv" \
-        "${envs[*]} python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 --no-vary $*"
+        "${envs[*]} python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 --no-vary --no-c4 $*"
     rm -rf "$out/fetch_$name" "$out/write_$name"
   else
     # second phase: the kernel statistics of the same workload, then the plain line
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$name" -- \
-        python3 "$root/bench.py" --steps 20 --warmup 3 --cpu-sites 0 --no-vary "$@" > "$sum/${tag}_bench_${name}_under_rocprof.json" 2> "$out/trace_$name.err"
+        python3 "$root/bench.py" --steps 20 --warmup 3 --cpu-sites 0 --no-vary --no-c4 "$@" > "$sum/${tag}_bench_${name}_under_rocprof.json" 2> "$out/trace_$name.err"
     python3 "$root/tools/summarize_rocprof.py" stats "$out/trace_$name" "$sum/${tag}_bench_${name}_kernel_stats.csv"
     rm -rf "$out/trace_$name"
     (cd "$root" && python3 bench.py "$@" > "$sum/${tag}_bench_$name.json" 2> "$out/bench_$name.err")
