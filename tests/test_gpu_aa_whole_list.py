@@ -58,7 +58,15 @@ def _evaluate(gpu, case, attrs, monkeypatch, fused, partial=True):
     ("balanced", 16, 333), ("balanced", 64, 1000), ("random", 12, 500), ("caterpillar", 40, 100),
     ("random", 50, 97), ("balanced", 128, 64), ("random", 30, 1), ("random", 200, 40), ("balanced", 8, 40000)])
 @pytest.mark.parametrize("attrs", [ATTRIB_PATTERN_TIP, 0])
-def test_whole_list_equals_per_level_and_oracle(gpu, orc, monkeypatch, shape, tips, sites, attrs):
+@pytest.mark.parametrize("tt", [None, "1", "0"])
+def test_whole_list_equals_per_level_and_oracle(gpu, orc, monkeypatch, shape, tips, sites, attrs, tt):
+    """tt: where the list's tip-tip ops run -- None: ahead of the list when it is new, inside it when it comes again
+    (the partial traversals of _evaluate make the full list come once only); "1": always inside, as lookups over the
+    two tip tables; "0": always ahead."""
+    if tt is not None:
+        if attrs == 0:
+            pytest.skip("no tip-tip ops without pattern tips")
+        monkeypatch.setenv("PLLHIP_AA_TT_INSIDE", tt)
     case = _case(gpu, shape, tips, sites)
     plan = case["plan"]
     pf, cf, sf, lf = _evaluate(gpu, case, attrs, monkeypatch, "2")
