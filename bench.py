@@ -230,14 +230,20 @@ def main():
     cat_rates = host_lib.compute_gamma_cats(W.GAMMA_ALPHA, R)
     rates = W.GTR_RATES if S == 4 else host_lib.aa_model("lg")[0]
     freqs = W.GTR_FREQS if S == 4 else host_lib.aa_model("lg")[1]
-    # each rank generates only its own shard (seeded by rank): [lo, hi) of the
-    # conceptual total alignment
-    if args.alignment == "simulated":
-        seqs = W.simulated_alignment(plan, hi - lo, rates, freqs, cat_rates, seed=42 + rank)
-    else:
-        seqs = W.random_alignment(T, hi - lo, S, seed=42 + rank)
+    # ONE alignment of total_sites columns, defined in blocks of 250,000 sites (block b: seed 42 + b), of which
+    # each rank makes only its own range [lo, hi): the N-GPU job evaluates the very alignment a one-GPU job of
+    # total_sites columns would, so its lnL can be checked (round 3 seeded every shard by rank: nothing to compare with)
+    seqs = W.global_alignment(plan, lo, hi, rates, freqs, cat_rates, seed=42, kind=args.alignment)
     fi = [0] * R
     ops_per_eval = len(plan.ops)
+
+    # ---- N > 1: the reference's lnL of THIS rank's range (all of it, in chunks through one small CPU partition),
+    # before anything touches the GPU; the ranks' values are summed after the timed region and compared with the
+    # lnL the product's all-reduce returned (lnl_rel_err_vs_reference).  One evaluation of 62 ops x 1 M sites
+    # is about half a second of one host core per rank.
+    shard_ref_lnl = None
+    if (world > 1 or inproc > 1) and args.cpu_sites > 0 and ref is not None:
+        shard_ref_lnl, _ = W.reference_lnl(ref, plan, seqs, S, R, attrs | ATTRIB_ARCH_AVX2)
 
     # ---- CPU baseline (rank 0, N=1 only), BEFORE anything touches the GPU (its
     # multi-core leg forks workers): the reference library's AVX2-flag path on a
@@ -389,6 +395,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    lnl_timed = lnl   # (the last timed step's value: at N > 1 the sum over the ranks, made by the library's all-reduce)
     site_updates = float(ops_per_eval) * total_sites * args.steps
     value = site_updates / elapsed / 1e6
     untimed_steps = 1 + len(ramp_steps) + args.warmup   # what really ran before the timed region
@@ -668,6 +675,17 @@ def main():
         lnl_rel_err = abs(g_lnl - cpu_ref_lnl) / abs(cpu_ref_lnl)
         gp.destroy()
 
+    lnl_ref_total = None
+    if shard_ref_lnl is not None:
+        # N > 1: sum of the reference's per-range values (torch.distributed; the product's own sum went through its
+        # RCCL all-reduce, or -- one process, library-sharded partition -- through the host sum of the shards)
+        lnl_ref_total = shard_ref_lnl
+        if world > 1:
+            t = torch.tensor([shard_ref_lnl], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            lnl_ref_total = float(t.item())
+        lnl_rel_err = abs(lnl_timed - lnl_ref_total) / abs(lnl_ref_total)
+
     repeats = None
     if args.site_repeats:
         rows = [part.repeats_classes(int(op["parent_clv_index"])) or (hi - lo) for op in plan.ops]
@@ -688,11 +706,24 @@ def main():
         c4_sites, c4_taxa = 8_000_000, 128
         plan4 = W.balanced_tree(c4_taxa, seed=42)
 
-        def c4_alignment(lo4, hi4, seed):
-            # a 250,000-site block simulated down the tree, repeated to the range's length
-            block = W.simulated_alignment(plan4, 250_000, W.GTR_RATES, W.GTR_FREQS, cat_rates, seed=seed)
-            reps4 = -(-(hi4 - lo4) // 250_000)
-            return [(b * reps4)[:hi4 - lo4] for b in block]
+        c4_cache = {}
+
+        def c4_alignment(lo4, hi4):
+            # columns [lo4, hi4) of ONE 8,000,000-site alignment: 250,000-site blocks simulated down the tree, four
+            # distinct ones in turn (seeds 4242..4245; generating 32 would take rank 0 minutes).  A rank's range is a
+            # slice of what the one-GPU leg evaluates whole, so the two lnL must agree (round 3: they could not)
+            return W.global_alignment(plan4, lo4, hi4, W.GTR_RATES, W.GTR_FREQS, cat_rates, seed=4242, distinct=4,
+                                      cache=c4_cache)
+
+        def c4_prefix_check(p4, seqs4, budget_s=5.0):
+            # bounded reference check for a partition this process holds whole: the reference's lnL of a prefix of the
+            # alignment (as many 50,000-site chunks as fit the budget) against the sum of the product's per-site lnL there
+            if ref is None or args.cpu_sites <= 0:
+                return None
+            r_lnl, n_ref = W.reference_lnl(ref, plan4, seqs4, 4, R, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2, budget_s=budget_s)
+            _, persite = p4.compute_edge_loglikelihood(*plan4.root_edge, fi, persite=True)
+            g = float(np.sum(persite[:n_ref], dtype=np.float64))
+            return {"sites": n_ref, "rel_err": abs(g - r_lnl) / abs(r_lnl)}
 
         def c4_time(p4, steps4, collective):
             lnl4 = None
@@ -720,7 +751,7 @@ def main():
         # (1) the denominator of the speed-up, measured HERE: the whole alignment on ONE GPU of this node
         # (rank 0's; 133 GB), in this run, before the sharded section -- boxes differ by 10-20 %, a
         # constant recorded elsewhere is kept as a labelled fallback only.  The other ranks wait.
-        one_ms, one_err, one_lnl = None, None, None
+        one_ms, one_err, one_lnl, one_check = None, None, None, None
         if rank == 0 and not args.no_c4_one_gpu:
             try:
                 devs1 = None
@@ -728,10 +759,13 @@ def main():
                     import ctypes
                     devs1 = [int(args.devices.split(",")[0])] if args.devices else [0]
                     amd.lib.pll_amd_set_devices((ctypes.c_int * 1)(*devs1), 1)
-                p1 = W.setup_partition(amd, plan4, c4_alignment(0, c4_sites, 4242), 4, R, ATTRIB_PATTERN_TIP)
+                seqs1 = c4_alignment(0, c4_sites)
+                p1 = W.setup_partition(amd, plan4, seqs1, 4, R, ATTRIB_PATTERN_TIP)
                 t_all, _, one_lnl = c4_time(p1, steps4, False)
                 one_ms = t_all / steps4 * 1e3
+                one_check = c4_prefix_check(p1, seqs1)
                 p1.destroy()
+                del seqs1
                 if inproc > 1:
                     devs = [int(x) for x in args.devices.split(",")] if args.devices else list(range(inproc))
                     amd.lib.pll_amd_set_devices((ctypes.c_int * len(devs))(*devs), len(devs))
@@ -747,16 +781,21 @@ def main():
                   "scaling": "strong", "n_gpus": 1, "steps": steps4,
                   "value": round((c4_taxa - 2) * c4_sites / (one_ms * 1e-3) / 1e6, 2) if one_ms else None,
                   "unit": "M CLV-site-updates/s", "ms_per_step": round(one_ms, 4) if one_ms else None,
-                  "lnl": one_lnl, "one_gpu_ms_per_step": round(one_ms, 4) if one_ms else None,
+                  "lnl": one_lnl, "lnl_check_vs_reference": one_check,
+                  "one_gpu_ms_per_step": round(one_ms, 4) if one_ms else None,
                   "one_gpu_source": "measured in this run on this node" if one_ms else None,
                   "error": one_err, "speedup_vs_one_gpu": 1.0 if one_ms else None}
         else:
             # (2) the same alignment divided over the GPUs.  A rank that fails must not leave the others in
             # a collective: every rank works inside try, then all agree on success BEFORE the next collective
-            err, p4 = None, None
+            err, p4, ref4 = None, None, None
             try:
                 lo4, hi4 = W.shard_bounds(c4_sites, world)[rank:rank + 2]
-                p4 = W.setup_partition(amd, plan4, c4_alignment(lo4, hi4, 4242 + rank), 4, R, ATTRIB_PATTERN_TIP)
+                seqs4 = c4_alignment(lo4, hi4)
+                if world > 1 and ref is not None and args.cpu_sites > 0:
+                    # the reference's lnL of this rank's range, all of it (126 ops x 8 M / N sites: seconds of one core)
+                    ref4, _ = W.reference_lnl(ref, plan4, seqs4, 4, R, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2)
+                p4 = W.setup_partition(amd, plan4, seqs4, 4, R, ATTRIB_PATTERN_TIP)
             except Exception as exc:
                 err = "%s: %s" % (type(exc).__name__, exc)
             ok = err is None
@@ -780,6 +819,18 @@ def main():
                     dist.broadcast(uid, src=0)
                     p4.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
                 t4, own4, lnl4 = c4_time(p4, steps4, use_comm)
+                # the N-GPU lnL against the reference: every rank's range summed (N > 1 processes), or a bounded
+                # prefix of the alignment (one process holding the library-sharded partition)
+                check4 = None
+                if world > 1:
+                    have = torch.tensor([0.0 if ref4 is None else 1.0], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(have, op=dist.ReduceOp.MIN)
+                    if have.item() >= 1.0:
+                        t = torch.tensor([ref4], dtype=torch.float64, device="cuda")
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                        check4 = {"sites": c4_sites, "rel_err": abs(lnl4 - float(t.item())) / abs(float(t.item()))}
+                else:
+                    check4 = c4_prefix_check(p4, seqs4)
                 per_rank4 = None
                 if use_comm:
                     t = torch.tensor([t4], dtype=torch.float64, device="cuda")
@@ -812,12 +863,19 @@ def main():
                                         ("FALLBACK, another box: profiles/r2_bench_c4_one_gpu.json" +
                                          (" (the one-GPU leg failed here: %s)" % one_err if one_err else "")) if recorded else None,
                       "one_gpu_lnl": one_lnl,
+                      # the same alignment whole on one GPU and divided over N: the two sums agree to the rounding of
+                      # two different summation trees (asserted: a wrong shard, seed or range shows up here)
+                      "lnl_vs_one_gpu_rel": abs(lnl4 - one_lnl) / abs(one_lnl) if one_lnl else None,
+                      "lnl_consistent": bool(abs(lnl4 - one_lnl) <= 1e-10 * abs(one_lnl)) if one_lnl else None,
+                      "lnl_check_vs_reference": check4, "one_gpu_lnl_check_vs_reference": one_check,
                       "speedup_vs_one_gpu": round(base_ms / ms4, 3) if base_ms else None}
+                if one_lnl and not c4["lnl_consistent"]:
+                    c4["error"] = "lnL of the divided alignment differs from the one-GPU evaluation of the same alignment"
     rccl_path = None
     if use_comm:
         import ctypes
         amd.lib.pll_amd_rccl_path.restype = ctypes.c_char_p
-        rccl_path = (amd.lib.pll_amd_rccl_path() or b"").decode() or None
+        rccl_path = {"path": (amd.lib.pll_amd_rccl_path() or b"").decode() or None, "nranks": world}
     if rank == 0:
         tt, ti, ii = plan.op_kinds() if not args.tip_clv else (0, 0, ops_per_eval)
         out = {
@@ -828,7 +886,8 @@ def main():
             "per_step_ms": per_step_ms, "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic (%s alignment, seed 42)" % args.alignment,
+            "dtype": "f64", "data": "synthetic (%s alignment in 250,000-site blocks, seeds 42 + block; rank r holds columns "
+                                    "[lo_r, hi_r) of it)" % args.alignment,
             "config": {"workload": "%d-state %s, %d Gamma rates, %d sites/GPU, %d-taxon %s "
                                    "tree, %s, %s scalers; step = pll_update_partials(%d ops: %d "
                                    "tip-tip, %d tip-inner, %d inner-inner) + "
@@ -842,7 +901,11 @@ def main():
                                                                   "one process, PLL_AMD_DEVICES" if inproc > 1 else
                                                                   "one process per GPU" if world > 1 else "single GPU"),
                        "site_repeats": repeats},
-            "lnl": lnl, "lnl_rel_err_vs_reference": lnl_rel_err,
+            "lnl": lnl_timed, "lnl_rel_err_vs_reference": lnl_rel_err,
+            "lnl_reference": ("sum over the ranks of the reference's lnL of each rank's whole range" if world > 1 else
+                              "the reference's lnL of the whole alignment" if inproc > 1 else
+                              "the reference's lnL of the CPU-baseline sample, against a product partition of the same sample")
+                             if lnl_rel_err is not None else None,
             "first_evaluation_ms": round(first_ms, 2),
             "ramp": ramp,
             "roofline": roofline, "api_calls": api, "kernels": per_kernel, "cpu_baseline": cpu,

@@ -195,6 +195,72 @@ __device__ __forceinline__ void rate_matvec_chain(const char * a14, const char *
   }
 }
 
+// ---- the same contraction in the order of the reference's TIP-INNER kernel, which is what a tip-inner op reaches
+// under the AVX2 flag too (core_partials.c:427-441 dispatches it to pll_core_update_partial_ti_avx, whose 20-state
+// kernel is core_partials_avx.c:1097-1340): the four accumulators strided by j mod 4 and the pairwise tree as above,
+// but every step is a multiplication and THEN an addition (:1239-1262) -- two roundings.  No matrix-core instruction
+// does that (its products are never rounded on their own), so this mat-vec runs on the vector unit:
+//   * the lane needs all 20 entries of its column (site s, this rate) and holds five of them as B operands
+//     (states 4q..4q+3 and 16+q); the other fifteen come from the three lanes s + 16 q' through the LDS crossbar
+//     (ds_bpermute: no LDS memory involved, the tile image may be refilled meanwhile);
+//   * row 4g+q of the rate's matrix is 160 contiguous bytes of LDS: ten 16-byte reads, the sixteen lanes of a q
+//     read the same address (broadcast), the four q's hit different banks;
+//   * 20 multiplications + 23 additions per output, 215 per lane and rate: 3440 issue cycles per wave and 16-site
+//     tile, about a third of the time HBM needs for the tile's 20.7 KB at two waves per SIMD.
+// prow: the lane's row q of matrix 0 of the child (bytes).  Result: the reference's bits.
+__device__ __forceinline__ double lane_fetch_f64(double v, unsigned int src_lane_x4)
+{
+  const int lo = __builtin_amdgcn_ds_bpermute((int)src_lane_x4, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute((int)src_lane_x4, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+template <int MAT_BYTE_OFFSET>
+__device__ __forceinline__ void rate_matvec_plain(const char * prow, const double (&bk)[5], unsigned int lane,
+                                                  double (&o)[5])
+{
+  const unsigned int s = lane & 15u;
+  double c[20];
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq)
+  {
+    const unsigned int src = (s + 16u * qq) * 4u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c[4 * qq + t] = lane_fetch_f64(bk[t], src);
+    c[16 + qq] = lane_fetch_f64(bk[4], src);
+  }
+#pragma unroll
+  for (int g = 0; g < 5; ++g)
+  {
+    // (chains 0 and 1, then chains 2 and 3: five 16-byte reads in flight instead of ten)
+    double a[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+    {
+      double2 row[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) row[j] = *reinterpret_cast<const double2 *>(prow + MAT_BYTE_OFFSET + g * 640 + j * 32 + h * 16);
+      double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+      {
+        e0 = e0 + row[j].x * c[4 * j + 2 * h];
+        e1 = e1 + row[j].y * c[4 * j + 2 * h + 1];
+      }
+      a[2 * h] = e0;
+      a[2 * h + 1] = e1;
+      asm volatile("" : "+v"(a[2 * h]), "+v"(a[2 * h + 1]));
+      asm volatile("" ::: "memory");
+    }
+    const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    o[g] = (a0 + a1) + (a2 + a3);
+    // (the sum is wanted here and one row is in flight at a time: see rate_matvec_chain)
+    asm volatile("" : "+v"(o[g]));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // x[k][g] for all rates of one child whose matrices start CHILD_BYTE_OFFSET bytes behind matrix 0
 template <int RC, int CHILD_BYTE_OFFSET>
 __device__ __forceinline__ void tile_matvec_chain(const char * a14, const char * a5, const double (&b)[RC][5],

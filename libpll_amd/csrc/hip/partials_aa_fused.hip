@@ -100,6 +100,7 @@ struct AfMatJob
 {
   const double * src;           // [rate][row][column]
   unsigned long long dst_off;   // bytes into the operand-order buffer
+  unsigned long long plain;     // 0: operand order of the matrix cores; 1: row order of the vector unit (af_matvec_plain)
 };
 struct AfTipJob
 {
@@ -125,11 +126,21 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
     for (unsigned int idx = threadIdx.x; idx < AF_MAT_B / 8; idx += blockDim.x)
     {
       double v = 0.0;
-      if (idx < 1600)
+      if (idx < 1600 && !mj[b].plain)
       {
         const unsigned int blk = idx >> 6, lane = idx & 63u, t = blk / 5, bb = blk - 5 * t;
         const unsigned int q = lane >> 4, rate = (lane >> 2) & 3u, i = lane & 3u;
         const unsigned int row = t < 4 ? 4 * i + t : 16 + i, col = bb < 4 ? 4 * q + bb : 16 + q;
+        v = src[rate * 400 + row * 20 + col];
+      }
+      else if (idx < 1600)
+      {
+        // Row order (the right block of a tip-inner op, af_matvec_plain): 50 pieces of 16 x 16 bytes; piece
+        // (pass, t, c) holds, for lane class (q, rate), columns 4c + 2 pass and 4c + 2 pass + 1 of the row whose
+        // output lane q keeps in x[.][t] -- state 4q + t, or 16 + q for t = 4.
+        const unsigned int e = idx >> 1, half = idx & 1u, piece = e >> 4, cls = e & 15u;
+        const unsigned int q = cls >> 2, rate = cls & 3u, pass = piece / 25, rem = piece - 25 * pass, t = rem / 5, cc = rem - 5 * t;
+        const unsigned int row = t < 4 ? 4 * q + t : 16 + q, col = 4 * cc + 2 * pass + half;
         v = src[rate * 400 + row * 20 + col];
       }
       out[idx] = v;
@@ -301,6 +312,80 @@ __device__ __forceinline__ void af_matvec(const char * mat_lane, unsigned int q,
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// x[j][t] = tip factor * (P . column)[state 4q + t | 16 + q] in the order of the reference's TIP-INNER kernel
+// (core_partials_avx.c:1229-1284; reached under the AVX2 flag too, core_partials.c:427-441): the four chains
+// strided by j mod 4 and the pairwise tree, every step a multiplication and THEN an addition.  The matrix
+// cores cannot round a product on its own, so a tip-inner op's one mat-vec runs on the vector unit:
+//   * the child (b, operand layout: five of a column's twenty entries per lane) goes through the wave's stage 0
+//     in the layout of a CLV, and every lane reads its column back, ten entries at a time (chains 0 and 1,
+//     then chains 2 and 3: 40 registers instead of 80 for the two sub-tiles);
+//   * the block is staged in ROW order (k_af_prepare): one 16-byte read gives two columns of the lane's row,
+//     the four lanes of a site group read the same address, the sixteen (q, rate) classes 256 contiguous bytes;
+//     every entry is read once and serves both sub-tiles;
+//   * the tip's factor stays where it was gathered to (stage 1) until the very multiplication that needs it:
+//     held in registers from the top of the op it cost 20 of the 128, and the kernel spilled;
+//   * per lane 200 multiplications + 230 additions + 10: ~1800 issue cycles per wave and op where the matrix
+//     cores need 1280 -- and 70 KB of LDS traffic per wave and op (50 block + 20 column) against 26.
+// stage_col: stage 0 + the lane's column (n, rate); stage_b / stage_b5: stage 0 + the lane's own entries
+// (af_read_tile); tip_b / tip_b5: the same places in stage 1; ymat: the block + 16 (4q + rate).
+__device__ __forceinline__ void af_matvec_plain(char * stage_b, char * stage_b5, const char * stage_col, const char * ymat,
+                                                const char * tip_b, const char * tip_b5, const double (&b)[AF_J][5],
+                                                double (&x)[AF_J][5])
+{
+#pragma unroll
+  for (int j = 0; j < AF_J; ++j)
+  {
+    *reinterpret_cast<double2 *>(stage_b + j * 2560) = make_double2(b[j][0], b[j][1]);
+    *reinterpret_cast<double2 *>(stage_b + j * 2560 + 16) = make_double2(b[j][2], b[j][3]);
+    *reinterpret_cast<double *>(stage_b5 + j * 2560) = b[j][4];
+  }
+  asm volatile("" ::: "memory"); // (LDS operations of a wave execute in order; the compiler reasons per thread)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    double2 c[AF_J][5];
+#pragma unroll
+    for (int j = 0; j < AF_J; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) c[j][cc] = *reinterpret_cast<const double2 *>(stage_col + j * 2560 + cc * 32 + pass * 16);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+    {
+      double a0[AF_J], a1[AF_J];
+#pragma unroll
+      for (int j = 0; j < AF_J; ++j) a0[j] = a1[j] = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc)
+      {
+        const double2 p = *reinterpret_cast<const double2 *>(ymat + ((pass * 25 + t * 5 + cc) * 256));
+#pragma unroll
+        for (int j = 0; j < AF_J; ++j)
+        {
+          a0[j] = a0[j] + p.x * c[j][cc].x;
+          a1[j] = a1[j] + p.y * c[j][cc].y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < AF_J; ++j)
+      {
+        const double pair = a0[j] + a1[j];
+        if (pass == 0) x[j][t] = pair;
+        else
+        {
+          const double tipf = *reinterpret_cast<const double *>((t < 4 ? tip_b + 8 * t : tip_b5) + j * 2560);
+          x[j][t] = tipf * (x[j][t] + pair);
+        }
+        asm volatile("" : "+v"(x[j][t])); // (wanted HERE: left alone the optimiser sinks the sums to where x is used)
+      }
+      // (one row's entries in flight at a time: left alone the compiler fetches the rows of all five outputs ahead --
+      // a hundred registers -- and parks what no longer fits in the accumulation registers, i.e. in the slots)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+
 // a tile in the lane layout of the MFMA operands, out of a stage in LDS
 __device__ __forceinline__ void af_read_tile(const char * stage_lane, const char * stage_lane5, double (&v)[AF_J][5])
 {
@@ -431,6 +516,8 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   const unsigned int boff = n * 640u + rate * 160u + q * 32u;        // its four states 4q.. of sub-tile 0 in a stage
   const unsigned int boff5 = n * 640u + rate * 160u + 128u + q * 8u; // state 16 + q
   const char * x0lane = lds + lane * 8u, * x1lane = lds + AF_MAT_B + lane * 8u, * ylane = lds + 2 * AF_MAT_B + lane * 8u;
+  const char * yrows = lds + 2 * AF_MAT_B + (q * 4u + rate) * 16u;   // the right block in row order (tip-inner ops)
+  const unsigned int coloff = n * 640u + rate * 160u;                // the lane's column in a stage
   const unsigned long long sink_a = (unsigned long long)(uintptr_t)(sink + ((size_t)blockIdx.x * 4u + wave) * 4u);
   const unsigned long long aorder_a = (unsigned long long)(uintptr_t)aorder;
 
@@ -511,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     };
     // what an op of kind `nkind` gathers an op ahead, with its characters (in ch): a lookup its
     // table entries -- LDS-DMA with one address per lane, straight into the two stages in the
-    // layout of the stores --, a tip-inner op the tip's factor (a row of its table per site, into stage 0)
+    // layout of the stores --, a tip-inner op the tip's factor (a row of its table per site, into stage 1)
     auto next_gathers = [&](unsigned int nkind, unsigned long long tab_l, unsigned long long tab_r, const unsigned int (&ch)[4]) __attribute__((always_inline)) {
       if (AF_EXP(4u)) return;
       if (nkind == 2u)
@@ -552,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
           const unsigned int q1 = (unsigned int)__shfl((int)c1, (int)sl, 64);
           o1[it] = (q1 * 40u + rr) * 16u;
         }
-        af_dma_gather5(st0_b, tab_l, o1);
+        af_dma_gather5(st1_b, tab_l, o1); // (stage 1: stage 0 takes the inner child's columns, af_matvec_plain)
       }
     };
 
@@ -971,12 +1058,12 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     if (kind == 0)
     {
       o.xoff = (unsigned int)(mj.size() * AF_MAT_B);
-      mj.push_back(AfMatJob{f.lmat, (unsigned long long)o.xoff});
+      mj.push_back(AfMatJob{f.lmat, (unsigned long long)o.xoff, 0ull});
     }
     if (kind <= 1)
     {
       r.yoff = (unsigned int)(mj.size() * AF_MAT_B);
-      mj.push_back(AfMatJob{f.rmat, (unsigned long long)r.yoff});
+      mj.push_back(AfMatJob{f.rmat, (unsigned long long)r.yoff, kind == 1 ? 1ull : 0ull});
     }
     if (kind == 1)
     {

@@ -78,6 +78,8 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
   const char * la14, * la5, * ra14, * ra5;
   chain_lane_bases(ptab, lane, la14, la5);
   chain_lane_bases(ptab_r, lane, ra14, ra5);
+  // (tip-inner: the inner child's products on the vector unit in the reference's non-fused order, aa_mfma.hpp)
+  const char * const rrow = reinterpret_cast<const char *>(ptab_r) + q * 160u;
   char * region = reinterpret_cast<char *>(ptab_r + RC * 400) + wave * G::REGION_B;
   constexpr int ROW_B = G::ROW_G * 16;
 
@@ -280,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
       if (k >= RC) return;
       constexpr int kk = k < RC ? k : 0;
       double yk[5];
-      rate_matvec_chain<kk * 3200>(ra14, ra5, b[kk], lane, yk);
+      if (KIND == 1) rate_matvec_plain<kk * 3200>(rrow, b[kk], lane, yk);
+      else rate_matvec_chain<kk * 3200>(ra14, ra5, b[kk], lane, yk);
       small_rate[kk] = true;
 #pragma unroll
       for (int g = 0; g < 5; ++g)
@@ -639,6 +642,18 @@ int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count
   }
 }
 
+// tip-inner ops whose tip tables (PartialsArgs::ltab) the caller has made itself; no scaling
+static int launch_ti_with_tables(pllhip_ctx * c, const PartialsBatch & b, unsigned int count)
+{
+  const bool nt = pllhip_use_nt(c);
+  switch (b.op[0].rate_cats)
+  {
+    case 1: return launch_rc<1, 1>(c, b, count, SCALE_NONE, nt);
+    case 2: return launch_rc<2, 1>(c, b, count, SCALE_NONE, nt);
+    default: return launch_rc<4, 1>(c, b, count, SCALE_NONE, nt);
+  }
+}
+
 // ---- host side of the lookup ops (see k_aa_cherry_rounds)
 //
 // ops[i]: the inner-inner op; kid1[i] / kid2[i]: the tip-tip ops that produced its children
@@ -669,6 +684,7 @@ static __global__ void k_aa_cherry_consts(unsigned char * hi, unsigned char * lo
   {
     hi[t] = (unsigned char)(t < ms * ms ? t / ms : 0);
     lo[t] = (unsigned char)(t < ms * ms ? t % ms : 0);
+    lo[rows + t] = 0; // (a row of zero characters as long as the pair list)
   }
   if (t < rows * RC * 20) ones[t] = 1.0;
   if (t < RC * 400) ident[t] = ((t % 400) / 20 == t % 20) ? 1.0 : 0.0;
@@ -721,7 +737,7 @@ static int cherry_scratch(pllhip_ctx * c, size_t rows, size_t row_elems, unsigne
     // per lookup op of a chunk: pair CLVs of the two children, TL, TR; then the constants
     const size_t per_op = 4 * rows * row_elems;
     HIP_TRY(hipMalloc((void **)&c->cherry_pool, (chunk * per_op + rows * row_elems + (size_t)R * 400) * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&c->cherry_codes, 2 * rows));
+    HIP_TRY(hipMalloc((void **)&c->cherry_codes, 3 * rows));
     ++c->layout_epoch;
     if (!c->cherry_zero)
     {
@@ -749,8 +765,8 @@ static int cherry_tables(pllhip_ctx * c, double * pool, const PartialsArgs * ops
   const size_t per_op = 4 * rows * row_elems;
   double * ones = c->cherry_pool + chunk * per_op;
   double * ident = ones + rows * row_elems;
-  PartialsBatch tt, ii;
-  unsigned int ntab = 0;
+  PartialsBatch tt, ii, ti;
+  unsigned int ntab = 0, nii = 0, nti = 0;
   TipMats h_lmats;
   memset(&h_lmats, 0, sizeof(h_lmats));
   bool any_tip_left = false;
@@ -781,14 +797,28 @@ static int cherry_tables(pllhip_ctx * c, double * pool, const PartialsArgs * ops
       t.rate_cats = R;
       t.states = 20;
       t.maxstates = ms;
-      // P x child by the inner-inner kernel; the other factor is identity x ones = 1
-      PartialsArgs & u = ii.op[ntab++];
+      ++ntab;
+      // P x child by the kernel the op itself would have run, the other factor being exactly 1:
+      //   inner-inner op: the inner-inner kernel (fused chains, core_partials_avx2.c:632-750), identity x ones;
+      //   tip-inner op:   the tip-inner kernel (products and sums rounded separately, core_partials_avx.c:1229-1284),
+      //                   a tip table of ones and a row of zero characters
+      PartialsArgs & u = tip_left ? ti.op[nti++] : ii.op[nii++];
       memset(&u, 0, sizeof(u));
       u.parent = table[s];
-      u.left = pair_clv[s];
-      u.right = ones;
-      u.lmat = s == 0 ? op.lmat : op.rmat;
-      u.rmat = ident;
+      if (tip_left)
+      {
+        u.right = pair_clv[s];
+        u.rmat = op.rmat;
+        u.ltab = ones; // [code][rate][state], every entry 1.0
+        u.ltip = c->cherry_codes + 2 * rows;
+      }
+      else
+      {
+        u.left = pair_clv[s];
+        u.right = ones;
+        u.lmat = s == 0 ? op.lmat : op.rmat;
+        u.rmat = ident;
+      }
       u.tipmap = c->tipmap;
       u.zero = c->d_zero;
       u.sites = (unsigned int)pairs;
@@ -810,8 +840,8 @@ static int cherry_tables(pllhip_ctx * c, double * pool, const PartialsArgs * ops
   }
   int rc = pllhip_launch_aa_batch(c, tt, ntab, 2, SCALE_NONE);
   if (rc) return rc;
-  rc = pllhip_launch_aa_batch(c, ii, ntab, 0, SCALE_NONE);
-  if (rc) return rc;
+  if (nii && (rc = pllhip_launch_aa_batch(c, ii, nii, 0, SCALE_NONE))) return rc;
+  if (nti && (rc = launch_ti_with_tables(c, ti, nti))) return rc;
   for (unsigned int i = 0; i < n; ++i) any_tip_left = any_tip_left || h_lmats.m[i];
   if (any_tip_left)
   {

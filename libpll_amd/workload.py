@@ -316,6 +316,65 @@ def simulated_alignment(plan, sites, rates, freqs, cat_rates, seed=42, gap_frac=
     return out
 
 
+ALIGNMENT_BLOCK = 250_000
+
+
+def global_alignment(plan, lo, hi, rates, freqs, cat_rates, seed=42, block=ALIGNMENT_BLOCK, distinct=0,
+                     cache=None, kind="simulated"):
+    """Columns [lo, hi) of ONE alignment that is defined block by block, so that every rank of a
+    multi-GPU job can make its own site range without anybody making the whole: block b -- sites
+    [b * block, (b + 1) * block) -- is `simulated_alignment` with seed + b (distinct = 0) or, to bound
+    the cost of a very long alignment, seed + b % distinct (the alignment then repeats after
+    `distinct` blocks; kind = "random": i.i.d. characters instead).  A range is a slice of the whole by construction: rank r's [lo, hi) of an
+    N-GPU run are the very columns a one-GPU run evaluates at positions lo..hi-1, which is what makes
+    the N-GPU lnL checkable (the reference's sum runs over ONE alignment,
+    core_likelihood_avx.c:1246-1259).  cache: a dict that keeps generated blocks between calls."""
+    if not 0 <= lo <= hi:
+        raise ValueError("bad site range [%d, %d)" % (lo, hi))
+    cache = {} if cache is None else cache
+    parts = [[] for _ in range(plan.tips)]
+    for b in range(lo // block, -(-hi // block) if hi > lo else lo // block):
+        key = b % distinct if distinct else b
+        if key not in cache:
+            cache[key] = (simulated_alignment(plan, block, rates, freqs, cat_rates, seed=seed + key) if kind == "simulated"
+                          else random_alignment(plan.tips, block, len(freqs), seed=seed + key))
+        first, last = max(lo, b * block) - b * block, min(hi, (b + 1) * block) - b * block
+        for t in range(plan.tips):
+            parts[t].append(cache[key][t][first:last])
+    return [b"".join(x) for x in parts]
+
+
+def reference_lnl(ref, plan, seqs, states, rate_cats, attributes, chunk=50_000, budget_s=None, root_edge=None):
+    """lnL of an alignment through a CPU library with the reference's API (oracle/_ref in bench.py and
+    the tests), in site chunks that reuse ONE small partition: lnL is a sum over sites, and a partition
+    of the whole would need the alignment's CLVs in host memory (133 GB for BASELINE config 4).
+    Returns (lnl, sites evaluated): all of them, or -- with budget_s -- as many whole chunks as fit the
+    time budget (at least one), so that a caller can bound the check and compare the same prefix."""
+    import time
+    sites = len(seqs[0])
+    edge = plan.root_edge if root_edge is None else root_edge
+    cmap = ref.map("nt" if states == 4 else "aa")
+    total, done, part, t0 = 0.0, 0, None, time.perf_counter()
+    while done < sites:
+        n = min(chunk, sites - done)
+        piece = [s[done:done + n] for s in seqs]
+        if part is None or n != chunk:
+            if part is not None:
+                part.destroy()
+            part = setup_partition(ref, plan, piece, states, rate_cats, attributes)
+        else:
+            for i, s in enumerate(piece):
+                part.set_tip_states(i, cmap, s)
+        part.update_partials(plan.ops)
+        total += part.compute_edge_loglikelihood(*edge, [0] * rate_cats)
+        done += n
+        if budget_s is not None and time.perf_counter() - t0 > budget_s:
+            break
+    if part is not None:
+        part.destroy()
+    return total, done
+
+
 # ---- site sharding (multi-GPU) -------------------------------------------------------
 
 def shard_bounds(sites, nranks, granule=256):

@@ -170,6 +170,68 @@ def test_product_host_logic_two_ranks_gloo(tmp_path, amd):
     assert "HOST_OK" in out.stdout
 
 
+# ---------------------------------------------------------------- bench.py's alignment: one, indexed by global site
+
+ALIGN_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from libpll_amd import workload as W
+from libpll_amd.pllapi import PllLibrary, ATTRIB_PATTERN_TIP, ATTRIB_ARCH_AVX2
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ref = PllLibrary(os.path.join(sys.argv[1], "oracle", "_ref", "libpll_ref.so"))
+plan = W.balanced_tree(16, seed=42)
+cat = ref.compute_gamma_cats(W.GAMMA_ALPHA, 4)
+total, block = 5000, 700      # (ranges that begin and end inside blocks)
+b = W.shard_bounds(total, world)
+lo, hi = b[rank], b[rank + 1]
+mine = W.global_alignment(plan, lo, hi, W.GTR_RATES, W.GTR_FREQS, cat, seed=42, block=block)
+whole = W.global_alignment(plan, 0, total, W.GTR_RATES, W.GTR_FREQS, cat, seed=42, block=block)
+# a rank's range IS a slice of the alignment a one-GPU run evaluates whole
+assert all(w[lo:hi] == m for w, m in zip(whole, mine))
+assert len(set(whole[0][i * block:(i + 1) * block] for i in range(total // block))) > 1, "blocks differ"
+# ... with a cycle of distinct blocks (BASELINE config 4's generator) as well
+rep = W.global_alignment(plan, lo, hi, W.GTR_RATES, W.GTR_FREQS, cat, seed=7, block=block, distinct=3)
+rep_whole = W.global_alignment(plan, 0, total, W.GTR_RATES, W.GTR_FREQS, cat, seed=7, block=block, distinct=3)
+assert all(w[lo:hi] == m for w, m in zip(rep_whole, rep))
+assert rep_whole[0][0:block] == rep_whole[0][3 * block:4 * block]
+# the sum over the ranks of the reference's lnL of each range == the reference's lnL of the whole: what
+# bench.py reports as lnl_rel_err_vs_reference at N > 1 compares the product's all-reduced lnL with exactly this sum
+attrs = ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2
+part, n = W.reference_lnl(ref, plan, mine, 4, 4, attrs, chunk=900)
+assert n == hi - lo
+t = torch.tensor([part], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.SUM)
+full, _ = W.reference_lnl(ref, plan, whole, 4, 4, attrs, chunk=total)
+assert abs(t.item() - full) <= 1e-13 * abs(full), (t.item(), full)
+# a time-boxed prefix is whole chunks, at least one
+pre, n_pre = W.reference_lnl(ref, plan, whole, 4, 4, attrs, chunk=900, budget_s=0.0)
+assert n_pre == 900
+if rank == 0:
+    print("ALIGN_OK bounds=%s lnl=%.6f" % (b, full))
+dist.destroy_process_group()
+'''
+
+
+def test_bench_alignment_is_one_alignment_two_ranks_gloo(tmp_path, ref):
+    """bench.py at N > 1 (VERDICT r3 item 3): every rank makes its own columns of ONE alignment
+    (W.global_alignment), so the N-GPU lnL has something to be compared with; the per-rank reference
+    values sum to the reference's value of the whole."""
+    script = tmp_path / "align_worker.py"
+    script.write_text(ALIGN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(free_port()), str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "ALIGN_OK" in out.stdout
+
+
 # ---------------------------------------------------------------- the product, one rank per GPU
 
 PRODUCT_WORKER = r'''
