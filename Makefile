@@ -35,9 +35,17 @@ $(BUILD)/hip_%.o: libpll_amd/csrc/hip/%.hip include/pllhip.h $(wildcard libpll_a
 
 # partials_aa_fused.hip keeps its values in the accumulation registers a0..a109 behind the compiler's
 # back (inline assembly): the matrix-core instructions must then keep THEIR accumulators in ordinary
-# registers, or the compiler parks them in a0.. between two assembly blocks (seen).  tools/check_agprs.py
-# (run by tests/test_host.py) verifies on the generated code that nothing but the slot assembly touches them.
-HIPFLAGS_partials_aa_fused := -mllvm -amdgpu-mfma-vgpr-form
+# registers, or the compiler parks them in a0.. between two assembly blocks (seen), and nothing may be
+# spilled there either.  Clobber lists do not guarantee that, so the build itself checks: the object is
+# compiled with -save-temps and tools/check_agprs.py reads the assembly of THIS compilation (this ARCH, these
+# flags, this compiler) -- an instruction outside the slot assembly that names a0..a109 fails the build.
+HIPFLAGS_partials_aa_fused := -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-spill-vgpr-to-agpr=0
+
+$(BUILD)/hip_partials_aa_fused.o: libpll_amd/csrc/hip/partials_aa_fused.hip include/pllhip.h $(wildcard libpll_amd/csrc/hip/*.hpp) $(wildcard libpll_amd/csrc/hip/*.inc) tools/check_agprs.py | $(BUILD)
+	rm -rf $(BUILD)/aa_fused_tmp && mkdir -p $(BUILD)/aa_fused_tmp
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_partials_aa_fused) -save-temps=obj -c $< -o $(BUILD)/aa_fused_tmp/hip_partials_aa_fused.o
+	python3 tools/check_agprs.py $(AGPR_CHECK_FLAGS) $(BUILD)/aa_fused_tmp/partials_aa_fused-hip-amdgcn-amd-amdhsa-$(ARCH).s
+	mv $(BUILD)/aa_fused_tmp/hip_partials_aa_fused.o $@
 
 $(OUT): $(HOST_OBJ) $(HIP_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -Wl,-soname,libpll_amd.so -Wl,-rpath,/opt/rocm/lib \

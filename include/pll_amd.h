@@ -642,6 +642,11 @@ PLL_EXPORT int pll_amd_sync_clv(pll_partition_t * partition, unsigned int clv_in
 PLL_EXPORT int pll_amd_sync_scaler(pll_partition_t * partition, unsigned int scaler_index);
 PLL_EXPORT int pll_amd_sync_pmatrix(pll_partition_t * partition, unsigned int matrix_index);
 PLL_EXPORT int pll_amd_sync_sumtable(pll_partition_t * partition, double * sumtable);
+/* Outside mirror mode pll_update_sumtable does not fill the caller's buffer -- but it does MARK it: the entries of
+ * the first site (states * rate_cats doubles) are set to this signalling NaN, so that a client which reads the
+ * buffer without pll_amd_sync_sumtable finds NaNs that propagate (and trap under feenableexcept(FE_INVALID)), not
+ * yesterday's table or zeros.  pll_amd_sync_sumtable and mirror mode overwrite them with the table. */
+#define PLL_AMD_SUMTABLE_POISON 0x7FF453554D544142ull /* sNaN, payload "SUMTAB" */
 /* Tell the library a sumtable buffer is about to be freed or refilled by hand: its key is
  * forgotten, so a new buffer at the same address is not mistaken for the old table. */
 PLL_EXPORT int pll_amd_forget_sumtable(pll_partition_t * partition, const double * sumtable);

@@ -245,6 +245,9 @@ PLLHIP_EXPORT int pllhip_identify_repeats(pllhip_ctx_t * ctx, unsigned int paren
                                           unsigned int max_classes, unsigned int * classes);
 PLLHIP_EXPORT int pllhip_get_site_id(pllhip_ctx_t * ctx, unsigned int clv_index,
                                      unsigned int * h_site_id);
+/* rows CLV slot clv_index is stored in (0: one per site).  A context sharded over several devices identifies per shard
+ * and reports *classes = 0 to the caller (its mirrors arrive expanded); this is the sum over its shards. */
+PLLHIP_EXPORT unsigned int pllhip_repeats_rows(pllhip_ctx_t * ctx, unsigned int clv_index);
 
 /* ---- multi-GPU: one process per GPU, RCCL sum of the scalar results ---- */
 PLLHIP_EXPORT int pllhip_comm_unique_id(void * id128);

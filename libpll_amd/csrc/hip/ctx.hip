@@ -10,6 +10,9 @@
 //   tipchars      [tips][sites rounded up to 256 B] u8
 //   pmatrix       [prob_matrices][rate_cats][states][states] f64  (KBs; L2-resident)
 #include <dlfcn.h>
+#include <unistd.h>
+#include <sched.h>
+#include <time.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -17,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "ctx.hpp"
 
@@ -56,6 +60,61 @@ static int dev_alloc(T ** p, size_t count, bool zero, hipStream_t s)
   return 0;
 }
 
+// ---- Quiescing the HIP runtime before anything is torn down (round 4; the crash hunt of DESIGN.md section 3).
+// Since round 3 a result-returning call does not wait for the STREAM: the host spins on a word the kernel writes
+// (pllhip_result_wait_host).  The host thread then runs AHEAD of the runtime's own completion processing: nobody
+// waits on the command's signal, so the runtime retires the launch on its asynchronous signal-handler thread,
+// whenever that thread gets to it.  A client that destroys its partition and exits right after its last call tears
+// streams, queues and finally the runtime down under that thread: use-after-free INSIDE the runtime -- 1 run in
+// 2,500 of the reference's derivatives programs died with SIGABRT (std::system_error from a mutex in freed memory,
+// thrown on the handler thread; round 3 saw the same race once as SIGSEGV); 0 of 18,000 with PLLHIP_SPIN=0,
+// 0 of 19,400 with a pause before exit (profiles/r4_crash_soak_*.log).
+//
+// The fix orders teardown behind the handler thread instead of pausing: a host function is enqueued on the stream
+// and waited for.  Host functions run on that very thread, in stream order, so when it has run every earlier
+// launch of the stream has been retired there.  (The wait is bounded: a runtime that never calls back costs 50 ms
+// per destroy, not a hang.)  And an exit handler, registered after the runtime's own, drains the device once more.
+static void pllhip_fence_mark(void * flag)
+{
+  __atomic_store_n(static_cast<int *>(flag), 1, __ATOMIC_RELEASE);
+}
+
+static void pllhip_stream_quiesce(hipStream_t stream)
+{
+  static const bool off = getenv("PLLHIP_QUIESCE") && atoi(getenv("PLLHIP_QUIESCE")) == 0; // (A/B of the crash hunt)
+  (void)hipStreamSynchronize(stream);
+  if (off) return;
+  // (the flag must outlive a callback that fires after the timeout: leaked on that path only)
+  int * flag = new int(0);
+  if (hipLaunchHostFunc(stream, pllhip_fence_mark, flag) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    delete flag;
+    return;
+  }
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  bool done = false;
+  for (unsigned int spins = 0; !(done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0); ++spins)
+  {
+    if ((spins & 63u) == 63u)
+    {
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 50000000ll) break;
+      sched_yield(); // (the handler thread may want this core)
+    }
+  }
+  (void)hipStreamSynchronize(stream); // the host function's own command
+  if (done) delete flag;
+}
+
+static void pllhip_exit_drain()
+{
+  (void)hipDeviceSynchronize();
+  if (const char * e = getenv("PLLHIP_EXIT_GRACE_US")) // (experiment knob of the crash hunt)
+    if (atoi(e) > 0) usleep((useconds_t)atoi(e));
+}
+
 extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** out)
 {
   *out = nullptr;
@@ -78,6 +137,11 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   int ndev = 0;
   int rc = pllhip_device_count(&ndev);
   if (rc) return rc;
+  {
+    // registered after the HIP runtime's own exit handlers (it is initialised by now): runs before them
+    static const bool once = (atexit(pllhip_exit_drain), true);
+    (void)once;
+  }
   if (shape->device < 0 || shape->device >= ndev)
   {
     pllhip_set_error("pllhip_ctx_create: device %d not present (%d visible)",
@@ -151,6 +215,9 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   HIP_TRY(hipHostMalloc((void **)&c->h_result, 4 * sizeof(double), hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void **)&c->h_result_dev, c->h_result, 0));
   memset(c->h_result, 0, 4 * sizeof(double));
+  HIP_TRY(hipHostMalloc((void **)&c->h_partials, PLLHIP_HOSTSUM_MAX * sizeof(double2), hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void **)&c->h_partials_dev, c->h_partials, 0));
+  memset(c->h_partials, 0, PLLHIP_HOSTSUM_MAX * sizeof(double2));
   // (arrival tickets of the reducing kernels: one word per group of 64 workgroups + one)
   if ((rc = dev_alloc(&c->d_counter, (size_t)(PLLHIP_REDUCE_BLOCKS / 64 + 4) * sizeof(unsigned int), true, c->stream))) goto fail;
 
@@ -294,7 +361,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   if (c && !c->shards.empty()) { pllhip_group_destroy(c); return; }
   if (!c) return;
   (void)hipSetDevice(c->sh.device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream) pllhip_stream_quiesce(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
   void * bufs[] = {c->clv_arena, c->tipchars, c->scaler_arena, c->pmatrix, c->eigenvals,
                    c->eigenvecs, c->inv_eigenvecs, c->freqs, c->prop_invar, c->rates,
@@ -326,12 +393,15 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
     for (void * p : {(void *)r.site_id, (void *)r.lrow, (void *)r.rrow})
       if (p) (void)hipFree(p);
   if (c->h_result) (void)hipHostFree(c->h_result);
+  if (c->h_partials) (void)hipHostFree(c->h_partials);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  if (const char * e = getenv("PLLHIP_DESTROY_GRACE_US"))
+    if (atoi(e) > 0) usleep((useconds_t)atoi(e));
 }
 
 extern "C" int pllhip_wait(pllhip_ctx_t * c)
@@ -562,9 +632,40 @@ extern "C" int pllhip_partial_tt_from_lookup(pllhip_ctx_t * c, unsigned int pare
   return rc;
 }
 
+// ---- a SHARD's CLV / scale buffer as one row per site, however it is stored.  A partition over several devices
+// with PLL_ATTRIB_SITE_REPEATS (round 4) identifies its classes per shard -- repeats are a property of a site range --
+// and the host layer sees such a group as "stored per site": the expansion happens here, shard by shard.
+template <typename T>
+static int expand_rows(pllhip_ctx * s, unsigned int owner_clv, T * h, size_t per)
+{
+  const unsigned int classes = s->rows[owner_clv].classes, sites = s->sh.sites;
+  std::vector<unsigned int> sid(sites);
+  const int rc = pllhip_get_site_id(s, owner_clv, sid.data());
+  if (rc) return rc;
+  const std::vector<T> rows(h, h + (size_t)classes * per);
+  for (size_t n = 0; n < sites; ++n) memcpy(h + n * per, rows.data() + (size_t)sid[n] * per, per * sizeof(T));
+  return 0;
+}
+
+static int shard_clv_per_site(pllhip_ctx * s, unsigned int idx, double * h)
+{
+  const int rc = pllhip_get_clv(s, idx, h);
+  if (rc || s->rows.empty() || idx >= s->rows.size() || !s->rows[idx].classes) return rc;
+  return expand_rows(s, idx, h, s->span);
+}
+
+static int shard_scaler_per_site(pllhip_ctx * s, unsigned int idx, unsigned int * h)
+{
+  const int rc = pllhip_get_scaler(s, idx, h);
+  if (rc || s->rows.empty() || idx >= s->scaler_owner.size() || s->scaler_owner[idx] < 0) return rc;
+  const unsigned int owner = (unsigned int)s->scaler_owner[idx];
+  if (owner >= s->rows.size() || !s->rows[owner].classes) return 0;
+  return expand_rows(s, owner, h, (size_t)(s->sh.rate_scalers ? s->sh.rate_cats : 1));
+}
+
 extern "C" int pllhip_get_clv(pllhip_ctx_t * c, unsigned int idx, double * h)
 {
-  PLLHIP_ALL_SHARDS(c, pllhip_get_clv(s, idx, h + lo * c->span));
+  PLLHIP_ALL_SHARDS(c, shard_clv_per_site(s, idx, h + lo * c->span));
   if (idx >= c->clv.size() || !c->clv[idx])
   {
     pllhip_set_error("pllhip_get_clv: index %u has no CLV", idx);
@@ -575,7 +676,7 @@ extern "C" int pllhip_get_clv(pllhip_ctx_t * c, unsigned int idx, double * h)
 
 extern "C" int pllhip_get_scaler(pllhip_ctx_t * c, unsigned int idx, unsigned int * h)
 {
-  PLLHIP_ALL_SHARDS(c, pllhip_get_scaler(s, idx, h + lo * (c->sh.rate_scalers ? c->sh.rate_cats : 1)));
+  PLLHIP_ALL_SHARDS(c, shard_scaler_per_site(s, idx, h + lo * (c->sh.rate_scalers ? c->sh.rate_cats : 1)));
   if (idx >= c->sh.scale_buffers) { pllhip_set_error("pllhip_get_scaler: index %u", idx); return -1; }
   return d2h(c, h, pllhip_scaler_ptr(c, (int)idx), c->scaler_elems * sizeof(unsigned int));
 }

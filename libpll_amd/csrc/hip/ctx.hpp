@@ -12,6 +12,7 @@
 
 #define PLLHIP_MAX_RATE_CATS 64
 #define PLLHIP_REDUCE_BLOCKS 65536 /* upper bound on blocks of a reducing kernel */
+#define PLLHIP_HOSTSUM_MAX 8192    /* workgroup sums (x components) the host adds itself; larger grids: k_final_sum */
 
 struct ncclComm;
 
@@ -92,6 +93,7 @@ struct pllhip_ctx
   unsigned char * cherry_zero = nullptr;     // [sites] zero characters (the absent second tip of a tip-inner lookup op)
   double * cherry_pool_all = nullptr;        // the tables of ALL lookup ops of a list (partials_aa_fused.hip)
   unsigned int cherry_pool_all_ops = 0;      // lookup ops it has room for
+  bool cherry_pool_failed = false;           // its allocation failed once: no lookup ops on this context any more
   struct pllhip_aa_fused_cache * aa_fused = nullptr; // 20-state whole-list kernel: its kept plan
   size_t pairtab_elems = 0;
   void * h_plan[2] = {nullptr, nullptr};
@@ -112,6 +114,10 @@ struct pllhip_ctx
   unsigned long long result_seq = 0;   // number of the last result-returning launch
   bool no_spin = false;                // env PLLHIP_SPIN=0: wait for the stream instead (A/B measurements)
   double * h_result_dev = nullptr;     // device address of h_result
+  // workgroup sums of a result-returning kernel, written by the kernel straight into host memory and added by
+  // the host (likelihood.hip: pllhip_result_wait_host): {value, sequence number} per workgroup and component
+  double2 * h_partials = nullptr, * h_partials_dev = nullptr;
+  unsigned int hostsum_grid = 0, hostsum_ncomp = 0; // the call in flight
   unsigned int * d_counter = nullptr;  // arrival counter of the reducing kernels
   double * d_persite = nullptr;        // [sites], lazily allocated
 
@@ -146,6 +152,8 @@ struct pllhip_ctx
     size_t row_cap = 0;
   };
   std::vector<node_rows> rows;          // empty unless repeats were ever identified
+  std::vector<int> scaler_owner;        // per scale buffer: the CLV slot it was last written with (a buffer written
+                                        // with a CLV stored by class is stored by class too); kept once `rows` exists
   struct pllhip_rep_work * rep_work = nullptr; // sort / scan buffers of repeats.hip
   size_t clv_arena_bytes = 0;            // all CLVs of the partition
   bool no_batch = false;                 // PLLHIP_NO_BATCH=1: one launch per op (measurements)
@@ -326,6 +334,7 @@ int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);
 // 20-state fast kernels (matrix cores / round-based tip-tip) for `count` mutually
 // independent ops of one kind and mode; returns 1 if the case is not covered
 bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind);
+unsigned int pllhip_aa_lookup_budget(const pllhip_ctx * c);
 int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count, int kind, int mode);
 bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode);
 bool pllhip_aa_cherry_pays(const pllhip_ctx * c, unsigned int lookups, unsigned int levels);

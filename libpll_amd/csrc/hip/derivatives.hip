@@ -636,7 +636,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
       const unsigned int cap = e && atoi(e) > 0 ? (unsigned int)atoi(e) : (unsigned int)c->num_cus * 2;
       if (grid > cap) grid = cap;
     }
-    a.reduce = pllhip_reduce_out(c, grid);
+    a.reduce = pllhip_reduce_out(c, grid, 2);
     // A table that fits the 256 MiB Infinity Cache with room to spare is re-read by every Newton
     // iteration from there: no streaming hint on its loads (the hint is for CLV-sized streams that
     // nothing will touch again)
@@ -664,7 +664,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 3; // 47 KB of LDS per workgroup (env: tests)
     if (blocks > cap) blocks = cap;
     grid = (unsigned int)blocks;
-    a.reduce = pllhip_reduce_out(c, grid);
+    a.reduce = pllhip_reduce_out(c, grid, 2);
     const bool nt = pllhip_use_nt(c);
 #define DERIV_AA(RCV)                                                                               \
     do {                                                                                            \
@@ -684,7 +684,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     grid = pllhip_stream_grid(c, (size_t)a.sites, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
-    a.reduce = pllhip_reduce_out(c, grid);
+    a.reduce = pllhip_reduce_out(c, grid, 2);
     const size_t lds = (size_t)R * (S * 4 + 2) * sizeof(double);
     switch (S <= 16 ? S : 0u)
     {
@@ -700,7 +700,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     grid = pllhip_stream_grid(c, a.sites, 128);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
-    a.reduce = pllhip_reduce_out(c, grid);
+    a.reduce = pllhip_reduce_out(c, grid, 2);
     k_derivatives_gen<<<grid, 128, 0, c->stream>>>(a);
   }
   HIP_TRY(hipGetLastError());

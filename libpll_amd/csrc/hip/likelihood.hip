@@ -24,6 +24,8 @@
 // sites sequentially, agreement is ~1e-16*sqrt(sites) relative.  The final step
 // also adds the ascertainment-bias correction when one is set (asc_bias.hip).
 #include <stdlib.h>
+#include <string.h>
+#include <time.h>
 
 #include "ctx.hpp"
 #include "numerics.hpp"
@@ -31,7 +33,7 @@
 #include "lnl_common.hpp"
 
 
-ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid)
+ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncomp)
 {
   ReduceOut r;
   r.partials = c->block_partials;
@@ -54,7 +56,57 @@ ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid)
   static const int forced = getenv("PLLHIP_FUSE_REDUCE") ? atoi(getenv("PLLHIP_FUSE_REDUCE")) : -1;
   static const unsigned int max_grid = getenv("PLLHIP_FUSE_MAX_GRID") ? (unsigned int)atoi(getenv("PLLHIP_FUSE_MAX_GRID")) : 128u;
   r.fused = forced >= 0 ? (forced ? 1 : 0) : (grid <= max_grid ? 1 : 0);
+  // Larger grids (round 4): the workgroup sums go straight to host-mapped memory and the host adds them -- in
+  // k_final_sum's order, so the bits are those of rounds 1-3 -- instead of a one-workgroup launch behind the kernel
+  // (4.5-6.7 us per result-returning call).  Not with a communicator (the all-reduce wants the
+  // sum on the device), not for a shard of a group (collected after enqueueing everywhere), not with an
+  // ascertainment-bias term (a device value the final step adds).  PLLHIP_HOSTSUM=0 switches it off.
+  static const bool hostsum_on = !(getenv("PLLHIP_HOSTSUM") && atoi(getenv("PLLHIP_HOSTSUM")) == 0);
+  r.host_partials = nullptr;
+  c->hostsum_grid = 0;
+  if (hostsum_on && !r.fused && !c->comm && !c->defer && !r.extra && (size_t)grid * ncomp <= PLLHIP_HOSTSUM_MAX)
+  {
+    r.host_partials = c->h_partials_dev;
+    c->hostsum_grid = grid;
+    c->hostsum_ncomp = ncomp;
+  }
   return r;
+}
+
+// the host's final sum: k_final_sum's order -- thread t of 256 adds entries t, t + 256, ..., then the tree
+static void pllhip_host_final_sum(pllhip_ctx * c)
+{
+  const unsigned int nparts = c->hostsum_grid;
+  for (unsigned int comp = 0; comp < c->hostsum_ncomp; ++comp)
+  {
+    const double2 * part = c->h_partials + (size_t)comp * nparts;
+    double s[256];
+    for (unsigned int t = 0; t < 256; ++t)
+    {
+      double v = 0.0;
+      for (unsigned int i = t; i < nparts; i += 256) v += part[i].x;
+      s[t] = v;
+    }
+    for (unsigned int w = 128; w > 0; w >>= 1)
+      for (unsigned int t = 0; t < w; ++t) s[t] += s[t + w];
+    c->h_result[comp] = s[0];
+  }
+}
+
+// every workgroup's entry carries this call's sequence number?
+static bool pllhip_host_partials_landed(const pllhip_ctx * c, unsigned long long seq)
+{
+  const volatile double2 * part = c->h_partials;
+  const size_t n = (size_t)c->hostsum_grid * c->hostsum_ncomp;
+  for (size_t i = 0; i < n; ++i)
+  {
+    const double y = part[i].y;
+    unsigned long long got;
+    memcpy(&got, &y, sizeof(got));
+    if (got != seq) return false;
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return true;
 }
 
 // adds `nparts` workgroup values of `ncomp` components in a fixed order
@@ -83,32 +135,72 @@ __global__ __launch_bounds__(256) void k_final_sum(ReduceOut ro, unsigned int np
   if (threadIdx.x == 0) pllhip_publish_seq(ro);
 }
 
-// Bounded spin on the host-mapped word; beyond ~2 ms (a long kernel, a profiler in between, memory that is
-// not coherent after all) the stream's own completion is waited for, as before round 3.
+// Bounded spin on the host-mapped word: bounded by TIME (a count of PAUSE instructions is 15-50 ms on
+// cores where PAUSE takes 140 cycles, and a whole core was burnt for that long under every multi-millisecond
+// kernel).  The spin is for the short kernels behind a result-returning call (a 15 us derivative kernel, a 50 us
+// lnL kernel: the stream wait costs 6 us more than the spin); after 200 us -- a long kernel, a profiler in
+// between, memory that is not coherent after all -- the stream's own completion is waited for, as before round 3.
+#if defined(__x86_64__) || defined(__i386__)
+#define PLLHIP_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define PLLHIP_CPU_RELAX() asm volatile("yield" ::: "memory")
+#else
+#define PLLHIP_CPU_RELAX() asm volatile("" ::: "memory")
+#endif
 int pllhip_result_wait_host(pllhip_ctx * c, const ReduceOut & ro, bool stream_work_follows)
 {
-  if (!ro.host_seq || stream_work_follows)
+  const bool hostsum = ro.host_partials != nullptr;
+  if ((!ro.host_seq && !(hostsum && !c->no_spin)) || stream_work_follows)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hostsum)
+    {
+      if (!pllhip_host_partials_landed(c, ro.seq))
+      {
+        pllhip_set_error("a result-returning kernel has finished but its workgroup sums are not in host memory");
+        return -1;
+      }
+      pllhip_host_final_sum(c);
+    }
     return 0;
   }
   const volatile unsigned long long * word = reinterpret_cast<const volatile unsigned long long *>(c->h_result + 3);
-  for (unsigned int spins = 0; spins < 400000u; ++spins)
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (;;)
   {
-    if (*word == ro.seq)
+    for (unsigned int spins = 0; spins < 64u; ++spins)
     {
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      return 0;
+      if (hostsum ? pllhip_host_partials_landed(c, ro.seq) : *word == ro.seq)
+      {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (hostsum) pllhip_host_final_sum(c);
+        return 0;
+      }
+      PLLHIP_CPU_RELAX();
     }
-    __builtin_ia32_pause();
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 200000ll) break;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  // (the stream is drained: the word has been written -- unless the memory is not coherent, in which case the
+  // values are read through the same mapping and are just as late; the copy-back path does not depend on either)
+  if (hostsum)
+  {
+    if (!pllhip_host_partials_landed(c, ro.seq))
+    {
+      pllhip_set_error("a result-returning kernel has finished but its workgroup sums are not in host memory");
+      return -1;
+    }
+    pllhip_host_final_sum(c);
+  }
   return 0;
 }
 
 int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp)
 {
-  if (ro.fused) return 0;
+  if (ro.fused || ro.host_partials) return 0;
   k_final_sum<<<1, 256, 0, c->stream>>>(ro, grid, ncomp);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -18,7 +18,10 @@ struct ReduceOut
   unsigned long long seq;
   const double * extra;    // [NCOMP] added to the finished sums (asc-bias correction) or nullptr
   int fused;               // 1: the last-arriving workgroup finishes the sum in this launch (small grids);
-                           // 0: a one-workgroup k_final_sum launch follows (measured: pllhip_reduce_out)
+                           // 0: a one-workgroup k_final_sum launch follows (measured: pllhip_reduce_out) ...
+  double2 * host_partials; // ... unless this is set (round 4): every workgroup stores {its sum, seq} -- ONE 16-byte
+                           // store -- into host-mapped memory, [NCOMP][gridDim.x], and the HOST adds them in
+                           // k_final_sum's order once every entry carries this call's seq: no second launch
 };
 
 struct LnlArgs
@@ -101,7 +104,15 @@ __device__ __forceinline__ void grid_sum(const double (&v_in)[NCOMP], const Redu
       for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) t += s_wave[cidx][w];
       if (!ro.fused)
       {
-        ro.partials[(size_t)cidx * nparts + blockIdx.x] = t;
+        if (ro.host_partials)
+        {
+          // value and sequence number travel together (a lane's 16 aligned bytes are one write): the host never
+          // sees one without the other, and nobody waits for anybody on the device
+          const pll_v2d e = {t, __longlong_as_double((long long)ro.seq)};
+          *reinterpret_cast<pll_v2d *>(ro.host_partials + (size_t)cidx * nparts + blockIdx.x) = e;
+        }
+        else
+          ro.partials[(size_t)cidx * nparts + blockIdx.x] = t;
         continue;
       }
       // write-through (sc1) store: visible at device scope without an L2 write-back
@@ -197,7 +208,7 @@ __device__ __forceinline__ double site_loglk(const LnlArgs & a, double terma, si
 
 // fills a ReduceOut from the context (host_result only when no all-reduce follows);
 // pllhip_finish_reduce launches the final pass when the kernel did not fuse it
-ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid);
+ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncomp = 1);
 int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp);
 // after the launches of a result-returning call: wait until h_result holds this call's values
 // (`stream_work_follows`: copies or a collective were enqueued behind the kernel -- wait for the stream)

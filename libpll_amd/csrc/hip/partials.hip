@@ -543,6 +543,14 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
 {
   PLLHIP_ALL_SHARDS(c, pllhip_update_partials(s, ops, count)); // (enqueued on every device; nothing waits)
   HIP_TRY(hipSetDevice(c->sh.device));
+  if (!c->rows.empty())
+  {
+    // (site repeats: which CLV each scale buffer belongs to -- a shard of a group expands its own mirrors, ctx.hip)
+    if (c->scaler_owner.size() != c->sh.scale_buffers) c->scaler_owner.assign(c->sh.scale_buffers, -1);
+    for (unsigned int i = 0; i < count; ++i)
+      if (ops[i].parent_scaler >= 0 && (unsigned int)ops[i].parent_scaler < c->sh.scale_buffers)
+        c->scaler_owner[ops[i].parent_scaler] = (int)ops[i].parent_clv;
+  }
   // Dependencies between the ops of a list follow BUFFER INDICES, not tree shape
   // (unrooted trees reuse CLV slots, partials.c:184-212).  Each op gets a level:
   // one more than the highest level among the earlier ops it must not overtake --

@@ -116,9 +116,12 @@ struct AfTipJob
 __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict__ mj, unsigned int nmat,
                                                     const AfTipJob * __restrict__ tj, unsigned int ntip,
                                                     char * aorder, char * titab,
-                                                    const unsigned int * __restrict__ tipmap, unsigned int ms)
+                                                    const unsigned int * __restrict__ tipmap, unsigned int ms,
+                                                    unsigned int * __restrict__ tile_counter)
 {
   const unsigned int b = blockIdx.x;
+  // (the list kernel's tile counter: reset here instead of by a fill kernel of its own, round 4)
+  if (b == 0 && threadIdx.x == 0) *tile_counter = 0u;
   if (b < nmat)
   {
     const double * src = mj[b].src;
@@ -129,8 +132,18 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
       if (idx < 1600 && !mj[b].plain)
       {
         const unsigned int blk = idx >> 6, lane = idx & 63u, t = blk / 5, bb = blk - 5 * t;
-        const unsigned int q = lane >> 4, rate = (lane >> 2) & 3u, i = lane & 3u;
-        const unsigned int row = t < 4 ? 4 * i + t : 16 + i, col = bb < 4 ? 4 * q + bb : 16 + q;
+        const unsigned int q = lane >> 4, i = lane & 3u;
+        unsigned int rate = (lane >> 2) & 3u;
+        unsigned int row = t < 4 ? 4 * i + t : 16 + i, col = bb < 4 ? 4 * q + bb : 16 + q;
+        if (bb == 4)
+        {
+          // (round 4) the fifth step of the four chains -- columns 16..19 -- runs on the vector unit (af_group): lane
+          // class (q, rate) reads ITS output row's four entries as 32 contiguous bytes: entry (4 (4q + rate) + m)
+          const unsigned int cls = lane >> 2, m = lane & 3u, cq = cls >> 2;
+          rate = cls & 3u;
+          row = t < 4 ? 4 * cq + t : 16 + cq;
+          col = 16 + m;
+        }
         v = src[rate * 400 + row * 20 + col];
       }
       else if (idx < 1600)
@@ -248,26 +261,48 @@ struct AfSlot
 // matrix-core latencies behind but itself (two waves per SIMD).
 struct AfAops
 {
-  double a1[4], a4;
+  double a1[4];   // A operands of the four chains' first MFMA (k-chunks {m, m+4, m+8, m+12})
+  double2 a5[2];  // the lane's own output row, columns 16..19: the chains' fifth step, on the vector unit
 };
-__device__ __forceinline__ void af_fetch_a(const char * mat_lane, int t, AfAops & a)
+__device__ __forceinline__ void af_fetch_a(const char * mat_lane, const char * mat_cls, int t, AfAops & a)
 {
 #pragma unroll
   for (int m = 0; m < 4; ++m) a.a1[m] = *reinterpret_cast<const double *>(mat_lane + (t * 5 + m) * 512);
-  a.a4 = *reinterpret_cast<const double *>(mat_lane + (t * 5 + 4) * 512);
+  a.a5[0] = *reinterpret_cast<const double2 *>(mat_cls + (t * 5 + 4) * 512);
+  a.a5[1] = *reinterpret_cast<const double2 *>(mat_cls + (t * 5 + 4) * 512 + 16);
 }
-__device__ __forceinline__ void af_group(const AfAops & a, unsigned int q, const double (&b)[AF_J][5], double (&acc)[AF_J][4])
+// Round 4: the fifth step of a chain (state 16 + m) was a second MFMA whose A operand is zero except in k-slot m --
+// half of all the matrix-core instructions of the kernel, 16 cycles each, for one useful product out of sixteen.
+// It is one FMA on the vector unit now: acc[m] = fma(P[row][16 + m], column[16 + m], acc[m]) -- the very operation the
+// zero-padded MFMA performed (its other three steps added +0 products: tools/mfma_order_probe.hip), same bits.
+// c5[j][m] = entry 16 + m of the lane's column: held by lane q' = m of the column (B operand word 4), fetched once
+// per child through the LDS crossbar (af_column_tail).
+__device__ __forceinline__ void af_group(const AfAops & a, const double (&b)[AF_J][5], const double (&c5)[AF_J][4],
+                                         double (&acc)[AF_J][4])
 {
 #pragma unroll
   for (int j = 0; j < AF_J; ++j)
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[j][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.a1[m], b[j][m], 0.0, 0, 0, 0);
+  const double a5[4] = {a.a5[0].x, a.a5[0].y, a.a5[1].x, a.a5[1].y};
+#pragma unroll
+  for (int j = 0; j < AF_J; ++j)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[j][m] = fma(a5[m], c5[j][m], acc[j][m]);
+}
+__device__ __forceinline__ void af_column_tail(const double (&b)[AF_J][5], unsigned int lane, double (&c5)[AF_J][4])
+{
 #pragma unroll
   for (int m = 0; m < 4; ++m)
   {
-    const double am = (q == (unsigned int)m) ? a.a4 : 0.0;
+    const unsigned int src = ((lane & 15u) + 16u * m) * 4u;
 #pragma unroll
-    for (int j = 0; j < AF_J; ++j) acc[j][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, b[j][4], acc[j][m], 0, 0, 0);
+    for (int j = 0; j < AF_J; ++j)
+    {
+      const int lo = __builtin_amdgcn_ds_bpermute((int)src, __double2loint(b[j][4]));
+      const int hi = __builtin_amdgcn_ds_bpermute((int)src, __double2hiint(b[j][4]));
+      c5[j][m] = __hiloint2double(hi, lo);
+    }
   }
 }
 template <bool MUL>
@@ -283,33 +318,24 @@ __device__ __forceinline__ void af_sum(const double (&acc)[AF_J][4], int t, doub
   }
 }
 template <bool MUL>
-__device__ __forceinline__ void af_matvec(const char * mat_lane, unsigned int q, const double (&b)[AF_J][5],
-                                          double (&x)[AF_J][5])
+__device__ __forceinline__ void af_matvec(const char * mat_lane, const char * mat_cls, unsigned int lane,
+                                          const double (&b)[AF_J][5], double (&x)[AF_J][5])
 {
-  AfAops a0, a1;
-  double acc0[AF_J][4], acc1[AF_J][4];
-  af_fetch_a(mat_lane, 0, a0);
-  __builtin_amdgcn_sched_barrier(0);
-  af_fetch_a(mat_lane, 1, a1);
-  af_group(a0, q, b, acc0);
-  __builtin_amdgcn_sched_barrier(0);
-  af_fetch_a(mat_lane, 2, a0);
-  af_group(a1, q, b, acc1);
-  af_sum<MUL>(acc0, 0, x);
-  __builtin_amdgcn_sched_barrier(0);
-  af_fetch_a(mat_lane, 3, a1);
-  af_group(a0, q, b, acc0);
-  af_sum<MUL>(acc1, 1, x);
-  __builtin_amdgcn_sched_barrier(0);
-  af_fetch_a(mat_lane, 4, a0);
-  af_group(a1, q, b, acc1);
-  af_sum<MUL>(acc0, 2, x);
-  __builtin_amdgcn_sched_barrier(0);
-  af_group(a0, q, b, acc0);
-  af_sum<MUL>(acc1, 3, x);
-  __builtin_amdgcn_sched_barrier(0);
-  af_sum<MUL>(acc0, 4, x);
-  __builtin_amdgcn_sched_barrier(0);
+  // One row group at a time: its A operands, eight MFMAs, eight FMAs, the sums.  (Rounds 3's version fetched the
+  // operands of group t + 1 ahead of the MFMAs of group t and deferred the sums -- worth 1 % then, and 32 registers,
+  // which the column tail and the wider fifth-step operands need now: the kernel must stay within 128, see the slots.)
+  double c5[AF_J][4];
+  af_column_tail(b, lane, c5);
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+  {
+    AfAops a;
+    double acc[AF_J][4];
+    af_fetch_a(mat_lane, mat_cls, t, a);
+    af_group(a, b, c5, acc);
+    af_sum<MUL>(acc, t, x);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // x[j][t] = tip factor * (P . column)[state 4q + t | 16 + q] in the order of the reference's TIP-INNER kernel
@@ -516,6 +542,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   const unsigned int boff = n * 640u + rate * 160u + q * 32u;        // its four states 4q.. of sub-tile 0 in a stage
   const unsigned int boff5 = n * 640u + rate * 160u + 128u + q * 8u; // state 16 + q
   const char * x0lane = lds + lane * 8u, * x1lane = lds + AF_MAT_B + lane * 8u, * ylane = lds + 2 * AF_MAT_B + lane * 8u;
+  const unsigned int cls32 = (q * 4u + rate) * 32u;                  // the lane's (q, rate) class within a fifth-step block
   const char * yrows = lds + 2 * AF_MAT_B + (q * 4u + rate) * 16u;   // the right block in row order (tip-inner ops)
   const unsigned int coloff = n * 640u + rate * 160u;                // the lane's column in a stage
   const unsigned long long sink_a = (unsigned long long)(uintptr_t)(sink + ((size_t)blockIdx.x * 4u + wave) * 4u);
@@ -794,9 +821,10 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
   {
     k_af_prepare<<<k.nmat + k.ntip, 256, 0, c->stream>>>((const AfMatJob *)(plan + k.off_mat), k.nmat,
                                                          (const AfTipJob *)(plan + k.off_tip), k.ntip, k.d_aorder,
-                                                         k.d_titab, c->tipmap, c->maxstates);
+                                                         k.d_titab, c->tipmap, c->maxstates, c->d_tile_counter);
     HIP_TRY(hipGetLastError());
   }
+  else HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
   const size_t tiles = ((size_t)c->sh.sites + AF_WGS - 1) / AF_WGS;
   size_t grid = tiles;
   const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per workgroup)
@@ -806,7 +834,6 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
                                                                             : (unsigned int)std::max<size_t>(2, rounds / 3);
   const unsigned int static_rounds = rounds > dynamic_rounds ? (unsigned int)(rounds - dynamic_rounds) : 1u;
   unsigned int * counter = getenv("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
-  HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
 #ifdef PLLHIP_AF_TIMING
   {
     const unsigned int m = getenv("PLLHIP_AF_EXP") ? (unsigned int)atoi(getenv("PLLHIP_AF_EXP")) : 0u;
@@ -891,6 +918,8 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   std::vector<std::pair<int, int>> lk_kids(count, {-1, -1});
   bool any_scaler = false;
   const bool lookups_ok = pllhip_aa_cherry_covers(c, SCALE_SITE);
+  const unsigned int lookups_max = lookups_ok ? pllhip_aa_lookup_budget(c) : 0u; // (their tables' pool is bounded)
+  unsigned int lookups = 0;
   // Tip-tip ops INSIDE the list (kind 4 below): parent = tip table of the left matrix [character 1] (.) tip table of
   // the right matrix [character 2] is what a lookup op does with two other tables, so a tip-tip op is a lookup op
   // whose tables are the two tip tables k_af_prepare builds anyway and whose "pairs" are (0, character): no code of
@@ -909,18 +938,20 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     if (kinds[i] == 2 && (clv_touched[op.parent_clv] || (op.parent_scaler >= 0 && sc_touched[op.parent_scaler]))) return 1;
     any_scaler = any_scaler || modes[i] != SCALE_NONE;
     const int plain = kinds[i];
-    if (lookups_ok && plain == 0 && tt_writer[op.child1_clv] >= 0 && tt_writer[op.child2_clv] >= 0)
+    if (lookups < lookups_max && plain == 0 && tt_writer[op.child1_clv] >= 0 && tt_writer[op.child2_clv] >= 0)
     {
       lk_kids[i] = {tt_writer[op.child1_clv], tt_writer[op.child2_clv]};
       kinds[i] = 3;
+      ++lookups;
     }
-    else if (lookups_ok && plain == 1)
+    else if (lookups < lookups_max && plain == 1)
     {
       const unsigned int inner = pllhip_is_tip(c, op.child1_clv) ? op.child2_clv : op.child1_clv;
       if (tt_writer[inner] >= 0)
       {
         lk_kids[i] = {-2, tt_writer[inner]};
         kinds[i] = 3;
+        ++lookups;
       }
     }
     tt_writer[op.parent_clv] = plain == 2 ? (int)i : -1;
@@ -1003,6 +1034,8 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   {
     rc = pllhip_aa_lookup_tables(c, k.lk_ops.data(), k.lk_k1.data(), k.lk_k2.data(), (unsigned int)k.lk_ops.size(),
                                  tabs.data());
+    // (the pool could not be allocated: once more, now without lookup ops -- the context remembers)
+    if (rc == 1 && c->cherry_pool_failed) return aa_fused_update(c, ops, count, tt_wanted);
     if (rc) return rc;
   }
   lap("lookup tables (launches)");

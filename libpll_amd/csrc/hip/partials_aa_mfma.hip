@@ -662,7 +662,7 @@ bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode)
 {
   const char * e = getenv("PLLHIP_AA_CHERRY"); // 0: never, 2: whatever the partition's size (tests)
   const bool off = e && atoi(e) == 0;
-  return !off && c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
+  return !off && !c->cherry_pool_failed && c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
          c->rows.empty() && mode != SCALE_RATE && c->maxstates >= 1 && c->maxstates <= 32 && !c->sh.asc_states;
 }
 
@@ -888,6 +888,22 @@ int pllhip_launch_aa_cherries(pllhip_ctx * c, const PartialsArgs * ops, const Pa
   return 0;
 }
 
+// How many lookup ops a list may have: their tables (4 x (maxstates^2 + 64) x rate_cats x 20 doubles each, 1.5 MB for
+// the protein alphabet) live in one pool next to the CLVs; a tree with thousands of cherries would take gigabytes
+// (ADVICE r3).  1 GiB by default (PLLHIP_AA_LOOKUP_MB), never more than 1/16 of the CLV arena's size + 64 MB; ops
+// beyond that stay ordinary inner-inner / tip-inner ops.
+unsigned int pllhip_aa_lookup_budget(const pllhip_ctx * c)
+{
+  const size_t rows = (size_t)c->maxstates * c->maxstates + PLLHIP_TAIL_SITES;
+  const size_t per_op = 4 * rows * (size_t)c->sh.rate_cats * 20 * sizeof(double);
+  size_t budget = (size_t)1 << 30;
+  if (const char * e = getenv("PLLHIP_AA_LOOKUP_MB"))
+    if (atoi(e) >= 0) budget = (size_t)atoi(e) << 20;
+  const size_t share = c->clv_arena_bytes / 16 + ((size_t)64 << 20);
+  if (budget > share) budget = share;
+  return (unsigned int)(budget / (per_op ? per_op : 1));
+}
+
 // The tables of ALL `count` lookup ops of a list at once (the whole-list kernel,
 // partials_aa_fused.hip, walks a tile of sites through every op): same builders, a pool of
 // their own that grows with the list.
@@ -908,7 +924,16 @@ int pllhip_aa_lookup_tables(pllhip_ctx * c, const PartialsArgs * ops, const Part
     c->cherry_pool_all = nullptr;
     c->cherry_pool_all_ops = 0;
     const size_t n = ((size_t)count + 15) & ~(size_t)15;
-    HIP_TRY(hipMalloc((void **)&c->cherry_pool_all, n * per_op * sizeof(double)));
+    if (hipMalloc((void **)&c->cherry_pool_all, n * per_op * sizeof(double)) != hipSuccess)
+    {
+      // Not an error of the call: the list runs without lookup ops (the caller plans it again; return value 1 =
+      // "not taken").  Remembered, so that later calls do not repeat the synchronisation, the free and the failing
+      // allocation.
+      (void)hipGetLastError();
+      c->cherry_pool_all = nullptr;
+      c->cherry_pool_failed = true;
+      return 1;
+    }
     c->cherry_pool_all_ops = (unsigned int)n;
     ++c->layout_epoch;
   }

@@ -114,10 +114,14 @@ __device__ __forceinline__ unsigned int rec_pcnt(const Rec & r) { return r.w[15]
 // list and read back by the list kernel with one 16-byte gather per lane and sub-step
 // (32 KB per op at 4 rate categories: L2-resident).  Table 0 is all zeros: what ops without a
 // tip gather from (every op issues the same loads).
+// (round 4: the launch also resets the tile counters of the list kernel behind it -- counter g is word 32 g, one
+// 128-byte line each -- which used to be a fill kernel of its own per call, 4.3 us)
 template <int RC>
-__global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedPairJob * __restrict__ jobs, unsigned int njobs)
+__global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedPairJob * __restrict__ jobs, unsigned int njobs,
+                                                         unsigned int * __restrict__ tile_counters)
 {
   const unsigned int i = blockIdx.x;
+  if (i == 0 && tile_counters) tile_counters[threadIdx.x * 32u] = 0u;
   if (i >= njobs) return;
   const double * lm = jobs[i].lmat, * rm = jobs[i].rmat;
   double * tab = jobs[i].tab;
@@ -1340,7 +1344,8 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
 {
   const unsigned int count = c->fused_last_count, nslots = c->fused_last_nslots, njobs = c->fused_last_jobs;
   const int mode = c->fused_last_mode;
-  HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, PLLHIP_TILE_COUNTER_BYTES, c->stream));
+  static_assert(PLLHIP_TILE_COUNTER_BYTES == 256 * 128, "one counter per thread of k_dna_pair_tables' first workgroup");
+  if (!njobs) HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, PLLHIP_TILE_COUNTER_BYTES, c->stream)); // (no table launch to do it)
   const FusedRec * d_plan = (const FusedRec *)c->d_plan;
   const FusedPairJob * d_jobs = (const FusedPairJob *)(static_cast<const char *>(c->d_plan) + c->fused_last_jobs_offset);
   const FusedBases bases = {c->pmatrix, c->d_pairtab,
@@ -1349,10 +1354,10 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
   {
     switch (c->sh.rate_cats)
     {
-      case 1: k_dna_pair_tables<1><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
-      case 2: k_dna_pair_tables<2><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
-      case 8: k_dna_pair_tables<8><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
-      default: k_dna_pair_tables<4><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs); break;
+      case 1: k_dna_pair_tables<1><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, c->d_tile_counter); break;
+      case 2: k_dna_pair_tables<2><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, c->d_tile_counter); break;
+      case 8: k_dna_pair_tables<8><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, c->d_tile_counter); break;
+      default: k_dna_pair_tables<4><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, c->d_tile_counter); break;
     }
     HIP_TRY(hipGetLastError());
   }

@@ -119,8 +119,19 @@ extern "C" int pllhip_identify_repeats(pllhip_ctx_t * c, unsigned int parent, un
 {
   if (!c->shards.empty())
   {
-    pllhip_set_error("site repeats are not available to a partition sharded over several devices");
-    return -1;
+    // One partition over several devices (round 4): every shard identifies the classes of ITS site range -- two
+    // sites are in one class iff their classes at both children agree, which never looks beyond the range -- with
+    // its own limit (half its sites).  The group reports 0: the host layer treats its CLVs as stored per site (the
+    // mirrors are expanded shard by shard, pllhip_get_clv); pllhip_repeats_rows counts the rows really stored.
+    pllhip_device_guard guard;
+    for (pllhip_ctx * s : c->shards)
+    {
+      unsigned int unused = 0;
+      const int rc = pllhip_identify_repeats(s, parent, child1, child2, s->sh.sites / 2, &unused);
+      if (rc) return rc;
+    }
+    *classes_out = 0;
+    return 0;
   }
   HIP_TRY(hipSetDevice(c->sh.device));
   *classes_out = 0;
@@ -208,6 +219,21 @@ extern "C" int pllhip_identify_repeats(pllhip_ctx_t * c, unsigned int parent, un
   r.classes = classes;
   *classes_out = classes;
   return 0;
+}
+
+// rows CLV slot `idx` is stored in, over all shards (its sites where a shard stores it per site); 0: nowhere by class
+extern "C" unsigned int pllhip_repeats_rows(pllhip_ctx_t * c, unsigned int idx)
+{
+  if (c->shards.empty()) return (c->rows.empty() || idx >= c->rows.size()) ? 0u : c->rows[idx].classes;
+  unsigned long long total = 0;
+  bool any = false;
+  for (pllhip_ctx * s : c->shards)
+  {
+    const unsigned int k = (s->rows.empty() || idx >= s->rows.size()) ? 0u : s->rows[idx].classes;
+    any = any || k;
+    total += k ? k : s->sh.sites;
+  }
+  return any ? (unsigned int)total : 0u;
 }
 
 extern "C" int pllhip_get_site_id(pllhip_ctx_t * c, unsigned int idx, unsigned int * h_site_id)

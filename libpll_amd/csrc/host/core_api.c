@@ -18,6 +18,7 @@
  * core_derivatives.c:125 (sumtable ii), :277 (sumtable ti), :501 (derivatives);
  * core_pmatrix.c:24.
  */
+#include <pthread.h>
 #include <stdio.h>
 
 #include "internal.h"
@@ -26,8 +27,9 @@
  * A traversal through pll_core_update_partial_tt / _ti / _ii changes shape on almost every call (tips,
  * CLVs, scale buffers differ), so ONE kept context would be torn down and rebuilt -- stream, arenas,
  * pinned buffers -- call after call.  A few are kept, least recently used out first.
- * They live until pll_amd_core_release(), which a thread that used pll_core_* should call before it
- * exits (thread-local storage has no destructor in C). */
+ * They live until pll_amd_core_release(), or until the thread exits: a pthread key's destructor releases them
+ * (six device contexts leaked per worker thread that never called the release function; the main
+ * thread's are simply still there when the process ends). */
 #define CORE_CTX_KEPT 6
 static __thread struct
 {
@@ -36,6 +38,15 @@ static __thread struct
   unsigned long long stamp;
 } t_kept[CORE_CTX_KEPT];
 static __thread unsigned long long t_clock;
+
+static pthread_key_t t_kept_key;
+static pthread_once_t t_kept_once = PTHREAD_ONCE_INIT;
+static void kept_at_thread_exit(void * unused)
+{
+  (void)unused;
+  pll_amd_core_release();
+}
+static void kept_make_key(void) { (void)pthread_key_create(&t_kept_key, kept_at_thread_exit); }
 
 void pll_amd_core_release(void)
 {
@@ -105,6 +116,9 @@ static pllhip_ctx_t * scratch(unsigned int states, unsigned int sites, unsigned 
   }
   t_kept[victim].shape = sh;
   t_kept[victim].stamp = ++t_clock;
+  /* (a non-NULL value makes the key's destructor run when this thread exits) */
+  (void)pthread_once(&t_kept_once, kept_make_key);
+  (void)pthread_setspecific(t_kept_key, (void *)t_kept);
   return t_kept[victim].ctx;
 }
 

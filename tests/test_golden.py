@@ -62,7 +62,10 @@ def host_tip_encoding(g, cmap):
     return lut[seqs], tipmap
 
 
-def check_outputs(g, pmats, clv_of, scaler_of, lnl, persite, sumtable, derivs, exact_lnl):
+def check_outputs(g, pmats, clv_of, scaler_of, lnl, persite, sumtable, derivs, exact_lnl, mfma_lnl=False):
+    """mfma_lnl: the 20-state DEFAULT path -- P-matrices, every CLV and every scaler count still bit for bit
+    (inner-inner ops on the matrix cores in the reference's order, tip-inner ops on the vector unit); the
+    edge-lnL and sumtable kernels add a row's products in one fused chain: last-bit differences there."""
     S = g["states"]
     exact = S in (4, 20, 5)
     for i in range(len(g["matrix_indices"])):
@@ -73,12 +76,12 @@ def check_outputs(g, pmats, clv_of, scaler_of, lnl, persite, sumtable, derivs, e
         if int(op["parent_scaler_index"]) >= 0:
             assert (scaler_of(int(op["parent_scaler_index"])) == g["scalers"][i]).all(), "scaler %d" % i
     if exact:
-        assert rel_err(persite, g["persite_lnl"]) < 1e-13
+        assert rel_err(persite, g["persite_lnl"]) < (1e-11 if mfma_lnl else 1e-13)
     if exact_lnl:
         assert lnl == float(g["lnl"])
     else:
-        assert abs(lnl - float(g["lnl"])) <= 1e-12 * abs(float(g["lnl"]))
-    assert sumtable_err(sumtable, g["sumtable"]) < 1e-12
+        assert abs(lnl - float(g["lnl"])) <= (1e-11 if mfma_lnl else 1e-12) * abs(float(g["lnl"]))
+    assert sumtable_err(sumtable, g["sumtable"]) < (1e-10 if mfma_lnl else 1e-12)
     assert rel_err(derivs, g["deriv"]) < 1e-10
 
 
@@ -110,13 +113,19 @@ def test_oracle_matches_golden(orc, amd, path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("aa_path", ["default", "vector-kernels"])
 @pytest.mark.parametrize("path", FIXTURES, ids=IDS)
-def test_hip_matches_golden(gpu, path, monkeypatch, dna_path):
+def test_hip_matches_golden(gpu, path, monkeypatch, dna_path, aa_path):
     """The product, driven exactly like a reference client, reproduces the
-    reference's stored outputs."""
+    reference's stored outputs -- 20-state fixtures on the DEFAULT path (matrix cores; round 4: every CLV and
+    scaler count bit for bit there too) and on the all-vector kernels (PLLHIP_AA_EXACT=1: per-site lnL
+    bit for bit as well)."""
     g = load(path)
     S, R, plan = g["states"], g["rate_cats"], g["plan"]
-    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")   # the stored outputs are compared bit for bit
+    if S != 20 and aa_path != "default":
+        pytest.skip("PLLHIP_AA_EXACT only affects 20-state kernels")
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "1" if aa_path == "vector-kernels" else "0")
+    monkeypatch.setenv("PLLHIP_AA_CHERRY", "2")  # (the table-lookup ops also for these small partitions)
     p = gpu.partition_create(plan.tips, plan.clv_buffers, S, g["sites"], 1, plan.prob_matrices, R,
                              plan.scale_buffers, g["attributes"])
     p.set_frequencies(0, g["freqs"])
@@ -143,5 +152,6 @@ def test_hip_matches_golden(gpu, path, monkeypatch, dna_path):
     d = np.array([p.compute_likelihood_derivatives(e[1], e[3], float(t), [0] * R, st)
                   for t in g["deriv_t"]])
     check_outputs(g, [p.get_pmatrix(int(m)) for m in plan.matrix_indices], p.get_clv,
-                  p.get_scaler, lnl, ps, p.get_sumtable(st), d, exact_lnl=False)
+                  p.get_scaler, lnl, ps, p.get_sumtable(st), d, exact_lnl=False,
+                  mfma_lnl=(S == 20 and aa_path == "default" and R in (1, 2, 4)))
     p.destroy()

@@ -165,3 +165,47 @@ def test_config5_slice_against_reference(gpu, ref, c5_data, repeats):
     assert rel_err(np.array(da), np.array(dr)) < 1e-10, (da, dr)
     a.destroy()
     r.destroy()
+
+
+# ---- BASELINE config 3 (20-state LG, 4 rates, 64 taxa) and the same data on a 200-taxon random tree: slices
+# against the GENUINE REFERENCE on the DEFAULT path (until round 4 every 20-state check that was
+# tied to the reference itself ran the non-default vector kernels)
+@pytest.fixture(scope="module", params=["balanced-64", "random-200"])
+def c3_data(request, gpu):
+    plan = W.balanced_tree(64, seed=42) if request.param == "balanced-64" else W.random_tree(200, seed=42)
+    rates, freqs = gpu.aa_model("lg")
+    seqs = W.simulated_alignment(plan, 50_000, rates, freqs, gpu.compute_gamma_cats(W.GAMMA_ALPHA, R), seed=42)
+    return request.param, plan, seqs
+
+
+@pytest.mark.parametrize("path", ["whole-list", "levels"])
+def test_config3_slice_against_reference(gpu, ref, c3_data, monkeypatch, path):
+    """50,000 sites of C3 -- and of an LG alignment on a 200-taxon random tree: tip-inner ops, scaling events,
+    evictions -- through the genuine reference (AVX2 flag) and through the product's DEFAULT 20-state path, whole
+    list and per level: the scale buffer of EVERY op bitwise, CLVs bitwise (every fifth op and the last five: a
+    CLV is 32 MB), per-site lnL to 1e-11 (the edge kernel on the matrix cores sums a row in one fused chain),
+    lnL to 1e-12."""
+    name, plan, seqs = c3_data
+    monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
+    monkeypatch.setenv("PLLHIP_FUSED", "2" if path == "whole-list" else "0")
+    a = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP)
+    r = W.setup_partition(ref, plan, seqs, 20, R, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2)
+    a.update_partials(plan.ops)
+    a.update_partials(plan.ops)     # (the same list again: the whole-list plan with its tip-tip ops inside)
+    r.update_partials(plan.ops)
+    top = 0
+    for i, op in enumerate(plan.ops):
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        rs = r.get_scaler(sc)
+        assert (a.get_scaler(sc) == rs).all(), "%s: scale buffer of op %d" % (name, i)
+        top = max(top, int(rs.max()))
+        if i % 5 == 0 or i >= len(plan.ops) - 5:
+            assert bits_equal(a.get_clv(node), r.get_clv(node)), "%s: CLV of op %d" % (name, i)
+    if name == "random-200":
+        assert top >= 1, "the 200-taxon tree was meant to scale"
+    la, pa = a.compute_edge_loglikelihood(*plan.root_edge, FI, persite=True)
+    lr, pr = r.compute_edge_loglikelihood(*plan.root_edge, FI, persite=True)
+    assert rel_err(pa, pr) < 1e-11
+    assert abs(la - lr) <= 1e-12 * abs(lr)
+    a.destroy()
+    r.destroy()

@@ -57,7 +57,7 @@ def bind(lib):
                           (20, "random", 9, 150, True, False), (20, "balanced", 8, 97, False, True),
                           (5, "random", 9, 120, True, False)])
 def test_tree_through_core_api(gpu, orc, monkeypatch, states, shape, tips, sites, pattern_tip, rate_scalers):
-    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")
+    monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)   # (the default path: 20 states on the matrix cores)
     L = bind(gpu)
     if states in (4, 20):
         case = make_case(states, shape, tips, sites, seed=tips * 7 + sites)

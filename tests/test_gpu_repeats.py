@@ -94,7 +94,7 @@ def test_repeats_against_the_oracle(gpu, orc, monkeypatch, states, shape, tips, 
     """Not a self-comparison: the partition WITH site repeats against liboracle.so directly
     (which knows nothing of repeats) -- expanded CLVs and scale buffers of every op bitwise,
     per-site lnL to 1e-13, lnL, sumtable and derivatives to the tolerances of the plain tests."""
-    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")   # compare CLVs bit for bit
+    monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)   # (the default path: CLVs are bit for bit there too)
     case = make_case(states, shape, tips, sites, rate_cats=rate_cats, seed=3 * tips + sites, gap_frac=0.02)
     rng = np.random.default_rng(sites + 1)
     pool = rng.integers(0, sites, size=sites // 5 + 1)

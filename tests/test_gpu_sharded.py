@@ -82,7 +82,7 @@ def assert_same(a, b):
                           (20, "balanced", 8, 777, ATTRIB_RATE_SCALERS, 0.0),
                           (7, "random", 9, 1100, ATTRIB_PATTERN_TIP, 0.0)])
 def test_sharded_equals_unsharded(gpu, orc, monkeypatch, states, shape, tips, sites, attrs, pinv):
-    monkeypatch.setenv("PLLHIP_AA_EXACT", "1")
+    monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)   # (the default path: 20 states on the matrix cores)
     monkeypatch.setenv("PLLHIP_FUSED", "2")     # 4 states: the whole-list kernel also on these small shards
     if states in (4, 20):
         case = make_case(states, shape, tips, sites, seed=tips + sites)
@@ -188,9 +188,7 @@ def test_sharded_ascertainment_bias(gpu, kind):
 def test_sharded_refusals(gpu):
     case = make_case(4, "balanced", 8, 600, seed=1)
     with devices(gpu, [0, 0]):
-        with pytest.raises(PllError):
-            build_partition(gpu, case, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)
-        assert gpu.errno() == 202
+        # (site repeats over several devices: available since round 4, test_sharded_with_site_repeats)
         p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
     with pytest.raises(PllError):
         p.comm_init(0, 1, b"\0" * 128)
@@ -231,3 +229,43 @@ def test_sharded_at_config_2_size(gpu):
         p.destroy()
     assert bits_equal(res[0][1], res[1][1])
     assert abs(res[0][0] - res[1][0]) <= 1e-12 * abs(res[0][0])
+
+
+@pytest.mark.parametrize("states,shape,tips,sites,rate_scalers",
+                         [(4, "random", 20, 3001, False), (4, "balanced", 16, 2000, True), (20, "random", 12, 900, False)])
+def test_sharded_with_site_repeats(gpu, monkeypatch, states, shape, tips, sites, rate_scalers):
+    """One partition over several devices WITH PLL_ATTRIB_SITE_REPEATS (round 4; BASELINE config 4's split and
+    config 5's feature together): every shard identifies the classes of its own site range, and everything a
+    client can observe -- expanded CLVs and scale buffers, per-site lnL, sumtable bitwise; lnL, derivatives --
+    equals the unsharded PLAIN partition.  Repeated columns make most nodes stored by class on every shard."""
+    monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
+    case = make_case(states, shape, tips, sites, seed=tips + sites, gap_frac=0.02)
+    rng = np.random.default_rng(sites)
+    pool = rng.integers(0, sites, size=sites // 6 + 1)
+    pick = pool[rng.integers(0, len(pool), size=sites)]
+    case["seqs"] = [bytes(np.frombuffer(s, dtype=np.uint8)[pick]) for s in case["seqs"]]
+    plan, R = case["plan"], case["rate_cats"]
+    attrs = ATTRIB_PATTERN_TIP | (ATTRIB_RATE_SCALERS if rate_scalers else 0)
+    plain = build_partition(gpu, case, attrs)
+    whole = full_state(plain, plan, R)
+    plain.destroy()
+    for devs in device_lists(gpu):
+        with devices(gpu, devs):
+            p = build_partition(gpu, case, attrs | ATTRIB_SITE_REPEATS)
+        assert gpu.lib.pll_amd_shard_count(p.ptr) > 1
+        got = full_state(p, plan, R)
+        assert_same(got, whole)
+        rows = [p.repeats_classes(int(op["parent_clv_index"])) for op in plan.ops]
+        assert sum(1 for r in rows if 0 < r < sites) > len(plan.ops) // 2, "most nodes are stored by class"
+        # a topology-neutral change (branch length) and a tip change, then again: still the plain partition's values
+        changed = int(plan.ops[0]["parent_clv_index"])
+        p.update_prob_matrices([0] * R, [changed], [0.41])
+        q = build_partition(gpu, case, attrs)
+        q.update_prob_matrices([0] * R, [changed], [0.41])
+        for x in (p, q):
+            x.update_partials(plan.ops)
+        a = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+        b = q.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+        assert bits_equal(a[1], b[1]) and abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+        p.destroy()
+        q.destroy()

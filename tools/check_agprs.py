@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """The 20-state whole-list kernel (partials_aa_fused.hip) keeps its slots in the accumulation registers
-a0..a109, which only its own inline assembly may touch.  This compiles the file to assembly with the
-Makefile's flags and checks that no instruction outside an inline-assembly block names one of them.
+a0..a109, which only its own inline assembly may touch.  This checks that no instruction outside an
+inline-assembly block names one of them -- in the assembly file given as argument (the Makefile passes the
+-save-temps output of the compilation that makes the object: a hit fails the build), or, without one, in a
+compilation of its own with the Makefile's flags.  Scratch use by the kernel fails too: what is spilled at 128
+registers is what the compiler next parks in the accumulation registers.
 Exit status 0 = clean.  (hipcc cross-compiles: no GPU needed.)"""
 import os
 import re
@@ -13,14 +16,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    src = os.path.join(ROOT, "libpll_amd", "csrc", "hip", "partials_aa_fused.hip")
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "af.s")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-               "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + os.path.join(ROOT, "include"),
-               "-I" + os.path.join(ROOT, "libpll_amd", "csrc", "hip"), "-S", "--cuda-device-only", "-o", out, src]
-        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-        text = open(out).read()
+    # with a path: the assembly the build has just produced (Makefile, -save-temps of the very compilation that
+    # makes the object); without: compile here with the Makefile's flags for gfx950
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    allow_scratch = "--allow-scratch" in sys.argv   # (tool builds with cycle stamps keep their tables in scratch)
+    if args:
+        text = open(args[0]).read()
+    else:
+        src = os.path.join(ROOT, "libpll_amd", "csrc", "hip", "partials_aa_fused.hip")
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "af.s")
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+                   "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
+                   "-I" + os.path.join(ROOT, "include"),
+                   "-I" + os.path.join(ROOT, "libpll_amd", "csrc", "hip"), "-S", "--cuda-device-only", "-o", out, src]
+            subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+            text = open(out).read()
     bad, in_asm, kernel = [], False, None
     reg = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
     kernels = 0
@@ -40,10 +51,13 @@ def main():
                     bad.append((n, line.strip()))
         if line.strip() == "s_endpgm":
             kernel = None
-    print("%d kernels checked, %d instructions outside the slot assembly touch a0..a109" % (kernels, len(bad)))
+    scratch = [l.strip() for l in text.splitlines() if ".private_segment_fixed_size:" in l and l.split(":")[1].strip() != "0"]
+    # (k_af_prepare and k_aa_fused<...> are all the kernels of the file: none may use scratch)
+    print("%d kernels checked, %d instructions outside the slot assembly touch a0..a109, %d kernels with scratch"
+          % (kernels, len(bad), len(scratch)))
     for n, line in bad[:10]:
         print("  line %d: %s" % (n, line))
-    return 1 if bad or kernels == 0 else 0
+    return 1 if bad or (scratch and not allow_scratch) or kernels == 0 else 0
 
 
 if __name__ == "__main__":

@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--parent-gpu", type=int, default=1, help="the parent keeps a partition alive on the GPU")
     ap.add_argument("--exact", default="both", choices=["both", "0", "1"])
     ap.add_argument("--malloc-check", type=float, default=0.33, help="share of the runs with MALLOC_CHECK_=3")
+    ap.add_argument("--spin", default="mix", choices=["mix", "0", "1"], help="PLLHIP_SPIN of the runs (mix: 0 in a quarter)")
+    ap.add_argument("--env", action="append", default=[], help="KEY=VALUE for every run (may repeat)")
     args = ap.parse_args()
 
     names = [t for t in TESTS if t not in args.skip.split(",")]
@@ -87,8 +89,8 @@ def main():
             log.write(s + "\n")
             log.flush()
 
-    say("== crash_soak: %d runs, %d workers, %d (program, mode) combinations, seed %d, parent_gpu %d, exact %s"
-        % (args.runs, args.workers, len(combos), args.seed, args.parent_gpu, args.exact))
+    say("== crash_soak: %d runs, %d workers, %d (program, mode) combinations, seed %d, parent_gpu %d, exact %s, spin %s, env %s"
+        % (args.runs, args.workers, len(combos), args.seed, args.parent_gpu, args.exact, args.spin, args.env))
 
     def worker(w):
         rng = random.Random(args.seed * 1000 + w)
@@ -104,7 +106,9 @@ def main():
             knobs["MALLOC_PERTURB_"] = str(rng.randrange(1, 256))
             if rng.random() < args.malloc_check:
                 knobs["MALLOC_CHECK_"] = "3"
-            knobs["PLLHIP_SPIN"] = "0" if rng.random() < 0.25 else "1"
+            knobs["PLLHIP_SPIN"] = args.spin if args.spin != "mix" else ("0" if rng.random() < 0.25 else "1")
+            for kv in args.env:
+                knobs[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
             knobs["PLLHIP_AA_EXACT"] = {"both": str(rng.randrange(2)), "0": "0", "1": "1"}[args.exact]
             knobs["SEGV_BACKTRACE_MAPS"] = "1"
             env.update(knobs)
