@@ -10,9 +10,14 @@ pll_operation_t (all rate categories and states, scaler included).
 
 Workload at N=1 = BASELINE.json configs[1]: 4-state GTR, 4 Gamma rates,
 1,000,000 synthetic sites, 64-taxon balanced tree, PLL_ATTRIB_PATTERN_TIP,
-per-site scalers.  For N>1 every rank holds its own 1,000,000-site shard of an
+per-site scalers.  For N>1 every rank holds its own 1,000,000-site range of ONE
 N x 1,000,000-site alignment (weak scaling, no data-path collective; one
-8-byte RCCL all-reduce of lnL per step).
+8-byte RCCL all-reduce of lnL per step).  The alignment is defined in blocks of
+250,000 sites (block b: seed 42 + b; libpll_amd/workload.py: global_alignment), each
+rank makes only its own columns, and what the N GPUs compute is CHECKED (round 4):
+every rank evaluates its whole range with the reference on the CPU before it
+touches the GPU, the values are summed over the ranks, and
+`lnl_rel_err_vs_reference` compares the product's all-reduced lnL with that sum.
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself -- a fresh
 `python -m torch.distributed.run` child, before this process has touched a GPU -- and fails if
@@ -20,7 +25,10 @@ fewer than N devices are visible.  The line also carries `c4_strong`: BASELINE c
 (8,000,000 sites, 128 taxa) as a strong-scaling job -- at N=1 (default workload only, ~5 s) the
 whole alignment on this GPU, the one-GPU point of the curve; for N>1 divided over the N GPUs, with
 the speed-up against the whole alignment evaluated on rank 0's GPU IN THE SAME RUN (boxes differ by
-10-20 %; --no-c4-one-gpu falls back to a recorded figure and says so), and per-rank step times.
+10-20 %; --no-c4-one-gpu falls back to a recorded figure and says so), and per-rank step times.  Rank r's
+columns are a slice of the alignment rank 0 evaluates whole (four distinct 250,000-site blocks in turn), so
+`c4_strong.lnl` must equal `c4_strong.one_gpu_lnl` to rounding (`lnl_vs_one_gpu_rel`, `lnl_consistent`), and
+`lnl_check_vs_reference` compares it with the sum of the ranks' reference values.
 `--in-process` instead drives the N GPUs from ONE process through the library's own sharding of
 a partition (PLL_AMD_DEVICES; host sum of the per-device lnL, no RCCL).
 
