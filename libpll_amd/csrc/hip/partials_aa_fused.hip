@@ -95,6 +95,7 @@ constexpr unsigned int AF_RELOAD_B = 128u;
 constexpr unsigned int AF_SYNC_LEFT = 2048u;   // an inner-inner op behind a lookup: a barrier of its own ahead of the left products
 constexpr unsigned int AF_ZERO_COUNTS = 1024u; // (bits 8-9: the next op's kind) a tip-tip op inside the list: never
                                                // scales, but clears its scale buffer (core_partials_avx.c:598-599)
+constexpr unsigned int AF_ONE_TABLE = 4096u;   // a lookup with ONE table (round 4: a tip-tip op's pair table): nothing to multiply
 
 struct AfMatJob
 {
@@ -107,6 +108,16 @@ struct AfTipJob
   const double * lmat;          // the tip's matrices
   unsigned long long dst_off;   // bytes into the tip-table buffer
 };
+// Round 4: a tip-tip op of the list as ONE gather.  parent = tip table of the left matrix [character 1] (.) tip table
+// of the right matrix [character 2] depends on the two characters only: maxstates^2 rows of 640 bytes, tabulated per
+// op by k_af_prepare with the very multiplication the list kernel did per site (same bits).  The op then gathers one
+// row per site instead of two and multiplies nothing: half the gather instructions and LDS reads of a tip-tip op --
+// and the texture path is what the lock-step of a workgroup's waves queues on.
+struct AfPairJob
+{
+  const double * lmat, * rmat;
+  unsigned long long dst_off;   // bytes into the pair-table buffer
+};
 
 // ---- per list: every matrix block of the list in operand order, every tip table
 // Operand order: 25 blocks of 64 doubles, block (t, b), t = row group, b = 0..3 the first MFMA of
@@ -117,7 +128,8 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
                                                     const AfTipJob * __restrict__ tj, unsigned int ntip,
                                                     char * aorder, char * titab,
                                                     const unsigned int * __restrict__ tipmap, unsigned int ms,
-                                                    unsigned int * __restrict__ tile_counter)
+                                                    unsigned int * __restrict__ tile_counter,
+                                                    const AfPairJob * __restrict__ pj, unsigned int npair, char * pairtab)
 {
   const unsigned int b = blockIdx.x;
   // (the list kernel's tile counter: reset here instead of by a fill kernel of its own, round 4)
@@ -168,6 +180,22 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
     {
       const unsigned int code = t / 80, ki = t - 80 * code;
       out[t] = masksum_seq(lmat + (size_t)ki * 20, tipmap[code], 20);
+    }
+  }
+  else if (b - nmat - ntip < npair * ms)
+  {
+    // one workgroup per (op, character 1): row (c1 ms + c2) = left factor of c1 (.) right factor of c2 -- the two
+    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds
+    const unsigned int job = (b - nmat - ntip) / ms, c1 = (b - nmat - ntip) - job * ms;
+    const AfPairJob & j = pj[job];
+    __shared__ double left[80];
+    if (threadIdx.x < 80) left[threadIdx.x] = masksum_seq(j.lmat + (size_t)threadIdx.x * 20, tipmap[c1], 20);
+    __syncthreads();
+    double * out = reinterpret_cast<double *>(pairtab + j.dst_off) + (size_t)c1 * ms * 80;
+    for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
+    {
+      const unsigned int c2 = t / 80, ki = t - 80 * c2;
+      out[t] = left[ki] * masksum_seq(j.rmat + (size_t)ki * 20, tipmap[c2], 20);
     }
   }
 }
@@ -570,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     if ((r1[18] & AF_KIND_MASK) <= 1u) stage_matrix(ybuf_b, r1[17]);
     if (((r1[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x1buf_b, r1[16]);
   }
-  unsigned int ch_p[4], ch_q[4]; // tip characters of the next op / the op after next, in turn: lane l holds those of site l & 7
+  unsigned int ch_p, ch_q; // tip characters of the next op / the op after next, in turn: lane l holds row (l >> 3) & 3, site l & 7
   for (size_t round = 0;; ++round)
   {
     // a workgroup's first tiles are its own by a fixed stride, the last rounds' worth come from a
@@ -616,22 +644,31 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     tmp.c[1] = cj[1];                                              \
     AF_SLOT_WRITE(slot, tmp)                                       \
   }
-    // the tip characters of the op BEHIND record r (words 8..15: its four rows)
-    auto request_chars = [&](const AfW<0, 28> & r, unsigned int (&c)[4]) __attribute__((always_inline)) {
-      unsigned int l7 = lane & 7u;
-      asm volatile("" : "+v"(l7)); // (see the stores: keeps the address "scalar base + lane offset")
+    // the tip characters of the op BEHIND record r (words 8..15: its four rows), ONE load (round 4: they were four,
+    // and every vector-memory instruction of this kernel queues behind the other waves' on the texture path): lane l
+    // takes the character of row (l >> 3) & 3 at site l & 7 of the tile; af_chars deals them out
+    auto request_chars = [&](const AfW<0, 28> & r, unsigned int & c) __attribute__((always_inline)) {
+      const unsigned int sel = (lane >> 3) & 3u;
+      const unsigned long long base = sel == 0u ? r.quad(8) : sel == 1u ? r.quad(10) : sel == 2u ? r.quad(12) : r.quad(14);
+      c = *(const unsigned char PLL_GLOBAL *)(base + site0 + (lane & 7u));
+    };
+    // character of row k at the lane's own site (l & 7) of the tile
+    auto af_chars = [&](unsigned int c, unsigned int (&ch)[4]) __attribute__((always_inline)) {
+      const unsigned int l7 = lane & 7u;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) c[k] = *(const unsigned char PLL_GLOBAL *)(af_base(r.quad(8 + 2 * k) + site0) + l7);
+      for (unsigned int k = 0; k < 4; ++k) ch[k] = (unsigned int)__shfl((int)c, (int)(8u * k + l7), 64);
     };
     // what an op of kind `nkind` gathers an op ahead, with its characters (in ch): a lookup its
     // table entries -- LDS-DMA with one address per lane, straight into the two stages in the
     // layout of the stores --, a tip-inner op the tip's factor (a row of its table per site, into stage 1)
-    auto next_gathers = [&](unsigned int nkind, unsigned long long tab_l, unsigned long long tab_r, const unsigned int (&ch)[4]) __attribute__((always_inline)) {
+    auto next_gathers = [&](unsigned int nkind, bool one_table, unsigned long long tab_l, unsigned long long tab_r, unsigned int chars) __attribute__((always_inline)) {
       if (AF_EXP(4u)) return;
       if (nkind == 2u)
       {
         unsigned int lane_l = lane;
         asm volatile("" : "+v"(lane_l)); // (site and column of five granules: recomputed, not kept)
+        unsigned int ch[4];
+        af_chars(chars, ch);
         unsigned int c1 = ch[0], c2 = ch[1], c3 = ch[2], c4 = ch[3];
         if (c1 >= ms) c1 = 0;
         if (c2 >= ms) c2 = 0;
@@ -649,14 +686,14 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
           o2[it] = (q2 * 40u + rr) * 16u;
         }
         af_dma_gather5(st0_b, tab_l, o1);
-        af_dma_gather5(st1_b, tab_r, o2);
+        if (!one_table) af_dma_gather5(st1_b, tab_r, o2);
       }
       else if (nkind == 1u)
       {
         // the tip's factor: row `code` of its table is 640 bytes laid out like a site of a CLV
         unsigned int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
-        unsigned int c1 = ch[0];
+        unsigned int c1 = (unsigned int)__shfl((int)chars, (int)(lane & 7u), 64);
         if (c1 >= ms) c1 = 0;
         unsigned int o1[5];
 #pragma unroll
@@ -692,7 +729,10 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
       }
       request_chars(h, ch_p); // op 0's
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      next_gathers(__builtin_amdgcn_readfirstlane(rc_a[18]) & AF_KIND_MASK, rc_a.quad(4), rc_a.quad(6), ch_p);
+      {
+        const unsigned int f0 = __builtin_amdgcn_readfirstlane(rc_a[18]);
+        next_gathers(f0 & AF_KIND_MASK, (f0 & AF_ONE_TABLE) != 0u, rc_a.quad(4), rc_a.quad(6), ch_p);
+      }
       // op 1's (used at the end of op 0): a record names the rows of the op after next, the last op's those of op 1
       const AfW<8, 8> r1 = af_load<8, 8>(plan, nops);
       AfW<0, 28> rows1 = rc_a;
@@ -778,6 +818,9 @@ struct pllhip_aa_fused_cache
   size_t aorder_cap = 0;
   char * d_titab = nullptr;
   size_t titab_cap = 0;
+  char * d_pairtab = nullptr;          // pair tables of the list's tip-tip ops (AfPairJob)
+  size_t pairtab_cap = 0, off_pair = 0;
+  unsigned int npair = 0;
   bool tried_inside = false;          // the list in last_ops has been planned with its tip-tip ops inside (or found unfit for it)
 };
 
@@ -790,6 +833,7 @@ void pllhip_aa_fused_free(pllhip_ctx * c)
   if (k->done) (void)hipEventDestroy(k->done);
   if (k->d_aorder) (void)hipFree(k->d_aorder);
   if (k->d_titab) (void)hipFree(k->d_titab);
+  if (k->d_pairtab) (void)hipFree(k->d_pairtab);
   delete k;
   c->aa_fused = nullptr;
 }
@@ -817,11 +861,12 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
     if (rc) return rc;
   }
   const char * plan = static_cast<const char *>(k.d_plan);
-  if (k.nmat + k.ntip)
+  if (k.nmat + k.ntip + k.npair)
   {
-    k_af_prepare<<<k.nmat + k.ntip, 256, 0, c->stream>>>((const AfMatJob *)(plan + k.off_mat), k.nmat,
-                                                         (const AfTipJob *)(plan + k.off_tip), k.ntip, k.d_aorder,
-                                                         k.d_titab, c->tipmap, c->maxstates, c->d_tile_counter);
+    k_af_prepare<<<k.nmat + k.ntip + k.npair * c->maxstates, 256, 0, c->stream>>>(
+        (const AfMatJob *)(plan + k.off_mat), k.nmat, (const AfTipJob *)(plan + k.off_tip), k.ntip, k.d_aorder,
+        k.d_titab, c->tipmap, c->maxstates, c->d_tile_counter, (const AfPairJob *)(plan + k.off_pair), k.npair,
+        k.d_pairtab);
     HIP_TRY(hipGetLastError());
   }
   else HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
@@ -1042,8 +1087,15 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   std::vector<AaRec> recs(n + 2);
   std::vector<AfMatJob> mj;
   std::vector<AfTipJob> tj;
+  std::vector<AfPairJob> pj;
+  std::vector<unsigned int> tt_pair_pos;
   memset(recs.data(), 0, recs.size() * sizeof(AaRec));
   const size_t tip_tab_b = (size_t)c->maxstates * 80 * sizeof(double);
+  const size_t pair_tab_b = (size_t)c->maxstates * tip_tab_b;
+  // (the pool of the pair tables shares the lookup tables' budget: what the lookups of this list left of it)
+  const bool pairs_on = !(getenv("PLLHIP_AA_TT_PAIRS") && atoi(getenv("PLLHIP_AA_TT_PAIRS")) == 0);
+  const size_t lookup_tab_b = 4 * ((size_t)c->maxstates * c->maxstates + PLLHIP_TAIL_SITES) * 80 * sizeof(double);
+  const size_t pair_budget_b = !pairs_on ? 0 : (size_t)(lookups_max > lookups ? lookups_max - lookups : 0) * lookup_tab_b;
   const unsigned long long zero_row = (unsigned long long)(uintptr_t)c->fused_zero_row;
   k.mode = any_scaler ? SCALE_SITE : SCALE_NONE;
   auto slot4 = [](int s) { return (unsigned int)(s > 0 ? s : 0) & 15u; };
@@ -1104,9 +1156,20 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       r.tab_l = (unsigned long long)(tj.size() * tip_tab_b); // (made absolute below)
       tj.push_back(AfTipJob{f.lmat, (unsigned long long)(tj.size() * tip_tab_b)});
     }
-    if (tt_op)
+    if (tt_op && (pj.size() + 1) * pair_tab_b <= pair_budget_b)
     {
-      // (offsets into the tip tables, made absolute below; "pair" (0, character) is row `character`)
+      // ONE table over the character pairs (AfPairJob; offset made absolute below): row c1 ms + c2
+      r.tab_l = (unsigned long long)(pj.size() * pair_tab_b);
+      pj.push_back(AfPairJob{args[oi].lmat, args[oi].rmat, (unsigned long long)(pj.size() * pair_tab_b)});
+      r.flags |= AF_ONE_TABLE;
+      o.row[0] = (unsigned long long)(uintptr_t)args[oi].ltip;
+      o.row[1] = (unsigned long long)(uintptr_t)args[oi].rtip;
+      tt_pair_pos.push_back(pos);
+    }
+    else if (tt_op)
+    {
+      // (beyond the pool's budget: the two tip tables, multiplied per site.  Offsets into the tip tables, made
+      // absolute below; "pair" (0, character) is row `character`)
       r.tab_l = (unsigned long long)(tj.size() * tip_tab_b);
       tj.push_back(AfTipJob{args[oi].lmat, (unsigned long long)(tj.size() * tip_tab_b)});
       r.tab_r = (unsigned long long)(tj.size() * tip_tab_b);
@@ -1164,6 +1227,15 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     k.titab_cap = (tj.size() + 1) * tip_tab_b * 2;
     HIP_TRY(hipMalloc((void **)&k.d_titab, k.titab_cap));
   }
+  if (k.pairtab_cap < (pj.size() + 1) * pair_tab_b)
+  {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (k.d_pairtab) HIP_TRY(hipFree(k.d_pairtab));
+    k.d_pairtab = nullptr;
+    k.pairtab_cap = (pj.size() + 1) * pair_tab_b;
+    HIP_TRY(hipMalloc((void **)&k.d_pairtab, k.pairtab_cap));
+  }
+  for (unsigned int pos : tt_pair_pos) recs[pos + 1].tab_l += (unsigned long long)(uintptr_t)k.d_pairtab;
   for (unsigned int pos = 0; pos < n; ++pos)
     if ((recs[pos + 1].flags & AF_KIND_MASK) == 1u) recs[pos + 1].tab_l += (unsigned long long)(uintptr_t)k.d_titab;
   for (unsigned int pos : tt_inside_pos)
@@ -1173,8 +1245,8 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   }
 
   const size_t rec_b = recs.size() * sizeof(AaRec), mat_b = (mj.size() + 1) * sizeof(AfMatJob),
-               tip_b = (tj.size() + 1) * sizeof(AfTipJob);
-  const size_t bytes = rec_b + mat_b + tip_b;
+               tip_b = (tj.size() + 1) * sizeof(AfTipJob), pair_b = (pj.size() + 1) * sizeof(AfPairJob);
+  const size_t bytes = rec_b + mat_b + tip_b + pair_b;
   if (k.plan_cap < bytes)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1192,11 +1264,14 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   memcpy(stage, recs.data(), rec_b);
   if (!mj.empty()) memcpy(stage + rec_b, mj.data(), mj.size() * sizeof(AfMatJob));
   if (!tj.empty()) memcpy(stage + rec_b + mat_b, tj.data(), tj.size() * sizeof(AfTipJob));
+  if (!pj.empty()) memcpy(stage + rec_b + mat_b + tip_b, pj.data(), pj.size() * sizeof(AfPairJob));
   HIP_TRY(hipMemcpyAsync(k.d_plan, k.h_plan, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(k.done, c->stream));
   k.pending = true;
   k.off_mat = rec_b;
   k.off_tip = rec_b + mat_b;
+  k.off_pair = rec_b + mat_b + tip_b;
+  k.npair = (unsigned int)pj.size();
   k.nmat = (unsigned int)mj.size();
   k.ntip = (unsigned int)tj.size();
   k.nops = n;
@@ -1206,7 +1281,8 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     for (unsigned int pos = 0; pos < n; ++pos) synced += (recs[pos + 1].flags & AF_SYNC_LEFT) ? 1u : 0u;
     fprintf(stderr, "pllhip 20-state list kernel: %u ops = %zu tip-tip ahead + %zu tip-tip in the list + %zu lookups + %zu on the matrix cores "
                     "(%u of them behind a lookup: a barrier more), %u operands reloaded\n",
-            count, k.tt_ops.size(), tt_inside_pos.size(), k.lk_ops.size(), (size_t)n - k.lk_ops.size() - tt_inside_pos.size(), synced, reloads);
+            count, k.tt_ops.size(), tt_inside_pos.size() + tt_pair_pos.size(), k.lk_ops.size(),
+            (size_t)n - k.lk_ops.size() - tt_inside_pos.size() - tt_pair_pos.size(), synced, reloads);
   }
   lap("encode + upload");
   rc = aa_fused_launch(c, true);

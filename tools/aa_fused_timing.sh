@@ -5,7 +5,7 @@
 #   bash tools/aa_fused_timing.sh            (on the GPU box)
 lib=build/aftiming/libpll_amd.so
 if [ "$1" = build ]; then
-  make -s -j8 BUILD=build/aftiming OUT=$lib EXTRA_HIPFLAGS=-DPLLHIP_AF_TIMING AGPR_CHECK_FLAGS=--allow-scratch lib
+  make -s -j8 BUILD=build/aftiming OUT=$lib EXTRA_HIPFLAGS=-DPLLHIP_AF_TIMING AGPR_CHECK_FLAGS="--allow-scratch --report-only" lib
   exit $?
 fi
 for cfg in "c3 --states 20 --taxa 64 --sites 200000" "c3_random --states 20 --taxa 64 --sites 200000 --tree random"; do

@@ -20,6 +20,7 @@ def main():
     # makes the object); without: compile here with the Makefile's flags for gfx950
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     allow_scratch = "--allow-scratch" in sys.argv   # (tool builds with cycle stamps keep their tables in scratch)
+    report_only = "--report-only" in sys.argv       # (tool builds: their printf at the end of a tile uses the file freely)
     if args:
         text = open(args[0]).read()
     else:
@@ -57,6 +58,8 @@ def main():
           % (kernels, len(bad), len(scratch)))
     for n, line in bad[:10]:
         print("  line %d: %s" % (n, line))
+    if report_only:
+        return 0
     return 1 if bad or (scratch and not allow_scratch) or kernels == 0 else 0
 
 
