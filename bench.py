@@ -241,7 +241,10 @@ def main():
     # ONE alignment of total_sites columns, defined in blocks of 250,000 sites (block b: seed 42 + b), of which
     # each rank makes only its own range [lo, hi): the N-GPU job evaluates the very alignment a one-GPU job of
     # total_sites columns would, so its lnL can be checked (round 3 seeded every shard by rank: nothing to compare with)
-    seqs = W.global_alignment(plan, lo, hi, rates, freqs, cat_rates, seed=42, kind=args.alignment)
+    # (--total-sites, e.g. config 4 whole on one GPU: four distinct blocks in turn, or generating the alignment
+    # takes longer than measuring it)
+    seqs = W.global_alignment(plan, lo, hi, rates, freqs, cat_rates, seed=42, kind=args.alignment,
+                              distinct=4 if strong else 0)
     fi = [0] * R
     ops_per_eval = len(plan.ops)
 

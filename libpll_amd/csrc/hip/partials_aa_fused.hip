@@ -685,8 +685,14 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
           o1[it] = (q1 * 40u + rr) * 16u;
           o2[it] = (q2 * 40u + rr) * 16u;
         }
-        af_dma_gather5(st0_b, tab_l, o1);
-        if (!one_table) af_dma_gather5(st1_b, tab_r, o2);
+        // (a single table goes to stage 1: stage 0 is where an op transposes its result, so an inner-inner op can
+        // issue the NEXT op's one gather while it still multiplies -- partials_aa_fused_op.inc, "early")
+        if (one_table) af_dma_gather5(st1_b, tab_l, o1);
+        else
+        {
+          af_dma_gather5(st0_b, tab_l, o1);
+          af_dma_gather5(st1_b, tab_r, o2);
+        }
       }
       else if (nkind == 1u)
       {
@@ -905,29 +911,17 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
 // launches per level), < 0 on error.
 static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count, bool tt_wanted);
 
-// A list seen for the first time is planned with its tip-tip ops AHEAD of the list kernel (the cheaper plan: 30
-// ops instead of 62 for BASELINE config 3, ~50 us of host time less, and what a list with reloads runs best with);
-// when the very same list comes again -- branch-length optimisation, repeated evaluations -- it is planned once
-// more with the tip-tip ops INSIDE the list (4-5 % faster from then on, kept).  Measured on C3's partition: new
-// full traversals 2.29 ms per step either way (2.50 with every new list planned inside), the repeated list 2.07
-// instead of 2.19.
+// Where a list's tip-tip ops run.  Round 3: AHEAD of the list kernel (a launch of k_aa_tt_rounds) for a list seen
+// for the first time -- the cheaper plan then, 30 ops instead of 62 for BASELINE config 3 -- and INSIDE the list, as
+// lookups over the two tip tables, once the very same list came again, unless that plan reloaded more than one
+// operand.  Round 4: inside, always.  A tip-tip op of the list is ONE gather from its pair table now (AfPairJob) and
+// the planner takes a third of the time (bump-allocated lists): measured with the tip-tip ops ahead / inside
+// (profiles/r4_aa_tt_inside_ab.txt, one box): C3 2.10 / 1.80 ms, 64-taxon random tree 2.68 / 2.47, 200-taxon random
+// tree (26 operands reloaded with the tip-tip ops ahead: every tip-tip result a matrix op consumes) 4.49 / 4.35.
+// PLLHIP_AA_TT_INSIDE=0 puts them ahead again.
 int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count)
 {
-  if (c->aa_fused)
-  {
-    pllhip_aa_fused_cache & k = *c->aa_fused;
-    const bool same = k.last_ops.size() == count && k.epoch == c->layout_epoch && k.maxstates == c->maxstates &&
-                      !getenv("PLLHIP_FUSED_DEBUG") && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0;
-    if (same && !k.tried_inside && !getenv("PLLHIP_AA_TT_INSIDE"))
-    {
-      k.last_ops.clear(); // (plan it again)
-      const int rc = aa_fused_update(c, ops, count, true);
-      if (c->aa_fused) c->aa_fused->tried_inside = true;
-      return rc;
-    }
-  }
-  const int rc = aa_fused_update(c, ops, count, false);
-  return rc;
+  return aa_fused_update(c, ops, count, true);
 }
 
 static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count, bool tt_wanted)
@@ -1043,7 +1037,6 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   int rc = pllhip_fused_plan(geom, rops.data(), rargs.data(), rkinds.data(), n, AF_NSLOT, fplan, &reloads);
   if (rc) return rc;
   lap("plan (order, slots)");
-  if (tt_inside && !tt_env && reloads > 1) return aa_fused_update(c, ops, count, false);
 
   // ---- encode
   if (!c->fused_zero_row)

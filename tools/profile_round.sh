@@ -7,7 +7,7 @@
 # gpurun_out/<tag>/summary/ (what gets copied into profiles/) and writes the index bench.py reads
 # `roofline.traffic` from.
 set -u
-tag=${1:-r3}
+tag=${1:-r4}
 root=$(pwd)
 out=$root/gpurun_out/$tag
 sum=$out/summary
@@ -53,6 +53,22 @@ workloads() {
 }
 phase=pmc
 workloads
+# BASELINE config 4 WHOLE on this GPU (133 GB): the HBM counters of the one-GPU point of the strong-scaling curve
+# (the program directly behind "--")
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --output-format csv -d "$out/${ctr}_c4_whole" -- \
+      python3 "$root/bench.py" --total-sites 8000000 --taxa 128 --steps 3 --warmup 1 --cpu-sites 0 --no-vary --no-c4 > "$out/pmcpass_c4_whole_$ctr.json" 2> "$out/${ctr}_c4_whole.err"
+done
+python3 "$root/tools/summarize_rocprof.py" hbm "$out/FETCH_SIZE_c4_whole" "$out/WRITE_SIZE_c4_whole" "$sum/${tag}_pmc_hbm_traffic_c4_whole.csv" \
+    "python3 bench.py --total-sites 8000000 --taxa 128 --steps 3 --warmup 1 --cpu-sites 0 --no-vary --no-c4"
+rm -rf "$out/FETCH_SIZE_c4_whole" "$out/WRITE_SIZE_c4_whole"
+for shape in "c3_random_200 --states 20 --sites 100000 --taxa 200 --tree random"; do
+  set -- $shape; nm=$1; shift
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/mfma_$nm" -- \
+      python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary "$@" > /dev/null 2> "$out/mfma_$nm.err"
+  python3 "$root/tools/summarize_rocprof.py" pmc "$out/mfma_$nm" "$sum/${tag}_pmc_mfma_$nm.csv" "python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 --no-vary $*"
+  rm -rf "$out/mfma_$nm"
+done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/mfma_c3" -- \
     python3 "$root/bench.py" --steps 5 --warmup 1 --cpu-sites 0 --no-vary --states 20 --sites 200000 > /dev/null 2> "$out/mfma_c3.err"
 python3 "$root/tools/summarize_rocprof.py" pmc "$out/mfma_c3" "$sum/${tag}_pmc_mfma_c3.csv" "python3 bench.py --steps 5 --warmup 1 --cpu-sites 0 --no-vary --states 20 --sites 200000"
@@ -63,6 +79,8 @@ cat > "$sum/pmc_spec.json" <<EOF
   "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
  {"csv": "${tag}_pmc_hbm_traffic_c4_shard.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
   "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 128, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
+ {"csv": "${tag}_pmc_hbm_traffic_c4_whole.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
+  "workload": {"states": 4, "rate_cats": 4, "sites": 8000000, "taxa": 128, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
  {"csv": "${tag}_pmc_hbm_traffic_c5_shape.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
   "workload": {"states": 4, "rate_cats": 4, "sites": 500000, "taxa": 200, "tree": "random", "tip_clv": false, "rate_scalers": false}},
  {"csv": "${tag}_pmc_hbm_traffic_c2_tip_clv.csv", "kernel_match": "k_dna_fused", "kernel_class": "whole-list",
@@ -88,6 +106,11 @@ phase=lines
 workloads
 # BASELINE config 4 on ONE GPU (133 GB): the strong-scaling reference point
 (cd "$root" && python3 bench.py --total-sites 8000000 --taxa 128 --cpu-sites 0 --steps 10 > "$sum/${tag}_bench_c4_one_gpu.json" 2> "$out/bench_c4_one_gpu.err")
+# the N > 1 paths on this one GPU: one process, a partition the library shards over "four devices" (ordinal 0 four
+# times) -- lnL checked against the reference and against the one-GPU evaluation of the same alignment --, and the
+# RCCL path (communicator, lnL all-reduce) on one rank
+(cd "$root" && python3 bench.py --gpus 4 --in-process --devices 0,0,0,0 --sites 250000 --steps 10 > "$sum/${tag}_bench_in_process_4_shards.json" 2> "$out/bench_inproc4.err")
+(cd "$root" && python3 bench.py --force-comm --no-c4 --steps 10 > "$sum/${tag}_bench_force_comm.json" 2> "$out/bench_forcecomm.err")
 # site repeats on the C5 shape
 (cd "$root" && python3 bench.py --sites 500000 --taxa 200 --tree random --site-repeats --cpu-sites 0 > "$sum/${tag}_bench_c5_shape_site_repeats.json" 2> "$out/bench_c5rep.err")
 ls -la "$sum"
