@@ -394,6 +394,16 @@ __device__ __forceinline__ void af_matvec_plain(char * stage_b, char * stage_b5,
     *reinterpret_cast<double *>(stage_b5 + j * 2560) = b[j][4];
   }
   asm volatile("" ::: "memory"); // (LDS operations of a wave execute in order; the compiler reasons per thread)
+  // The entries of output row t + 1 are requested as those of row t are used up, each into the register its
+  // predecessor has just left (the reads return in order; a compiler barrier per entry keeps them where they are
+  // written: left alone the compiler fetches all five rows ahead, a hundred registers -- or none ahead, and every row
+  // waits for LDS): the row's latency hides behind the previous row's forty operations.
+  auto row_entry = [&](int pass, int t, int cc) __attribute__((always_inline)) {
+    return *reinterpret_cast<const double2 *>(ymat + ((pass * 25 + t * 5 + cc) * 256));
+  };
+  double2 p[5];
+#pragma unroll
+  for (int cc = 0; cc < 5; ++cc) p[cc] = row_entry(0, 0, cc);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass)
   {
@@ -411,13 +421,16 @@ __device__ __forceinline__ void af_matvec_plain(char * stage_b, char * stage_b5,
 #pragma unroll
       for (int cc = 0; cc < 5; ++cc)
       {
-        const double2 p = *reinterpret_cast<const double2 *>(ymat + ((pass * 25 + t * 5 + cc) * 256));
 #pragma unroll
         for (int j = 0; j < AF_J; ++j)
         {
-          a0[j] = a0[j] + p.x * c[j][cc].x;
-          a1[j] = a1[j] + p.y * c[j][cc].y;
+          a0[j] = a0[j] + p[cc].x * c[j][cc].x;
+          a1[j] = a1[j] + p[cc].y * c[j][cc].y;
         }
+        asm volatile("" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1])); // (this entry is used up HERE)
+        if (t < 4) p[cc] = row_entry(pass, t + 1, cc);
+        else if (pass == 0) p[cc] = row_entry(1, 0, cc);
+        asm volatile("" ::: "memory");
       }
 #pragma unroll
       for (int j = 0; j < AF_J; ++j)
@@ -431,8 +444,6 @@ __device__ __forceinline__ void af_matvec_plain(char * stage_b, char * stage_b5,
         }
         asm volatile("" : "+v"(x[j][t])); // (wanted HERE: left alone the optimiser sinks the sums to where x is used)
       }
-      // (one row's entries in flight at a time: left alone the compiler fetches the rows of all five outputs ahead --
-      // a hundred registers -- and parks what no longer fits in the accumulation registers, i.e. in the slots)
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }

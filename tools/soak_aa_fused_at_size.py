@@ -34,6 +34,8 @@ bad, t0 = 0, time.time()
 for seed in range(first, first + count):
     plan = W.random_tree(T, seed=1000 + seed)
     rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, len(plan.ops)))                       # a partial traversal after a branch-length change
+    t_new = float(rng.uniform(0.01, 1.2))
     out = {}
     for fused, p in parts.items():
         p.update_prob_matrices([0] * R, plan.matrix_indices, plan.branch_lengths)
@@ -41,8 +43,7 @@ for seed in range(first, first + count):
         a = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
         p.update_partials(plan.ops)                               # the kept plan
         b = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
-        n = int(rng.integers(1, len(plan.ops)))                   # a partial traversal after a branch-length change
-        p.update_prob_matrices([0] * R, [int(plan.ops[-n]["child1_matrix_index"])], [float(rng.uniform(0.01, 1.2))])
+        p.update_prob_matrices([0] * R, [int(plan.ops[-n]["child1_matrix_index"])], [t_new])
         p.update_partials(plan.ops[-n:])
         c = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
         scs = [p.get_scaler(int(op["parent_scaler_index"])) for op in plan.ops[-3:]]
