@@ -93,17 +93,22 @@ static void pllhip_host_final_sum(pllhip_ctx * c)
   }
 }
 
-// every workgroup's entry carries this call's sequence number?
-static bool pllhip_host_partials_landed(const pllhip_ctx * c, unsigned long long seq)
+// every workgroup's entry carries this call's sequence number?  (*from: entries below it have been seen to carry it
+// already -- a poll goes on where the last one stopped instead of reading all of them again)
+static bool pllhip_host_partials_landed(const pllhip_ctx * c, unsigned long long seq, size_t * from = nullptr)
 {
   const volatile double2 * part = c->h_partials;
   const size_t n = (size_t)c->hostsum_grid * c->hostsum_ncomp;
-  for (size_t i = 0; i < n; ++i)
+  for (size_t i = from ? *from : 0; i < n; ++i)
   {
     const double y = part[i].y;
     unsigned long long got;
     memcpy(&got, &y, sizeof(got));
-    if (got != seq) return false;
+    if (got != seq)
+    {
+      if (from) *from = i;
+      return false;
+    }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return true;
@@ -167,11 +172,12 @@ int pllhip_result_wait_host(pllhip_ctx * c, const ReduceOut & ro, bool stream_wo
   const volatile unsigned long long * word = reinterpret_cast<const volatile unsigned long long *>(c->h_result + 3);
   struct timespec t0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
+  size_t seen = 0;
   for (;;)
   {
     for (unsigned int spins = 0; spins < 64u; ++spins)
     {
-      if (hostsum ? pllhip_host_partials_landed(c, ro.seq) : *word == ro.seq)
+      if (hostsum ? pllhip_host_partials_landed(c, ro.seq, &seen) : *word == ro.seq)
       {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         if (hostsum) pllhip_host_final_sum(c);

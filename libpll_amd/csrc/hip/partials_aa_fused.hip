@@ -610,13 +610,13 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     if (((r1[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x1buf_b, r1[16]);
   }
   unsigned int ch_p, ch_q; // tip characters of the next op / the op after next, in turn: lane l holds row (l >> 3) & 3, site l & 7
-  for (size_t round = 0;; ++round)
+  for (unsigned int round = 0;; ++round) // (32 bits: as a size_t its bound lived in a register pair of every lane)
   {
     // a workgroup's first tiles are its own by a fixed stride, the last rounds' worth come from a
     // counter (the XCDs do not write at the same rate, partials_fused.hip)
     size_t tile;
     if (round < static_rounds || !next_tile)
-      tile = (size_t)blockIdx.x + round * gridDim.x;
+      tile = (size_t)blockIdx.x + (size_t)round * gridDim.x;
     else
     {
       if (threadIdx.x == 0) *tile_word = atomicAdd(next_tile, 1u);
@@ -663,64 +663,67 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
       const unsigned long long base = sel == 0u ? r.quad(8) : sel == 1u ? r.quad(10) : sel == 2u ? r.quad(12) : r.quad(14);
       c = *(const unsigned char PLL_GLOBAL *)(base + site0 + (lane & 7u));
     };
-    // character of row k at the lane's own site (l & 7) of the tile
-    auto af_chars = [&](unsigned int c, unsigned int (&ch)[4]) __attribute__((always_inline)) {
-      const unsigned int l7 = lane & 7u;
+    // The table row each of the tile's eight sites reads, as WAVE-UNIFORM values: the characters sit packed in one
+    // register (lane 8 r + s: row r, site s), so v_readlane hands them to the scalar unit, which forms the pair
+    // indices.  (Round 3 dealt the characters out with ds_bpermute and fetched every granule's row index with another:
+    // fourteen trips through the LDS crossbar per gathered op, ten of them for a second table a tip-tip op does not have.)
+    // byte offsets of the lane's five granules: granule it * 64 + lane of the tile is granule rr of site sl's row; the
+    // 64 granules of a step belong to at most three consecutive sites, whose bounds are compile-time constants.  (The
+    // rows of a step's sites are read when the step needs them: eight of them held at once cost scalar registers the
+    // kernel does not have.)
+    auto gather_offsets = [&](unsigned int chars, bool pairs, unsigned int first_row, unsigned int (&o)[5]) __attribute__((always_inline)) {
+      const unsigned int cc = chars >= ms ? 0u : chars;
+      auto row_of = [&](unsigned int sidx) __attribute__((always_inline)) {
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)cc, (int)(8u * first_row + sidx));
+        if (!pairs) return hi;
+        return hi * ms + (unsigned int)__builtin_amdgcn_readlane((int)cc, (int)(8u * first_row + 8u + sidx));
+      };
+      unsigned int lane_l = lane;
+      asm volatile("" : "+v"(lane_l)); // (recomputed, not kept)
 #pragma unroll
-      for (unsigned int k = 0; k < 4; ++k) ch[k] = (unsigned int)__shfl((int)c, (int)(8u * k + l7), 64);
+      for (unsigned int it = 0; it < 5; ++it)
+      {
+        const unsigned int a = (it * 64u) / 40u, b1 = 40u * (a + 1u) - it * 64u, b2 = 40u * (a + 2u) - it * 64u;
+        unsigned int r = row_of(a + 1u), sl = a + 1u;
+        if (b2 < 64u)
+        {
+          const unsigned int r2 = row_of(a + 2u);
+          r = lane_l < b2 ? r : r2;
+          sl = lane_l < b2 ? sl : a + 2u;
+        }
+        {
+          const unsigned int r0 = row_of(a);
+          r = lane_l < b1 ? r0 : r;
+          sl = lane_l < b1 ? a : sl;
+        }
+        o[it] = r * 640u + (lane_l + it * 64u - 40u * sl) * 16u;
+        asm volatile("" : "+v"(o[it])); // (one step's scalars at a time)
+      }
     };
-    // what an op of kind `nkind` gathers an op ahead, with its characters (in ch): a lookup its
+    // what an op of kind `nkind` gathers an op ahead, with its characters (in chars): a lookup its
     // table entries -- LDS-DMA with one address per lane, straight into the two stages in the
     // layout of the stores --, a tip-inner op the tip's factor (a row of its table per site, into stage 1)
     auto next_gathers = [&](unsigned int nkind, bool one_table, unsigned long long tab_l, unsigned long long tab_r, unsigned int chars) __attribute__((always_inline)) {
       if (AF_EXP(4u)) return;
+      unsigned int o[5];
       if (nkind == 2u)
       {
-        unsigned int lane_l = lane;
-        asm volatile("" : "+v"(lane_l)); // (site and column of five granules: recomputed, not kept)
-        unsigned int ch[4];
-        af_chars(chars, ch);
-        unsigned int c1 = ch[0], c2 = ch[1], c3 = ch[2], c4 = ch[3];
-        if (c1 >= ms) c1 = 0;
-        if (c2 >= ms) c2 = 0;
-        if (c3 >= ms) c3 = 0;
-        if (c4 >= ms) c4 = 0;
-        const unsigned int p1 = c1 * ms + c2, p2 = c3 * ms + c4;
-        unsigned int o1[5], o2[5];
-#pragma unroll
-        for (unsigned int it = 0; it < 5; ++it)
-        {
-          const unsigned int gi = it * 64u + lane_l, sl = gi / 40u, rr = gi - 40u * sl;
-          const unsigned int q1 = (unsigned int)__shfl((int)p1, (int)sl, 64);
-          const unsigned int q2 = (unsigned int)__shfl((int)p2, (int)sl, 64);
-          o1[it] = (q1 * 40u + rr) * 16u;
-          o2[it] = (q2 * 40u + rr) * 16u;
-        }
+        gather_offsets(chars, true, 0u, o);
         // (a single table goes to stage 1: stage 0 is where an op transposes its result, so an inner-inner op can
         // issue the NEXT op's one gather while it still multiplies -- partials_aa_fused_op.inc, "early")
-        if (one_table) af_dma_gather5(st1_b, tab_l, o1);
+        if (one_table) af_dma_gather5(st1_b, tab_l, o);
         else
         {
-          af_dma_gather5(st0_b, tab_l, o1);
-          af_dma_gather5(st1_b, tab_r, o2);
+          af_dma_gather5(st0_b, tab_l, o);
+          gather_offsets(chars, true, 2u, o);
+          af_dma_gather5(st1_b, tab_r, o);
         }
       }
       else if (nkind == 1u)
       {
         // the tip's factor: row `code` of its table is 640 bytes laid out like a site of a CLV
-        unsigned int lane_l = lane;
-        asm volatile("" : "+v"(lane_l));
-        unsigned int c1 = (unsigned int)__shfl((int)chars, (int)(lane & 7u), 64);
-        if (c1 >= ms) c1 = 0;
-        unsigned int o1[5];
-#pragma unroll
-        for (unsigned int it = 0; it < 5; ++it)
-        {
-          const unsigned int gi = it * 64u + lane_l, sl = gi / 40u, rr = gi - 40u * sl;
-          const unsigned int q1 = (unsigned int)__shfl((int)c1, (int)sl, 64);
-          o1[it] = (q1 * 40u + rr) * 16u;
-        }
-        af_dma_gather5(st1_b, tab_l, o1); // (stage 1: stage 0 takes the inner child's columns, af_matvec_plain)
+        gather_offsets(chars, false, 0u, o);
+        af_dma_gather5(st1_b, tab_l, o); // (stage 1: stage 0 takes the inner child's columns, af_matvec_plain)
       }
     };
 
