@@ -614,10 +614,14 @@ PLL_EXPORT void pll_amd_core_release(void);
 
 /* ---- additions of this library (no reference counterpart) ---- */
 
-/* Device the NEXT pll_partition_create OF THE CALLING THREAD binds to (default: env
- * PLL_AMD_DEVICE, else LOCAL_RANK, else 0).  Per thread, like pll_errno (pll.c:24-25): distinct
- * threads may create distinct partitions concurrently, as with the reference. */
+/* Device the NEXT pll_partition_create OF THE CALLING THREAD binds to.  Kept per thread, like pll_errno
+ * (pll.c:24-25) -- distinct threads may create partitions on distinct devices concurrently, as the reference lets
+ * threads create partitions concurrently -- WITH a process-wide default: a thread that has not set a device uses what
+ * any thread set last (a client that selects its device once on the main thread and creates partitions from workers
+ * gets that device there), then env PLL_AMD_DEVICE, else LOCAL_RANK, else 0.  pll_amd_get_device() = what a partition
+ * created now by the calling thread would get.  pll_amd_set_devices() below follows the same rule. */
 PLL_EXPORT int pll_amd_set_device(int device);
+PLL_EXPORT int pll_amd_get_device(void);
 PLL_EXPORT int pll_amd_device_count(void);
 /* One partition over several GPUs of this process: the NEXT pll_partition_create splits its
  * sites into contiguous ranges over these devices (default: env PLL_AMD_DEVICES = "0-7",

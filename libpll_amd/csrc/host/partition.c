@@ -165,6 +165,7 @@ static int default_device(void)
 }
 
 int pll_amd_core_device(void) { return default_device(); }
+int pll_amd_get_device(void) { return default_device(); }
 
 static void free_ptr_array(void ** a, unsigned int n)
 {

@@ -387,3 +387,51 @@ def test_whole_list_kernel_keeps_out_of_the_slot_registers():
                          timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "4 kernels checked, 0 instructions" in out.stdout
+
+
+def test_device_selection_per_thread_with_a_process_wide_default(amd):
+    """pll_amd_set_device: a thread that has set a device uses its own; a thread that has not uses what any thread
+    set last (round 3 made the setting thread-local only: a client that selects its device once on the main thread
+    and creates partitions from worker threads silently fell back to the environment there)."""
+    import ctypes
+    import threading
+    lib = amd.lib
+    lib.pll_amd_get_device.restype = ctypes.c_int
+    seen = {}
+
+    def worker(name, own):
+        if own is not None:
+            lib.pll_amd_set_device(own)
+        seen[name] = lib.pll_amd_get_device()
+
+    lib.pll_amd_set_device(3)                       # main thread: also the process-wide default
+    t = threading.Thread(target=worker, args=("inherits", None))
+    t.start(); t.join()
+    assert seen["inherits"] == 3
+    t = threading.Thread(target=worker, args=("own", 1))
+    t.start(); t.join()
+    assert seen["own"] == 1
+    assert lib.pll_amd_get_device() == 3           # the main thread keeps its own value ...
+    t = threading.Thread(target=worker, args=("later", None))
+    t.start(); t.join()
+    assert seen["later"] == 1                       # ... a thread without one sees the LAST setting of any thread
+    lib.pll_amd_set_device(0)
+
+
+def test_bench_alignment_blocks():
+    """workload.global_alignment (bench.py's alignment since round 4): a range is a slice of the whole, whatever
+    the block boundaries; `distinct` makes the blocks repeat; reference_lnl's chunks add up."""
+    from libpll_amd import workload as W
+    plan = W.balanced_tree(8, seed=42)
+    cat = np.array([0.1, 0.5, 1.0, 2.4])
+    whole = W.global_alignment(plan, 0, 2300, W.GTR_RATES, W.GTR_FREQS, cat, seed=9, block=500)
+    assert len(whole) == 8 and all(len(s) == 2300 for s in whole)
+    for lo, hi in ((0, 500), (499, 501), (250, 2300), (1000, 1000), (2299, 2300)):
+        part = W.global_alignment(plan, lo, hi, W.GTR_RATES, W.GTR_FREQS, cat, seed=9, block=500)
+        assert all(w[lo:hi] == p for w, p in zip(whole, part))
+    rep = W.global_alignment(plan, 0, 2000, W.GTR_RATES, W.GTR_FREQS, cat, seed=9, block=500, distinct=2)
+    assert rep[0][:500] == rep[0][1000:1500] and rep[0][:500] == whole[0][:500] and rep[0][500:1000] == whole[0][500:1000]
+    rnd = W.global_alignment(plan, 100, 900, W.GTR_RATES, W.GTR_FREQS, cat, seed=9, block=500, kind="random")
+    assert len(rnd[0]) == 800
+    with pytest.raises(ValueError):
+        W.global_alignment(plan, 10, 5, W.GTR_RATES, W.GTR_FREQS, cat)
