@@ -157,6 +157,9 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_SPIN")) c->no_spin = atoi(e) == 0;
+  if (const char * e = getenv("PLLHIP_HOSTSUM")) c->no_hostsum = atoi(e) == 0;
+  if (const char * e = getenv("PLLHIP_FUSE_REDUCE")) c->fuse_forced = atoi(e) ? 1 : 0;
+  if (const char * e = getenv("PLLHIP_FUSE_MAX_GRID")) c->fuse_max_grid = (unsigned int)atoi(e);
   if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e); // 0 / 1; 2: the whole-list kernel's counts too
   if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_FUSED"))

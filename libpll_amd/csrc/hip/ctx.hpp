@@ -113,6 +113,9 @@ struct pllhip_ctx
   double * h_result = nullptr;         // pinned, host-mapped [4]: [0..2] results, [3] the sequence word the host spins on
   unsigned long long result_seq = 0;   // number of the last result-returning launch
   bool no_spin = false;                // env PLLHIP_SPIN=0: wait for the stream instead (A/B measurements)
+  bool no_hostsum = false;             // env PLLHIP_HOSTSUM=0: k_final_sum instead of the host's sum of workgroup sums
+  int fuse_forced = -1;                // env PLLHIP_FUSE_REDUCE=0/1: the final sum never / always inside the reducing kernel
+  unsigned int fuse_max_grid = 128;    // env PLLHIP_FUSE_MAX_GRID (all read when the context is created)
   double * h_result_dev = nullptr;     // device address of h_result
   // workgroup sums of a result-returning kernel, written by the kernel straight into host memory and added by
   // the host (likelihood.hip: pllhip_result_wait_host): {value, sequence number} per workgroup and component

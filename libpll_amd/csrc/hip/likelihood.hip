@@ -53,18 +53,15 @@ ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncom
   // atomic round trip, and the finisher reads all partials past the L2 -- 45.8 us per derivative call
   // at 1954 workgroups against 33.9 us with the separate 6 us launch, 31.3 against 28.8 at 512
   // (tools/call_floor_ab.sh).  Small grids are latency-bound and save the launch.
-  static const int forced = getenv("PLLHIP_FUSE_REDUCE") ? atoi(getenv("PLLHIP_FUSE_REDUCE")) : -1;
-  static const unsigned int max_grid = getenv("PLLHIP_FUSE_MAX_GRID") ? (unsigned int)atoi(getenv("PLLHIP_FUSE_MAX_GRID")) : 128u;
-  r.fused = forced >= 0 ? (forced ? 1 : 0) : (grid <= max_grid ? 1 : 0);
+  r.fused = c->fuse_forced >= 0 ? c->fuse_forced : (grid <= c->fuse_max_grid ? 1 : 0);
   // Larger grids (round 4): the workgroup sums go straight to host-mapped memory and the host adds them -- in
   // k_final_sum's order, so the bits are those of rounds 1-3 -- instead of a one-workgroup launch behind the kernel
   // (4.5-6.7 us per result-returning call).  Not with a communicator (the all-reduce wants the
   // sum on the device), not for a shard of a group (collected after enqueueing everywhere), not with an
   // ascertainment-bias term (a device value the final step adds).  PLLHIP_HOSTSUM=0 switches it off.
-  static const bool hostsum_on = !(getenv("PLLHIP_HOSTSUM") && atoi(getenv("PLLHIP_HOSTSUM")) == 0);
   r.host_partials = nullptr;
   c->hostsum_grid = 0;
-  if (hostsum_on && !r.fused && !c->comm && !c->defer && !r.extra && (size_t)grid * ncomp <= PLLHIP_HOSTSUM_MAX)
+  if (!c->no_hostsum && !r.fused && !c->comm && !c->defer && !r.extra && (size_t)grid * ncomp <= PLLHIP_HOSTSUM_MAX)
   {
     r.host_partials = c->h_partials_dev;
     c->hostsum_grid = grid;

@@ -117,3 +117,64 @@ def test_lookup_op_threshold(gpu, monkeypatch, taxa, sites):
             monkeypatch.setenv("PLLHIP_AA_CHERRY", mode)
         res[mode] = observe(gpu, plan, seqs, 20)
     assert same(res["default"], res["0"]) and same(res["default"], res["2"])
+
+
+@pytest.mark.parametrize("states,sites", [(4, 8_000), (4, 33_000), (4, 300_000), (20, 3_000), (20, 60_000), (5, 70_000)])
+def test_final_sum_on_the_host_or_on_the_device(gpu, monkeypatch, states, sites):
+    """Round 4: reducing kernels with more than 128 workgroups write their workgroup sums to host-mapped memory and
+    the HOST adds them (in k_final_sum's order); below that the last workgroup finishes the sum in the launch.
+    PLLHIP_HOSTSUM=0 (the one-workgroup k_final_sum launch again), PLLHIP_SPIN=0 (stream wait instead of polling)
+    and PLLHIP_FUSE_REDUCE=0/1 must all give the same lnL and derivatives to the last bit."""
+    if states in (4, 20):
+        plan = W.balanced_tree(16, seed=2)
+        seqs = W.random_alignment(16, sites, states, seed=sites)
+    else:
+        from helpers import odd_state_case, build_partition
+        case = odd_state_case(states, tips=9, sites=sites, seed=4)
+    res = {}
+    for name, env in (("default", {}), ("device sum", {"PLLHIP_HOSTSUM": "0"}), ("stream wait", {"PLLHIP_SPIN": "0"}),
+                      ("device sum + stream wait", {"PLLHIP_HOSTSUM": "0", "PLLHIP_SPIN": "0"}),
+                      ("separate launch always", {"PLLHIP_FUSE_REDUCE": "0"})):
+        for k in ("PLLHIP_HOSTSUM", "PLLHIP_SPIN", "PLLHIP_FUSE_REDUCE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if states in (4, 20):
+            p = W.setup_partition(gpu, plan, seqs, states, 4, ATTRIB_PATTERN_TIP)
+            R = 4
+        else:
+            p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+            plan, R = case["plan"], case["rate_cats"]
+        p.update_partials(plan.ops)
+        e = plan.root_edge
+        lnl, ps = p.compute_edge_loglikelihood(*e, [0] * R, persite=True)
+        lnl2 = p.compute_edge_loglikelihood(*e, [0] * R)
+        st = p.alloc_sumtable()
+        p.update_sumtable(e[0], e[2], e[1], e[3], [0] * R, st)
+        d = [p.compute_likelihood_derivatives(e[1], e[3], t, [0] * R, st) for t in (0.05, 0.4)]
+        res[name] = (lnl, lnl2, d)
+        p.destroy()
+    for name, got in res.items():
+        assert got[0] == got[1], name
+        if "always" not in name:   # (the separate launch on a small grid adds in another order than the fused finish)
+            assert got == res["default"], name
+        else:
+            assert abs(got[0] - res["default"][0]) <= 1e-13 * abs(got[0])
+
+
+@pytest.mark.parametrize("budget_mb", ["0", "1", "2"])
+def test_lookup_table_budget(gpu, monkeypatch, budget_mb):
+    """20 states, whole-list kernel: the lookup tables and the tip-tip ops' pair tables share a pool with a budget
+    (PLLHIP_AA_LOOKUP_MB).  Ops beyond it stay ordinary ops / fall back to the two tip tables: with no
+    pool at all, with room for one table and by default the bits are the same."""
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "0")
+    monkeypatch.setenv("PLLHIP_FUSED", "2")
+    monkeypatch.setenv("PLLHIP_AA_CHERRY", "2")
+    plan = W.random_tree(40, seed=6)
+    seqs = W.random_alignment(40, 3_000, 20, seed=77)
+    monkeypatch.delenv("PLLHIP_AA_LOOKUP_MB", raising=False)
+    want = observe(gpu, plan, seqs, 20)
+    monkeypatch.setenv("PLLHIP_AA_LOOKUP_MB", budget_mb)
+    assert same(observe(gpu, plan, seqs, 20), want)
+    monkeypatch.setenv("PLLHIP_AA_TT_PAIRS", "0")      # (tip-tip ops of the list over the two tip tables, as in round 3)
+    assert same(observe(gpu, plan, seqs, 20), want)
