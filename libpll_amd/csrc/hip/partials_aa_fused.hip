@@ -23,15 +23,17 @@
 //             halves -- the left block of op i+1 arrives while op i multiplies by its right
 //             block -- in "operand order": the 64 lanes of one MFMA read 512 contiguous bytes
 //             (k_af_prepare permutes every matrix of the list once per call).
-//   order     the reference's (core_partials_avx2.c:632-750): four FMA chains strided by
-//             j mod 4, then (a0+a1)+(a2+a3); the MFMA adds its four products as a chain of
-//             FMAs in k order (tools/mfma_order_probe.hip), so a k-chunk {m, m+4, m+8, m+12}
-//             is four steps of chain m -- CLVs and scaler counts are the reference's bit for bit
-//             (inner-inner ops; the reference's tip-inner kernel does not fuse, core_partials_avx.c:1097).
-//   tip-tip   ops run ahead of the list as before (k_aa_tt_rounds: a pure write stream at the
-//             write ceiling already); an inner-inner op over two of them -- or a tip-inner op over
-//             one -- is a table lookup over character pairs (partials_aa_mfma.hip), done here per
-//             tile in the 16-bytes-per-lane layout of the stores and handed on through LDS.
+//   order     the reference's, op kind by op kind -- CLVs and scaler counts are its bits.  Inner-inner ops
+//             (core_partials_avx2.c:632-750): four FMA chains strided by j mod 4, then (a0+a1)+(a2+a3); the MFMA adds its
+//             four products as a chain of FMAs in k order (tools/mfma_order_probe.hip), so a k-chunk {m, m+4, m+8, m+12}
+//             is four steps of chain m, and the fifth step (state 16 + m) is one FMA on the vector unit (round 4: it was
+//             a second, zero-padded MFMA).  Tip-inner ops (core_partials_avx.c:1097-1340, multiply and add rounded
+//             separately): their one mat-vec runs on the vector unit (af_matvec_plain, round 4).
+//   tip-tip   ops run INSIDE the list (round 4: always; PLLHIP_AA_TT_INSIDE=0 puts them ahead again as a launch of
+//             k_aa_tt_rounds): the parent depends on the two tip characters only, so each op gathers ONE row per site
+//             from a pair table that k_af_prepare makes per op (AfPairJob).  An inner-inner op over two tip-tip results
+//             -- or a tip-inner op over one -- is a table lookup over character pairs as well (partials_aa_mfma.hip):
+//             two rows, one multiplication, done per tile in the 16-bytes-per-lane layout of the stores.
 //   reload    an operand that has no slot (written by an earlier call, or by a tip-tip op whose
 //             reader is not a lookup, or evicted) is copied from HBM by LDS-DMA during the op
 //             before its reader.
@@ -841,7 +843,6 @@ struct pllhip_aa_fused_cache
   char * d_pairtab = nullptr;          // pair tables of the list's tip-tip ops (AfPairJob)
   size_t pairtab_cap = 0, off_pair = 0;
   unsigned int npair = 0;
-  bool tried_inside = false;          // the list in last_ops has been planned with its tip-tip ops inside (or found unfit for it)
 };
 
 void pllhip_aa_fused_free(pllhip_ctx * c)
@@ -959,7 +960,6 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       !getenv("PLLHIP_FUSED_DEBUG") && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
     return aa_fused_launch(c, false);
   k.last_ops.clear();
-  k.tried_inside = false;
 
   // ---- classify.  Tip-tip ops run ahead of the list: allowed only if nothing earlier in the list
   // wrote or read what they write (they read tips only).  An inner-inner op over two tip-tip

@@ -40,12 +40,16 @@
 // the f64 machine balance, so HBM is the bound: 200 MFMAs x 17 cycles per 64
 // elements per SIMD is ~25 % of the time HBM needs for the tile's 31 KB.
 //
-// Numerics.  The matrix core accumulates the 20 products of a row as a chain of
-// fused multiply-adds in state order; the reference's AVX2 kernel uses four
-// interleaved chains and a pairwise tree.  Results agree to ~2e-16 relative but
-// not bitwise, so this kernel is used unless PLLHIP_AA_EXACT=1 asks for the
-// bit-exact kernel (partials_gen_tile.hip, k_gen_wide in the AVX2-flag order).  Scaler counts still match
-// exactly unless a CLV entry lies within an ulp of 2^-256.
+// Numerics.  Every CLV and scaler count of these kernels is the reference's bit for bit:
+//   inner-inner  the four FMA chains strided by j mod 4 and the pairwise tree of core_partials_avx2.c:632-750, which
+//                v_mfma_f64_4x4x4 reproduces step for step when the contraction is chunked as {m, m+4, m+8, m+12} and
+//                the fifth step follows (round 3; aa_mfma.hpp: rate_matvec_chain);
+//   tip-inner    the reference's kernel for these ops, also under the AVX2 flag, multiplies and adds separately
+//                (core_partials.c:427-441 -> core_partials_avx.c:1097-1340): the inner child's mat-vec runs on the
+//                vector unit in that order (round 4; aa_mfma.hpp: rate_matvec_plain), the tip's factor is a table row;
+//   tip-tip      one multiplication of two table rows.
+// PLLHIP_AA_EXACT=1 selects the all-vector kernels of partials_gen_tile.hip instead (k_gen_wide in the AVX2-flag
+// order): same CLVs, and per-site lnL bit for bit too (the lnL / sumtable kernels of this path sum a row in one chain).
 #include "ctx.hpp"
 #include "numerics.hpp"
 
