@@ -384,6 +384,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   if (c->cherry_codes) (void)hipFree(c->cherry_codes);
   if (c->cherry_zero) (void)hipFree(c->cherry_zero);
   if (c->cherry_pool_all) (void)hipFree(c->cherry_pool_all);
+  if (c->split_verdicts) (void)hipFree(c->split_verdicts);
   pllhip_aa_fused_free(c);
   for (int b = 0; b < 2; ++b)
   {

@@ -94,6 +94,7 @@ struct pllhip_ctx
   double * cherry_pool_all = nullptr;        // the tables of ALL lookup ops of a list (partials_aa_fused.hip)
   unsigned int cherry_pool_all_ops = 0;      // lookup ops it has room for
   bool cherry_pool_failed = false;           // its allocation failed once: no lookup ops on this context any more
+  unsigned int * split_verdicts = nullptr;   // 20 states x 8 categories: per-site verdicts of an op's first half when the op works in place
   struct pllhip_aa_fused_cache * aa_fused = nullptr; // 20-state whole-list kernel: its kept plan
   size_t pairtab_elems = 0;
   void * h_plan[2] = {nullptr, nullptr};

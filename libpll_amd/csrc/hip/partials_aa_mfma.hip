@@ -60,9 +60,22 @@
 // KIND 0: inner-inner.  KIND 1: tip-inner -- the left factor is not a mat-vec but
 // a row of the precomputed tip table (a.ltab, [code][rate][state]), which takes
 // the place of the left P-matrix in LDS; the right child goes through the MFMAs.
-template <int RC, int MODE, bool NT, int KIND, bool GATHER>
+//
+// SPLIT (round 4): 20-state data with EIGHT rate categories.  A tile of 16 sites x 8 categories does not fit the LDS
+// budget (two images per wave, 20 KB each; 51 KB of matrices), so an op runs as TWO launches of the 4-category kernel,
+// each over half the categories of every site (SPLIT = 1: categories 0..3, SPLIT = 2: categories 4..7; the site
+// stride in HBM is that of 8 categories, the matrices and tip tables are those of the half).  Per-rate scalers need
+// nothing else.  With per-site scalers a site scales iff ALL EIGHT categories are small: the first launch stores its
+// products unscaled and leaves its verdict per site in the parent's scale buffer (1 = all small), the second reads it,
+// decides, scales its own half in registers and -- rarely -- the first half in place.  Same arithmetic per entry as the
+// reference's kernels (core_partials_avx2.c:568-803, core_partials_avx.c:1097-1340), same scaling rule: same bits.
+// Until round 4 such partitions ran on the all-vector kernels at a third of this rate.
+template <int RC, int MODE, bool NT, int KIND, bool GATHER, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 {
+  static_assert(SPLIT == 0 || (RC == 4 && !GATHER), "halves of 8 categories; no site repeats");
+  constexpr int RT = SPLIT ? 2 * RC : RC;   // categories of the CLV
+  constexpr int RF = SPLIT == 2 ? RC : 0;   // first category of this launch
   const PartialsArgs & a = batch.op[blockIdx.y];
   using G = aa_geom<RC>;
   extern __shared__ double smem[];
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
   constexpr int ROW_B = G::ROW_G * 16;
 
   unsigned int toff[G::N_IT];
-  tile_offsets<RC>(lane, toff);
+  tile_offsets<RC, RT, RF>(lane, toff);
   unsigned int store_mask = 0; // bit it: granule it*64+lane of the image is data (not pad, not past the tile)
 #pragma unroll
   for (int it = 0; it < G::N_IT; ++it)
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     }
     // destination = (uniform) start of the tile in the parent CLV + the same per-lane
     // offsets the DMA uses; pad lanes and sites past the end do not store
-    const unsigned long long ob = (unsigned long long)(a.parent + prev_site0 * (size_t)(RC * 20));
+    const unsigned long long ob = (unsigned long long)(a.parent + prev_site0 * (size_t)(RT * 20));
     const unsigned int olo = __builtin_amdgcn_readfirstlane((unsigned int)ob);
     const unsigned int ohi = __builtin_amdgcn_readfirstlane((unsigned int)(ob >> 32));
     char * obase = reinterpret_cast<char *>(((unsigned long long)ohi << 32) | olo);
@@ -147,15 +160,19 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 #pragma unroll
     for (int it = 0; it < G::N_IT; ++it)
     {
-      const unsigned int site = toff[it] / (unsigned int)(RC * 160);
+      const unsigned int site = toff[it] / (unsigned int)(RT * 160);
       if (((store_mask >> it) & 1u) && site < left_sites)
         st16<NT>(reinterpret_cast<double2 *>(obase + toff[it]), v[it].x, v[it].y);
     }
     const size_t n = prev_site0 + s;
-    if (MODE == SCALE_SITE && q == 0 && n < sites) a.pscaler[n] = psc[0];
+    if (MODE == SCALE_SITE && q == 0 && n < sites)
+    {
+      if (SPLIT == 1) const_cast<unsigned int *>(a.lidx)[n] = psc[0]; // (the verdict buffer, see the scaling step)
+      else a.pscaler[n] = psc[0];
+    }
     if (MODE == SCALE_RATE && q == 0 && n < sites)
 #pragma unroll
-      for (int k = 0; k < RC; ++k) a.pscaler[n * RC + k] = psc[k];
+      for (int k = 0; k < RC; ++k) a.pscaler[n * RT + RF + k] = psc[k];
     // the image is about to be refilled by a DMA: its reads must have left LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
@@ -189,12 +206,12 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 #pragma unroll
     for (int k = 0; k < RC; ++k)
     {
-      const size_t e = (MODE == SCALE_RATE) ? (size_t)frow * RC + k : (size_t)frow;
+      const size_t e = (MODE == SCALE_RATE) ? (size_t)frow * RT + RF + k : (size_t)frow;
       const bool used = (MODE == SCALE_RATE) || (MODE == SCALE_SITE && k == 0);
       fsc_next[k] = used ? first_sc[has_first ? e : 0] : 0u;
     }
     if (GATHER) dma_tile_rows<RC, NT>(first_clv, frow, toff, region);
-    else dma_tile<RC, NT>(first_clv, tile * 16, toff, region);
+    else dma_tile<RC, NT, RT>(first_clv, tile * 16, toff, region);
   };
   {
     // prologue: the rows of the first tile have to be here before anything can be requested
@@ -233,12 +250,12 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 #pragma unroll
       for (int k = 0; k < RC; ++k)
       {
-        const size_t e = (MODE == SCALE_RATE) ? (size_t)srow * RC + k : (size_t)srow;
+        const size_t e = (MODE == SCALE_RATE) ? (size_t)srow * RT + RF + k : (size_t)srow;
         const bool used = (MODE == SCALE_RATE) || (MODE == SCALE_SITE && k == 0);
         ssc[k] = used ? rs[has_r ? e : 0] : 0u;
       }
       if (GATHER) dma_tile_rows<RC, NT>(a.right, srow, toff, region);
-      else dma_tile<RC, NT>(a.right, site0, toff, region);
+      else dma_tile<RC, NT, RT>(a.right, site0, toff, region);
       tile_matvec_chain<RC, 0>(la14, la5, b, lane, xl); // overlaps the right child's DMA and the stores
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -301,9 +318,37 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     right_rate(std::integral_constant<int, 1>{});
     right_rate(std::integral_constant<int, 2>{});
     right_rate(std::integral_constant<int, 3>{});
-    if (MODE == SCALE_SITE)
+    if (MODE == SCALE_SITE && SPLIT == 1)
     {
-      const bool scale = column_all(small_site, s);
+      // first half of eight categories: no decision yet -- the verdict of these four goes to the verdict buffer (the
+      // parent's scale buffer, a.lidx; a scratch array when that buffer is also a child's: the op works in place)
+      psc[0] = column_all(small_site, s) ? 1u : 0u;
+    }
+    else if (MODE == SCALE_SITE)
+    {
+      bool scale = column_all(small_site, s);
+      if (SPLIT == 2)
+      {
+        // second half: the site scales iff the first half said "all small" too; its entries (written unscaled by the
+        // first launch) are then scaled in place -- rare: a wave-uniform mask of such sites, 40 granules each
+        const size_t n = site0 + s;
+        const unsigned int first_half = (n < sites) ? a.lidx[n] : 0u;
+        scale = scale && first_half != 0u;
+        const unsigned long long fix = __ballot(scale && q == 0 && n < sites);
+        if (fix)
+        {
+          double2 * prow = reinterpret_cast<double2 *>(a.parent + site0 * (size_t)(RT * 20));
+          for (unsigned int sl = 0; sl < 16u; ++sl)
+            if ((fix >> sl) & 1ull)
+              if (lane < (unsigned int)(RC * 10))
+              {
+                double2 v = prow[(size_t)sl * (RT * 10) + lane];
+                v.x *= PLLHIP_SCALE_FACTOR;
+                v.y *= PLLHIP_SCALE_FACTOR;
+                prow[(size_t)sl * (RT * 10) + lane] = v;
+              }
+        }
+      }
       if (scale)
 #pragma unroll
         for (int k = 0; k < RC; ++k)
@@ -399,7 +444,7 @@ __global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsBatch batch)
   }
 }
 
-template <int RC, int KIND>
+template <int RC, int KIND, int SPLIT = 0>
 static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode, bool nt)
 {
   using G = aa_geom<RC>;
@@ -411,7 +456,7 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   for (unsigned int i = 0; i < count; ++i)
   {
     if (b.op[i].sites > rows_max) rows_max = b.op[i].sites;
-    gather = gather || b.op[i].lidx || b.op[i].ridx;
+    gather = gather || (!SPLIT && (b.op[i].lidx || b.op[i].ridx)); // (SPLIT: lidx is the verdict buffer)
   }
   const size_t tiles = (rows_max + 15) / 16;
   // Two workgroups per CU share its 160 KB of LDS; each holds the P tables (or the tip
@@ -438,9 +483,14 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   } while (0)
 #define AA_LAUNCH(MODEV)                                                                      \
   do {                                                                                        \
-    if (gather) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND, true>));                  \
-    else if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true, KIND, false>));                 \
-    else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND, false>));                        \
+    if (SPLIT) {                                                                              \
+      if (gather) return 1; /* (no site repeats with eight categories) */                     \
+      if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true, KIND, false, SPLIT>));             \
+      else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND, false, SPLIT>));               \
+    }                                                                                         \
+    else if (gather) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND, true, 0>));          \
+    else if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true, KIND, false, 0>));              \
+    else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND, false, 0>));                     \
   } while (0)
   if (mode == SCALE_NONE) AA_LAUNCH(0);
   else if (mode == SCALE_SITE) AA_LAUNCH(1);
@@ -586,17 +636,73 @@ __global__ __launch_bounds__(256) void k_aa_cherry_rounds(CherryBatch batch)
 bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind)
 {
   const unsigned int R = c->sh.rate_cats;
-  if (c->aa_exact || c->sh.states != 20 || !(R == 1 || R == 2 || R == 4)) return false;
+  // (8 categories, round 4: two launches of the 4-category kernel per op, k_aa_ii_mfma's SPLIT; PLLHIP_AA_RC8=0: the
+  // all-vector kernels as before)
+  static const bool rc8 = !(getenv("PLLHIP_AA_RC8") && atoi(getenv("PLLHIP_AA_RC8")) == 0);
+  if (c->aa_exact || c->sh.states != 20 || !(R == 1 || R == 2 || R == 4 || (R == 8 && rc8))) return false;
   if (kind == 0) return true;
   // tip kinds: both tables of an op must fit the workgroup's LDS next to its other data
   return c->maxstates > 0 && c->maxstates <= 32 &&
          2 * (size_t)c->maxstates * R * 20 * sizeof(double) <= 60 * 1024;
 }
 
+// Eight rate categories: the two halves of every op of the batch (k_aa_ii_mfma's SPLIT).  Each half sees the
+// matrices -- and, for a tip-inner op, a tip table -- of its four categories; the per-site verdict of the first half
+// travels in the parent's scale buffer unless that buffer is also a child's (an op that works in place).
+static int launch_rc8_halves(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int kind, int mode, bool nt)
+{
+  const size_t per = (size_t)b.op[0].maxstates * 4 * 20; // a half's tip table
+  if (kind == 1)
+  {
+    const size_t need = 2 * 2 * per * PLLHIP_BATCH_MAX;
+    if (c->tiptab_elems < need)
+    {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (c->d_tiptab) HIP_TRY(hipFree(c->d_tiptab));
+      c->d_tiptab = nullptr;
+      HIP_TRY(hipMalloc((void **)&c->d_tiptab, need * sizeof(double)));
+      ++c->layout_epoch;
+      c->tiptab_elems = need;
+    }
+  }
+  for (int half = 0; half < 2; ++half)
+  {
+    PartialsBatch h = b;
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      PartialsArgs & a = h.op[i];
+      if (a.lmat) a.lmat += (size_t)half * 4 * 400;
+      if (a.rmat) a.rmat += (size_t)half * 4 * 400;
+      a.lidx = a.pscaler;
+      a.ridx = nullptr;
+      if (mode == SCALE_SITE && a.pscaler && (a.pscaler == a.lscaler || a.pscaler == a.rscaler))
+      {
+        if (!c->split_verdicts)
+          HIP_TRY(hipMalloc((void **)&c->split_verdicts, (size_t)PLLHIP_BATCH_MAX * ((size_t)c->sh.sites + PLLHIP_TAIL_SITES) * sizeof(unsigned int)));
+        a.lidx = c->split_verdicts + (size_t)i * ((size_t)c->sh.sites + PLLHIP_TAIL_SITES);
+      }
+    }
+    if (kind == 1)
+    {
+      // the tip's row sums over this half's four categories (k_aa_tip_tables reads the pre-offset matrices)
+      double * tab = c->d_tiptab + (size_t)half * 2 * per * PLLHIP_BATCH_MAX;
+      k_aa_tip_tables<<<dim3(8, count), 256, 0, c->stream>>>(h, tab, h.op[0].maxstates, 4, 0);
+      HIP_TRY(hipGetLastError());
+      for (unsigned int i = 0; i < count; ++i) h.op[i].ltab = tab + (size_t)i * 2 * per;
+    }
+    int rc;
+    if (kind == 1) rc = half == 0 ? launch_rc<4, 1, 1>(c, h, count, mode, nt) : launch_rc<4, 1, 2>(c, h, count, mode, nt);
+    else rc = half == 0 ? launch_rc<4, 0, 1>(c, h, count, mode, nt) : launch_rc<4, 0, 2>(c, h, count, mode, nt);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count, int kind, int mode)
 {
   const unsigned int R = b.op[0].rate_cats;
   const bool nt = pllhip_use_nt(c);
+  if (R == 8 && kind <= 1) return launch_rc8_halves(c, b, count, kind, mode, nt);
   if (kind >= 1)
   {
     // tip row-sum tables of every op of the batch, one launch
@@ -626,6 +732,7 @@ int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count
     {
       case 1: return launch_tt<1>(c, b, count, mode, nt);
       case 2: return launch_tt<2>(c, b, count, mode, nt);
+      case 8: return launch_tt<8>(c, b, count, mode, nt);
       default: return launch_tt<4>(c, b, count, mode, nt);
     }
   }
@@ -666,7 +773,7 @@ bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode)
 {
   const char * e = getenv("PLLHIP_AA_CHERRY"); // 0: never, 2: whatever the partition's size (tests)
   const bool off = e && atoi(e) == 0;
-  return !off && !c->cherry_pool_failed && c->sh.states == 20 && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
+  return !off && !c->cherry_pool_failed && c->sh.states == 20 && c->sh.rate_cats <= 4 && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
          c->rows.empty() && mode != SCALE_RATE && c->maxstates >= 1 && c->maxstates <= 32 && !c->sh.asc_states;
 }
 

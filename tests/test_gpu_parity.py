@@ -127,6 +127,42 @@ def test_rate_category_counts(gpu, orc, aa_mode, states, rate_cats):
     p.destroy()
 
 
+@pytest.mark.parametrize("shape,tips,sites,pattern_tip,expect_min", [
+    ("caterpillar", 400, 8, ATTRIB_PATTERN_TIP, 5), ("caterpillar", 300, 40, 0, 3), ("random", 40, 333, ATTRIB_PATTERN_TIP, 0),
+    ("balanced", 32, 1029, 0, 0)])
+@pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_eight_rate_categories_20_states(gpu, orc, aa_mode, monkeypatch, shape, tips, sites, pattern_tip, expect_min,
+                                         rate_scalers, in_place):
+    """20 states x 8 rate categories: on the default path every inner-inner and tip-inner op is TWO launches of the
+    4-category matrix-core kernel (partials_aa_mfma.hip, SPLIT), the per-site scaling verdict of the first half
+    travelling in the parent's scale buffer -- or in a scratch array when the op scales in place (parent scale buffer =
+    the inner child's, in_place).  CLVs and scaler counts bit for bit, with scaling events, in both scaling modes,
+    with waves that walk several tiles."""
+    if in_place and shape != "caterpillar":
+        pytest.skip("one scale buffer all the way down needs a ladder")
+    import dataclasses
+    monkeypatch.setenv("PLLHIP_AA_GRID_CAP", "3")
+    case = make_case(20, shape, tips, sites, rate_cats=8, seed=tips, alpha=0.5,
+                     branch=0.5 if shape == "caterpillar" else None, weights=False, ambiguity=shape != "caterpillar",
+                     gap_frac=0.0 if shape == "caterpillar" else 0.05)
+    case["rates"], case["freqs"] = gpu.aa_model("lg")
+    if in_place:
+        plan = case["plan"]
+        ops = plan.ops.copy()
+        for f in ("parent_scaler_index", "child1_scaler_index", "child2_scaler_index"):
+            ops[f] = np.where(ops[f] >= 0, 0, ops[f])
+        edge = tuple(0 if (i in (1, 3) and v >= 0) else v for i, v in enumerate(plan.root_edge))
+        case["plan"] = dataclasses.replace(plan, ops=ops, root_edge=edge)
+    attrs = pattern_tip | rate_scalers
+    p = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    compare(p, o, case, 8, aa_mode == "exact")
+    last = int(case["plan"].ops[-1]["parent_scaler_index"])
+    assert p.get_scaler(last).min() >= expect_min
+    p.destroy()
+
+
 @pytest.mark.parametrize("states", [5, 7])
 @pytest.mark.parametrize("pattern_tip", [0, ATTRIB_PATTERN_TIP])
 def test_odd_state_counts(gpu, orc, states, pattern_tip):
