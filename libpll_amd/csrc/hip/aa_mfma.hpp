@@ -28,10 +28,12 @@ struct aa_geom
 // to the tile's first byte in HBM: granule P = it*64 + lane of the padded image is
 // (site P / ROW_G, column P % ROW_G); the pad column re-loads the row's last granule.
 // Computed once per kernel: 11 VGPRs instead of 64-bit addresses rebuilt per tile.
-// (RT / RF: the CLV's rate categories in all and the first one of the RC this kernel instance works on -- RT = RC,
-// RF = 0 unless a launch takes HALF the categories of an 8-category partition, partials_aa_mfma.hip "SPLIT")
-template <int RC, int RT = RC, int RF = 0>
-__device__ __forceinline__ void tile_offsets(unsigned int lane, unsigned int (&off)[aa_geom<RC>::N_IT])
+// (rt / rf: the CLV's rate categories in all and the first one of the RC this kernel instance works on -- rt = RC,
+// rf = 0 unless a launch takes a CHUNK of the categories of a partition with 3, 5, 6, 7, 8 ... of them,
+// partials_aa_mfma.hip "SPLIT"; compile-time constants wherever the caller's are)
+template <int RC>
+__device__ __forceinline__ void tile_offsets(unsigned int lane, unsigned int (&off)[aa_geom<RC>::N_IT],
+                                             unsigned int rt = RC, unsigned int rf = 0)
 {
   using G = aa_geom<RC>;
 #pragma unroll
@@ -42,20 +44,21 @@ __device__ __forceinline__ void tile_offsets(unsigned int lane, unsigned int (&o
     const int site = P / G::ROW_G;
     int col = P - site * G::ROW_G;
     if (col > G::ROW_G - 2) col = G::ROW_G - 2;
-    off[it] = (unsigned int)((site * (RT * 10) + RF * 10 + col) * 16);
+    off[it] = ((unsigned int)site * (rt * 10u) + rf * 10u + (unsigned int)col) * 16u;
   }
 }
 
 // copy the 16-site tile starting at site0 (wave-uniform) of `clv` into the wave's LDS
 // image.  Sites past the end of the CLV are read too (every per-site array carries
 // PLLHIP_TAIL_SITES of slack); what is computed from them is never stored.
-template <int RC, bool NT, int RT = RC>
+template <int RC, bool NT>
 __device__ __forceinline__ void dma_tile(const double * __restrict__ clv, size_t site0,
-                                         const unsigned int (&off)[aa_geom<RC>::N_IT], char * region)
+                                         const unsigned int (&off)[aa_geom<RC>::N_IT], char * region,
+                                         unsigned int rt = RC)
 {
   using G = aa_geom<RC>;
   // the tile's base address is the same in every lane: say so, it then lives in SGPRs
-  const unsigned long long b = (unsigned long long)(clv + site0 * (size_t)(RT * 20));
+  const unsigned long long b = (unsigned long long)(clv + site0 * (size_t)(rt * 20u));
   const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b);
   const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
   const char * base = reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);

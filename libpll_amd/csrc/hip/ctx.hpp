@@ -305,11 +305,14 @@ struct PartialsArgs
   // computed from (a tip character when that child is a tip); nullptr = same index
   const unsigned int * lidx;
   const unsigned int * ridx;
+  // 20 states, a launch over a CHUNK of the rate categories (partials_aa_mfma.hip, SPLIT): its first category;
+  // rate_cats stays the CLV's count, lmat / rmat / ltab are the chunk's, lidx is the per-site verdict buffer
+  unsigned int rate_first, pad_;
 };
 
 // Several mutually independent ops (one tree level) run in ONE launch:
 // blockIdx.y selects the op.  The op descriptors travel as kernel arguments
-// (24 x 144 B < the 4 KB kernarg segment), so batching needs no staging copy.
+// (24 x 152 B < the 4 KB kernarg segment), so batching needs no staging copy.
 // Every per-site device array carries this many sites of zeroed slack behind its last
 // element, so that a wave working on the last (partial) round of 64 sites may load
 // unconditionally and unclamped; what it computes there is masked out of every result.
@@ -338,6 +341,7 @@ int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count);
 // 20-state fast kernels (matrix cores / round-based tip-tip) for `count` mutually
 // independent ops of one kind and mode; returns 1 if the case is not covered
 bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind);
+bool pllhip_aa_chunks_enabled(); // 20 states, rate_cats other than 1, 2, 4 on the matrix-core kernels (PLLHIP_AA_CHUNKS)
 unsigned int pllhip_aa_lookup_budget(const pllhip_ctx * c);
 int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count, int kind, int mode);
 bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode);

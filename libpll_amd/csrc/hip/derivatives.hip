@@ -557,6 +557,116 @@ __global__ __launch_bounds__(128) void k_derivatives_gen(DerivArgs a)
   block_sum2(acc_d, acc_dd, a.reduce);
 }
 
+// 20 states, category counts other than 1, 2, 4 (round 4): the same walk with a tile's categories in CHUNKS of RC
+// (the largest of 4, 2, 1 dividing the count; k_lnl_aa_chunks in likelihood_aa_mfma.hip is the lnL's): rate_cats / RC
+// DMAs of RC x 160 bytes per site, the three sums of a site accumulated chunk by chunk in category order.  The table of
+// exponentials (rate_cats x 80 doubles) comes from the staged device copy, not from the kernel arguments.
+template <int RC, bool NT>
+__global__ __launch_bounds__(256) void k_derivatives_aa_chunks(DerivArgs a)
+{
+  using G = aa_geom<RC>;
+  extern __shared__ double smem[]; // [diag RT x 20 x 4][4 images][freqs RT x 20][model RT x 2]
+  const unsigned int RT = a.rate_cats, H = RT / RC;
+  double * s_diag = smem;
+  double * s_freqs = smem + RT * 80u + 4 * (G::REGION_B / 8);
+  double * s_model = s_freqs + RT * 20u;
+  for (unsigned int t = threadIdx.x; t < RT * 80u; t += blockDim.x) s_diag[t] = a.diagp[t];
+  for (unsigned int t = threadIdx.x; t < RT * 20u; t += blockDim.x)
+    s_freqs[t] = a.freqs[(size_t)a.params_indices[t / 20u] * 20 + t % 20u];
+  for (unsigned int t = threadIdx.x; t < RT; t += blockDim.x)
+  {
+    s_model[2 * t] = a.prop_invar[a.params_indices[t]];
+    s_model[2 * t + 1] = a.rate_weights[t];
+  }
+  __syncthreads();
+
+  const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned int s = lane & 15u, q = lane >> 4;
+  char * region = reinterpret_cast<char *>(smem + RT * 80u) + wave * G::REGION_B;
+  unsigned int toff[G::N_IT];
+  tile_offsets<RC>(lane, toff, RT);
+
+  const size_t sites = a.sites;
+  const size_t tiles = (sites + 15) / 16;
+  const size_t nwaves = (size_t)gridDim.x * 4;
+  const size_t first = (size_t)blockIdx.x * 4 + wave;
+  const int * invp = a.invariant ? a.invariant : reinterpret_cast<const int *>(a.pattern_weights);
+  const bool has_inv = a.invariant != nullptr;
+  double acc_d = 0.0, acc_dd = 0.0;
+  unsigned int w_next = 0;
+  int inv_next = -1;
+  if (first < tiles)
+  {
+    w_next = a.pattern_weights[first * 16 + s];
+    inv_next = invp[has_inv ? first * 16 + s : 0];
+    dma_tile<RC, NT>(a.sumtable, first * 16, toff, region, RT);
+  }
+  for (size_t tile = first; tile < tiles; tile += nwaves)
+  {
+    const size_t next = tile + nwaves;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int w_cur = w_next;
+    int inv_cur = has_inv ? inv_next : -1;
+    asm volatile("" : "+v"(w_cur), "+v"(inv_cur));
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+    for (unsigned int h = 0; h < H; ++h)
+    {
+      if (h > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      double b[RC][5];
+      read_b_operands<RC>(region, s, q, b);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (h + 1 < H) dma_tile<RC, NT>(a.sumtable + (h + 1) * RC * 20, tile * 16, toff, region, RT);
+      else if (next < tiles)
+      {
+        w_next = a.pattern_weights[next * 16 + s];
+        inv_next = invp[has_inv ? next * 16 + s : 0];
+        dma_tile<RC, NT>(a.sumtable, next * 16, toff, region, RT);
+      }
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+      {
+        const unsigned int kk = h * RC + k;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+        {
+          const double * dg = s_diag + (kk * 20 + 4 * c + q) * 4;
+          c0 = fma(b[k][c], dg[0], c0);
+          c1 = fma(b[k][c], dg[1], c1);
+          c2 = fma(b[k][c], dg[2], c2);
+        }
+        c0 += __shfl_xor(c0, 16, 64);
+        c1 += __shfl_xor(c1, 16, 64);
+        c2 += __shfl_xor(c2, 16, 64);
+        c0 += __shfl_xor(c0, 32, 64);
+        c1 += __shfl_xor(c1, 32, 64);
+        c2 += __shfl_xor(c2, 32, 64);
+        const double pinv = s_model[2 * kk], w = s_model[2 * kk + 1];
+        if (pinv > 0.0)
+        {
+          // core_derivatives.c:481-491
+          const double inv_lk = (inv_cur == -1) ? 0.0 : s_freqs[kk * 20 + inv_cur] * pinv;
+          c0 = c0 * (1.0 - pinv) + inv_lk;
+          c1 = c1 * (1.0 - pinv);
+          c2 = c2 * (1.0 - pinv);
+        }
+        l0 += c0 * w;
+        l1 += c1 * w;
+        l2 += c2 * w;
+      }
+    }
+    if (q == 0 && tile * 16 + s < sites)
+    {
+      const double d1 = -l1 / l0;
+      const double d2 = d1 * d1 - l2 / l0;
+      const double pw = (double)w_cur;
+      acc_d += pw * d1;
+      acc_dd += pw * d2;
+    }
+  }
+  block_sum2(acc_d, acc_dd, a.reduce);
+}
+
 extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot,
                                              int parent_scaler, int child_scaler,
                                              const unsigned int * h_params_indices,
@@ -582,6 +692,9 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   const bool asc_epilogue = c->sh.asc_states && (c->asc_type & PLLHIP_AB_MASK) &&
                             (c->asc_type & PLLHIP_AB_MASK) != PLLHIP_AB_STAMATAKIS;
   const bool aa_tile = (S == 20 && !c->aa_exact && (R == 1 || R == 2 || R == 4));
+  // (other category counts: the tile walk chunk by chunk, its table staged; 150 KB of LDS at most)
+  const bool aa_chunks = (S == 20 && !c->aa_exact && !aa_tile && pllhip_aa_chunks_enabled() &&
+                          (size_t)R * 102 * sizeof(double) + 4 * 11 * 1024 <= 150 * 1024);
   DerivArgs a;
   if (dna || aa_tile) memcpy(a.diag_inline, h_diagptable, dbytes);
   if (!(dna || aa_tile) || asc_epilogue)
@@ -679,6 +792,33 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
       default: DERIV_AA(4); break;
     }
 #undef DERIV_AA
+  }
+  else if (aa_chunks)
+  {
+    const size_t tiles = ((size_t)a.sites + 15) / 16;
+    size_t blocks = (tiles + 3) / 4;
+    const unsigned int rc = R % 4 == 0 ? 4u : (R % 2 == 0 ? 2u : 1u);
+    const size_t region = rc == 4 ? aa_geom<4>::REGION_B : (rc == 2 ? aa_geom<2>::REGION_B : aa_geom<1>::REGION_B);
+    const size_t lds = (size_t)R * 102 * sizeof(double) + 4 * region;
+    const size_t per_cu = lds <= 48 * 1024 ? 3 : (lds <= 76 * 1024 ? 2 : 1);
+    const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * per_cu;
+    if (blocks > cap) blocks = cap;
+    grid = (unsigned int)blocks;
+    a.reduce = pllhip_reduce_out(c, grid, 2);
+    const bool nt = pllhip_use_nt(c);
+#define DERIV_AA_CHUNKS(RCV)                                                                                         \
+    do {                                                                                                             \
+      if (nt) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_derivatives_aa_chunks<RCV, true>),    \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+                k_derivatives_aa_chunks<RCV, true><<<grid, 256, lds, c->stream>>>(a); }                              \
+      else { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_derivatives_aa_chunks<RCV, false>),      \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+             k_derivatives_aa_chunks<RCV, false><<<grid, 256, lds, c->stream>>>(a); }                                \
+    } while (0)
+    if (rc == 4) DERIV_AA_CHUNKS(4);
+    else if (rc == 2) DERIV_AA_CHUNKS(2);
+    else DERIV_AA_CHUNKS(1);
+#undef DERIV_AA_CHUNKS
   }
   else if (R <= 64 && (size_t)R * (S * 4 + 2) * sizeof(double) <= 65536)
   {

@@ -14,44 +14,36 @@
 // Numerics: one fused chain per row (as the CLV kernel), then lane sums in a
 // fixed order; per-site lnL agrees with the reference to ~1e-15 relative.
 // PLLHIP_AA_EXACT=1 selects the bit-exact vector kernel (likelihood.hip).
-//
-// H (round 4): EIGHT rate categories as two halves of four per tile (H = 2, RC = 4): a tile of 16 sites x 8
-// categories is two images, so the wave takes the child and parent tiles of categories 0..3, then those of 4..7 --
-// four DMAs per tile instead of two, each of half the size, all eight matrices (or the 8-category tip table) in LDS --
-// and keeps the eight category terms in registers for the per-site tail.  Until then such partitions took the vector
-// kernel: 1.46 ms per call on 200,000 sites, a fifth of a whole evaluation.
 #include <stdlib.h>
 
 #include "aa_mfma.hpp"
 #include "lnl_common.hpp"
 
-template <int RC, int KIND, bool NT, bool GATHER, int H = 1>
+template <int RC, int KIND, bool NT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
 {
-  static_assert(H == 1 || (H == 2 && RC == 4 && !GATHER), "halves of 8 categories; no site repeats");
-  constexpr int RT = RC * H; // categories of the CLVs
   using G = aa_geom<RC>;
   extern __shared__ double smem[];
-  // LDS: [P-matrices RT x 20 x 20 (II) | pi-weighted tip table maxstates x RT x 20 (TI)][4 images]
-  const unsigned int head = (KIND == EDGE_II) ? RT * 400u : (KIND == EDGE_TI ? a.maxstates * RT * 20u : 0u);
+  // LDS: [P-matrices RC x 20 x 20 (II) | pi-weighted tip table maxstates x RC x 20 (TI)][4 images]
+  const unsigned int head = (KIND == EDGE_II) ? RC * 400u : (KIND == EDGE_TI ? a.maxstates * RC * 20u : 0u);
   double * tab = smem;
   if (KIND == EDGE_II)
     for (unsigned int t = threadIdx.x; t < head; t += blockDim.x) tab[t] = a.pmat[t];
   if (KIND == EDGE_TI)
     for (unsigned int t = threadIdx.x; t < head; t += blockDim.x)
     {
-      const unsigned int code = t / (RT * 20), kk = (t / 20) % RT, j = t % 20;
+      const unsigned int code = t / (RC * 20), kk = (t / 20) % RC, j = t % 20;
       // rowsum * pi (core_likelihood_avx2.c:191-233)
       tab[t] = masksum_seq(a.pmat + ((size_t)kk * 20 + j) * 20, a.tipmap[code], 20) *
                a.freqs[(size_t)a.freqs_indices[kk] * 20 + j];
     }
   // per-category model words the per-site tail needs: in LDS, because a global load
   // issued while the next tile's DMA is in flight returns only after that DMA
-  __shared__ double s_model[RT][2];  // prop_invar, rate weight
-  __shared__ double s_freqs[RT][20]; // frequencies of the category's rate matrix
-  for (unsigned int t = threadIdx.x; t < RT * 20u; t += blockDim.x)
+  __shared__ double s_model[RC][2];  // prop_invar, rate weight
+  __shared__ double s_freqs[RC][20]; // frequencies of the category's rate matrix
+  for (unsigned int t = threadIdx.x; t < RC * 20u; t += blockDim.x)
     s_freqs[t / 20u][t % 20u] = a.freqs[(size_t)a.freqs_indices[t / 20u] * 20 + t % 20u];
-  if (threadIdx.x < RT)
+  if (threadIdx.x < RC)
   {
     s_model[threadIdx.x][0] = a.prop_invar[a.freqs_indices[threadIdx.x]];
     s_model[threadIdx.x][1] = a.rate_weights[threadIdx.x];
@@ -62,18 +54,15 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
   const unsigned int s = lane & 15u, q = lane >> 4;
   char * region = reinterpret_cast<char *>(smem + head) + wave * G::REGION_B;
 
-  // pi_k[4g+q] for this lane (H = 2: read from LDS half by half, 80 registers otherwise)
+  // pi_k[4g+q] for this lane
   double pi[RC][5];
-  auto load_pi = [&](int half) {
 #pragma unroll
-    for (int k = 0; k < RC; ++k)
+  for (int k = 0; k < RC; ++k)
 #pragma unroll
-      for (int g = 0; g < 5; ++g) pi[k][g] = s_freqs[half * RC + k][4 * g + q];
-  };
-  if (H == 1) load_pi(0);
+    for (int g = 0; g < 5; ++g) pi[k][g] = s_freqs[k][4 * g + q];
 
   unsigned int toff[G::N_IT];
-  tile_offsets<RC, RT>(lane, toff); // (a half's categories: the CLV pointer is moved, not the offsets)
+  tile_offsets<RC>(lane, toff);
   const size_t sites = a.sites;
   const size_t tiles = (sites + 15) / 16;
   const size_t nwaves = (size_t)gridDim.x * 4;
@@ -92,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
   const unsigned int * csp = has_cs ? a.cscaler : a.zero;
   const int * invp = a.invariant ? a.invariant : reinterpret_cast<const int *>(a.zero);
   const bool has_inv = a.invariant != nullptr;
-  unsigned int w_next = 0, code_next = 0, ps_next[RT], cs_next[RT];
+  unsigned int w_next = 0, code_next = 0, ps_next[RC], cs_next[RC];
   int inv_next = -1;
   // Site repeats (GATHER): site n of a CLV stored by class lives in row a.pidx[n] /
   // a.cidx[n] (nullptr = n), and so do its scaler counts.  The rows of a tile are needed
@@ -109,15 +98,15 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     inv_next = invp[has_inv ? n : 0];
     if (KIND == EDGE_TI) code_next = a.tip[n];
 #pragma unroll
-    for (int k = 0; k < RT; ++k)
+    for (int k = 0; k < RC; ++k)
     {
       const bool used = per_rate || k == 0;
-      const size_t ep = per_rate ? (size_t)prow * RT + k : (size_t)prow;
-      const size_t ec = per_rate ? (size_t)crow * RT + k : (size_t)crow;
+      const size_t ep = per_rate ? (size_t)prow * RC + k : (size_t)prow;
+      const size_t ec = per_rate ? (size_t)crow * RC + k : (size_t)crow;
       ps_next[k] = used ? psp[has_ps ? ep : 0] : 0u;
       cs_next[k] = used ? csp[has_cs ? ec : 0] : 0u;
     }
-    if (!GATHER) dma_tile<RC, NT, RT>(KIND == EDGE_II ? a.child : a.parent, tile * 16, toff, region);
+    if (!GATHER) dma_tile<RC, NT>(KIND == EDGE_II ? a.child : a.parent, tile * 16, toff, region);
     else if (KIND == EDGE_II) dma_tile_rows<RC, NT>(a.child, crow, toff, region);
     else dma_tile_rows<RC, NT>(a.parent, prow, toff, region);
   };
@@ -141,92 +130,81 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // this tile's per-site words have landed with the DMA: take them out of the
     // registers the next request will overwrite
-    unsigned int w_cur = w_next, code = code_next, sc_cur[RT]; // (scaler counts: parent + child)
+    unsigned int w_cur = w_next, code = code_next, ps_cur[RC], cs_cur[RC];
     int inv_cur = has_inv ? inv_next : -1;
     const unsigned int prow_cur = prow_next; // rows of THIS tile (its second operand is still to come)
     prow_next = prow_next2;
     crow_next = crow_next2;
     asm volatile("" : "+v"(w_cur), "+v"(code), "+v"(inv_cur), "+v"(prow_next), "+v"(crow_next));
 #pragma unroll
-    for (int k = 0; k < RT; ++k)
+    for (int k = 0; k < RC; ++k)
     {
-      sc_cur[k] = ps_next[k] + cs_next[k];
-      asm volatile("" : "+v"(sc_cur[k]));
+      ps_cur[k] = ps_next[k];
+      cs_cur[k] = cs_next[k];
+      asm volatile("" : "+v"(ps_cur[k]), "+v"(cs_cur[k]));
     }
-    if (KIND == EDGE_TI && code >= a.maxstates) code = 0;
-
-    double term[RT];
-    // one half of the tile's categories (H = 1: all of them); its first operand tile is in the image
-    auto half_terms = [&](auto hc) __attribute__((always_inline)) {
-      constexpr int h = decltype(hc)::value;
-      if (h >= H) return;
-      if (h > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (H > 1) load_pi(h);
-      if (KIND == EDGE_II)
-      {
-        read_b_operands<RC>(region, s, q, b);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (GATHER) dma_tile_rows<RC, NT>(a.parent, prow_cur, toff, region);
-        else dma_tile<RC, NT, RT>(a.parent + h * RC * 20, site0, toff, region);
-        tile_matvec<RC>(tab + h * RC * 400, b, lane, x);
-#pragma unroll
-        for (int k = 0; k < RC; ++k)
-#pragma unroll
-          for (int g = 0; g < 5; ++g) x[k][g] = x[k][g] * pi[k][g];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      else
-      {
-#pragma unroll
-        for (int k = 0; k < RC; ++k)
-#pragma unroll
-          for (int g = 0; g < 5; ++g)
-            x[k][g] = (KIND == EDGE_TI) ? tab[(code * RT + h * RC + k) * 20 + 4 * g + q] : pi[k][g];
-      }
-      read_b_operands<RC>(region, s, q, b); // parent CLV, states 4g+q
+    if (KIND == EDGE_II)
+    {
+      read_b_operands<RC>(region, s, q, b);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (h + 1 < H)
-        // the other half of this tile
-        dma_tile<RC, NT, RT>((KIND == EDGE_II ? a.child : a.parent) + (h + 1) * RC * 20, site0, toff, region);
-      else if (next < tiles)
-      {
-        request_tile(next, prow_next, crow_next);
-        const size_t after = next + nwaves < tiles ? next + nwaves : next;
-        prow_next2 = rows_of(a.pidx, after);
-        crow_next2 = rows_of(a.cidx, after);
-      }
+      if (GATHER) dma_tile_rows<RC, NT>(a.parent, prow_cur, toff, region);
+      else dma_tile<RC, NT>(a.parent, site0, toff, region);
+      tile_matvec<RC>(tab, b, lane, x);
 #pragma unroll
       for (int k = 0; k < RC; ++k)
-      {
-        double t = 0.0;
 #pragma unroll
-        for (int g = 0; g < 5; ++g) t += x[k][g] * b[k][g];
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        term[(h < H ? h : 0) * RC + k] = t;
-      }
-    };
-    half_terms(std::integral_constant<int, 0>{});
-    half_terms(std::integral_constant<int, 1>{});
+        for (int g = 0; g < 5; ++g) x[k][g] = x[k][g] * pi[k][g];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    else
+    {
+      if (KIND == EDGE_TI && code >= a.maxstates) code = 0;
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+#pragma unroll
+        for (int g = 0; g < 5; ++g)
+          x[k][g] = (KIND == EDGE_TI) ? tab[(code * RC + k) * 20 + 4 * g + q] : pi[k][g];
+    }
+    read_b_operands<RC>(region, s, q, b); // parent CLV, states 4g+q
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (next < tiles)
+    {
+      request_tile(next, prow_next, crow_next);
+      const size_t after = next + nwaves < tiles ? next + nwaves : next;
+      prow_next2 = rows_of(a.pidx, after);
+      crow_next2 = rows_of(a.cidx, after);
+    }
+
+    double term[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+    {
+      double t = 0.0;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) t += x[k][g] * b[k][g];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      term[k] = t;
+    }
 
     // lanes 0..15: one site each
     const size_t n = site0 + s;
     if (q == 0 && n < sites)
     {
-      unsigned int site_scalings = 0, rel[RT];
+      unsigned int site_scalings = 0, rel[RC];
       if (per_rate)
       {
         unsigned int mn = 0xffffffffu;
 #pragma unroll
-        for (int k = 0; k < RT; ++k)
+        for (int k = 0; k < RC; ++k)
         {
-          const unsigned int v = sc_cur[k];
+          const unsigned int v = ps_cur[k] + cs_cur[k];
           rel[k] = v;
           mn = v < mn ? v : mn;
         }
         site_scalings = mn;
 #pragma unroll
-        for (int k = 0; k < RT; ++k)
+        for (int k = 0; k < RC; ++k)
         {
           const unsigned int d = rel[k] - mn;
           rel[k] = d > PLLHIP_SCALE_RATE_MAXDIFF ? PLLHIP_SCALE_RATE_MAXDIFF : d;
@@ -235,12 +213,12 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
       else
       {
 #pragma unroll
-        for (int k = 0; k < RT; ++k) rel[k] = 0;
-        site_scalings = sc_cur[0];
+        for (int k = 0; k < RC; ++k) rel[k] = 0;
+        site_scalings = ps_cur[0] + cs_cur[0];
       }
       double terma = 0.0;
 #pragma unroll
-      for (int k = 0; k < RT; ++k)
+      for (int k = 0; k < RC; ++k)
       {
         // category term -> weighted contribution (core_likelihood_avx2.c:480-500)
         double tr = term[k];
@@ -265,22 +243,20 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
   block_sum_to_partials(acc, a.reduce);
 }
 
-template <int RC, int H = 1>
+template <int RC>
 static int launch_lnl_rc(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
 {
   using G = aa_geom<RC>;
-  constexpr int RT = RC * H;
   const size_t tiles = ((size_t)a.sites + 15) / 16;
   size_t blocks = (tiles + 3) / 4;
   const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per wave)
   if (blocks > cap) blocks = cap;
-  const size_t head = (kind == EDGE_II) ? (size_t)RT * 400
-                                        : (kind == EDGE_TI ? (size_t)a.maxstates * RT * 20 : 0);
+  const size_t head = (kind == EDGE_II) ? (size_t)RC * 400
+                                        : (kind == EDGE_TI ? (size_t)a.maxstates * RC * 20 : 0);
   const size_t lds = head * sizeof(double) + 4 * (size_t)G::REGION_B;
   if (lds > 80 * 1024) return 1;
   const bool nt = pllhip_use_nt(c);
   const bool gather = a.pidx || a.cidx;
-  if (H > 1 && gather) return 1;
   const dim3 grid((unsigned int)blocks), block(256);
   a.reduce = pllhip_reduce_out(c, (unsigned int)blocks);
 #define LNL_ONE(KERNEL)                                                                        \
@@ -291,13 +267,210 @@ static int launch_lnl_rc(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * g
   } while (0)
 #define LNL_KIND(KINDV)                                                     \
   do {                                                                      \
-    if (H > 1) {                                                            \
-      if (nt) LNL_ONE((k_lnl_aa_mfma<RC, KINDV, true, false, H>));          \
-      else LNL_ONE((k_lnl_aa_mfma<RC, KINDV, false, false, H>));            \
-    }                                                                       \
-    else if (gather) LNL_ONE((k_lnl_aa_mfma<RC, KINDV, false, true>));      \
+    if (gather) LNL_ONE((k_lnl_aa_mfma<RC, KINDV, false, true>));           \
     else if (nt) LNL_ONE((k_lnl_aa_mfma<RC, KINDV, true, false>));          \
     else LNL_ONE((k_lnl_aa_mfma<RC, KINDV, false, false>));                 \
+  } while (0)
+  if (kind == EDGE_II) LNL_KIND(EDGE_II);
+  else if (kind == EDGE_TI) LNL_KIND(EDGE_TI);
+  else LNL_KIND(ROOT);
+#undef LNL_KIND
+#undef LNL_ONE
+  HIP_TRY(hipGetLastError());
+  *grid_out = (unsigned int)blocks;
+  return 0;
+}
+
+// ---- category counts other than 1, 2, 4 (round 4): the tile's categories in CHUNKS of RC (the largest of 4, 2, 1 that
+// divides the count): per chunk the child tile, the 25 MFMAs per category, the parent tile -- 2 x rate_cats / RC DMAs of
+// RC x 160 bytes per site instead of two of the whole row --, all matrices (or the whole tip table) in LDS, the site's
+// sum over categories accumulated chunk by chunk in the lane that finishes the site (same order of additions as the
+// kernel above: k = 0, 1, 2 ...).  Until then such partitions took the vector kernel (likelihood.hip): 8 categories,
+// 200,000 sites 1,458 us per call, this kernel 87.  No site repeats (such partitions never store by class).
+template <int RC, int KIND, bool NT>
+__global__ __launch_bounds__(256, 2) void k_lnl_aa_chunks(LnlArgs a)
+{
+  using G = aa_geom<RC>;
+  extern __shared__ double smem[];
+  const unsigned int RT = a.rate_cats, H = RT / RC;
+  // LDS: [P-matrices RT x 20 x 20 (II) | pi-weighted tip table maxstates x RT x 20 (TI)][4 images][freqs RT x 20][model RT x 2]
+  const unsigned int head = (KIND == EDGE_II) ? RT * 400u : (KIND == EDGE_TI ? a.maxstates * RT * 20u : 0u);
+  double * tab = smem;
+  double * s_freqs = smem + head + 4 * (G::REGION_B / 8); // [k][20]
+  double * s_model = s_freqs + RT * 20u;                  // [k][prop_invar, rate weight]
+  if (KIND == EDGE_II)
+    for (unsigned int t = threadIdx.x; t < head; t += blockDim.x) tab[t] = a.pmat[t];
+  if (KIND == EDGE_TI)
+    for (unsigned int t = threadIdx.x; t < head; t += blockDim.x)
+    {
+      const unsigned int code = t / (RT * 20), kk = (t / 20) % RT, j = t % 20;
+      // rowsum * pi (core_likelihood_avx2.c:191-233)
+      tab[t] = masksum_seq(a.pmat + ((size_t)kk * 20 + j) * 20, a.tipmap[code], 20) *
+               a.freqs[(size_t)a.freqs_indices[kk] * 20 + j];
+    }
+  for (unsigned int t = threadIdx.x; t < RT * 20u; t += blockDim.x)
+    s_freqs[t] = a.freqs[(size_t)a.freqs_indices[t / 20u] * 20 + t % 20u];
+  for (unsigned int t = threadIdx.x; t < RT; t += blockDim.x)
+  {
+    s_model[2 * t] = a.prop_invar[a.freqs_indices[t]];
+    s_model[2 * t + 1] = a.rate_weights[t];
+  }
+  __syncthreads();
+
+  const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned int s = lane & 15u, q = lane >> 4;
+  char * region = reinterpret_cast<char *>(smem + head) + wave * G::REGION_B;
+  unsigned int toff[G::N_IT];
+  tile_offsets<RC>(lane, toff, RT); // (a chunk's categories: the CLV pointer is moved, not the offsets)
+  const size_t sites = a.sites;
+  const size_t tiles = (sites + 15) / 16;
+  const size_t nwaves = (size_t)gridDim.x * 4;
+  const bool per_rate = a.rate_scalers && KIND != ROOT;
+  double acc = 0.0;
+
+  const size_t first = (size_t)blockIdx.x * 4 + wave;
+  const bool has_ps = a.pscaler != nullptr, has_cs = (KIND == EDGE_II && a.cscaler != nullptr);
+  const unsigned int * psp = has_ps ? a.pscaler : a.zero;
+  const unsigned int * csp = has_cs ? a.cscaler : a.zero;
+  const int * invp = a.invariant ? a.invariant : reinterpret_cast<const int *>(a.zero);
+  const bool has_inv = a.invariant != nullptr;
+  const double * const first_clv = (KIND == EDGE_II) ? a.child : a.parent;
+  unsigned int w_next = 0, code_next = 0, sc_next = 0;
+  int inv_next = -1;
+  // per-site words first, then the first chunk's first operand (loads return in order)
+  auto request_tile = [&](size_t tile) {
+    const size_t n = tile * 16 + s;
+    w_next = a.pattern_weights[n];
+    inv_next = invp[has_inv ? n : 0];
+    if (KIND == EDGE_TI) code_next = a.tip[n];
+    sc_next = per_rate ? 0u : psp[has_ps ? n : 0] + csp[has_cs ? n : 0];
+    dma_tile<RC, NT>(first_clv, tile * 16, toff, region, RT);
+  };
+  if (first < tiles) request_tile(first);
+  for (size_t tile = first; tile < tiles; tile += nwaves)
+  {
+    const size_t site0 = tile * 16, n = site0 + s;
+    const size_t next = tile + nwaves;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int w_cur = w_next, code = code_next, site_scalings = sc_next;
+    int inv_cur = has_inv ? inv_next : -1;
+    asm volatile("" : "+v"(w_cur), "+v"(code), "+v"(inv_cur), "+v"(site_scalings));
+    if (KIND == EDGE_TI && code >= a.maxstates) code = 0;
+    if (per_rate)
+    {
+      // the site's smallest count over ALL categories comes first (core_likelihood.c:320-331); rare mode: plain loads
+      unsigned int mn = 0xffffffffu;
+      for (unsigned int k = 0; k < RT; ++k)
+      {
+        const unsigned int v = psp[has_ps ? n * RT + k : 0] + csp[has_cs ? n * RT + k : 0];
+        mn = v < mn ? v : mn;
+      }
+      site_scalings = mn;
+    }
+    double terma = 0.0;
+    for (unsigned int h = 0; h < H; ++h)
+    {
+      double b[RC][5], x[RC][5], pi[RC][5];
+      unsigned int rel[RC];
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+      {
+        rel[k] = 0u;
+        if (per_rate)
+        {
+          const size_t e = n * RT + h * RC + k;
+          const unsigned int d = psp[has_ps ? e : 0] + csp[has_cs ? e : 0] - site_scalings;
+          rel[k] = d > PLLHIP_SCALE_RATE_MAXDIFF ? PLLHIP_SCALE_RATE_MAXDIFF : d;
+        }
+#pragma unroll
+        for (int g = 0; g < 5; ++g) pi[k][g] = s_freqs[(h * RC + k) * 20 + 4 * g + q];
+      }
+      if (h > 0 || per_rate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (KIND == EDGE_II)
+      {
+        read_b_operands<RC>(region, s, q, b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_tile<RC, NT>(a.parent + h * RC * 20, site0, toff, region, RT);
+        tile_matvec<RC>(tab + h * RC * 400, b, lane, x);
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+          for (int g = 0; g < 5; ++g) x[k][g] = x[k][g] * pi[k][g];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+          for (int g = 0; g < 5; ++g)
+            x[k][g] = (KIND == EDGE_TI) ? tab[(code * RT + h * RC + k) * 20 + 4 * g + q] : pi[k][g];
+      }
+      read_b_operands<RC>(region, s, q, b); // parent CLV, states 4g+q
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (h + 1 < H) dma_tile<RC, NT>(first_clv + (h + 1) * RC * 20, site0, toff, region, RT); // the tile's next chunk
+      else if (next < tiles) request_tile(next);
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+      {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) t += x[k][g] * b[k][g];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        // category term -> weighted contribution (core_likelihood_avx2.c:480-500); lanes 0..15 own a site each
+        if (rel[k] > 0) t *= scale_minlh(rel[k]);
+        const double pinv = s_model[2 * (h * RC + k)];
+        const double w = s_model[2 * (h * RC + k) + 1];
+        if (pinv > 0.0)
+        {
+          const double inv_lk = (inv_cur == -1) ? 0.0 : s_freqs[(h * RC + k) * 20 + inv_cur];
+          terma += w * (t * (1.0 - pinv) + inv_lk * pinv);
+        }
+        else
+          terma += t * w;
+      }
+    }
+    if (q == 0 && n < sites)
+    {
+      double lk = log(terma);
+      if (site_scalings) lk += (double)site_scalings * log(PLLHIP_SCALE_THRESHOLD);
+      lk *= (double)w_cur;
+      if (a.persite) a.persite[n] = lk;
+      acc += lk;
+    }
+  }
+  block_sum_to_partials(acc, a.reduce);
+}
+
+template <int RC>
+static int launch_lnl_chunks(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * grid_out)
+{
+  using G = aa_geom<RC>;
+  if (a.pidx || a.cidx) return 1;
+  const unsigned int RT = a.rate_cats;
+  const size_t tiles = ((size_t)a.sites + 15) / 16;
+  size_t blocks = (tiles + 3) / 4;
+  const size_t head = (kind == EDGE_II) ? (size_t)RT * 400 : (kind == EDGE_TI ? (size_t)a.maxstates * RT * 20 : 0);
+  const size_t lds = (head + (size_t)RT * 22) * sizeof(double) + 4 * (size_t)G::REGION_B;
+  if (lds > 150 * 1024) return 1;
+  // (two workgroups per CU while their LDS allows)
+  const size_t per_cu = lds <= 80 * 1024 ? 2 : 1;
+  const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * per_cu;
+  if (blocks > cap) blocks = cap;
+  const bool nt = pllhip_use_nt(c);
+  const dim3 grid((unsigned int)blocks), block(256);
+  a.reduce = pllhip_reduce_out(c, (unsigned int)blocks);
+#define LNL_ONE(KERNEL)                                                                        \
+  do {                                                                                         \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+    hipLaunchKernelGGL(KERNEL, grid, block, lds, c->stream, a);                                \
+  } while (0)
+#define LNL_KIND(KINDV)                                          \
+  do {                                                           \
+    if (nt) LNL_ONE((k_lnl_aa_chunks<RC, KINDV, true>));         \
+    else LNL_ONE((k_lnl_aa_chunks<RC, KINDV, false>));           \
   } while (0)
   if (kind == EDGE_II) LNL_KIND(EDGE_II);
   else if (kind == EDGE_TI) LNL_KIND(EDGE_TI);
@@ -318,11 +491,10 @@ int pllhip_launch_lnl_aa_mfma(pllhip_ctx * c, LnlArgs & a, int kind, unsigned in
     case 1: return launch_lnl_rc<1>(c, a, kind, grid_out);
     case 2: return launch_lnl_rc<2>(c, a, kind, grid_out);
     case 4: return launch_lnl_rc<4>(c, a, kind, grid_out);
-    case 8:
-    {
-      static const bool rc8 = !(getenv("PLLHIP_AA_RC8") && atoi(getenv("PLLHIP_AA_RC8")) == 0);
-      return rc8 ? launch_lnl_rc<4, 2>(c, a, kind, grid_out) : 1;
-    }
-    default: return 1;
+    default: break;
   }
+  if (!pllhip_aa_chunks_enabled()) return 1;
+  if (a.rate_cats % 4 == 0) return launch_lnl_chunks<4>(c, a, kind, grid_out);
+  if (a.rate_cats % 2 == 0) return launch_lnl_chunks<2>(c, a, kind, grid_out);
+  return launch_lnl_chunks<1>(c, a, kind, grid_out);
 }

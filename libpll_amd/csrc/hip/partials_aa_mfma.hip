@@ -61,22 +61,25 @@
 // a row of the precomputed tip table (a.ltab, [code][rate][state]), which takes
 // the place of the left P-matrix in LDS; the right child goes through the MFMAs.
 //
-// SPLIT (round 4): 20-state data with EIGHT rate categories.  A tile of 16 sites x 8 categories does not fit the LDS
-// budget (two images per wave, 20 KB each; 51 KB of matrices), so an op runs as TWO launches of the 4-category kernel,
-// each over half the categories of every site (SPLIT = 1: categories 0..3, SPLIT = 2: categories 4..7; the site
-// stride in HBM is that of 8 categories, the matrices and tip tables are those of the half).  Per-rate scalers need
-// nothing else.  With per-site scalers a site scales iff ALL EIGHT categories are small: the first launch stores its
-// products unscaled and leaves its verdict per site in the parent's scale buffer (1 = all small), the second reads it,
-// decides, scales its own half in registers and -- rarely -- the first half in place.  Same arithmetic per entry as the
-// reference's kernels (core_partials_avx2.c:568-803, core_partials_avx.c:1097-1340), same scaling rule: same bits.
-// Until round 4 such partitions ran on the all-vector kernels at a third of this rate.
+// SPLIT (round 4): 20-state data with a number of rate categories other than 1, 2 or 4 -- 8 (Gamma with eight
+// categories), 3, 5, 6, 7, 10 ... (free-rate models).  A tile of 16 sites x 8 categories does not fit the LDS budget (two
+// images per wave, 20 KB each; 51 KB of matrices) and other counts have no tile geometry at all, so an op runs as
+// SEVERAL launches of this kernel, each over a CHUNK of 4, 2 or 1 categories of every site (R = 8: 4 + 4; 6: 4 + 2; 7:
+// 4 + 2 + 1; 3: 2 + 1): the site stride in HBM is that of all categories (a.rate_cats), the chunk starts at category
+// a.rate_first, matrices and tip tables are the chunk's.  SPLIT = 1: the first chunk, 3: a middle one, 2: the last.
+// Per-rate scalers need nothing else.  With per-site scalers a site scales iff ALL categories are small: every chunk
+// but the last stores its products unscaled and leaves / ANDs its verdict per site in the parent's scale buffer (1 =
+// all small so far), the last reads it, decides, scales its own chunk in registers and -- rarely -- the earlier ones in
+// place.  Same arithmetic per entry as the reference's kernels (core_partials_avx2.c:568-803,
+// core_partials_avx.c:1097-1340), same scaling rule: same bits.  Until round 4 such partitions ran on the all-vector
+// kernels at a third of this rate.
 template <int RC, int MODE, bool NT, int KIND, bool GATHER, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 {
-  static_assert(SPLIT == 0 || (RC == 4 && !GATHER), "halves of 8 categories; no site repeats");
-  constexpr int RT = SPLIT ? 2 * RC : RC;   // categories of the CLV
-  constexpr int RF = SPLIT == 2 ? RC : 0;   // first category of this launch
+  static_assert(SPLIT == 0 || !GATHER, "chunks of the categories do not follow row maps");
   const PartialsArgs & a = batch.op[blockIdx.y];
+  const unsigned int RT = SPLIT ? a.rate_cats : (unsigned int)RC; // categories of the CLV
+  const unsigned int RF = SPLIT ? a.rate_first : 0u;              // first category of this launch
   using G = aa_geom<RC>;
   extern __shared__ double smem[];
   // LDS: [left part][right P-matrices RC x 20 x 20][4 wave images]
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
   constexpr int ROW_B = G::ROW_G * 16;
 
   unsigned int toff[G::N_IT];
-  tile_offsets<RC, RT, RF>(lane, toff);
+  tile_offsets<RC>(lane, toff, RT, RF);
   unsigned int store_mask = 0; // bit it: granule it*64+lane of the image is data (not pad, not past the tile)
 #pragma unroll
   for (int it = 0; it < G::N_IT; ++it)
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     }
     // destination = (uniform) start of the tile in the parent CLV + the same per-lane
     // offsets the DMA uses; pad lanes and sites past the end do not store
-    const unsigned long long ob = (unsigned long long)(a.parent + prev_site0 * (size_t)(RT * 20));
+    const unsigned long long ob = (unsigned long long)(a.parent + prev_site0 * (size_t)(RT * 20u));
     const unsigned int olo = __builtin_amdgcn_readfirstlane((unsigned int)ob);
     const unsigned int ohi = __builtin_amdgcn_readfirstlane((unsigned int)(ob >> 32));
     char * obase = reinterpret_cast<char *>(((unsigned long long)ohi << 32) | olo);
@@ -160,14 +163,14 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
 #pragma unroll
     for (int it = 0; it < G::N_IT; ++it)
     {
-      const unsigned int site = toff[it] / (unsigned int)(RT * 160);
+      const unsigned int site = SPLIT ? (unsigned int)((it * 64 + (int)lane) / G::ROW_G) : toff[it] / (unsigned int)(RC * 160);
       if (((store_mask >> it) & 1u) && site < left_sites)
         st16<NT>(reinterpret_cast<double2 *>(obase + toff[it]), v[it].x, v[it].y);
     }
     const size_t n = prev_site0 + s;
     if (MODE == SCALE_SITE && q == 0 && n < sites)
     {
-      if (SPLIT == 1) const_cast<unsigned int *>(a.lidx)[n] = psc[0]; // (the verdict buffer, see the scaling step)
+      if (SPLIT == 1 || SPLIT == 3) const_cast<unsigned int *>(a.lidx)[n] = psc[0]; // (the verdict buffer, see the scaling step)
       else a.pscaler[n] = psc[0];
     }
     if (MODE == SCALE_RATE && q == 0 && n < sites)
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
       fsc_next[k] = used ? first_sc[has_first ? e : 0] : 0u;
     }
     if (GATHER) dma_tile_rows<RC, NT>(first_clv, frow, toff, region);
-    else dma_tile<RC, NT, RT>(first_clv, tile * 16, toff, region);
+    else dma_tile<RC, NT>(first_clv, tile * 16, toff, region, RT);
   };
   {
     // prologue: the rows of the first tile have to be here before anything can be requested
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
         ssc[k] = used ? rs[has_r ? e : 0] : 0u;
       }
       if (GATHER) dma_tile_rows<RC, NT>(a.right, srow, toff, region);
-      else dma_tile<RC, NT, RT>(a.right, site0, toff, region);
+      else dma_tile<RC, NT>(a.right, site0, toff, region, RT);
       tile_matvec_chain<RC, 0>(la14, la5, b, lane, xl); // overlaps the right child's DMA and the stores
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -318,34 +321,36 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     right_rate(std::integral_constant<int, 1>{});
     right_rate(std::integral_constant<int, 2>{});
     right_rate(std::integral_constant<int, 3>{});
-    if (MODE == SCALE_SITE && SPLIT == 1)
+    if (MODE == SCALE_SITE && (SPLIT == 1 || SPLIT == 3))
     {
-      // first half of eight categories: no decision yet -- the verdict of these four goes to the verdict buffer (the
+      // not the last chunk of the categories: no decision yet -- the verdict so far goes to the verdict buffer (the
       // parent's scale buffer, a.lidx; a scratch array when that buffer is also a child's: the op works in place)
-      psc[0] = column_all(small_site, s) ? 1u : 0u;
+      const size_t n = site0 + s;
+      const unsigned int before = (SPLIT == 3 && n < sites) ? a.lidx[n] : 1u;
+      psc[0] = (column_all(small_site, s) && before != 0u) ? 1u : 0u;
     }
     else if (MODE == SCALE_SITE)
     {
       bool scale = column_all(small_site, s);
       if (SPLIT == 2)
       {
-        // second half: the site scales iff the first half said "all small" too; its entries (written unscaled by the
-        // first launch) are then scaled in place -- rare: a wave-uniform mask of such sites, 40 granules each
+        // last chunk: the site scales iff the earlier chunks said "all small" too; their entries (written unscaled by
+        // those launches) are then scaled in place -- rare: a wave-uniform mask of such sites, 10 granules per category
         const size_t n = site0 + s;
-        const unsigned int first_half = (n < sites) ? a.lidx[n] : 0u;
-        scale = scale && first_half != 0u;
+        const unsigned int earlier = (n < sites) ? a.lidx[n] : 0u;
+        scale = scale && earlier != 0u;
         const unsigned long long fix = __ballot(scale && q == 0 && n < sites);
         if (fix)
         {
-          double2 * prow = reinterpret_cast<double2 *>(a.parent + site0 * (size_t)(RT * 20));
+          double2 * prow = reinterpret_cast<double2 *>(a.parent + site0 * (size_t)(RT * 20u));
           for (unsigned int sl = 0; sl < 16u; ++sl)
             if ((fix >> sl) & 1ull)
-              if (lane < (unsigned int)(RC * 10))
+              for (unsigned int g = lane; g < RF * 10u; g += 64u)
               {
-                double2 v = prow[(size_t)sl * (RT * 10) + lane];
+                double2 v = prow[(size_t)sl * (RT * 10u) + g];
                 v.x *= PLLHIP_SCALE_FACTOR;
                 v.y *= PLLHIP_SCALE_FACTOR;
-                prow[(size_t)sl * (RT * 10) + lane] = v;
+                prow[(size_t)sl * (RT * 10u) + g] = v;
               }
         }
       }
@@ -397,11 +402,15 @@ __global__ __launch_bounds__(256) void k_aa_tip_tables(PartialsBatch batch, doub
 // tip-tip: parent = ltab[code_l] (.) rtab[code_r].  One lane per 16 bytes, waves
 // in rounds of 64 sites (codes fetched once per round, one site per lane), the
 // GS = 10*RC store instructions of a round each one contiguous KiB.
-template <int RC, int MODE, bool NT, bool GATHER>
+// (CHUNK: the launch writes RC of the a.rate_cats categories of every site, from a.rate_first on -- see k_aa_ii_mfma's
+// SPLIT; the scale buffer is cleared by the chunk that starts at category 0)
+template <int RC, int MODE, bool NT, bool GATHER, bool CHUNK = false>
 __global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsBatch batch)
 {
+  static_assert(!CHUNK || !GATHER, "chunks of the categories do not follow row maps");
   const PartialsArgs & a = batch.op[blockIdx.y];
-  constexpr unsigned int GS = RC * 10; // 16-byte granules per site
+  constexpr unsigned int GS = RC * 10; // 16-byte granules per site (of this launch)
+  const unsigned int GT = CHUNK ? a.rate_cats * 10u : GS, G0 = CHUNK ? a.rate_first * 10u : 0u;
   extern __shared__ double smem[];
   const unsigned int per = a.maxstates * RC * 20;
   double * tl = smem, * tr = smem + per;
@@ -434,13 +443,18 @@ __global__ __launch_bounds__(256) void k_aa_tt_rounds(PartialsBatch batch)
       const double2 x = *reinterpret_cast<const double2 *>(tl + c1 * RC * 20 + rr * 2);
       const double2 y = *reinterpret_cast<const double2 *>(tr + c2 * RC * 20 + rr * 2);
       // plain stores: a write-only stream is slower with the non-temporal hint (see partials.hip)
-      if (gbase + gg < gend) st16<false>(out + gbase + gg, x.x * y.x, x.y * y.y);
+      if (gbase + gg < gend)
+        st16<false>(CHUNK ? out + (site0 + sl) * GT + G0 + rr : out + gbase + gg, x.x * y.x, x.y * y.y);
     }
     // no scaling test on tip-tip; the scaler is cleared (core_partials_avx.c:552-553)
+    if (CHUNK && a.rate_first != 0u) continue;
     if (MODE == SCALE_SITE && site0 + lane < sites) a.pscaler[site0 + lane] = 0u;
     if (MODE == SCALE_RATE)
-      for (unsigned int t = lane; t < 64 * RC; t += 64)
-        if (site0 * RC + t < sites * RC) a.pscaler[site0 * RC + t] = 0u;
+    {
+      const unsigned int RA = CHUNK ? a.rate_cats : (unsigned int)RC;
+      for (unsigned int t = lane; t < 64 * RA; t += 64)
+        if (site0 * RA + t < sites * RA) a.pscaler[site0 * RA + t] = 0u;
+    }
   }
 }
 
@@ -484,7 +498,7 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
 #define AA_LAUNCH(MODEV)                                                                      \
   do {                                                                                        \
     if (SPLIT) {                                                                              \
-      if (gather) return 1; /* (no site repeats with eight categories) */                     \
+      if (gather) return 1; /* (chunks of the categories do not follow row maps) */           \
       if (nt) AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, true, KIND, false, SPLIT>));             \
       else AA_LAUNCH_ONE((k_aa_ii_mfma<RC, MODEV, false, KIND, false, SPLIT>));               \
     }                                                                                         \
@@ -501,7 +515,7 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   return 0;
 }
 
-template <int RC>
+template <int RC, bool CHUNK = false>
 static int launch_tt(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int mode, bool nt)
 {
   const PartialsArgs & a = b.op[0];
@@ -510,7 +524,7 @@ static int launch_tt(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   for (unsigned int i = 0; i < count; ++i)
   {
     if (b.op[i].sites > rows_max) rows_max = b.op[i].sites;
-    gather = gather || b.op[i].lidx || b.op[i].ridx;
+    gather = gather || (!CHUNK && (b.op[i].lidx || b.op[i].ridx));
   }
   const size_t rounds = (rows_max + 63) / 64;
   size_t blocks = (rounds + 3) / 4;
@@ -520,7 +534,8 @@ static int launch_tt(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   const dim3 grid((unsigned int)blocks, count), block(256);
 #define TT_LAUNCH(MODEV)                                                                         \
   do {                                                                                           \
-    if (gather) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false, true>), grid, block, lds, c->stream, b); \
+    if (CHUNK) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false, false, true>), grid, block, lds, c->stream, b); \
+    else if (gather) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false, true>), grid, block, lds, c->stream, b); \
     else if (nt) hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, true, false>), grid, block, lds, c->stream, b); \
     else hipLaunchKernelGGL((k_aa_tt_rounds<RC, MODEV, false, false>), grid, block, lds, c->stream, b); \
   } while (0)
@@ -633,28 +648,49 @@ __global__ __launch_bounds__(256) void k_aa_cherry_rounds(CherryBatch batch)
   }
 }
 
+bool pllhip_aa_chunks_enabled()
+{
+  static const bool on = !(getenv("PLLHIP_AA_CHUNKS") && atoi(getenv("PLLHIP_AA_CHUNKS")) == 0) &&
+                         !(getenv("PLLHIP_AA_RC8") && atoi(getenv("PLLHIP_AA_RC8")) == 0);
+  return on;
+}
+
 bool pllhip_aa_fast_covers(const pllhip_ctx * c, int kind)
 {
   const unsigned int R = c->sh.rate_cats;
-  // (8 categories, round 4: two launches of the 4-category kernel per op, k_aa_ii_mfma's SPLIT; PLLHIP_AA_RC8=0: the
-  // all-vector kernels as before)
-  static const bool rc8 = !(getenv("PLLHIP_AA_RC8") && atoi(getenv("PLLHIP_AA_RC8")) == 0);
-  if (c->aa_exact || c->sh.states != 20 || !(R == 1 || R == 2 || R == 4 || (R == 8 && rc8))) return false;
+  // (category counts other than 1, 2, 4 -- round 4: several launches per op, each over a chunk of 4, 2 or 1 of the
+  // categories, k_aa_ii_mfma's SPLIT; PLLHIP_AA_CHUNKS=0: the all-vector kernels as before)
+  if (c->aa_exact || c->sh.states != 20 || R == 0) return false;
+  const bool whole = R == 1 || R == 2 || R == 4;
+  if (!whole && !pllhip_aa_chunks_enabled()) return false;
   if (kind == 0) return true;
-  // tip kinds: both tables of an op must fit the workgroup's LDS next to its other data
+  // tip kinds: both tables of an op (of a chunk) must fit the workgroup's LDS next to its other data
   return c->maxstates > 0 && c->maxstates <= 32 &&
-         2 * (size_t)c->maxstates * R * 20 * sizeof(double) <= 60 * 1024;
+         2 * (size_t)c->maxstates * (R < 4 ? R : 4) * 20 * sizeof(double) <= 60 * 1024;
 }
 
-// Eight rate categories: the two halves of every op of the batch (k_aa_ii_mfma's SPLIT).  Each half sees the
-// matrices -- and, for a tip-inner op, a tip table -- of its four categories; the per-site verdict of the first half
-// travels in the parent's scale buffer unless that buffer is also a child's (an op that works in place).
-static int launch_rc8_halves(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int kind, int mode, bool nt)
+// Category counts other than 1, 2, 4: every op of the batch chunk by chunk (k_aa_ii_mfma's SPLIT, k_aa_tt_rounds'
+// CHUNK).  Each launch sees the matrices -- and, for a tip child, a tip table -- of its categories; the per-site
+// verdict of the chunks so far travels in the parent's scale buffer unless that buffer is also a child's (an op that
+// scales in place).
+template <int RC, int KIND>
+static int launch_chunk(pllhip_ctx * c, const PartialsBatch & h, unsigned int count, int mode, bool nt, int split)
 {
-  const size_t per = (size_t)b.op[0].maxstates * 4 * 20; // a half's tip table
-  if (kind == 1)
+  switch (split)
   {
-    const size_t need = 2 * 2 * per * PLLHIP_BATCH_MAX;
+    case 1: return launch_rc<RC, KIND, 1>(c, h, count, mode, nt);
+    case 3: return launch_rc<RC, KIND, 3>(c, h, count, mode, nt);
+    default: return launch_rc<RC, KIND, 2>(c, h, count, mode, nt);
+  }
+}
+
+static int launch_chunks(pllhip_ctx * c, const PartialsBatch & b, unsigned int count, int kind, int mode, bool nt)
+{
+  const unsigned int R = b.op[0].rate_cats, ms = b.op[0].maxstates;
+  if (kind >= 1)
+  {
+    // tip tables of all chunks side by side: [chunk][op][left, right][code][category of the chunk][state]
+    const size_t need = 2 * (size_t)ms * R * 20 * PLLHIP_BATCH_MAX;
     if (c->tiptab_elems < need)
     {
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -665,35 +701,52 @@ static int launch_rc8_halves(pllhip_ctx * c, const PartialsBatch & b, unsigned i
       c->tiptab_elems = need;
     }
   }
-  for (int half = 0; half < 2; ++half)
+  for (unsigned int rf = 0; rf < R;)
   {
+    const unsigned int left = R - rf, rc = left >= 4 ? 4u : (left >= 2 ? 2u : 1u);
+    const int split = rf == 0 ? 1 : (rf + rc == R ? 2 : 3);
     PartialsBatch h = b;
     for (unsigned int i = 0; i < count; ++i)
     {
       PartialsArgs & a = h.op[i];
-      if (a.lmat) a.lmat += (size_t)half * 4 * 400;
-      if (a.rmat) a.rmat += (size_t)half * 4 * 400;
+      if (a.lmat) a.lmat += (size_t)rf * 400;
+      if (a.rmat) a.rmat += (size_t)rf * 400;
+      a.rate_first = rf;
       a.lidx = a.pscaler;
       a.ridx = nullptr;
-      if (mode == SCALE_SITE && a.pscaler && (a.pscaler == a.lscaler || a.pscaler == a.rscaler))
+      if (kind != 2 && mode == SCALE_SITE && a.pscaler && (a.pscaler == a.lscaler || a.pscaler == a.rscaler))
       {
+        const size_t per_op = (size_t)c->sh.sites + PLLHIP_TAIL_SITES;
         if (!c->split_verdicts)
-          HIP_TRY(hipMalloc((void **)&c->split_verdicts, (size_t)PLLHIP_BATCH_MAX * ((size_t)c->sh.sites + PLLHIP_TAIL_SITES) * sizeof(unsigned int)));
-        a.lidx = c->split_verdicts + (size_t)i * ((size_t)c->sh.sites + PLLHIP_TAIL_SITES);
+          HIP_TRY(hipMalloc((void **)&c->split_verdicts, (size_t)PLLHIP_BATCH_MAX * per_op * sizeof(unsigned int)));
+        a.lidx = c->split_verdicts + (size_t)i * per_op;
       }
     }
-    if (kind == 1)
+    if (kind >= 1)
     {
-      // the tip's row sums over this half's four categories (k_aa_tip_tables reads the pre-offset matrices)
-      double * tab = c->d_tiptab + (size_t)half * 2 * per * PLLHIP_BATCH_MAX;
-      k_aa_tip_tables<<<dim3(8, count), 256, 0, c->stream>>>(h, tab, h.op[0].maxstates, 4, 0);
+      // the tips' row sums over this chunk's categories (k_aa_tip_tables reads the pre-offset matrices)
+      const size_t per = (size_t)ms * rc * 20;
+      double * tab = c->d_tiptab + 2 * (size_t)ms * rf * 20 * PLLHIP_BATCH_MAX;
+      k_aa_tip_tables<<<dim3(8, count), 256, 0, c->stream>>>(h, tab, ms, rc, kind == 2 ? 1 : 0);
       HIP_TRY(hipGetLastError());
-      for (unsigned int i = 0; i < count; ++i) h.op[i].ltab = tab + (size_t)i * 2 * per;
+      for (unsigned int i = 0; i < count; ++i)
+      {
+        h.op[i].ltab = tab + (size_t)i * 2 * per;
+        h.op[i].rtab = h.op[i].ltab + per;
+      }
     }
-    int rc;
-    if (kind == 1) rc = half == 0 ? launch_rc<4, 1, 1>(c, h, count, mode, nt) : launch_rc<4, 1, 2>(c, h, count, mode, nt);
-    else rc = half == 0 ? launch_rc<4, 0, 1>(c, h, count, mode, nt) : launch_rc<4, 0, 2>(c, h, count, mode, nt);
-    if (rc) return rc;
+    int rcode;
+    if (kind == 2)
+      rcode = rc == 4 ? launch_tt<4, true>(c, h, count, mode, nt)
+                      : (rc == 2 ? launch_tt<2, true>(c, h, count, mode, nt) : launch_tt<1, true>(c, h, count, mode, nt));
+    else if (kind == 1)
+      rcode = rc == 4 ? launch_chunk<4, 1>(c, h, count, mode, nt, split)
+                      : (rc == 2 ? launch_chunk<2, 1>(c, h, count, mode, nt, split) : launch_chunk<1, 1>(c, h, count, mode, nt, split));
+    else
+      rcode = rc == 4 ? launch_chunk<4, 0>(c, h, count, mode, nt, split)
+                      : (rc == 2 ? launch_chunk<2, 0>(c, h, count, mode, nt, split) : launch_chunk<1, 0>(c, h, count, mode, nt, split));
+    if (rcode) return rcode;
+    rf += rc;
   }
   return 0;
 }
@@ -702,7 +755,7 @@ int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count
 {
   const unsigned int R = b.op[0].rate_cats;
   const bool nt = pllhip_use_nt(c);
-  if (R == 8 && kind <= 1) return launch_rc8_halves(c, b, count, kind, mode, nt);
+  if (!(R == 1 || R == 2 || R == 4)) return launch_chunks(c, b, count, kind, mode, nt);
   if (kind >= 1)
   {
     // tip row-sum tables of every op of the batch, one launch
@@ -732,7 +785,6 @@ int pllhip_launch_aa_batch(pllhip_ctx * c, PartialsBatch & b, unsigned int count
     {
       case 1: return launch_tt<1>(c, b, count, mode, nt);
       case 2: return launch_tt<2>(c, b, count, mode, nt);
-      case 8: return launch_tt<8>(c, b, count, mode, nt);
       default: return launch_tt<4>(c, b, count, mode, nt);
     }
   }
@@ -773,7 +825,7 @@ bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode)
 {
   const char * e = getenv("PLLHIP_AA_CHERRY"); // 0: never, 2: whatever the partition's size (tests)
   const bool off = e && atoi(e) == 0;
-  return !off && !c->cherry_pool_failed && c->sh.states == 20 && c->sh.rate_cats <= 4 && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
+  return !off && !c->cherry_pool_failed && c->sh.states == 20 && (c->sh.rate_cats == 1 || c->sh.rate_cats == 2 || c->sh.rate_cats == 4) && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
          c->rows.empty() && mode != SCALE_RATE && c->maxstates >= 1 && c->maxstates <= 32 && !c->sh.asc_states;
 }
 

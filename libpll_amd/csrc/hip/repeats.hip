@@ -149,9 +149,9 @@ extern "C" int pllhip_identify_repeats(pllhip_ctx_t * c, unsigned int parent, un
   // 20 states: only the matrix-core kernels follow row maps; on the bit-exact vector
   // kernels (PLLHIP_AA_EXACT=1, or a rate_cats / tip alphabet they do not cover) every
   // CLV simply stays stored per site
-  // (eight rate categories run as two half-category launches per op, which do not gather rows either)
+  // (category counts other than 1, 2, 4 run as several chunk launches per op, which do not gather rows either)
   if (c->sh.states == 20 &&
-      (c->sh.rate_cats > 4 || !(pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) && c->maxstates <= 32)))
+      (!(c->sh.rate_cats == 1 || c->sh.rate_cats == 2 || c->sh.rate_cats == 4) || !(pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) && c->maxstates <= 32)))
   {
     if (c->rows.empty()) c->rows.resize(nodes);
     c->rows[parent].classes = 0;

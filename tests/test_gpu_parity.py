@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from helpers import (make_case, odd_state_case, many_state_case, build_partition, oracle_run, bits_equal, rel_err,
-                     sumtable_err)
+                     sumtable_err, invariant_of)
 from libpll_amd import workload as W
 from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, SCALE_BUFFER_NONE,
                                PllError)
@@ -132,18 +132,22 @@ def test_rate_category_counts(gpu, orc, aa_mode, states, rate_cats):
     ("balanced", 32, 1029, 0, 0)])
 @pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
 @pytest.mark.parametrize("in_place", [False, True])
-def test_eight_rate_categories_20_states(gpu, orc, aa_mode, monkeypatch, shape, tips, sites, pattern_tip, expect_min,
-                                         rate_scalers, in_place):
-    """20 states x 8 rate categories: on the default path every inner-inner and tip-inner op is TWO launches of the
-    4-category matrix-core kernel (partials_aa_mfma.hip, SPLIT), the per-site scaling verdict of the first half
-    travelling in the parent's scale buffer -- or in a scratch array when the op scales in place (parent scale buffer =
-    the inner child's, in_place).  CLVs and scaler counts bit for bit, with scaling events, in both scaling modes,
-    with waves that walk several tiles."""
+@pytest.mark.parametrize("rate_cats", [3, 7, 8, 12])
+def test_chunked_rate_categories_20_states(gpu, orc, aa_mode, monkeypatch, shape, tips, sites, pattern_tip, expect_min,
+                                           rate_scalers, in_place, rate_cats):
+    """20 states with a number of rate categories other than 1, 2, 4: on the default path every op is SEVERAL launches
+    of the matrix-core kernels, each over a chunk of 4, 2 or 1 categories (partials_aa_mfma.hip, SPLIT / CHUNK: 3 = 2 +
+    1, 7 = 4 + 2 + 1, 8 = 4 + 4, 12 = 4 + 4 + 4), the per-site scaling verdict of the chunks so far travelling in the
+    parent's scale buffer -- or in a scratch array when the op scales in place (parent scale buffer = the inner
+    child's, in_place).  CLVs and scaler counts bit for bit, with scaling events, in both scaling modes, with waves that
+    walk several tiles; the edge lnL (chunk by chunk too, likelihood_aa_mfma.hip) to the default path's tolerance."""
     if in_place and shape != "caterpillar":
         pytest.skip("one scale buffer all the way down needs a ladder")
+    if rate_cats in (3, 12) and shape in ("random", "balanced") and rate_scalers:
+        pytest.skip("covered by the other counts")
     import dataclasses
     monkeypatch.setenv("PLLHIP_AA_GRID_CAP", "3")
-    case = make_case(20, shape, tips, sites, rate_cats=8, seed=tips, alpha=0.5,
+    case = make_case(20, shape, tips, sites, rate_cats=rate_cats, seed=tips, alpha=0.5,
                      branch=0.5 if shape == "caterpillar" else None, weights=False, ambiguity=shape != "caterpillar",
                      gap_frac=0.0 if shape == "caterpillar" else 0.05)
     case["rates"], case["freqs"] = gpu.aa_model("lg")
@@ -157,9 +161,58 @@ def test_eight_rate_categories_20_states(gpu, orc, aa_mode, monkeypatch, shape, 
     attrs = pattern_tip | rate_scalers
     p = build_partition(gpu, case, attrs)
     o = oracle_run(orc, gpu, p, case, attrs)
-    compare(p, o, case, 8, aa_mode == "exact")
+    compare(p, o, case, rate_cats, aa_mode == "exact")
     last = int(case["plan"].ops[-1]["parent_scaler_index"])
     assert p.get_scaler(last).min() >= expect_min
+    p.destroy()
+
+
+@pytest.mark.parametrize("rate_cats", [3, 6, 8])
+@pytest.mark.parametrize("pattern_tip", [0, ATTRIB_PATTERN_TIP])
+@pytest.mark.parametrize("rate_scalers", [0, ATTRIB_RATE_SCALERS])
+def test_chunked_rate_categories_lnl_and_derivatives(gpu, orc, aa_mode, monkeypatch, rate_cats, pattern_tip, rate_scalers):
+    """The calls behind the CLV updates on such partitions: edge lnL over an inner-inner and over a tip-inner edge,
+    root lnL, with invariant sites and pattern weights; sumtable (chunk launches too) and derivatives."""
+    monkeypatch.setenv("PLLHIP_AA_GRID_CAP", "2")
+    exact = aa_mode == "exact"
+    attrs = pattern_tip | rate_scalers
+    case = make_case(20, "random", 12, 700, rate_cats=rate_cats, seed=rate_cats + 40, alpha=0.6)
+    seqs = [bytearray(s) for s in case["seqs"]]
+    for col in range(0, 700, 3):
+        for s in seqs:
+            s[col] = seqs[0][col]
+    case["seqs"] = [bytes(s) for s in seqs]
+    case["rates"], case["freqs"] = gpu.aa_model("wag")
+    p = build_partition(gpu, case, attrs, pinv=0.25)
+    o = oracle_run(orc, gpu, p, case, attrs, pinv=0.25)
+    R = rate_cats
+    compare(p, o, case, R, exact)
+    plan = case["plan"]
+    tol = PERSITE_RTOL if exact else MFMA_LNL_RTOL
+    # an edge with a tip at one end: the last tip-inner (or, with tips as CLVs, any) op's parent and its tip child
+    op = [q for q in plan.ops if int(q["child2_clv_index"]) < plan.tips or int(q["child1_clv_index"]) < plan.tips][-1]
+    tipside = 1 if int(op["child1_clv_index"]) < plan.tips else 2
+    edge = (int(op["parent_clv_index"]), int(op["parent_scaler_index"]), int(op["child%d_clv_index" % tipside]), -1,
+            int(op["child%d_matrix_index" % tipside]))
+    lnl, ps = p.compute_edge_loglikelihood(*edge, [0] * R, persite=True)
+    lnl_o, ps_o = o.edge_loglikelihood(*edge, persite=True)
+    assert rel_err(ps, ps_o) < tol and abs(lnl - lnl_o) <= tol * abs(lnl_o)
+    e = plan.root_edge
+    if not rate_scalers:
+        # root lnL (core_likelihood.c:25-209) restated on the CLV the device holds
+        lnl, ps = p.compute_root_loglikelihood(e[0], e[1], [0] * R, persite=True)
+        clv, sc, inv = p.get_clv(e[0]), p.get_scaler(e[1]).astype(np.float64), invariant_of(p)
+        fr = np.asarray(case["freqs"], dtype=np.float64)
+        inv_lk = np.where(inv >= 0, fr[np.maximum(inv, 0)], 0.0) * 0.25
+        site = ((clv @ fr) * 0.75 + inv_lk[:, None]).sum(axis=1) / R
+        ps_o = (np.log(site) + sc * np.log(2.0 ** -256)) * case["pw"]
+        assert rel_err(ps, ps_o) < 1e-11 and abs(lnl - ps_o.sum()) <= 1e-11 * abs(lnl)
+    st = p.alloc_sumtable()
+    p.update_sumtable(e[0], e[2], e[1], e[3], [0] * R, st)
+    so = o.sumtable(e[0], e[2], e[1], e[3])
+    assert sumtable_err(p.get_sumtable(st), so) < (1e-12 if exact else 1e-10)
+    for t in (0.003, 0.2):
+        assert rel_err(p.compute_likelihood_derivatives(e[1], e[3], t, [0] * R, st), o.derivatives(so, t)) < DERIV_RTOL
     p.destroy()
 
 
