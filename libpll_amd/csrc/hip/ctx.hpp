@@ -354,8 +354,22 @@ struct AaLookupTables
   const double * tl, * tr;                    // [pair][rate][state]
   const unsigned char * t1, * t2, * t3, * t4; // characters: pair 1 = (t1, t2), pair 2 = (t3, t4)
 };
+// One table of a lookup op as a job for k_af_prepare (partials_aa_fused.hip; round 4: the tables of a whole list in
+// the launch that prepares its matrices, instead of six launches of the tabulating kernels): row (c1 ms + c2) =
+// pm x (tip table of kl [c1] (.) tip table of kr [c2]) in the order of the kernel the op itself would have run --
+// mode 0: inner-inner (fused chains, core_partials_avx2.c:632-750), mode 1: tip-inner (products and sums rounded
+// separately, core_partials_avx.c:1229-1284) --, or, mode 2, rows (c1 ms + 0) = the tip table of kl itself.
+struct AaLookupJob
+{
+  const double * pm, * kl, * kr;
+  double * dst;
+  unsigned int mode, pad;
+};
+// jobs == nullptr: the tables are built here and now (launches of the tabulating kernels); otherwise only their
+// places are assigned and jobs[2 i], jobs[2 i + 1] describe the two tables of op i
 int pllhip_aa_lookup_tables(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
-                            const PartialsArgs * kid2, unsigned int count, AaLookupTables * out);
+                            const PartialsArgs * kid2, unsigned int count, AaLookupTables * out,
+                            AaLookupJob * jobs = nullptr);
 // partials_aa_fused.hip: a 20-state op list in one site-blocked launch; returns 1 if the list (or
 // the partition) is not one it takes -- the caller then launches per level
 int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count);

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
                                                     char * aorder, char * titab,
                                                     const unsigned int * __restrict__ tipmap, unsigned int ms,
                                                     unsigned int * __restrict__ tile_counter,
-                                                    const AfPairJob * __restrict__ pj, unsigned int npair, char * pairtab)
+                                                    const AfPairJob * __restrict__ pj, unsigned int npair, char * pairtab,
+                                                    const AaLookupJob * __restrict__ lj, unsigned int nlk)
 {
   const unsigned int b = blockIdx.x;
   // (the list kernel's tile counter: reset here instead of by a fill kernel of its own, round 4)
@@ -198,6 +199,39 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
     {
       const unsigned int c2 = t / 80, ki = t - 80 * c2;
       out[t] = left[ki] * masksum_seq(j.rmat + (size_t)ki * 20, tipmap[c2], 20);
+    }
+  }
+  else if (b - nmat - ntip - npair * ms < nlk * ms)
+  {
+    // (round 4) a lookup op's table, one workgroup per (table, character 1): rows (c1 ms + c2) = P x child over the
+    // character pairs the child -- a tip-tip result -- can be: the child as the branch above makes it, then the
+    // mat-vec in the order of the kernel the op would have run (AaLookupJob, ctx.hpp).  Until then six launches of
+    // those kernels ahead of every list (tip tables, tip-tip over all pairs, inner-inner x "ones"): 60 us.
+    const unsigned int job = (b - nmat - ntip - npair * ms) / ms, c1 = (b - nmat - ntip - npair * ms) - job * ms;
+    const AaLookupJob & j = lj[job];
+    double * out = j.dst + (size_t)c1 * ms * 80;
+    if (j.mode == 2u)
+    {
+      // the tip's own factor: row (c1, 0) is its table's row c1 (the op's second character row is all zeros)
+      if (threadIdx.x < 80) out[threadIdx.x] = masksum_seq(j.kl + (size_t)threadIdx.x * 20, tipmap[c1], 20);
+      return;
+    }
+    __shared__ double lk_left[80];
+    __shared__ double lk_child[32 * 80];
+    if (threadIdx.x < 80) lk_left[threadIdx.x] = masksum_seq(j.kl + (size_t)threadIdx.x * 20, tipmap[c1], 20);
+    __syncthreads();
+    for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
+    {
+      const unsigned int c2 = t / 80, ki = t - 80 * c2;
+      lk_child[t] = lk_left[ki] * masksum_seq(j.kr + (size_t)ki * 20, tipmap[c2], 20);
+    }
+    __syncthreads();
+    for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
+    {
+      const unsigned int c2 = t / 80, ki = t - 80 * c2, kk = ki / 20;
+      const double * row = j.pm + (size_t)ki * 20;
+      const double * v = lk_child + c2 * 80 + kk * 20;
+      out[t] = j.mode == 0u ? dot_strided4<true>(row, v, 20u) : dot_strided4<false>(row, v, 20u);
     }
   }
 }
@@ -843,6 +877,8 @@ struct pllhip_aa_fused_cache
   char * d_pairtab = nullptr;          // pair tables of the list's tip-tip ops (AfPairJob)
   size_t pairtab_cap = 0, off_pair = 0;
   unsigned int npair = 0;
+  size_t off_lk = 0;                   // lookup-table jobs (AaLookupJob; nlk == 0: the tables come from launches of their own)
+  unsigned int nlk = 0;
 };
 
 void pllhip_aa_fused_free(pllhip_ctx * c)
@@ -873,7 +909,7 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
     const int rc = pllhip_launch_aa_batch(c, b, nb, 2, mode);
     if (rc) return rc;
   }
-  if (!k.lk_ops.empty() && !tables_built)
+  if (!k.lk_ops.empty() && !tables_built && !k.nlk)
   {
     // (same pool, same places: the records' addresses hold while the epoch does)
     std::vector<AaLookupTables> tabs(k.lk_ops.size());
@@ -882,12 +918,12 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
     if (rc) return rc;
   }
   const char * plan = static_cast<const char *>(k.d_plan);
-  if (k.nmat + k.ntip + k.npair)
+  if (k.nmat + k.ntip + k.npair + k.nlk)
   {
-    k_af_prepare<<<k.nmat + k.ntip + k.npair * c->maxstates, 256, 0, c->stream>>>(
+    k_af_prepare<<<k.nmat + k.ntip + (k.npair + k.nlk) * c->maxstates, 256, 0, c->stream>>>(
         (const AfMatJob *)(plan + k.off_mat), k.nmat, (const AfTipJob *)(plan + k.off_tip), k.ntip, k.d_aorder,
         k.d_titab, c->tipmap, c->maxstates, c->d_tile_counter, (const AfPairJob *)(plan + k.off_pair), k.npair,
-        k.d_pairtab);
+        k.d_pairtab, (const AaLookupJob *)(plan + k.off_lk), k.nlk);
     HIP_TRY(hipGetLastError());
   }
   else HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
@@ -1082,10 +1118,14 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   }
   // the lookup tables' addresses are needed in the records: build them now (their pool may move)
   std::vector<AaLookupTables> tabs(k.lk_ops.size());
+  // (round 4: the tables are made by k_af_prepare, AaLookupJob; PLLHIP_AA_LOOKUP_DIRECT=0: by launches of the
+  // tabulating kernels ahead of it, as in round 3)
+  const bool lk_direct = !(getenv("PLLHIP_AA_LOOKUP_DIRECT") && atoi(getenv("PLLHIP_AA_LOOKUP_DIRECT")) == 0);
+  std::vector<AaLookupJob> lj(lk_direct ? 2 * k.lk_ops.size() : 0);
   if (!k.lk_ops.empty())
   {
     rc = pllhip_aa_lookup_tables(c, k.lk_ops.data(), k.lk_k1.data(), k.lk_k2.data(), (unsigned int)k.lk_ops.size(),
-                                 tabs.data());
+                                 tabs.data(), lk_direct ? lj.data() : nullptr);
     // (the pool could not be allocated: once more, now without lookup ops -- the context remembers)
     if (rc == 1 && c->cherry_pool_failed) return aa_fused_update(c, ops, count, tt_wanted);
     if (rc) return rc;
@@ -1252,8 +1292,9 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   }
 
   const size_t rec_b = recs.size() * sizeof(AaRec), mat_b = (mj.size() + 1) * sizeof(AfMatJob),
-               tip_b = (tj.size() + 1) * sizeof(AfTipJob), pair_b = (pj.size() + 1) * sizeof(AfPairJob);
-  const size_t bytes = rec_b + mat_b + tip_b + pair_b;
+               tip_b = (tj.size() + 1) * sizeof(AfTipJob), pair_b = (pj.size() + 1) * sizeof(AfPairJob),
+               lk_b = (lj.size() + 1) * sizeof(AaLookupJob);
+  const size_t bytes = rec_b + mat_b + tip_b + pair_b + lk_b;
   if (k.plan_cap < bytes)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1272,12 +1313,15 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   if (!mj.empty()) memcpy(stage + rec_b, mj.data(), mj.size() * sizeof(AfMatJob));
   if (!tj.empty()) memcpy(stage + rec_b + mat_b, tj.data(), tj.size() * sizeof(AfTipJob));
   if (!pj.empty()) memcpy(stage + rec_b + mat_b + tip_b, pj.data(), pj.size() * sizeof(AfPairJob));
+  if (!lj.empty()) memcpy(stage + rec_b + mat_b + tip_b + pair_b, lj.data(), lj.size() * sizeof(AaLookupJob));
   HIP_TRY(hipMemcpyAsync(k.d_plan, k.h_plan, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(k.done, c->stream));
   k.pending = true;
   k.off_mat = rec_b;
   k.off_tip = rec_b + mat_b;
   k.off_pair = rec_b + mat_b + tip_b;
+  k.off_lk = rec_b + mat_b + tip_b + pair_b;
+  k.nlk = (unsigned int)lj.size();
   k.npair = (unsigned int)pj.size();
   k.nmat = (unsigned int)mj.size();
   k.ntip = (unsigned int)tj.size();

@@ -1071,7 +1071,7 @@ unsigned int pllhip_aa_lookup_budget(const pllhip_ctx * c)
 // partials_aa_fused.hip, walks a tile of sites through every op): same builders, a pool of
 // their own that grows with the list.
 int pllhip_aa_lookup_tables(pllhip_ctx * c, const PartialsArgs * ops, const PartialsArgs * kid1,
-                            const PartialsArgs * kid2, unsigned int count, AaLookupTables * out)
+                            const PartialsArgs * kid2, unsigned int count, AaLookupTables * out, AaLookupJob * jobs)
 {
   const unsigned int R = c->sh.rate_cats, ms = c->maxstates;
   const size_t rows = (size_t)ms * ms + PLLHIP_TAIL_SITES;
@@ -1099,6 +1099,23 @@ int pllhip_aa_lookup_tables(pllhip_ctx * c, const PartialsArgs * ops, const Part
     }
     c->cherry_pool_all_ops = (unsigned int)n;
     ++c->layout_epoch;
+  }
+  if (jobs)
+  {
+    // places only (the same ones cherry_tables uses); the caller's prepare kernel fills them
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      double * base = c->cherry_pool_all + (size_t)i * per_op;
+      double * t0 = base + 2 * rows * row_elems, * t1 = base + 3 * rows * row_elems;
+      const PartialsArgs & op = ops[i];
+      const bool tip_left = kid1[i].lmat == nullptr; // a tip-inner lookup op: the left factor is the tip's own table
+      out[i] = AaLookupTables{t0, t1, tip_left ? op.ltip : kid1[i].ltip, tip_left ? c->cherry_zero : kid1[i].rtip,
+                              kid2[i].ltip, kid2[i].rtip};
+      jobs[2 * i] = tip_left ? AaLookupJob{nullptr, op.lmat, nullptr, t0, 2u, 0u}
+                             : AaLookupJob{op.lmat, kid1[i].lmat, kid1[i].rmat, t0, 0u, 0u};
+      jobs[2 * i + 1] = AaLookupJob{op.rmat, kid2[i].lmat, kid2[i].rmat, t1, tip_left ? 1u : 0u, 0u};
+    }
+    return 0;
   }
   for (unsigned int first = 0; first < count; first += chunk)
   {
