@@ -72,20 +72,23 @@ def assert_same(a, b):
         assert (a["scs"][sc] == b["scs"][sc]).all(), "scaler %d" % sc
 
 
-@pytest.mark.parametrize("states,shape,tips,sites,attrs,pinv",
-                         [(4, "random", 20, 3001, ATTRIB_PATTERN_TIP, 0.0),
-                          (4, "balanced", 16, 1000, ATTRIB_PATTERN_TIP | ATTRIB_RATE_SCALERS, 0.0),
-                          (4, "caterpillar", 300, 700, ATTRIB_PATTERN_TIP, 0.0),
-                          (4, "random", 12, 2500, 0, 0.0),
-                          (4, "random", 14, 1500, ATTRIB_PATTERN_TIP, 0.2),
-                          (20, "random", 12, 900, ATTRIB_PATTERN_TIP, 0.0),
-                          (20, "balanced", 8, 777, ATTRIB_RATE_SCALERS, 0.0),
-                          (7, "random", 9, 1100, ATTRIB_PATTERN_TIP, 0.0)])
-def test_sharded_equals_unsharded(gpu, orc, monkeypatch, states, shape, tips, sites, attrs, pinv):
+@pytest.mark.parametrize("states,shape,tips,sites,attrs,pinv,rate_cats",
+                         [(4, "random", 20, 3001, ATTRIB_PATTERN_TIP, 0.0, 4),
+                          (4, "balanced", 16, 1000, ATTRIB_PATTERN_TIP | ATTRIB_RATE_SCALERS, 0.0, 4),
+                          (4, "caterpillar", 300, 700, ATTRIB_PATTERN_TIP, 0.0, 4),
+                          (4, "random", 12, 2500, 0, 0.0, 4),
+                          (4, "random", 14, 1500, ATTRIB_PATTERN_TIP, 0.2, 4),
+                          (20, "random", 12, 900, ATTRIB_PATTERN_TIP, 0.0, 4),
+                          (20, "balanced", 8, 777, ATTRIB_RATE_SCALERS, 0.0, 4),
+                          # (20 states x 6 / 8 categories: every op in chunks of the categories, round 4)
+                          (20, "random", 12, 900, ATTRIB_PATTERN_TIP, 0.1, 6),
+                          (20, "caterpillar", 120, 600, ATTRIB_RATE_SCALERS, 0.0, 8),
+                          (7, "random", 9, 1100, ATTRIB_PATTERN_TIP, 0.0, 4)])
+def test_sharded_equals_unsharded(gpu, orc, monkeypatch, states, shape, tips, sites, attrs, pinv, rate_cats):
     monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)   # (the default path: 20 states on the matrix cores)
     monkeypatch.setenv("PLLHIP_FUSED", "2")     # 4 states: the whole-list kernel also on these small shards
     if states in (4, 20):
-        case = make_case(states, shape, tips, sites, seed=tips + sites)
+        case = make_case(states, shape, tips, sites, seed=tips + sites, rate_cats=rate_cats)
     else:
         from helpers import odd_state_case
         case = odd_state_case(states, tips=tips, sites=sites, seed=5)
