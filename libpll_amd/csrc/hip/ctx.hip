@@ -385,6 +385,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   if (c->cherry_zero) (void)hipFree(c->cherry_zero);
   if (c->cherry_pool_all) (void)hipFree(c->cherry_pool_all);
   if (c->split_verdicts) (void)hipFree(c->split_verdicts);
+  if (c->root_counts) (void)hipFree(c->root_counts);
   pllhip_aa_fused_free(c);
   for (int b = 0; b < 2; ++b)
   {

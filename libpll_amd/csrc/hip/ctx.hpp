@@ -94,6 +94,10 @@ struct pllhip_ctx
   double * cherry_pool_all = nullptr;        // the tables of ALL lookup ops of a list (partials_aa_fused.hip)
   unsigned int cherry_pool_all_ops = 0;      // lookup ops it has room for
   bool cherry_pool_failed = false;           // its allocation failed once: no lookup ops on this context any more
+  // a shard of a group, root lnL with per-rate scale buffers: the entries the reference would read (see
+  // pllhip_group_root_loglikelihood, shard.hip), and the switch that makes pllhip_root_loglikelihood use them
+  unsigned int * root_counts = nullptr;
+  const unsigned int * root_scaler_override = nullptr;
   unsigned int * split_verdicts = nullptr;   // 20 states x 8 categories: per-site verdicts of an op's first half when the op works in place
   struct pllhip_aa_fused_cache * aa_fused = nullptr; // 20-state whole-list kernel: its kept plan
   size_t pairtab_elems = 0;

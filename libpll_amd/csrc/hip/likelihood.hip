@@ -1137,7 +1137,7 @@ extern "C" int pllhip_root_loglikelihood(pllhip_ctx_t * c, unsigned int clv_inde
   memset(&a, 0, sizeof(a));
   if (fill_freqs_indices(c, a, h_freqs_indices)) return -1;
   a.parent = c->clv[clv_index];
-  a.pscaler = pllhip_scaler_ptr(c, scaler_index);
+  a.pscaler = c->root_scaler_override ? c->root_scaler_override : pllhip_scaler_ptr(c, scaler_index);
   if (!c->rows.empty() && c->rows[clv_index].classes) a.pidx = c->rows[clv_index].site_id;
   return run_lnl(c, a, ROOT, h_persite_lnl, h_lnl);
 }

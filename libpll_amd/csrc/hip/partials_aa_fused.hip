@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
                                                     const AaLookupJob * __restrict__ lj, unsigned int nlk)
 {
   const unsigned int b = blockIdx.x;
+  __shared__ double sh_m1[1600], sh_m2[1600]; // a job's matrices (pair and lookup tables)
+  __shared__ double sh_left[80];              // the row of character 1
+  __shared__ double sh_child[32 * 80];        // a lookup table's child over (c1, every c2)
   // (the list kernel's tile counter: reset here instead of by a fill kernel of its own, round 4)
   if (b == 0 && threadIdx.x == 0) *tile_counter = 0u;
   if (b < nmat)
@@ -188,17 +191,24 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
   else if (b - nmat - ntip < npair * ms)
   {
     // one workgroup per (op, character 1): row (c1 ms + c2) = left factor of c1 (.) right factor of c2 -- the two
-    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds
+    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds.  (The
+    // matrices come through LDS, read with coalesced loads: a lane summing its own row out of global memory made
+    // this launch 15 us, and 35 with the lookup ops' tables below.)
     const unsigned int job = (b - nmat - ntip) / ms, c1 = (b - nmat - ntip) - job * ms;
     const AfPairJob & j = pj[job];
-    __shared__ double left[80];
-    if (threadIdx.x < 80) left[threadIdx.x] = masksum_seq(j.lmat + (size_t)threadIdx.x * 20, tipmap[c1], 20);
+    for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x)
+    {
+      sh_m1[t] = j.lmat[t];
+      sh_m2[t] = j.rmat[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
     __syncthreads();
     double * out = reinterpret_cast<double *>(pairtab + j.dst_off) + (size_t)c1 * ms * 80;
     for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
     {
       const unsigned int c2 = t / 80, ki = t - 80 * c2;
-      out[t] = left[ki] * masksum_seq(j.rmat + (size_t)ki * 20, tipmap[c2], 20);
+      out[t] = sh_left[ki] * masksum_seq(sh_m2 + ki * 20, tipmap[c2], 20);
     }
   }
   else if (b - nmat - ntip - npair * ms < nlk * ms)
@@ -216,21 +226,26 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
       if (threadIdx.x < 80) out[threadIdx.x] = masksum_seq(j.kl + (size_t)threadIdx.x * 20, tipmap[c1], 20);
       return;
     }
-    __shared__ double lk_left[80];
-    __shared__ double lk_child[32 * 80];
-    if (threadIdx.x < 80) lk_left[threadIdx.x] = masksum_seq(j.kl + (size_t)threadIdx.x * 20, tipmap[c1], 20);
+    for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x)
+    {
+      sh_m1[t] = j.kl[t];
+      sh_m2[t] = j.kr[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
     __syncthreads();
     for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
     {
       const unsigned int c2 = t / 80, ki = t - 80 * c2;
-      lk_child[t] = lk_left[ki] * masksum_seq(j.kr + (size_t)ki * 20, tipmap[c2], 20);
+      sh_child[t] = sh_left[ki] * masksum_seq(sh_m2 + ki * 20, tipmap[c2], 20);
     }
+    for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x) sh_m1[t] = j.pm[t]; // (the left tip matrix is done with)
     __syncthreads();
     for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
     {
       const unsigned int c2 = t / 80, ki = t - 80 * c2, kk = ki / 20;
-      const double * row = j.pm + (size_t)ki * 20;
-      const double * v = lk_child + c2 * 80 + kk * 20;
+      const double * row = sh_m1 + ki * 20;
+      const double * v = sh_child + c2 * 80 + kk * 20;
       out[t] = j.mode == 0u ? dot_strided4<true>(row, v, 20u) : dot_strided4<false>(row, v, 20u);
     }
   }

@@ -128,14 +128,63 @@ int pllhip_group_edge_loglikelihood(pllhip_ctx * g, unsigned int parent_clv, int
   });
 }
 
+// The reference's root kernel takes the count of site i from ENTRY i of the scale buffer (core_likelihood.c:197-198)
+// -- with per-rate scale buffers (sites x rate_cats entries) that is the count of site i / rate_cats, category
+// i % rate_cats: not site i's, but what the reference computes and what an unsharded partition reproduces.  A shard
+// holding sites [lo, hi) therefore needs entries [lo, hi) of the WHOLE buffer, which belong to the shards holding
+// sites lo / rate_cats ... hi / rate_cats: copied together here (rare call, rare attribute: every shard is waited for
+// first).  Found by the sharded test on a tree that scales (round 4): the lnL had silently differed from the unsharded
+// partition's whenever a scaling event had happened.
+static int gather_root_counts(pllhip_ctx * g, int scaler_index)
+{
+  const size_t R = g->sh.rate_cats, n = g->shards.size();
+  for (pllhip_ctx * s : g->shards)
+  {
+    HIP_TRY(hipSetDevice(s->sh.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  for (size_t i = 0; i < n; ++i)
+  {
+    pllhip_ctx * s = g->shards[i];
+    const size_t lo = g->shard_lo[i], hi = g->shard_lo[i + 1];
+    HIP_TRY(hipSetDevice(s->sh.device));
+    if (!s->root_counts)
+    {
+      HIP_TRY(hipMalloc((void **)&s->root_counts, ((size_t)s->sh.sites + PLLHIP_TAIL_SITES) * sizeof(unsigned int)));
+      HIP_TRY(hipMemsetAsync(s->root_counts, 0, ((size_t)s->sh.sites + PLLHIP_TAIL_SITES) * sizeof(unsigned int), s->stream));
+    }
+    for (size_t t = 0; t < n; ++t)
+    {
+      const size_t glo = g->shard_lo[t] * R, ghi = g->shard_lo[t + 1] * R; // entries of the whole buffer shard t holds
+      const size_t a = lo > glo ? lo : glo, b = hi < ghi ? hi : ghi;
+      if (a >= b) continue;
+      const unsigned int * src = pllhip_scaler_ptr(g->shards[t], scaler_index);
+      if (!src) continue;
+      HIP_TRY(hipMemcpyAsync(s->root_counts + (a - lo), src + (a - glo), (b - a) * sizeof(unsigned int),
+                             hipMemcpyDeviceToDevice, s->stream));
+    }
+    s->root_scaler_override = s->root_counts;
+  }
+  return 0;
+}
+
 int pllhip_group_root_loglikelihood(pllhip_ctx * g, unsigned int clv_index, int scaler_index,
                                     const unsigned int * h_freqs_indices, double * h_persite_lnl, double * h_lnl)
 {
   double unused = 0.0;
-  return fan_out_and_sum(g, 1, h_lnl, [&](pllhip_ctx * s, size_t lo) {
-    return pllhip_root_loglikelihood(s, clv_index, scaler_index, h_freqs_indices,
-                                     h_persite_lnl ? h_persite_lnl + lo : nullptr, &unused);
-  });
+  int rc = 0;
+  if (g->sh.rate_scalers && scaler_index >= 0 && scaler_index < (int)g->sh.scale_buffers)
+  {
+    pllhip_device_guard guard;
+    rc = gather_root_counts(g, scaler_index);
+  }
+  if (!rc)
+    rc = fan_out_and_sum(g, 1, h_lnl, [&](pllhip_ctx * s, size_t lo) {
+      return pllhip_root_loglikelihood(s, clv_index, scaler_index, h_freqs_indices,
+                                       h_persite_lnl ? h_persite_lnl + lo : nullptr, &unused);
+    });
+  for (pllhip_ctx * s : g->shards) s->root_scaler_override = nullptr;
+  return rc;
 }
 
 int pllhip_group_likelihood_derivatives(pllhip_ctx * g, unsigned int slot, int parent_scaler, int child_scaler,

@@ -76,6 +76,9 @@ def assert_same(a, b):
                          [(4, "random", 20, 3001, ATTRIB_PATTERN_TIP, 0.0, 4),
                           (4, "balanced", 16, 1000, ATTRIB_PATTERN_TIP | ATTRIB_RATE_SCALERS, 0.0, 4),
                           (4, "caterpillar", 300, 700, ATTRIB_PATTERN_TIP, 0.0, 4),
+                          # (per-rate scale buffers on a tree that scales: the root kernel reads ENTRY i of the
+                          # buffer for site i, core_likelihood.c:197-198 -- entries other shards hold)
+                          (4, "caterpillar", 300, 700, ATTRIB_PATTERN_TIP | ATTRIB_RATE_SCALERS, 0.0, 4),
                           (4, "random", 12, 2500, 0, 0.0, 4),
                           (4, "random", 14, 1500, ATTRIB_PATTERN_TIP, 0.2, 4),
                           (20, "random", 12, 900, ATTRIB_PATTERN_TIP, 0.0, 4),
