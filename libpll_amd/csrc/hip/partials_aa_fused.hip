@@ -126,6 +126,16 @@ struct AfPairJob
 // chain b, b = 4 the source of the second; lane (q, rate, i) of block (t, b) holds
 // P_rate[G_t(i)][4q + b] (b < 4) or P_rate[G_t(i)][16 + q], G_t(i) = 4i + t (t < 4), 16 + i:
 // the accumulator of group t then puts state 4q + t (or 16 + q) in lane q.
+// the entries of a 20-entry row selected by a state mask, added in ascending order (masksum_seq over registers: the
+// others contribute +0.0, which changes no bit of a sum that starts at +0.0)
+__device__ __forceinline__ double af_masksum20(const double (&r)[20], unsigned int mask)
+{
+  double a = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 20; ++jj) a += ((mask >> jj) & 1u) ? r[jj] : 0.0;
+  return a;
+}
+
 __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict__ mj, unsigned int nmat,
                                                     const AfTipJob * __restrict__ tj, unsigned int ntip,
                                                     char * aorder, char * titab,
@@ -191,9 +201,10 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
   else if (b - nmat - ntip < npair * ms)
   {
     // one workgroup per (op, character 1): row (c1 ms + c2) = left factor of c1 (.) right factor of c2 -- the two
-    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds.  (The
-    // matrices come through LDS, read with coalesced loads: a lane summing its own row out of global memory made
-    // this launch 15 us, and 35 with the lookup ops' tables below.)
+    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds.  The
+    // matrices come through LDS (coalesced loads); a thread keeps ITS row of the right matrix in registers and
+    // walks the second characters (a masked sum = the row's selected entries added in ascending order; adding +0.0
+    // for the others changes no bit).
     const unsigned int job = (b - nmat - ntip) / ms, c1 = (b - nmat - ntip) - job * ms;
     const AfPairJob & j = pj[job];
     for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x)
@@ -205,10 +216,15 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
     if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
     __syncthreads();
     double * out = reinterpret_cast<double *>(pairtab + j.dst_off) + (size_t)c1 * ms * 80;
-    for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
+    if (threadIdx.x < 240)
     {
-      const unsigned int c2 = t / 80, ki = t - 80 * c2;
-      out[t] = sh_left[ki] * masksum_seq(sh_m2 + ki * 20, tipmap[c2], 20);
+      const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u;
+      double r[20];
+#pragma unroll
+      for (int jj = 0; jj < 20; ++jj) r[jj] = sh_m2[ki * 20 + jj];
+      const double l = sh_left[ki];
+      for (unsigned int c2 = g; c2 < ms; c2 += 3)
+        out[c2 * 80 + ki] = l * af_masksum20(r, tipmap[c2]);
     }
   }
   else if (b - nmat - ntip - npair * ms < nlk * ms)
@@ -234,19 +250,29 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
     __syncthreads();
     if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
     __syncthreads();
-    for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
+    const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u; // (threads 240..255: no row)
+    if (threadIdx.x < 240)
     {
-      const unsigned int c2 = t / 80, ki = t - 80 * c2;
-      sh_child[t] = sh_left[ki] * masksum_seq(sh_m2 + ki * 20, tipmap[c2], 20);
+      double r[20];
+#pragma unroll
+      for (int jj = 0; jj < 20; ++jj) r[jj] = sh_m2[ki * 20 + jj];
+      const double l = sh_left[ki];
+      for (unsigned int c2 = g; c2 < ms; c2 += 3) sh_child[c2 * 80 + ki] = l * af_masksum20(r, tipmap[c2]);
     }
     for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x) sh_m1[t] = j.pm[t]; // (the left tip matrix is done with)
     __syncthreads();
-    for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
+    if (threadIdx.x < 240)
     {
-      const unsigned int c2 = t / 80, ki = t - 80 * c2, kk = ki / 20;
-      const double * row = sh_m1 + ki * 20;
-      const double * v = sh_child + c2 * 80 + kk * 20;
-      out[t] = j.mode == 0u ? dot_strided4<true>(row, v, 20u) : dot_strided4<false>(row, v, 20u);
+      // the thread's row of P in registers, the children of its second characters out of LDS
+      double prow[20];
+#pragma unroll
+      for (int jj = 0; jj < 20; ++jj) prow[jj] = sh_m1[ki * 20 + jj];
+      const unsigned int kk = ki / 20u;
+      for (unsigned int c2 = g; c2 < ms; c2 += 3)
+      {
+        const double * v = sh_child + c2 * 80 + kk * 20;
+        out[c2 * 80 + ki] = j.mode == 0u ? dot_strided4<true>(prow, v, 20u) : dot_strided4<false>(prow, v, 20u);
+      }
     }
   }
 }

@@ -9,4 +9,3 @@ import csv
 for r in list(csv.reader(open('/tmp/stats.csv')))[1:5]: print(r[0][:40], r[1], float(r[3])/1e3)"
 rm -rf $R/gpurun_out/prep_trace
 done
-cd $R; bash tools/c2_process_spread.sh
