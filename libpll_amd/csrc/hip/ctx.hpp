@@ -98,7 +98,9 @@ struct pllhip_ctx
   // pllhip_group_root_loglikelihood, shard.hip), and the switch that makes pllhip_root_loglikelihood use them
   unsigned int * root_counts = nullptr;
   const unsigned int * root_scaler_override = nullptr;
-  unsigned int * split_verdicts = nullptr;   // 20 states x 8 categories: per-site verdicts of an op's first half when the op works in place
+  // 20 states, chunk launches (partials_aa_mfma.hip): per-site verdicts of an op's earlier chunks when the op scales in place
+  unsigned int * split_verdicts = nullptr;
+  unsigned int split_verdicts_ops = 0;        // ops of a launch it has room for
   struct pllhip_aa_fused_cache * aa_fused = nullptr; // 20-state whole-list kernel: its kept plan
   size_t pairtab_elems = 0;
   void * h_plan[2] = {nullptr, nullptr};

@@ -716,9 +716,18 @@ static int launch_chunks(pllhip_ctx * c, const PartialsBatch & b, unsigned int c
       a.ridx = nullptr;
       if (kind != 2 && mode == SCALE_SITE && a.pscaler && (a.pscaler == a.lscaler || a.pscaler == a.rscaler))
       {
+        // (one array per op of the launch that needs one, grown on demand: such ops are rare)
         const size_t per_op = (size_t)c->sh.sites + PLLHIP_TAIL_SITES;
-        if (!c->split_verdicts)
-          HIP_TRY(hipMalloc((void **)&c->split_verdicts, (size_t)PLLHIP_BATCH_MAX * per_op * sizeof(unsigned int)));
+        if (c->split_verdicts_ops < count)
+        {
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          if (c->split_verdicts) HIP_TRY(hipFree(c->split_verdicts));
+          c->split_verdicts = nullptr;
+          c->split_verdicts_ops = 0;
+          HIP_TRY(hipMalloc((void **)&c->split_verdicts, (size_t)count * per_op * sizeof(unsigned int)));
+          c->split_verdicts_ops = count;
+          // (earlier chunks of THIS op list have not run yet with the old array: rf == 0 is where an op first gets here)
+        }
         a.lidx = c->split_verdicts + (size_t)i * per_op;
       }
     }
