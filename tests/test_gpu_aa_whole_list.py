@@ -90,6 +90,30 @@ def test_whole_list_equals_per_level_and_oracle(gpu, orc, monkeypatch, shape, ti
     assert abs(lf - ref) <= 1e-11 * abs(ref)
 
 
+@pytest.mark.parametrize("tips,sites", [(24, 900), (40, 130)])
+def test_whole_list_with_another_character_map(gpu, orc, monkeypatch, tips, sites):
+    """20 states over a hand-made alphabet (A..T and a gap: 21 tip codes, not the protein map's 23):
+    the pair and lookup tables of the list -- made by its prepare launch, one workgroup per (table, first character) --
+    are indexed by the partition's OWN number of codes."""
+    from helpers import odd_state_case
+    case = odd_state_case(20, tips=tips, sites=sites, seed=tips)
+    plan = case["plan"]
+    attrs = ATTRIB_PATTERN_TIP
+    pf, cf, sf, lf = _evaluate(gpu, case, attrs, monkeypatch, "2")
+    assert pf.s.maxstates != 23
+    pf.destroy()
+    pl, cl, sl, ll = _evaluate(gpu, case, attrs, monkeypatch, "0")
+    o = oracle_run(orc, gpu, pl, case, attrs)
+    o.update_partials()
+    pl.destroy()
+    for op, a, b, x, y in zip(plan.ops, cf, cl, sf, sl):
+        node = int(op["parent_clv_index"])
+        assert bits_equal(a, b), "CLV %d: whole list != per level" % node
+        assert bits_equal(a, o.clv[node]), "CLV %d != oracle" % node
+        assert (x == y).all() and (x == o.scalers[int(op["parent_scaler_index"])]).all()
+    assert lf == ll
+
+
 def test_whole_list_without_scale_buffers(gpu, orc, monkeypatch):
     case = _case(gpu, "balanced", 32, 700)
     plan = case["plan"]
