@@ -1,3 +1,6 @@
+#!/bin/bash
+# Five bench.py processes in a row on one box (BASELINE config 2): how much of the spread between runs is the process,
+# how much the box.  bash tools/c2_process_spread.sh
 for i in 1 2 3 4 5; do
 python3 bench.py --cpu-sites 0 --no-vary --no-c4 2>/dev/null | python3 -c "
 import json,sys

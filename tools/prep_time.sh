@@ -1,3 +1,6 @@
+#!/bin/bash
+# On the GPU box: the whole-list test files, then the kernel statistics of three 20-state shapes (k_af_prepare beside
+# k_aa_fused).  bash tools/prep_time.sh
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 (cd $R && timeout 600 python -m pytest tests/test_gpu_aa_whole_list.py tests/test_golden.py -q -x 2>&1 | grep -E "passed|failed|rror" | tail -2)
