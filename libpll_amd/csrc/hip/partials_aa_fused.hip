@@ -323,11 +323,22 @@ __device__ __forceinline__ af_gptr af_base(unsigned long long uniform_address)
 // assembly on purpose: the compiler neither counts it nor waits for it; the waits are ours.  The
 // instruction's immediate offset moves BOTH addresses (tools/dma_offset_probe.hip), so N consecutive
 // KiB cost one M0 and N instructions.
+// M0 (the LDS address of an LDS-DMA) is a register the compiler reserves for itself, so an asm block may not simply
+// declare it clobbered: it is saved and put back around every run of DMA instructions -- two scalar instructions per
+// run, ~30 of the ~165 a wave executes per op.  The compiler never reads M0 in these kernels (tools/check_agprs.py
+// looks: no instruction outside these blocks mentions m0), so the assembly could simply OWN it
+// (-DPLLHIP_AF_SAVE_M0=0).  Measured late in round 4, three interleaved pairs on one box: C3 1.713-1.724 against
+// 1.710-1.713 ms, 200-taxon random tree 3.989 against 3.981 -- the scalar unit is not on the waves' critical path;
+// not worth leaning on a reserved register: the default saves.
+#ifndef PLLHIP_AF_SAVE_M0
+#define PLLHIP_AF_SAVE_M0 1
+#endif
 template <int N>
 __device__ __forceinline__ void af_dma_run(unsigned int lds_b, unsigned long long uniform_src, unsigned int lane16)
 {
   static_assert(N == 1 || N == 4, "immediate offsets reach 4095");
-  unsigned int m0_saved; // (M0 is the compiler's: put back, not declared clobbered)
+#if PLLHIP_AF_SAVE_M0
+  unsigned int m0_saved;
   if (N == 1)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(m0_saved) : "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory");
@@ -336,6 +347,16 @@ __device__ __forceinline__ void af_dma_run(unsigned int lds_b, unsigned long lon
                  "global_load_lds_dwordx4 %2, %3 offset:1024\n\tglobal_load_lds_dwordx4 %2, %3 offset:2048\n\t"
                  "global_load_lds_dwordx4 %2, %3 offset:3072\n\ts_mov_b32 m0, %0"
                  : "=&s"(m0_saved) : "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory");
+#else
+  if (N == 1)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 : : "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072"
+                 : : "s"(lds_b), "v"(lane16), "s"(uniform_src) : "memory");
+#endif
 }
 // a gather: five KiB of LDS from five lane offsets each (voff[it] relative to table); the first four
 // share an M0 -- the immediate offset that advances the LDS address advances the global one as well,
@@ -343,6 +364,7 @@ __device__ __forceinline__ void af_dma_run(unsigned int lds_b, unsigned long lon
 __device__ __forceinline__ void af_dma_gather5(unsigned int lds_b, unsigned long long table, const unsigned int (&voff)[5])
 {
   const unsigned int v0 = voff[0] + 3072u, v1 = voff[1] + 2048u, v2 = voff[2] + 1024u;
+#if PLLHIP_AF_SAVE_M0
   unsigned int m0_saved;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %8\n\t"
                "global_load_lds_dwordx4 %4, %8 offset:1024\n\tglobal_load_lds_dwordx4 %5, %8 offset:2048\n\t"
@@ -351,6 +373,15 @@ __device__ __forceinline__ void af_dma_gather5(unsigned int lds_b, unsigned long
                : "=&s"(m0_saved)
                : "s"(lds_b), "s"(lds_b + 4096u), "v"(v0), "v"(v1), "v"(v2), "v"(voff[3]), "v"(voff[4]), "s"(table - 3072ull), "s"(table)
                : "memory");
+#else
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
+               "global_load_lds_dwordx4 %3, %7 offset:1024\n\tglobal_load_lds_dwordx4 %4, %7 offset:2048\n\t"
+               "global_load_lds_dwordx4 %5, %7 offset:3072\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %6, %8"
+               :
+               : "s"(lds_b), "s"(lds_b + 4096u), "v"(v0), "v"(v1), "v"(v2), "v"(voff[3]), "v"(voff[4]), "s"(table - 3072ull), "s"(table)
+               : "memory");
+#endif
 }
 
 struct AfSlot

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The 20-state whole-list kernel (partials_aa_fused.hip) keeps its slots in the accumulation registers
 a0..a109, which only its own inline assembly may touch.  This checks that no instruction outside an
-inline-assembly block names one of them -- in the assembly file given as argument (the Makefile passes the
+inline-assembly block names one of them (nor M0, which the kernels' LDS-DMA assembly owns without saving it) -- in the assembly file given as argument (the Makefile passes the
 -save-temps output of the compilation that makes the object: a hit fails the build), or, without one, in a
 compilation of its own with the Makefile's flags.  Scratch use by the kernel fails too: what is spilled at 128
 registers is what the compiler next parks in the accumulation registers.
@@ -34,6 +34,7 @@ def main():
             subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
             text = open(out).read()
     bad, in_asm, kernel = [], False, None
+    bad_m0 = []   # M0 belongs to the kernels' LDS-DMA assembly (af_dma_run): nothing else may read or write it
     reg = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
     kernels = 0
     for n, line in enumerate(text.splitlines(), 1):
@@ -50,17 +51,19 @@ def main():
                 lo = int(m.group(1) or m.group(2))
                 if lo < 110:
                     bad.append((n, line.strip()))
+            if re.search(r"\bm0\b", code):
+                bad_m0.append((n, line.strip()))
         if line.strip() == "s_endpgm":
             kernel = None
     scratch = [l.strip() for l in text.splitlines() if ".private_segment_fixed_size:" in l and l.split(":")[1].strip() != "0"]
     # (k_af_prepare and k_aa_fused<...> are all the kernels of the file: none may use scratch)
-    print("%d kernels checked, %d instructions outside the slot assembly touch a0..a109, %d kernels with scratch"
-          % (kernels, len(bad), len(scratch)))
-    for n, line in bad[:10]:
+    print("%d kernels checked, %d instructions outside the slot assembly touch a0..a109, %d touch m0, %d kernels with scratch"
+          % (kernels, len(bad), len(bad_m0), len(scratch)))
+    for n, line in (bad + bad_m0)[:10]:
         print("  line %d: %s" % (n, line))
     if report_only:
         return 0
-    return 1 if bad or (scratch and not allow_scratch) or kernels == 0 else 0
+    return 1 if bad or bad_m0 or (scratch and not allow_scratch) or kernels == 0 else 0
 
 
 if __name__ == "__main__":
