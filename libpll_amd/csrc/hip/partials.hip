@@ -539,6 +539,64 @@ int pllhip_resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, 
   return resolve_op(c, op, a, kind, mode);
 }
 
+// Small partitions (fewer workgroup tiles than the device has slots: one "round"), round 4.  Below the sizes from
+// which the whole-list kernels always pay, the faster path depends on the LIST: a whole-list launch costs a fixed
+// preparation plus a time per op that does not depend on the site count (a tile walks the list alone), the per-level
+// path a launch per dependency level and op kind plus the bytes.  Both are estimated from the list -- its dependency
+// levels, its op kinds -- with constants measured on one MI355X (tools/small_partitions_ab.sh,
+// profiles/r4_small_partitions_ab.txt: 64-taxon balanced and 200-taxon random trees, 2,000-16,000 sites, full and
+// partial traversals; the per-level path of a 200-taxon random tree is 27 levels = 60 launches, that of a balanced
+// 64-taxon tree 6 levels).  Returns true when the whole-list launch is estimated faster.  Either path gives the
+// same bits; PLLHIP_FUSED=0 / 2 still forces one.
+static bool whole_list_pays_when_small(const pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count)
+{
+  static thread_local std::vector<unsigned short> level, made_by_tt;
+  const size_t nclv = c->clv.size();
+  level.assign(nclv, 0);
+  made_by_tt.assign(nclv, 0);
+  unsigned int per_level_kind[64][3];
+  memset(per_level_kind, 0, sizeof(per_level_kind));
+  unsigned int n_tt = 0, n_ti = 0, n_ii = 0, n_lookup = 0, launches = 0;
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    const pllhip_op_t & op = ops[i];
+    if (op.parent_clv >= nclv || op.child1_clv >= nclv || op.child2_clv >= nclv) return false; // (the path taken reports it)
+    const bool t1 = pllhip_is_tip(c, op.child1_clv), t2 = pllhip_is_tip(c, op.child2_clv);
+    const unsigned int l = 1u + std::max<unsigned int>(level[op.child1_clv], level[op.child2_clv]);
+    const unsigned int kind = t1 && t2 ? 2u : (t1 || t2 ? 1u : 0u);
+    if (kind == 2u) ++n_tt;
+    else if (kind == 1u)
+    {
+      if (made_by_tt[t1 ? op.child2_clv : op.child1_clv]) ++n_lookup; else ++n_ti;
+    }
+    else
+    {
+      if (made_by_tt[op.child1_clv] && made_by_tt[op.child2_clv]) ++n_lookup; else ++n_ii;
+    }
+    level[op.parent_clv] = (unsigned short)(l < 65535u ? l : 65535u);
+    made_by_tt[op.parent_clv] = kind == 2u;
+    if (l < 64u)
+    {
+      if (per_level_kind[l][kind]++ % PLLHIP_BATCH_MAX == 0) ++launches;
+    }
+    else ++launches;
+  }
+  const double sites = (double)c->sh.sites;
+  double whole_us, level_us;
+  if (c->sh.states == 4)
+  {
+    whole_us = 14.0 + 0.70 * count;
+    level_us = 5.5 * launches + (double)count * sites * 265.0 / 8.5e6;
+  }
+  else
+  {
+    // (20 states: the per-level path adds table launches per level -- tip tables, the lookup ops' tables and kernels)
+    whole_us = 32.0 + 1.6 * n_tt + 2.0 * n_lookup + 3.2 * n_ii + 3.4 * n_ti;
+    level_us = 7.5 * 2.2 * launches + (double)count * sites * 1300.0 / 7.0e6;
+  }
+  return whole_us < level_us;
+}
+
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_update_partials(s, ops, count)); // (enqueued on every device; nothing waits)
@@ -587,7 +645,12 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // whole list vs per level: 8 k sites 74 vs 63 us, 16 k 78 vs 79, 24 k 84 vs 93, 33 k 100 vs 121,
   // 50 k 118 vs 164.  A property of the device -- tiles against SIMDs -- not a tuned number.)
   const size_t fused_tile_sites = (size_t)PLLHIP_FUSED_J * 64 / (2 * c->sh.rate_cats);
-  const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 4 || c->force_fused;
+  static const bool small_rule = !(getenv("PLLHIP_FUSED_SMALL") && atoi(getenv("PLLHIP_FUSED_SMALL")) == 0);
+  const bool whole_list_kind = (dna_fast && (c->sh.rate_cats <= 4 || c->sh.rate_cats == 8)) || (aa_fast && c->sh.rate_cats == 4);
+  // (asked only below the sizes from which the whole-list kernels always pay: 16,384 sites, see below)
+  const bool small_pays = small_rule && whole_list_kind && !c->no_fused && !c->force_fused && c->rows.empty() && count >= 2 &&
+                          c->sh.sites < 16384 && whole_list_pays_when_small(c, ops, count);
+  const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 4 || c->force_fused || small_pays;
   // (8 rate categories: a tile is 8 sites, a P-matrix a whole 1 KB block per wave, a site's lanes a DPP row of 16.
   // Round 1's first attempt spilled and lost -- 5.6 against 10.2 G site-updates/s per level; the rebuilt kernel
   // needs 136-147 registers for it: 500 k sites x 64 taxa 1.49 ms against 3.07 per level, 20.9 against 10.1 G/s.)
@@ -645,7 +708,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // 20 states, 4 rate categories: the whole list in one site-blocked launch on the matrix cores
   // (partials_aa_fused.hip); from one workgroup tile (32 sites) per workgroup slot of the device on
   if (aa_fast && c->sh.rate_cats == 4 && !c->no_fused && count >= 2 &&
-      ((size_t)c->sh.sites / 32 >= (size_t)c->num_cus * 2 || c->force_fused))
+      ((size_t)c->sh.sites / 32 >= (size_t)c->num_cus * 2 || c->force_fused || small_pays))
   {
     pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
     const int rc = pllhip_aa_fused_update(c, ops, count);
