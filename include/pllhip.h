@@ -159,6 +159,14 @@ PLLHIP_EXPORT int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buff
                                         unsigned int nslots, unsigned int * order_out,
                                         unsigned int * reloads_out, int * slots_out);
 
+/* Host logic, no device: which path a partition below 16,384 sites takes for this op list (4 or 20 states) -- 1: the
+ * whole-list kernel, 0: the per-level launches, -1: an index out of range -- and, if the pointers are not NULL, the
+ * two estimated times in microseconds (partials.hip: a launch per dependency level and op kind plus the bytes, against
+ * a fixed preparation plus a time per op; constants measured on one MI355X, profiles/r4_small_partitions_ab.txt). */
+PLLHIP_EXPORT int pllhip_small_partition_estimate(unsigned int states, unsigned int sites, unsigned int tips,
+                                                  unsigned int clv_buffers, int pattern_tip, const pllhip_op_t * ops,
+                                                  unsigned int count, double * whole_us_out, double * level_us_out);
+
 /* Host logic of the same planner, no device: where the 4-state whole-list kernel keeps each op's tip characters.
  * tips[i]: bit 0 / 1 = op i (in the PLANNED order) has a left / right tip row.  chars_out[i]: bits 0-7 / 8-15 the
  * first lane of the left / right row in the wave's character registers, bit 16 / 17 = has a left / right tip;

@@ -547,11 +547,14 @@ int pllhip_resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, 
 // profiles/r4_small_partitions_ab.txt: 64-taxon balanced and 200-taxon random trees, 2,000-16,000 sites, full and
 // partial traversals; the per-level path of a 200-taxon random tree is 27 levels = 60 launches, that of a balanced
 // 64-taxon tree 6 levels).  Returns true when the whole-list launch is estimated faster.  Either path gives the
-// same bits; PLLHIP_FUSED=0 / 2 still forces one.
-static bool whole_list_pays_when_small(const pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count)
+// same bits; PLLHIP_FUSED=0 / 2 still forces one.  (Pure host logic, exported for the CPU tests: 1 = whole list, 0 = per
+// level, -1 = an index out of range.)
+extern "C" int pllhip_small_partition_estimate(unsigned int states, unsigned int sites, unsigned int tips,
+                                               unsigned int clv_buffers, int pattern_tip, const pllhip_op_t * ops,
+                                               unsigned int count, double * whole_us_out, double * level_us_out)
 {
   static thread_local std::vector<unsigned short> level, made_by_tt;
-  const size_t nclv = c->clv.size();
+  const size_t nclv = (size_t)tips + clv_buffers;
   level.assign(nclv, 0);
   made_by_tt.assign(nclv, 0);
   unsigned int per_level_kind[64][3];
@@ -560,8 +563,8 @@ static bool whole_list_pays_when_small(const pllhip_ctx * c, const pllhip_op_t *
   for (unsigned int i = 0; i < count; ++i)
   {
     const pllhip_op_t & op = ops[i];
-    if (op.parent_clv >= nclv || op.child1_clv >= nclv || op.child2_clv >= nclv) return false; // (the path taken reports it)
-    const bool t1 = pllhip_is_tip(c, op.child1_clv), t2 = pllhip_is_tip(c, op.child2_clv);
+    if (op.parent_clv >= nclv || op.child1_clv >= nclv || op.child2_clv >= nclv) return -1; // (the path taken reports it)
+    const bool t1 = pattern_tip && op.child1_clv < tips, t2 = pattern_tip && op.child2_clv < tips;
     const unsigned int l = 1u + std::max<unsigned int>(level[op.child1_clv], level[op.child2_clv]);
     const unsigned int kind = t1 && t2 ? 2u : (t1 || t2 ? 1u : 0u);
     if (kind == 2u) ++n_tt;
@@ -581,9 +584,8 @@ static bool whole_list_pays_when_small(const pllhip_ctx * c, const pllhip_op_t *
     }
     else ++launches;
   }
-  const double sites = (double)c->sh.sites;
   double whole_us, level_us;
-  if (c->sh.states == 4)
+  if (states == 4)
   {
     whole_us = 14.0 + 0.70 * count;
     level_us = 5.5 * launches + (double)count * sites * 265.0 / 8.5e6;
@@ -594,7 +596,15 @@ static bool whole_list_pays_when_small(const pllhip_ctx * c, const pllhip_op_t *
     whole_us = 32.0 + 1.6 * n_tt + 2.0 * n_lookup + 3.2 * n_ii + 3.4 * n_ti;
     level_us = 7.5 * 2.2 * launches + (double)count * sites * 1300.0 / 7.0e6;
   }
-  return whole_us < level_us;
+  if (whole_us_out) *whole_us_out = whole_us;
+  if (level_us_out) *level_us_out = level_us;
+  return whole_us < level_us ? 1 : 0;
+}
+
+static bool whole_list_pays_when_small(const pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count)
+{
+  return pllhip_small_partition_estimate(c->sh.states, c->sh.sites, c->sh.tips, (unsigned int)(c->clv.size() - c->sh.tips),
+                                         c->sh.pattern_tip ? 1 : 0, ops, count, nullptr, nullptr) == 1;
 }
 
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)

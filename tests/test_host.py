@@ -435,3 +435,53 @@ def test_bench_alignment_blocks():
     assert len(rnd[0]) == 800
     with pytest.raises(ValueError):
         W.global_alignment(plan, 10, 5, W.GTR_RATES, W.GTR_FREQS, cat)
+
+
+# ---------------------------------------------------------------- small partitions: which path (host logic)
+
+def _small_choice(amd, states, sites, plan, pattern_tip=1, ops=None):
+    ops = np.ascontiguousarray(plan.ops if ops is None else ops)
+    whole, level = C.c_double(), C.c_double()
+    amd.lib.pllhip_small_partition_estimate.restype = C.c_int
+    rc = amd.lib.pllhip_small_partition_estimate(C.c_uint(states), C.c_uint(sites), C.c_uint(plan.tips),
+                                                 C.c_uint(plan.clv_buffers), C.c_int(pattern_tip),
+                                                 ops.ctypes.data_as(C.c_void_p), C.c_uint(len(ops)),
+                                                 C.byref(whole), C.byref(level))
+    return rc, whole.value, level.value
+
+
+def test_small_partition_path_choice(amd):
+    """Below 16,384 sites the library chooses between the whole-list kernel and the per-level launches from the op
+    list (partials.hip, whole_list_pays_when_small).  The choices measured on the device
+    (profiles/r4_small_partitions_ab.txt: the default matched the faster path in every row) are pinned here."""
+    from libpll_amd import workload as W
+    bal64, rnd200, rnd64, bal128 = (W.balanced_tree(64, seed=42), W.random_tree(200, seed=42),
+                                    W.random_tree(64, seed=42), W.balanced_tree(128, seed=42))
+    ladder = W.caterpillar_tree(100, seed=42)
+    # 20 states
+    assert _small_choice(amd, 20, 2000, bal64)[0] == 0      # six levels: per level (120 against 167 us)
+    assert _small_choice(amd, 20, 4000, bal64)[0] == 0
+    assert _small_choice(amd, 20, 6000, bal64)[0] == 1      # 185 -> 170 us
+    assert _small_choice(amd, 20, 12000, bal64)[0] == 1     # 289 -> 184
+    assert _small_choice(amd, 20, 6000, rnd200)[0] == 1     # 767 -> 570
+    assert _small_choice(amd, 20, 3000, rnd64)[0] == 1      # 287 -> 200
+    assert _small_choice(amd, 20, 3000, bal128)[0] == 0     # 224 against 321
+    assert _small_choice(amd, 20, 10000, bal128)[0] == 1    # 456 -> 357
+    assert _small_choice(amd, 20, 3000, ladder)[0] == 1     # 1857 -> 407: a launch per op on the per-level path
+    # 4 states
+    assert _small_choice(amd, 4, 2000, bal64)[0] == 0       # 46 against 67 us
+    assert _small_choice(amd, 4, 12000, bal64)[0] == 0
+    assert _small_choice(amd, 4, 6000, rnd200)[0] == 1      # 200 -> 175
+    assert _small_choice(amd, 4, 3000, rnd64)[0] == 1       # 108 -> 71
+    assert _small_choice(amd, 4, 3000, bal128)[0] == 0      # 75 against 119
+    assert _small_choice(amd, 4, 3000, ladder)[0] == 1      # 717 -> 106
+    # a partial traversal -- the path from a changed branch to the root: one op per level -- always takes the whole list
+    chain = ladder.ops[-7:]
+    assert _small_choice(amd, 20, 2000, ladder, ops=chain)[0] == 1
+    assert _small_choice(amd, 4, 2000, ladder, ops=chain)[0] == 1
+    # estimates are positive and finite; a bad index is reported, not dereferenced
+    rc, whole, level = _small_choice(amd, 20, 8000, rnd200)
+    assert rc == 1 and 0 < whole < level < 1e6
+    bad = bal64.ops.copy()
+    bad["child1_clv_index"][3] = 10 ** 6
+    assert _small_choice(amd, 4, 2000, bal64, ops=bad)[0] == -1
