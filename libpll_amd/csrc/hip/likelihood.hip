@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
     if (GATHER && a.cidx) ci_round = a.cidx[r * 64 + lane];
     const size_t prow_own = GATHER ? (size_t)(unsigned int)__shfl((int)pi_round, (int)own, 64) : n_own;
     const size_t crow_own = GATHER ? (size_t)(unsigned int)__shfl((int)ci_round, (int)own, 64) : n_own;
-    const unsigned int ps_own = ps_site[site_ps ? prow_own : 0];
+    const unsigned int ps_own = ps_site[site_ps ? (a.pscaler_by_site ? n_own : prow_own) : 0];
     const unsigned int cs_own = cs_site[site_cs ? crow_own : 0];
     const int inv_raw = inv_site[has_inv ? n_own : 0];
     const int inv_own = has_inv ? inv_raw : -1;
@@ -1138,6 +1138,7 @@ extern "C" int pllhip_root_loglikelihood(pllhip_ctx_t * c, unsigned int clv_inde
   if (fill_freqs_indices(c, a, h_freqs_indices)) return -1;
   a.parent = c->clv[clv_index];
   a.pscaler = c->root_scaler_override ? c->root_scaler_override : pllhip_scaler_ptr(c, scaler_index);
+  a.pscaler_by_site = c->root_scaler_override != nullptr;
   if (!c->rows.empty() && c->rows[clv_index].classes) a.pidx = c->rows[clv_index].site_id;
   return run_lnl(c, a, ROOT, h_persite_lnl, h_lnl);
 }

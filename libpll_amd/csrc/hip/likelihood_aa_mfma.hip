@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_lnl_aa_mfma(LnlArgs a)
     for (int k = 0; k < RC; ++k)
     {
       const bool used = per_rate || k == 0;
-      const size_t ep = per_rate ? (size_t)prow * RC + k : (size_t)prow;
+      const size_t ep = per_rate ? (size_t)prow * RC + k : (a.pscaler_by_site ? n : (size_t)prow);
       const size_t ec = per_rate ? (size_t)crow * RC + k : (size_t)crow;
       ps_next[k] = used ? psp[has_ps ? ep : 0] : 0u;
       cs_next[k] = used ? csp[has_cs ? ec : 0] : 0u;

@@ -47,6 +47,9 @@ struct LnlArgs
   ReduceOut reduce;
   unsigned int sites, rate_cats, states, maxstates;
   int rate_scalers;
+  // 1: `pscaler` is indexed by the SITE even where the parent CLV is stored by class (pidx) -- a shard's root
+  // counts gathered from the whole buffer's entries (shard.hip: gather_root_counts)
+  int pscaler_by_site;
   unsigned int freqs_indices[PLLHIP_MAX_RATE_CATS];
 };
 

@@ -143,6 +143,21 @@ static int gather_root_counts(pllhip_ctx * g, int scaler_index)
     HIP_TRY(hipSetDevice(s->sh.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
+  // A shard that stores the buffer's owning CLV by class (PLL_ATTRIB_SITE_REPEATS) stores the buffer by class too:
+  // its entries are not the whole buffer's then.  Such a buffer goes through the host, expanded shard by shard the
+  // way pllhip_get_scaler hands it to the client (ctx.hip: shard_scaler_per_site).
+  bool by_class = false;
+  for (pllhip_ctx * s : g->shards)
+  {
+    const int owner = (size_t)scaler_index < s->scaler_owner.size() ? s->scaler_owner[scaler_index] : -1;
+    if (owner >= 0 && (size_t)owner < s->rows.size() && s->rows[owner].classes) by_class = true;
+  }
+  std::vector<unsigned int> whole;
+  if (by_class)
+  {
+    whole.resize((size_t)g->sh.sites * R);
+    if (pllhip_get_scaler(g, (unsigned int)scaler_index, whole.data())) return -1;
+  }
   for (size_t i = 0; i < n; ++i)
   {
     pllhip_ctx * s = g->shards[i];
@@ -152,6 +167,14 @@ static int gather_root_counts(pllhip_ctx * g, int scaler_index)
     {
       HIP_TRY(hipMalloc((void **)&s->root_counts, ((size_t)s->sh.sites + PLLHIP_TAIL_SITES) * sizeof(unsigned int)));
       HIP_TRY(hipMemsetAsync(s->root_counts, 0, ((size_t)s->sh.sites + PLLHIP_TAIL_SITES) * sizeof(unsigned int), s->stream));
+    }
+    if (by_class)
+    {
+      HIP_TRY(hipMemcpyAsync(s->root_counts, whole.data() + lo, (hi - lo) * sizeof(unsigned int),
+                             hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream)); // (`whole` goes at the end of this function; rare call)
+      s->root_scaler_override = s->root_counts;
+      continue;
     }
     for (size_t t = 0; t < n; ++t)
     {

@@ -16,7 +16,7 @@ import pytest
 
 from helpers import bits_equal, rel_err
 from libpll_amd import workload as W
-from libpll_amd.pllapi import ATTRIB_ARCH_AVX2, ATTRIB_PATTERN_TIP, ATTRIB_SITE_REPEATS, PllError
+from libpll_amd.pllapi import ATTRIB_ARCH_AVX2, ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_SITE_REPEATS, PllError
 
 pytestmark = pytest.mark.gpu
 
@@ -142,15 +142,17 @@ def test_config5_plain_and_site_repeats(gpu, c5_data):
     assert len({d for d, _ in a[2]}) == len(NEWTON_T)
 
 
+@pytest.mark.parametrize("scale_attr", [0, ATTRIB_RATE_SCALERS], ids=["per-site-scalers", "per-rate-scalers"])
 @pytest.mark.parametrize("repeats", [False, True])
-def test_config5_slice_against_reference(gpu, ref, c5_data, repeats):
+def test_config5_slice_against_reference(gpu, ref, c5_data, repeats, scale_attr):
     """The first 50,000 sites of the C5 alignment: scaler counts and CLVs bitwise, per-site lnL to 1e-13
     against the genuine reference, the five derivative pairs to 1e-10 -- plain and with site
-    repeats (expanded CLVs)."""
+    repeats (expanded CLVs); with per-site and with per-rate scale buffers (the reference's per-rate
+    rule, core_partials_avx.c:494-503, on a tree that scales)."""
     plan, full = c5_data
     seqs = [s[:50_000] for s in full]
-    a = W.setup_partition(gpu, plan, seqs, 4, R, ATTRIB_PATTERN_TIP | (ATTRIB_SITE_REPEATS if repeats else 0))
-    r = W.setup_partition(ref, plan, seqs, 4, R, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2)
+    a = W.setup_partition(gpu, plan, seqs, 4, R, ATTRIB_PATTERN_TIP | scale_attr | (ATTRIB_SITE_REPEATS if repeats else 0))
+    r = W.setup_partition(ref, plan, seqs, 4, R, ATTRIB_PATTERN_TIP | scale_attr | ATTRIB_ARCH_AVX2)
     a.update_partials(plan.ops)
     r.update_partials(plan.ops)
     for op in list(plan.ops[-5:]) + list(plan.ops[100:103]):
@@ -178,8 +180,9 @@ def c3_data(request, gpu):
     return request.param, plan, seqs
 
 
+@pytest.mark.parametrize("scale_attr", [0, ATTRIB_RATE_SCALERS], ids=["per-site-scalers", "per-rate-scalers"])
 @pytest.mark.parametrize("path", ["whole-list", "levels"])
-def test_config3_slice_against_reference(gpu, ref, c3_data, monkeypatch, path):
+def test_config3_slice_against_reference(gpu, ref, c3_data, monkeypatch, path, scale_attr):
     """50,000 sites of C3 -- and of an LG alignment on a 200-taxon random tree: tip-inner ops, scaling events,
     evictions -- through the genuine reference (AVX2 flag) and through the product's DEFAULT 20-state path, whole
     list and per level: the scale buffer of EVERY op bitwise, CLVs bitwise (every fifth op and the last five: a
@@ -188,8 +191,10 @@ def test_config3_slice_against_reference(gpu, ref, c3_data, monkeypatch, path):
     name, plan, seqs = c3_data
     monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
     monkeypatch.setenv("PLLHIP_FUSED", "2" if path == "whole-list" else "0")
-    a = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP)
-    r = W.setup_partition(ref, plan, seqs, 20, R, ATTRIB_PATTERN_TIP | ATTRIB_ARCH_AVX2)
+    if scale_attr and path == "whole-list":
+        pytest.skip("per-rate scale buffers: the 20-state whole-list kernel does not take them (per-level launches, the other case)")
+    a = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP | scale_attr)
+    r = W.setup_partition(ref, plan, seqs, 20, R, ATTRIB_PATTERN_TIP | scale_attr | ATTRIB_ARCH_AVX2)
     a.update_partials(plan.ops)
     a.update_partials(plan.ops)     # (the same list again: the whole-list plan with its tip-tip ops inside)
     r.update_partials(plan.ops)

@@ -419,8 +419,11 @@ def test_error_paths(gpu):
 
 # ---------------------------------------------------------------- full size
 
-def test_full_size_properties(gpu):
-    """BASELINE.json configs[1] (1,000,000 sites x 4 rates, 64 taxa): properties
+@pytest.mark.parametrize("scale_attr", [0, ATTRIB_RATE_SCALERS], ids=["per-site-scalers", "per-rate-scalers"])
+def test_full_size_properties(gpu, scale_attr):
+    """(per-rate scale buffers -- PLL_ATTRIB_RATE_SCALERS, the reference's per-rate rule core_partials_avx.c:494-503 --
+    reach the whole-list kernel at full size here; until round 5 only at <= 1,029 sites)
+    BASELINE.json configs[1] (1,000,000 sites x 4 rates, 64 taxa): properties
     that hold at any size, checked on the real workload:
       * sum(per-site lnL) == lnL                    (reduction is complete)
       * lnL(all) == lnL(first half) + lnL(second half)   (sites independent; this
@@ -434,7 +437,7 @@ def test_full_size_properties(gpu):
     seqs = W.simulated_alignment(plan, sites, W.GTR_RATES, W.GTR_FREQS,
                                  gpu.compute_gamma_cats(W.GAMMA_ALPHA, R), seed=42)
     fi = [0] * R
-    p = W.setup_partition(gpu, plan, seqs, 4, R, ATTRIB_PATTERN_TIP)
+    p = W.setup_partition(gpu, plan, seqs, 4, R, ATTRIB_PATTERN_TIP | scale_attr)
     p.update_partials(plan.ops)
     lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
     assert np.isfinite(lnl) and lnl < 0
@@ -458,7 +461,7 @@ def test_full_size_properties(gpu):
     assert abs(sum(halves) - lnl) <= 1e-12 * abs(lnl)
 
     n = 250_000   # tip-CLV mode needs 2x the CLV memory traffic; a quarter is plenty
-    q = W.setup_partition(gpu, plan, seqs, 4, R, 0, site_range=(0, n))
+    q = W.setup_partition(gpu, plan, seqs, 4, R, scale_attr, site_range=(0, n))
     q.update_partials(plan.ops)
     _, qps = q.compute_edge_loglikelihood(*plan.root_edge, fi, persite=True)
     assert bits_equal(qps, ps[:n])

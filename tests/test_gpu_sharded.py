@@ -238,7 +238,11 @@ def test_sharded_at_config_2_size(gpu):
 
 
 @pytest.mark.parametrize("states,shape,tips,sites,rate_scalers",
-                         [(4, "random", 20, 3001, False), (4, "balanced", 16, 2000, True), (20, "random", 12, 900, False)])
+                         [(4, "random", 20, 3001, False), (4, "balanced", 16, 2000, True), (20, "random", 12, 900, False),
+                          # (deep trees that SCALE: a shard stores a class-stored CLV's scale buffer by class too, and
+                          # the root kernel of a per-rate partition reads entries of the WHOLE buffer -- ADVICE r4)
+                          (4, "caterpillar", 300, 1500, True), (4, "caterpillar", 300, 1500, False),
+                          (20, "caterpillar", 150, 800, True)])
 def test_sharded_with_site_repeats(gpu, monkeypatch, states, shape, tips, sites, rate_scalers):
     """One partition over several devices WITH PLL_ATTRIB_SITE_REPEATS (round 4; BASELINE config 4's split and
     config 5's feature together): every shard identifies the classes of its own site range, and everything a
@@ -261,6 +265,8 @@ def test_sharded_with_site_repeats(gpu, monkeypatch, states, shape, tips, sites,
         assert gpu.lib.pll_amd_shard_count(p.ptr) > 1
         got = full_state(p, plan, R)
         assert_same(got, whole)
+        if shape == "caterpillar":
+            assert max(int(v.max()) for v in whole["scs"].values()) > 0, "this tree must scale"
         rows = [p.repeats_classes(int(op["parent_clv_index"])) for op in plan.ops]
         assert sum(1 for r in rows if 0 < r < sites) > len(plan.ops) // 2, "most nodes are stored by class"
         # a topology-neutral change (branch length) and a tip change, then again: still the plain partition's values
