@@ -159,6 +159,16 @@ PLLHIP_EXPORT int pllhip_fused_plan_dry(unsigned int tips, unsigned int clv_buff
                                         unsigned int nslots, unsigned int * order_out,
                                         unsigned int * reloads_out, int * slots_out);
 
+/* Host logic, no device (round 5): the op list as independent sub-lists ("segments": ops that share no buffer any of
+ * them writes -- the two sides of the root edge of a full traversal), which the whole-list kernels hand out as
+ * (tile of sites, segment) work items when the tiles alone do not fill the chip (partials_fused.hpp).  seg_out[i] =
+ * segment of op i, segment 0 the longest, every segment at least two ops; returns the number of segments (1: the list
+ * does not split; at most min(max_segments, 8)). */
+PLLHIP_EXPORT unsigned int pllhip_fused_segments_dry(unsigned int tips, unsigned int clv_buffers,
+                                                     unsigned int scale_buffers, int pattern_tip,
+                                                     const pllhip_op_t * ops, unsigned int count,
+                                                     unsigned int max_segments, unsigned int * seg_out);
+
 /* Host logic, no device: which path a partition below 16,384 sites takes for this op list (4 or 20 states) -- 1: the
  * whole-list kernel, 0: the per-level launches, -1: an index out of range -- and, if the pointers are not NULL, the
  * two estimated times in microseconds (partials.hip: a launch per dependency level and op kind plus the bytes, against

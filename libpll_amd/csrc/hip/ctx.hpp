@@ -78,6 +78,8 @@ struct pllhip_ctx
   unsigned int fused_last_jobs = 0, fused_last_count = 0, fused_last_nslots = 0;
   size_t fused_last_jobs_offset = 0; // pair-table jobs within d_plan
   size_t fused_last_rowtab_offset = 0;     // ... and of the tip-character row table (partials_fused.hip)
+  size_t fused_last_segs_offset = 0, fused_last_srcs_offset = 0; // ... the segment table, the reload sources
+  unsigned int fused_last_nsegs = 1, fused_last_longest = 0;      // segments of the kept plan; ops of its longest
   float last_timer_ms = 0.f;               // pllhip_timer_stop_ms's last result on this context's stream
   unsigned char * fused_zero_row = nullptr; // [sites + slack] zeros: the "tip" of an op without one
   int fused_last_mode = 0;

@@ -692,23 +692,57 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     // that give their slot up, and operands written by earlier calls, are copied back from
     // HBM by LDS-DMA one op ahead).  A list the planner does not take -- counts that were not
     // written together with their CLV -- runs per level.
-    std::vector<FusedOp> fplan;
-    unsigned int reloads = 0;
     const FusedGeom geom = {c->clv.size(), c->sh.scale_buffers, c->sh.tips, c->sh.pattern_tip != 0};
     // (PLLHIP_FUSED_WGS=2: the 8-wave, 7-slot configuration at once -- tests run both)
     const unsigned int first_wgs = getenv("PLLHIP_FUSED_WGS") && atoi(getenv("PLLHIP_FUSED_WGS")) == 2 ? 2u : 3u;
-    unsigned int nslots = pllhip_fused_slots(c, first_wgs);
-    int rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, fplan, &reloads);
-    if (rc > 0)
+    // Round 5: independent sub-lists (the two sides of the root edge of a full traversal) as SEGMENTS of one launch
+    // -- (tile, segment) work items -- while the tiles alone do not fill the chip's wave slots eight times over:
+    // below that a launch's time is quantised by rounds of the list's length (partials_fused.hpp).
+    // PLLHIP_FUSED_SEGMENTS=0 / n: never / up to n whatever the size.
+    unsigned int max_segs = (size_t)c->sh.sites / fused_tile_sites < (size_t)c->num_cus * 12 * 8 ? PLLHIP_FUSED_MAX_SEGS : 1u;
+    if (const char * e = getenv("PLLHIP_FUSED_SEGMENTS")) max_segs = (unsigned int)std::max(1, atoi(e));
+    std::vector<unsigned int> seg_of;
+    unsigned int nsegs = pllhip_fused_segments(geom, ops, count, max_segs, seg_of);
+    std::vector<std::vector<FusedOp>> fplans;
+    unsigned int nslots = 0;
+    int rc = 1;
+    for (; rc > 0; nsegs = 1) // (segments the planner does not take: once more as one list)
     {
-      nslots = pllhip_fused_slots(c, 2);
-      rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, fplan, &reloads);
+      for (unsigned int wgs = first_wgs; rc > 0 && wgs >= 2u; --wgs)
+      {
+        nslots = pllhip_fused_slots(c, wgs);
+        fplans.assign(nsegs, std::vector<FusedOp>());
+        rc = 0;
+        for (unsigned int sg = 0; sg < nsegs && rc == 0; ++sg)
+        {
+          unsigned int reloads = 0;
+          if (nsegs == 1)
+          {
+            rc = pllhip_fused_plan(geom, ops, args.data(), kinds.data(), count, nslots, fplans[0], &reloads);
+            continue;
+          }
+          std::vector<pllhip_op_t> sops;
+          std::vector<PartialsArgs> sargs;
+          std::vector<int> skinds, where;
+          for (unsigned int i = 0; i < count; ++i)
+            if (seg_of[i] == sg)
+            {
+              sops.push_back(ops[i]);
+              sargs.push_back(args[i]);
+              skinds.push_back(kinds[i]);
+              where.push_back((int)i);
+            }
+          rc = pllhip_fused_plan(geom, sops.data(), sargs.data(), skinds.data(), (unsigned int)sops.size(), nslots, fplans[sg], &reloads);
+          for (FusedOp & f : fplans[sg]) f.list_pos = where[f.list_pos];
+        }
+      }
+      if (nsegs == 1) break;
     }
     if (rc < 0) return rc;
     if (rc == 0)
     {
       pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II);
-      rc = pllhip_launch_fused(c, fplan, nslots);
+      rc = pllhip_launch_fused(c, fplans, nslots);
       if (rc == 0) c->fused_last_ops.assign(ops, ops + count);
       if (rc <= 0) return rc;
     }

@@ -98,6 +98,13 @@ constexpr unsigned int AF_SYNC_LEFT = 2048u;   // an inner-inner op behind a loo
 constexpr unsigned int AF_ZERO_COUNTS = 1024u; // (bits 8-9: the next op's kind) a tip-tip op inside the list: never
                                                // scales, but clears its scale buffer (core_partials_avx.c:598-599)
 constexpr unsigned int AF_ONE_TABLE = 4096u;   // a lookup with ONE table (round 4: a tip-tip op's pair table): nothing to multiply
+// (round 5) The records of a segment are LINKED: bits 14.. of `flags` name the record of the op that runs next -- the
+// last op's names op 0's again, AF_LAST set --, the header's `yoff` the segment's last record.  The kernel then
+// carries neither an op count nor an op number through the op loop: with segments both would be values of the
+// item instead of kernel arguments, two scalar registers more in a loop that has none to spare (the two records in
+// flight are 56 of them).
+constexpr unsigned int AF_LAST = 8192u;
+constexpr unsigned int AF_NEXT_SHIFT = 14u;
 
 struct AfMatJob
 {
@@ -667,8 +674,14 @@ struct AfWords { unsigned int w[11]; };
   }
 static_assert(AF_J == 2 && AF_NSLOT == 5, "the slot macros spell out two sub-tiles and five slots");
 
+// Round 5: SEGMENTS (partials_fused.hpp).  The list may come as up to eight independent sub-lists, each a plan of its
+// own (header, one record per op, the cyclic last record); the work items are (tile, segment) pairs, every tile of
+// segment 0 first.  A workgroup that moves on to another segment starts cold -- everybody done with the blocks in
+// LDS, the new segment's first blocks requested -- which the segment-major order makes a once-per-launch event.
+// segtab: [segment] = {first record, ops}.
 template <int MODE, bool NT>
-__global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ plan, unsigned int nops, unsigned int sites,
+__global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ plan0, const unsigned int * __restrict__ segtab,
+                                                     unsigned int nsegs, unsigned int sites,
                                                      const char * aorder, unsigned int ms, double2 * sink,
                                                      unsigned int * next_tile, unsigned int static_rounds)
 {
@@ -689,9 +702,18 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   const unsigned int boff = n * 640u + rate * 160u + q * 32u;        // its four states 4q.. of sub-tile 0 in a stage
   const unsigned int boff5 = n * 640u + rate * 160u + 128u + q * 8u; // state 16 + q
   const char * x0lane = lds + lane * 8u, * x1lane = lds + AF_MAT_B + lane * 8u, * ylane = lds + 2 * AF_MAT_B + lane * 8u;
-  const unsigned int cls32 = (q * 4u + rate) * 32u;                  // the lane's (q, rate) class within a fifth-step block
-  const char * yrows = lds + 2 * AF_MAT_B + (q * 4u + rate) * 16u;   // the right block in row order (tip-inner ops)
-  const unsigned int coloff = n * 640u + rate * 160u;                // the lane's column in a stage
+  // (round 5: the offsets that only the mat-vecs use are formed where they are used, from a copy of the lane number
+  // the optimiser cannot see through -- kept in registers across the op loop they were what the allocator, at its
+  // limit of 128, parked in a0: a slot; tools/check_agprs.py)
+  auto lane_again = [&]() __attribute__((always_inline)) {
+    unsigned int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  // the lane's (q, rate) class within a fifth-step block, x 32 bytes
+  auto cls32_of = [](unsigned int l) __attribute__((always_inline)) { return ((l >> 4) * 4u + ((l >> 2) & 3u)) * 32u; };
+  // the lane's column in a stage
+  auto coloff_of = [](unsigned int l) __attribute__((always_inline)) { return (l & 3u) * 640u + ((l >> 2) & 3u) * 160u; };
   const unsigned long long sink_a = (unsigned long long)(uintptr_t)(sink + ((size_t)blockIdx.x * 4u + wave) * 4u);
   const unsigned long long aorder_a = (unsigned long long)(uintptr_t)aorder;
 
@@ -709,18 +731,14 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   };
 
   const size_t tiles = ((size_t)sites + AF_WGS - 1) / AF_WGS;
+  const size_t items = tiles * nsegs; // (tile, segment) pairs, segment-major
   unsigned int xpar = 0u; // which left buffer the current op multiplies by
-  // the first two ops' blocks (from then on every op requests those of the ops ahead, cyclically)
-  {
-    const AfW<16, 3> h = af_load<16, 3>(plan, 0), r1 = af_load<16, 3>(plan, 1);
-    if (((h[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x0buf_b, h[16]);
-    if ((r1[18] & AF_KIND_MASK) <= 1u) stage_matrix(ybuf_b, r1[17]);
-    if (((r1[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x1buf_b, r1[16]);
-  }
+  unsigned int cur_rec0 = ~0u; // the segment the workgroup is in: its header's record number
+  const AaRec * const plan = plan0;
   unsigned int ch_p, ch_q; // tip characters of the next op / the op after next, in turn: lane l holds row (l >> 3) & 3, site l & 7
   for (unsigned int round = 0;; ++round) // (32 bits: as a size_t its bound lived in a register pair of every lane)
   {
-    // a workgroup's first tiles are its own by a fixed stride, the last rounds' worth come from a
+    // a workgroup's first items are its own by a fixed stride, the last rounds' worth come from a
     // counter (the XCDs do not write at the same rate, partials_fused.hip)
     size_t tile;
     if (round < static_rounds || !next_tile)
@@ -731,7 +749,31 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
       __syncthreads();
       tile = (size_t)static_rounds * gridDim.x + (unsigned int)__builtin_amdgcn_readfirstlane((int)*tile_word);
     }
-    if (tile >= tiles) break;
+    if (tile >= items) break;
+    unsigned int seg = 0u;
+    while (tile >= tiles)
+    {
+      tile -= tiles;
+      ++seg;
+    }
+    const unsigned int rec0 = ((af_words)(unsigned long long)(segtab + 2u * __builtin_amdgcn_readfirstlane(seg)))[0];
+    if (rec0 != cur_rec0)
+    {
+      // a cold start: everybody is done with the blocks in LDS (and this wave's own requests have landed), then
+      // the segment's first two ops' blocks (from then on every op requests those of the ops ahead, cyclically)
+      if (cur_rec0 != ~0u)
+      {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      cur_rec0 = rec0;
+      xpar = 0u;
+      const AfW<16, 3> h = af_load<16, 3>(plan, rec0), r1 = af_load<16, 3>(plan, rec0 + 1u);
+      if (((h[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x0buf_b, h[16]);
+      if ((r1[18] & AF_KIND_MASK) <= 1u) stage_matrix(ybuf_b, r1[17]);
+      if (((r1[18] >> 8) & AF_KIND_MASK) == 0u) stage_matrix(x1buf_b, r1[16]);
+    }
     const size_t site0 = tile * AF_WGS + (size_t)wave * AF_WS;
     const unsigned long long clv_off = (unsigned long long)site0 * 640u;
     const unsigned long long cnt_off = (unsigned long long)site0 * 4u;
@@ -836,9 +878,9 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     };
 
     // ---- prologue: what the ops before op 0 would have done for it (reloads, characters, gathers)
-    AfW<0, 28> rc_a = af_load<0, 28>(plan, 1), rc_b;
+    AfW<0, 28> rc_a = af_load<0, 28>(plan, rec0 + 1u), rc_b;
     {
-      const AfW<0, 28> h = af_load<0, 28>(plan, 0);
+      const AfW<0, 28> h = af_load<0, 28>(plan, rec0);
       const unsigned int hf = __builtin_amdgcn_readfirstlane(h[18]);
       // (the stages' last readers -- the tile before -- are done)
       if (hf & AF_RELOAD_A)
@@ -862,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
         next_gathers(f0 & AF_KIND_MASK, (f0 & AF_ONE_TABLE) != 0u, rc_a.quad(4), rc_a.quad(6), ch_p);
       }
       // op 1's (used at the end of op 0): a record names the rows of the op after next, the last op's those of op 1
-      const AfW<8, 8> r1 = af_load<8, 8>(plan, nops);
+      const AfW<8, 8> r1 = af_load<8, 8>(plan, h[17]); // (the header's yoff: the segment's last record)
       AfW<0, 28> rows1 = rc_a;
 #pragma unroll
       for (int t = 0; t < 8; ++t) rows1.w[8 + t] = r1[8 + t];
@@ -887,7 +929,8 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
 #else
 #define AF_TICK(ph)
 #endif
-    for (unsigned int i = 0;;)
+    bool af_last;
+    for (;;)
     {
 #define AF_RC rc_a
 #define AF_RN rc_b
@@ -898,7 +941,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
 #undef AF_RN
 #undef AF_CH_REQ
 #undef AF_CH_USE
-      if (++i == nops) break;
+      if (af_last) break;
 #define AF_RC rc_b
 #define AF_RN rc_a
 #define AF_CH_REQ ch_q
@@ -908,7 +951,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
 #undef AF_RN
 #undef AF_CH_REQ
 #undef AF_CH_USE
-      if (++i == nops) break;
+      if (af_last) break;
     }
 #if defined(PLLHIP_AF_TIMING) && !defined(PLLHIP_AF_NOTICKS)
     if (lane == 0 && round == 2 && wave == 1 && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == 202 || blockIdx.x == 303))
@@ -951,6 +994,8 @@ struct pllhip_aa_fused_cache
   unsigned int npair = 0;
   size_t off_lk = 0;                   // lookup-table jobs (AaLookupJob; nlk == 0: the tables come from launches of their own)
   unsigned int nlk = 0;
+  size_t off_seg = 0;                  // (round 5) the segment table: {first record, ops} per segment
+  unsigned int nsegs = 1;
 };
 
 void pllhip_aa_fused_free(pllhip_ctx * c)
@@ -999,7 +1044,7 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
     HIP_TRY(hipGetLastError());
   }
   else HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
-  const size_t tiles = ((size_t)c->sh.sites + AF_WGS - 1) / AF_WGS;
+  const size_t tiles = (((size_t)c->sh.sites + AF_WGS - 1) / AF_WGS) * k.nsegs; // (work items: (tile, segment) pairs)
   size_t grid = tiles;
   const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per workgroup)
   if (grid > cap) grid = cap;
@@ -1020,8 +1065,8 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_aa_fused<MODEV, NTV>),                               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_B));                                \
     k_aa_fused<MODEV, NTV><<<(unsigned int)grid, 256, AF_LDS_B, c->stream>>>(                                          \
-        (const AaRec *)k.d_plan, k.nops, c->sh.sites, k.d_aorder, c->maxstates, (double2 *)c->d_sink, counter,         \
-        static_rounds);                                                                                                \
+        (const AaRec *)k.d_plan, (const unsigned int *)(plan + k.off_seg), k.nsegs, c->sh.sites, k.d_aorder,           \
+        c->maxstates, (double2 *)c->d_sink, counter, static_rounds);                                                   \
   } while (0)
   if (k.mode == SCALE_NONE) { if (nt) AF_LAUNCH(SCALE_NONE, true); else AF_LAUNCH(SCALE_NONE, false); }
   else { if (nt) AF_LAUNCH(SCALE_SITE, true); else AF_LAUNCH(SCALE_SITE, false); }
@@ -1153,10 +1198,48 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     k.nops = 0;
     return 1;
   }
-  std::vector<FusedOp> fplan;
+  std::vector<FusedOp> fplan; // (the segments' plans one after the other; list_pos: position in rops)
   unsigned int reloads = 0;
   const FusedGeom geom = {nclv, nsc, c->sh.tips, c->sh.pattern_tip != 0};
-  int rc = pllhip_fused_plan(geom, rops.data(), rargs.data(), rkinds.data(), n, AF_NSLOT, fplan, &reloads);
+  // Round 5: independent sub-lists as segments of the launch, (tile, segment) work items, while the tiles alone do
+  // not fill the device's workgroup slots eight times over (partials_fused.hpp); PLLHIP_FUSED_SEGMENTS=0 / n: never /
+  // up to n whatever the size.
+  unsigned int max_segs = ((size_t)c->sh.sites + AF_WGS - 1) / AF_WGS < (size_t)c->num_cus * 2 * 8 ? PLLHIP_FUSED_MAX_SEGS : 1u;
+  if (const char * e = getenv("PLLHIP_FUSED_SEGMENTS")) max_segs = (unsigned int)std::max(1, atoi(e));
+  std::vector<unsigned int> seg_of, seg_first, seg_n;
+  const unsigned int nsegs = pllhip_fused_segments(geom, rops.data(), n, max_segs, seg_of);
+  int rc = 0;
+  if (nsegs == 1)
+  {
+    rc = pllhip_fused_plan(geom, rops.data(), rargs.data(), rkinds.data(), n, AF_NSLOT, fplan, &reloads);
+    seg_first.push_back(0u);
+    seg_n.push_back(n);
+  }
+  for (unsigned int sg = 0; nsegs > 1 && sg < nsegs && rc == 0; ++sg)
+  {
+    std::vector<pllhip_op_t> sops;
+    std::vector<PartialsArgs> sargs;
+    std::vector<int> skinds, where;
+    for (unsigned int i = 0; i < n; ++i)
+      if (seg_of[i] == sg)
+      {
+        sops.push_back(rops[i]);
+        sargs.push_back(rargs[i]);
+        skinds.push_back(rkinds[i]);
+        where.push_back((int)i);
+      }
+    std::vector<FusedOp> part;
+    unsigned int r = 0;
+    rc = pllhip_fused_plan(geom, sops.data(), sargs.data(), skinds.data(), (unsigned int)sops.size(), AF_NSLOT, part, &r);
+    reloads += r;
+    seg_first.push_back((unsigned int)fplan.size());
+    seg_n.push_back((unsigned int)part.size());
+    for (FusedOp & f : part)
+    {
+      f.list_pos = where[f.list_pos];
+      fplan.push_back(f);
+    }
+  }
   if (rc) return rc;
   lap("plan (order, slots)");
 
@@ -1203,12 +1286,13 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     if (rc) return rc;
   }
   lap("lookup tables (launches)");
-  std::vector<AaRec> recs(n + 2);
+  std::vector<AaRec> recs; // per segment: the header, one record per op, the record that names op 0 again
+  std::vector<unsigned int> segtab;
   std::vector<AfMatJob> mj;
   std::vector<AfTipJob> tj;
   std::vector<AfPairJob> pj;
-  std::vector<unsigned int> tt_pair_pos;
-  memset(recs.data(), 0, recs.size() * sizeof(AaRec));
+  std::vector<size_t> tt_pair_rec, tt_inside_rec, op_rec; // (absolute record numbers)
+  unsigned int synced = 0;
   const size_t tip_tab_b = (size_t)c->maxstates * 80 * sizeof(double);
   const size_t pair_tab_b = (size_t)c->maxstates * tip_tab_b;
   // (the pool of the pair tables shares the lookup tables' budget: what the lookups of this list left of it)
@@ -1235,20 +1319,29 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       r.slots |= slot4(f.rslot) << 16;
     }
   };
-  reloads_of(recs[0], fplan[0]);
-  // what each op brings along itself: its rows, its left block, its kind -- recorded with the op BEFORE
-  // it (the header for op 0; the last op names op 0 again: the list is walked tile after tile)
-  std::vector<AaRec> own(n);
-  std::vector<unsigned int> tt_inside_pos;
-  memset(own.data(), 0, n * sizeof(AaRec));
-  for (unsigned int pos = 0; pos < n; ++pos)
+  for (unsigned int sg = 0; sg < nsegs; ++sg)
   {
-    const FusedOp & f = fplan[pos];
+  const unsigned int first = seg_first[sg], m = seg_n[sg];
+  const size_t base = recs.size();
+  segtab.push_back((unsigned int)base);
+  segtab.push_back(m);
+  recs.resize(base + m + 2);
+  AaRec * const R = recs.data() + base;
+  memset(R, 0, (m + 2) * sizeof(AaRec));
+  reloads_of(R[0], fplan[first]);
+  // what each op brings along itself: its rows, its left block, its kind -- recorded with the op BEFORE
+  // it (the header for op 0; the last op names op 0 again: the segment is walked tile after tile)
+  std::vector<AaRec> own(m);
+  memset(own.data(), 0, m * sizeof(AaRec));
+  for (unsigned int pos = 0; pos < m; ++pos)
+  {
+    const FusedOp & f = fplan[first + pos];
     const int oi = orig[f.list_pos];
     const bool tt_op = kinds[oi] == 4;
     const int kind = kinds[oi] >= 3 ? 2 : kinds[oi];
-    AaRec & r = recs[pos + 1];
+    AaRec & r = R[pos + 1];
     AaRec & o = own[pos];
+    op_rec.push_back(base + pos + 1);
     r.parent = (unsigned long long)(uintptr_t)f.parent;
     r.pscaler = (unsigned long long)(uintptr_t)f.pscaler;
     r.flags = (unsigned int)kind;
@@ -1283,7 +1376,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       r.flags |= AF_ONE_TABLE;
       o.row[0] = (unsigned long long)(uintptr_t)args[oi].ltip;
       o.row[1] = (unsigned long long)(uintptr_t)args[oi].rtip;
-      tt_pair_pos.push_back(pos);
+      tt_pair_rec.push_back(base + pos + 1);
     }
     else if (tt_op)
     {
@@ -1295,11 +1388,11 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       tj.push_back(AfTipJob{args[oi].rmat, (unsigned long long)(tj.size() * tip_tab_b)});
       o.row[1] = (unsigned long long)(uintptr_t)args[oi].ltip;
       o.row[3] = (unsigned long long)(uintptr_t)args[oi].rtip;
-      tt_inside_pos.push_back(pos);
+      tt_inside_rec.push_back(base + pos + 1);
     }
     else if (kind == 2)
     {
-      const AaLookupTables & t = tabs[lk_index[pos]];
+      const AaLookupTables & t = tabs[lk_index[first + pos]];
       r.tab_l = (unsigned long long)(uintptr_t)t.tl;
       r.tab_r = (unsigned long long)(uintptr_t)t.tr;
       o.row[0] = (unsigned long long)(uintptr_t)t.t1;
@@ -1307,27 +1400,36 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       o.row[2] = (unsigned long long)(uintptr_t)t.t3;
       o.row[3] = (unsigned long long)(uintptr_t)t.t4;
     }
-    if (pos + 1 < n) reloads_of(r, fplan[pos + 1]);
+    if (pos + 1 < m) reloads_of(r, fplan[first + pos + 1]);
   }
   // The left block of op i is staged by the four waves, a part each, while they run op i - 2, and the barrier that
   // tells a wave that everybody's part has landed is barrier A of op i - 1 -- which a lookup does not have.  Until
   // the tip-tip ops joined the list (runs of tens of barrier-free ops, over which the waves drift apart by whole
   // ops) this went unnoticed: an inner-inner op behind a lookup then read its left block a few hundred cycles
   // after the waves had last met.  Such an op now begins with a barrier of its own.
-  for (unsigned int pos = 0; pos < n; ++pos)
-    if ((own[pos].flags & AF_KIND_MASK) == 0u && (own[(pos + n - 1) % n].flags & AF_KIND_MASK) == 2u)
-      recs[pos + 1].flags |= AF_SYNC_LEFT;
-  for (unsigned int pos = 0; pos <= n; ++pos)
+  for (unsigned int pos = 0; pos < m; ++pos)
+    if ((own[pos].flags & AF_KIND_MASK) == 0u && (own[(pos + m - 1) % m].flags & AF_KIND_MASK) == 2u)
+    {
+      R[pos + 1].flags |= AF_SYNC_LEFT;
+      ++synced;
+    }
+  for (unsigned int pos = 0; pos <= m; ++pos)
   {
-    // recs[pos] is the record before op `pos` (recs[0]: the header; recs[n] names op 0 again)
-    const AaRec & o = own[pos == n ? 0 : pos];
-    AaRec & r = recs[pos];
+    // R[pos] is the record before op `pos` (R[0]: the header; R[m] names op 0 again)
+    const AaRec & o = own[pos == m ? 0 : pos];
+    AaRec & r = R[pos];
     r.xoff = o.xoff;
     r.flags |= (o.flags & AF_KIND_MASK) << 8;
     // (rows: those of the op after next -- the header names op 0's)
-    const AaRec & o2 = pos == 0 ? own[0] : own[(pos + 1) % n];
+    const AaRec & o2 = pos == 0 ? own[0] : own[(pos + 1) % m];
     for (int t = 0; t < 4; ++t) r.row[t] = o2.row[t];
+    // the link: the record of the op that runs after this record's (the header's: op 0's; the last op's: op 0's again)
+    r.flags |= (unsigned int)(base + (pos == m ? 1u : pos + 1u)) << AF_NEXT_SHIFT;
+    if (pos == m) r.flags |= AF_LAST;
   }
+  R[0].yoff = (unsigned int)(base + m); // (the segment's last record: the prologue takes op 1's rows from it)
+  } // segments
+  if (recs.size() >= (1u << (32 - AF_NEXT_SHIFT))) return 1;
   if ((mj.size() + 1) * (size_t)AF_MAT_B > 0xffffffffull) return 1;
   // buffers: matrices in operand order, tip tables
   if (k.aorder_cap < (mj.size() + 1) * (size_t)AF_MAT_B)
@@ -1354,19 +1456,19 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     k.pairtab_cap = (pj.size() + 1) * pair_tab_b;
     HIP_TRY(hipMalloc((void **)&k.d_pairtab, k.pairtab_cap));
   }
-  for (unsigned int pos : tt_pair_pos) recs[pos + 1].tab_l += (unsigned long long)(uintptr_t)k.d_pairtab;
-  for (unsigned int pos = 0; pos < n; ++pos)
-    if ((recs[pos + 1].flags & AF_KIND_MASK) == 1u) recs[pos + 1].tab_l += (unsigned long long)(uintptr_t)k.d_titab;
-  for (unsigned int pos : tt_inside_pos)
+  for (size_t ri : tt_pair_rec) recs[ri].tab_l += (unsigned long long)(uintptr_t)k.d_pairtab;
+  for (size_t ri : op_rec)
+    if ((recs[ri].flags & AF_KIND_MASK) == 1u) recs[ri].tab_l += (unsigned long long)(uintptr_t)k.d_titab;
+  for (size_t ri : tt_inside_rec)
   {
-    recs[pos + 1].tab_l += (unsigned long long)(uintptr_t)k.d_titab;
-    recs[pos + 1].tab_r += (unsigned long long)(uintptr_t)k.d_titab;
+    recs[ri].tab_l += (unsigned long long)(uintptr_t)k.d_titab;
+    recs[ri].tab_r += (unsigned long long)(uintptr_t)k.d_titab;
   }
 
   const size_t rec_b = recs.size() * sizeof(AaRec), mat_b = (mj.size() + 1) * sizeof(AfMatJob),
                tip_b = (tj.size() + 1) * sizeof(AfTipJob), pair_b = (pj.size() + 1) * sizeof(AfPairJob),
-               lk_b = (lj.size() + 1) * sizeof(AaLookupJob);
-  const size_t bytes = rec_b + mat_b + tip_b + pair_b + lk_b;
+               lk_b = (lj.size() + 1) * sizeof(AaLookupJob), seg_b = 2 * PLLHIP_FUSED_MAX_SEGS * sizeof(unsigned int);
+  const size_t bytes = rec_b + mat_b + tip_b + pair_b + lk_b + seg_b;
   if (k.plan_cap < bytes)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1386,6 +1488,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   if (!tj.empty()) memcpy(stage + rec_b + mat_b, tj.data(), tj.size() * sizeof(AfTipJob));
   if (!pj.empty()) memcpy(stage + rec_b + mat_b + tip_b, pj.data(), pj.size() * sizeof(AfPairJob));
   if (!lj.empty()) memcpy(stage + rec_b + mat_b + tip_b + pair_b, lj.data(), lj.size() * sizeof(AaLookupJob));
+  memcpy(stage + rec_b + mat_b + tip_b + pair_b + lk_b, segtab.data(), segtab.size() * sizeof(unsigned int));
   HIP_TRY(hipMemcpyAsync(k.d_plan, k.h_plan, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(k.done, c->stream));
   k.pending = true;
@@ -1393,6 +1496,8 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   k.off_tip = rec_b + mat_b;
   k.off_pair = rec_b + mat_b + tip_b;
   k.off_lk = rec_b + mat_b + tip_b + pair_b;
+  k.off_seg = rec_b + mat_b + tip_b + pair_b + lk_b;
+  k.nsegs = nsegs;
   k.nlk = (unsigned int)lj.size();
   k.npair = (unsigned int)pj.size();
   k.nmat = (unsigned int)mj.size();
@@ -1400,12 +1505,10 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   k.nops = n;
   if (getenv("PLLHIP_FUSED_DEBUG"))
   {
-    unsigned int synced = 0;
-    for (unsigned int pos = 0; pos < n; ++pos) synced += (recs[pos + 1].flags & AF_SYNC_LEFT) ? 1u : 0u;
     fprintf(stderr, "pllhip 20-state list kernel: %u ops = %zu tip-tip ahead + %zu tip-tip in the list + %zu lookups + %zu on the matrix cores "
-                    "(%u of them behind a lookup: a barrier more), %u operands reloaded\n",
-            count, k.tt_ops.size(), tt_inside_pos.size() + tt_pair_pos.size(), k.lk_ops.size(),
-            (size_t)n - k.lk_ops.size() - tt_inside_pos.size() - tt_pair_pos.size(), synced, reloads);
+                    "(%u of them behind a lookup: a barrier more), %u operands reloaded, %u segment(s)\n",
+            count, k.tt_ops.size(), tt_inside_rec.size() + tt_pair_rec.size(), k.lk_ops.size(),
+            (size_t)n - k.lk_ops.size() - tt_inside_rec.size() - tt_pair_rec.size(), synced, reloads, nsegs);
   }
   lap("encode + upload");
   rc = aa_fused_launch(c, true);

@@ -158,8 +158,8 @@ __device__ __forceinline__ unsigned int group_and(unsigned int x)
 // WPS: waves per SIMD the register budget is sized for (3 = 168 VGPRs: twelve waves per CU)
 // NTP: cache policy -- 0 plain stores, 1 the tiles non-temporal, 2 the counts as well
 template <int RC, int J, int MODE, int NTP, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan, FusedBases bases,
-                                                        unsigned int nops, unsigned int sites, unsigned int nslots,
+__global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan0, FusedBases bases,
+                                                        unsigned int nops0, unsigned int sites, unsigned int nslots,
                                                         double2 * sink, unsigned int * next_tile, unsigned int dynamic_rounds,
                                                         unsigned int site_base, unsigned int tile_groups)
 {
@@ -197,6 +197,9 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   // predicates, and every address is a wave-uniform tile base plus a lane offset that
   // never changes.
   const size_t tiles = ((size_t)sites + TS - 1) / TS;
+  // (round 5) work items: (tile, segment) pairs, segment-major -- every tile of the longest segment first
+  const unsigned int nsegs = bases.nsegs;
+  const size_t items = tiles * nsegs;
   // Tile = wave number: the four waves of a workgroup take four adjacent tiles, and neighbouring
   // workgroups -- which the dispatcher deals to the eight XCDs in turn -- the next four.  Giving
   // each XCD a region of its own instead (a contiguous eighth, or chunks of 16 ... 4096 tiles
@@ -237,11 +240,29 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
   // the HBM peak (same box).  All tiles from the counter is slower again (atomics on one
   // address serialise at ~12 ns: 0.75 ms of them per launch at 1 M sites), and short lists keep
   // two rounds for that reason.
-  size_t static_rounds = tiles / nwaves > dynamic_rounds ? tiles / nwaves - dynamic_rounds : 1; // (the last rounds from the counter)
+  size_t static_rounds = items / nwaves > dynamic_rounds ? items / nwaves - dynamic_rounds : 1; // (the last rounds from the counter)
   if (!next_tile) static_rounds = ~(size_t)0;
   size_t round = 0;
-  for (size_t tile = wave; tile < tiles;)
+  for (size_t item = wave; item < items;)
   {
+    // the item's segment: its records, its length, where its first character rows are
+    size_t tile = item;
+    const FusedRec * plan = plan0;
+    unsigned int nops = nops0;
+    unsigned long long row_first = row0;
+    if (nsegs > 1u)
+    {
+      unsigned int seg = 0;
+      while (tile >= tiles)
+      {
+        tile -= tiles;
+        ++seg;
+      }
+      const const_words sg = (const_words)(unsigned long long)(bases.segs + __builtin_amdgcn_readfirstlane(seg));
+      plan = plan0 + sg[0];
+      nops = sg[1];
+      row_first = bases.rowtab[(size_t)sg[2] * 64u + lane];
+    }
     const size_t site0 = (size_t)site_base + tile * TS; // (site_base: this launch's block of the alignment)
 #ifdef PLLHIP_FUSED_TIMING
     const unsigned long long t_tile = __builtin_readcyclecounter();
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     // evicting -- with 8 M sites per row that cost the 133 GB partition a quarter of its speed; tool builds
     // that read every row from the first row's pages: 0.56 -> 0.76 of the HBM peak, profiles/r3_footprint.txt.
     // Sixty-four rows in one instruction wait for their translations together, long before they are used.)
-    pll_v4u cs = *(const pll_v4u PLL_GLOBAL *)(row0 + site0);
+    pll_v4u cs = *(const pll_v4u PLL_GLOBAL *)(row_first + site0);
     // What an op needs from memory besides is requested TWO ops ahead of it: its 16 bytes of [P_l | P_r].
     auto request = [&](FusedFetch<J> & f, const Rec & r) {
       const unsigned int off = (pm_left ? rec_req_lmat(r) : rec_req_rmat(r)) + pm_lane;
@@ -353,8 +374,7 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
     // waits for those loads before any slot is read.  (Per-lane 64-bit addresses and `off`:
     // the form the compiler itself emits for the builtin.)
     auto reload = [&](unsigned int src_index) {
-      // (the sources follow the two headers, the records and one record of padding)
-      const const_quads q = (const_quads)(unsigned long long)(reinterpret_cast<const FusedSrc *>(plan + nops + 3) + src_index);
+      const const_quads q = (const_quads)(unsigned long long)(bases.srcs + src_index);
       const unsigned long long src[2] = {q[0], q[1]}, csrc[2] = {q[2], q[3]};
       const unsigned long long where = q[4]; // lslot_b | rslot_b << 16 | lcnt_b << 32 | rcnt_b << 48
       const unsigned int slot_b[2] = {(unsigned int)where & 0xffffu, (unsigned int)(where >> 16) & 0xffffu};
@@ -626,11 +646,11 @@ __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restr
 #endif
     if (++round < static_rounds)
     {
-      tile += nwaves;
+      item += nwaves;
       continue;
     }
     asm volatile("" : "+v"(next_ticket));
-    tile = static_rounds * nwaves + tile_group + (size_t)tile_groups * (unsigned int)__builtin_amdgcn_readfirstlane((int)next_ticket);
+    item = static_rounds * nwaves + tile_group + (size_t)tile_groups * (unsigned int)__builtin_amdgcn_readfirstlane((int)next_ticket);
   }
 }
 
@@ -1058,7 +1078,8 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   const size_t lds = 4 * ((size_t)nslots * J * (64 * 16 + cw * 4) + (size_t)RC * 16 * sizeof(double));
   // three workgroups (12 waves) per CU when the slots leave room for them, else two; each wave
   // walks its share of the tiles
-  size_t grid = (tiles + 3) / 4;
+  const size_t nsegs = bases.nsegs; // (work items: (tile, segment) pairs)
+  size_t grid = (tiles * nsegs + 3) / 4;
   const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
@@ -1094,12 +1115,12 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   {
   const unsigned int bsites = (unsigned int)(sites - base < block_sites ? sites - base : block_sites);
   const size_t btiles = (bsites + tile_sites - 1) / tile_sites;
-  size_t bgrid = (btiles + 3) / 4;
+  size_t bgrid = (btiles * nsegs + 3) / 4;
   if (bgrid > cap) bgrid = cap;
   if (base) HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, PLLHIP_TILE_COUNTER_BYTES, c->stream));
-  const size_t rounds = btiles / (bgrid * 4);
+  const size_t rounds = btiles * nsegs / (bgrid * 4);
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
-                                      : (count >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
+                                      : (c->fused_last_longest >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
   // (eight counters, or what PLLHIP_FUSED_TILE_GROUPS says -- but never more than there are groups of eight
   // workgroups, or a counter's tiles would have no takers; and no more than the counter buffer holds)
   const size_t want_groups = getenv("PLLHIP_FUSED_TILE_GROUPS") ? (size_t)std::max(1, atoi(getenv("PLLHIP_FUSED_TILE_GROUPS"))) : 8;
@@ -1158,19 +1179,109 @@ extern "C" unsigned int pllhip_fused_char_batches_dry(const unsigned int * tips,
   return pllhip_fused_char_batches(tips, count, ts >= 16 ? ts / 16 : 1, chars_out, batch_out);
 }
 
-// Encode the plan for the device (FusedRec in partials_fused.hpp): two header records that
-// stand for ops -2 and -1, one record per op, one of padding (the last op's look-ahead load), the
-// reload sources, the pair-table jobs.  Returns 1 if the list is not one the kernel takes.
-int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots)
+// Independent sub-lists (FusedSeg in partials_fused.hpp).  Two ops belong together when one of them writes a
+// buffer -- CLV or scale buffer -- the other reads or writes; buffers nobody in the list writes (tips, operands of
+// earlier calls) tie nothing.  Union-find over the ops, then the components dealt longest first.
+unsigned int pllhip_fused_segments(const FusedGeom & geom, const pllhip_op_t * ops, unsigned int count,
+                                   unsigned int max_segments, std::vector<unsigned int> & seg_of)
 {
-  const unsigned int count = (unsigned int)plan.size();
+  seg_of.assign(count, 0u);
+  if (max_segments > PLLHIP_FUSED_MAX_SEGS) max_segments = PLLHIP_FUSED_MAX_SEGS;
+  if (count < 4 || max_segments < 2) return 1;
+  std::vector<unsigned int> parent(count);
+  for (unsigned int i = 0; i < count; ++i) parent[i] = i;
+  auto find = [&](unsigned int x) {
+    while (parent[x] != x) x = parent[x] = parent[parent[x]];
+    return x;
+  };
+  auto join = [&](unsigned int a, unsigned int b) {
+    a = find(a);
+    b = find(b);
+    if (a != b) parent[a > b ? a : b] = a < b ? a : b;
+  };
+  // first op that touches each WRITTEN buffer (-1: not written in this list, -2: written, nobody met yet)
+  std::vector<int> clv_first(geom.nclv, -1), sc_first(geom.nsc, -1);
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    if (ops[i].parent_clv >= geom.nclv || ops[i].child1_clv >= geom.nclv || ops[i].child2_clv >= geom.nclv ||
+        ops[i].parent_scaler >= (int)geom.nsc || ops[i].child1_scaler >= (int)geom.nsc || ops[i].child2_scaler >= (int)geom.nsc)
+      return 1; // (the path taken reports it)
+    clv_first[ops[i].parent_clv] = -2;
+    if (ops[i].parent_scaler >= 0) sc_first[ops[i].parent_scaler] = -2;
+  }
+  for (unsigned int i = 0; i < count; ++i)
+  {
+    auto touch = [&](std::vector<int> & first, int idx) {
+      if (idx < 0 || first[idx] == -1) return;
+      if (first[idx] == -2) first[idx] = (int)i;
+      else join((unsigned int)first[idx], i);
+    };
+    touch(clv_first, (int)ops[i].parent_clv);
+    touch(clv_first, (int)ops[i].child1_clv);
+    touch(clv_first, (int)ops[i].child2_clv);
+    touch(sc_first, ops[i].parent_scaler);
+    touch(sc_first, ops[i].child1_scaler);
+    touch(sc_first, ops[i].child2_scaler);
+  }
+  // components by size, longest first (ties: the one that begins first)
+  std::vector<unsigned int> size(count, 0u);
+  for (unsigned int i = 0; i < count; ++i) ++size[find(i)];
+  std::vector<unsigned int> roots;
+  for (unsigned int i = 0; i < count; ++i)
+    if (size[i]) roots.push_back(i);
+  if (roots.size() < 2) return 1;
+  std::stable_sort(roots.begin(), roots.end(), [&](unsigned int a, unsigned int b) { return size[a] > size[b]; });
+  // as many segments as have two ops each at least, and no more than shorten the longest
+  unsigned int nsegs = (unsigned int)std::min<size_t>(max_segments, roots.size());
+  std::vector<unsigned int> load, seg_of_root(count, 0u);
+  for (;; --nsegs)
+  {
+    load.assign(nsegs, 0u);
+    for (unsigned int r : roots)
+    {
+      const unsigned int k = (unsigned int)(std::min_element(load.begin(), load.end()) - load.begin());
+      seg_of_root[r] = k;
+      load[k] += size[r];
+    }
+    if (nsegs == 1 || *std::min_element(load.begin(), load.end()) >= 2) break;
+  }
+  if (nsegs == 1) return 1;
+  for (unsigned int i = 0; i < count; ++i) seg_of[i] = seg_of_root[find(i)];
+  return nsegs;
+}
+
+extern "C" unsigned int pllhip_fused_segments_dry(unsigned int tips, unsigned int clv_buffers, unsigned int scale_buffers,
+                                                  int pattern_tip, const pllhip_op_t * ops, unsigned int count,
+                                                  unsigned int max_segments, unsigned int * seg_out)
+{
+  const FusedGeom geom = {(size_t)tips + clv_buffers, scale_buffers, tips, pattern_tip != 0};
+  std::vector<unsigned int> seg_of;
+  const unsigned int n = pllhip_fused_segments(geom, ops, count, max_segments, seg_of);
+  for (unsigned int i = 0; i < count && seg_out; ++i) seg_out[i] = seg_of[i];
+  return n;
+}
+
+// Encode the plans for the device (FusedRec in partials_fused.hpp) -- one per segment: two header records that
+// stand for ops -2 and -1, one record per op, one of padding (the last op's look-ahead load) -- then the segment
+// table, the reload sources, the pair-table jobs, the character rows' addresses.  Returns 1 if the list is not one
+// the kernel takes.
+int pllhip_launch_fused(pllhip_ctx * c, const std::vector<std::vector<FusedOp>> & plans, unsigned int nslots)
+{
+  const unsigned int nsegs = (unsigned int)plans.size();
+  unsigned int count = 0, longest = 0;
+  for (const auto & plan : plans)
+  {
+    count += (unsigned int)plan.size();
+    longest = std::max(longest, (unsigned int)plan.size());
+  }
   const unsigned int R = c->sh.rate_cats;
-  if (count > PLLHIP_FUSED_MAX_OPS) return 1;
+  if (count > PLLHIP_FUSED_MAX_OPS || nsegs < 1 || nsegs > PLLHIP_FUSED_MAX_SEGS) return 1;
   // pair tables of the ops with a tip (k_dna_pair_tables), carved from one device buffer behind a
   // table of zeros
   const size_t per = (size_t)256 * R * 4; // doubles per table
   size_t ntab = 1;
-  for (const FusedOp & f : plan) ntab += (f.kind >= 1);
+  for (const auto & plan : plans)
+    for (const FusedOp & f : plan) ntab += (f.kind >= 1);
   if (ntab * per * sizeof(double) > 0xffffffffull ||
       (size_t)c->sh.prob_matrices * c->pmat_elems * sizeof(double) > 0xffffffffull)
     return 1;
@@ -1197,23 +1308,31 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   const unsigned int slot_bytes = J * 1024u, count_bytes = J * cw * 4u;
   if ((size_t)nslots * slot_bytes > 0xffffu) return 1;
 
-  std::vector<FusedRec> recs(count + 3);
+  std::vector<FusedRec> recs;
+  std::vector<FusedSeg> segs(nsegs);
   std::vector<FusedSrc> srcs;
   std::vector<FusedPairJob> jobs;
-  // Tip rows in the order the list uses them, in batches of what a wave's 64 x 16 bytes hold of a tile
-  // (pllhip_fused_char_batches).  rowtab[batch][lane]: the address the lane fetches from (+ the tile's first
-  // site); lanes without a row fetch zeros.
-  const unsigned int lpr = J * sps >= 16 ? J * sps / 16 : 1; // lanes per row
-  std::vector<unsigned int> chars_of(count, 0), batch_of(count, 0);
   std::vector<unsigned long long> rowtab;
+  int mode = SCALE_NONE;
+  const unsigned int lpr = J * sps >= 16 ? J * sps / 16 : 1; // lanes per row
+  for (unsigned int sg = 0; sg < nsegs; ++sg)
   {
-    std::vector<unsigned int> ntips(count);
-    for (unsigned int pos = 0; pos < count; ++pos) ntips[pos] = (plan[pos].ltip ? 1u : 0u) | (plan[pos].rtip ? 2u : 0u);
-    const unsigned int nbatches = pllhip_fused_char_batches(ntips.data(), count, lpr, chars_of.data(), batch_of.data());
-    if (nbatches > 255) return 1;
-    rowtab.assign((size_t)nbatches * 64, (unsigned long long)(uintptr_t)c->fused_zero_row);
-    for (unsigned int pos = 0; pos < count; ++pos)
+  const std::vector<FusedOp> & plan = plans[sg];
+  const unsigned int n = (unsigned int)plan.size();
+  // Tip rows in the order the segment uses them, in batches of what a wave's 64 x 16 bytes hold of a tile
+  // (pllhip_fused_char_batches).  rowtab[batch][lane]: the address the lane fetches from (+ the tile's first
+  // site); lanes without a row fetch zeros.  Batches are numbered across the segments.
+  std::vector<unsigned int> chars_of(n, 0), batch_of(n, 0);
+  const unsigned int batch0 = (unsigned int)(rowtab.size() / 64);
+  {
+    std::vector<unsigned int> ntips(n);
+    for (unsigned int pos = 0; pos < n; ++pos) ntips[pos] = (plan[pos].ltip ? 1u : 0u) | (plan[pos].rtip ? 2u : 0u);
+    const unsigned int nbatches = pllhip_fused_char_batches(ntips.data(), n, lpr, chars_of.data(), batch_of.data());
+    if (batch0 + nbatches > 255) return 1;
+    rowtab.resize((size_t)(batch0 + nbatches) * 64, (unsigned long long)(uintptr_t)c->fused_zero_row);
+    for (unsigned int pos = 0; pos < n; ++pos)
     {
+      batch_of[pos] += batch0;
       const unsigned char * rows[2] = {plan[pos].ltip, plan[pos].rtip};
       const unsigned int lane0[2] = {PLLHIP_FUSED_CH_LPOS(chars_of[pos]), PLLHIP_FUSED_CH_RPOS(chars_of[pos])};
       for (int o = 0; o < 2; ++o)
@@ -1221,9 +1340,8 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
           rowtab[(size_t)batch_of[pos] * 64 + lane0[o] + l] = (unsigned long long)(uintptr_t)rows[o] + l * 16u;
     }
   }
-  std::vector<unsigned int> table_of(count, 0); // byte offset of each op's pair table (0: zeros)
-  int mode = SCALE_NONE;
-  for (unsigned int pos = 0; pos < count; ++pos)
+  std::vector<unsigned int> table_of(n, 0); // byte offset of each op's pair table (0: zeros)
+  for (unsigned int pos = 0; pos < n; ++pos)
   {
     const FusedOp & f = plan[pos];
     if (f.kind >= 1)
@@ -1239,18 +1357,18 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   auto look_ahead = [&](FusedRec & r, long pos) -> int {
     r.chars = 0;
     r.req_lmat = r.req_rmat = 0;
-    if (pos + 1 >= 0 && pos + 1 < (long)count) r.chars = chars_of[pos + 1];
-    if (pos + 2 < (long)count)
+    if (pos + 1 >= 0 && pos + 1 < (long)n) r.chars = chars_of[pos + 1];
+    if (pos + 2 < (long)n)
     {
       const FusedOp & f = plan[pos + 2];
       // (the rows of op + 2 are fetched once op + 1's characters have been taken from the registers)
-      const unsigned int now = pos + 1 >= 0 ? batch_of[pos + 1] : 0u;
+      const unsigned int now = pos + 1 >= 0 ? batch_of[pos + 1] : batch0;
       if (batch_of[pos + 2] != now) r.chars |= PLLHIP_FUSED_CH_LOAD | batch_of[pos + 2] << 24;
       r.req_lmat = (unsigned int)((f.lmat - c->pmatrix) * sizeof(double));
       r.req_rmat = (unsigned int)((f.rmat - c->pmatrix) * sizeof(double));
     }
     r.src = 0;
-    if (pos + 1 >= 0 && pos + 1 < (long)count)
+    if (pos + 1 >= 0 && pos + 1 < (long)n)
     {
       const FusedOp & f = plan[pos + 1];
       r.gather_off = table_of[pos + 1];
@@ -1273,12 +1391,16 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
     }
     return 0;
   };
-  memset(recs.data(), 0, recs.size() * sizeof(FusedRec));
-  if (look_ahead(recs[0], -2) || look_ahead(recs[1], -1)) return 1;
-  for (unsigned int pos = 0; pos < count; ++pos)
+  const size_t first = recs.size();
+  segs[sg] = FusedSeg{(unsigned int)first, n, batch0, 0u};
+  recs.resize(first + n + 3);
+  FusedRec * rs = recs.data() + first;
+  memset(rs, 0, (n + 3) * sizeof(FusedRec));
+  if (look_ahead(rs[0], -2) || look_ahead(rs[1], -1)) return 1;
+  for (unsigned int pos = 0; pos < n; ++pos)
   {
     const FusedOp & f = plan[pos];
-    FusedRec & r = recs[pos + 2];
+    FusedRec & r = rs[pos + 2];
     r.flags = (unsigned int)f.kind & PLLHIP_FUSED_KIND_MASK;
     if (f.pslot >= 0) r.flags |= PLLHIP_FUSED_HAS_PSLOT;
     if (f.pscaler) r.flags |= PLLHIP_FUSED_SCALING;
@@ -1295,14 +1417,16 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
     r.list_pos = (unsigned short)f.list_pos;
     if (look_ahead(r, (long)pos)) return 1;
   }
-  recs[count + 2] = recs[count + 1]; // (loaded by the last op, never used)
-  recs[count + 2].flags &= ~PLLHIP_FUSED_RELOAD_NEXT;
+  rs[n + 2] = rs[n + 1]; // (loaded by the last op, never used)
+  rs[n + 2].flags &= ~PLLHIP_FUSED_RELOAD_NEXT;
+  } // segments
 
   const size_t rec_bytes = recs.size() * sizeof(FusedRec);
+  const size_t seg_bytes = (size_t)PLLHIP_FUSED_MAX_SEGS * sizeof(FusedSeg);
   const size_t src_bytes = (srcs.size() + 1) * sizeof(FusedSrc);
   const size_t job_bytes = (jobs.size() + 1) * sizeof(FusedPairJob);
   const size_t tab_bytes = rowtab.size() * sizeof(unsigned long long);
-  const size_t bytes = rec_bytes + src_bytes + job_bytes + tab_bytes;
+  const size_t bytes = rec_bytes + seg_bytes + src_bytes + job_bytes + tab_bytes;
   if (c->plan_cap < bytes)
   {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1326,19 +1450,24 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
   if (c->plan_pending[b]) HIP_TRY(hipEventSynchronize(c->plan_done[b]));
   char * stage = static_cast<char *>(c->h_plan[b]);
   memcpy(stage, recs.data(), rec_bytes);
-  if (!srcs.empty()) memcpy(stage + rec_bytes, srcs.data(), srcs.size() * sizeof(FusedSrc));
-  if (!jobs.empty()) memcpy(stage + rec_bytes + src_bytes, jobs.data(), jobs.size() * sizeof(FusedPairJob));
-  memcpy(stage + rec_bytes + src_bytes + job_bytes, rowtab.data(), tab_bytes);
+  memcpy(stage + rec_bytes, segs.data(), segs.size() * sizeof(FusedSeg));
+  if (!srcs.empty()) memcpy(stage + rec_bytes + seg_bytes, srcs.data(), srcs.size() * sizeof(FusedSrc));
+  if (!jobs.empty()) memcpy(stage + rec_bytes + seg_bytes + src_bytes, jobs.data(), jobs.size() * sizeof(FusedPairJob));
+  memcpy(stage + rec_bytes + seg_bytes + src_bytes + job_bytes, rowtab.data(), tab_bytes);
   HIP_TRY(hipMemcpyAsync(c->d_plan, c->h_plan[b], bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 96 * sizeof(double2))); // 1536 B per wave
   if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, PLLHIP_TILE_COUNTER_BYTES));
   // what a repeated call with the same op list needs (pllhip_relaunch_fused)
-  c->fused_last_jobs_offset = rec_bytes + src_bytes;
-  c->fused_last_rowtab_offset = rec_bytes + src_bytes + job_bytes;
+  c->fused_last_segs_offset = rec_bytes;
+  c->fused_last_srcs_offset = rec_bytes + seg_bytes;
+  c->fused_last_jobs_offset = rec_bytes + seg_bytes + src_bytes;
+  c->fused_last_rowtab_offset = rec_bytes + seg_bytes + src_bytes + job_bytes;
   c->fused_last_jobs = (unsigned int)jobs.size();
-  c->fused_last_count = count;
+  c->fused_last_count = plans[0].size();
+  c->fused_last_longest = longest;
+  c->fused_last_nsegs = nsegs;
   c->fused_last_nslots = nslots;
   c->fused_last_mode = mode;
   c->fused_last_epoch = c->layout_epoch;
@@ -1350,14 +1479,17 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsig
 // kernels run): tip tables and the list kernel again, no planning, no upload.
 int pllhip_relaunch_fused(pllhip_ctx * c)
 {
-  const unsigned int count = c->fused_last_count, nslots = c->fused_last_nslots, njobs = c->fused_last_jobs;
+  const unsigned int count = c->fused_last_count, nslots = c->fused_last_nslots, njobs = c->fused_last_jobs; // (count: segment 0's)
   const int mode = c->fused_last_mode;
   static_assert(PLLHIP_TILE_COUNTER_BYTES == 256 * 128, "one counter per thread of k_dna_pair_tables' first workgroup");
   if (!njobs) HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, PLLHIP_TILE_COUNTER_BYTES, c->stream)); // (no table launch to do it)
   const FusedRec * d_plan = (const FusedRec *)c->d_plan;
   const FusedPairJob * d_jobs = (const FusedPairJob *)(static_cast<const char *>(c->d_plan) + c->fused_last_jobs_offset);
   const FusedBases bases = {c->pmatrix, c->d_pairtab,
-                            (const unsigned long long *)(static_cast<const char *>(c->d_plan) + c->fused_last_rowtab_offset)};
+                            (const unsigned long long *)(static_cast<const char *>(c->d_plan) + c->fused_last_rowtab_offset),
+                            (const FusedSrc *)(static_cast<const char *>(c->d_plan) + c->fused_last_srcs_offset),
+                            (const FusedSeg *)(static_cast<const char *>(c->d_plan) + c->fused_last_segs_offset),
+                            c->fused_last_nsegs};
   if (njobs)
   {
     switch (c->sh.rate_cats)

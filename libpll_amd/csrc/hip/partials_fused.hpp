@@ -100,12 +100,33 @@ struct FusedPairJob
 unsigned int pllhip_fused_char_batches(const unsigned int * tips, unsigned int count, unsigned int lpr,
                                        unsigned int * chars_out, unsigned int * batch_out);
 
+// Round 5: SEGMENTS.  Ops that share no buffer any of them writes are independent lists -- the two sides of the root
+// edge of a full traversal, above all -- and a tile of sites may be taken through each of them by a different wave at
+// the same time.  A launch whose tiles do not fill the chip a few times over (the 25-125 k sites an 8-way split of
+// the BASELINE alignments leaves a GPU, real protein data) hands out (tile, segment) pairs instead of tiles: twice
+// the work items of half the length, so the time of a launch with fewer tiles than wave slots -- one tile's serial
+// walk of the list, ~1 us per op whatever the site count -- halves, and the last round's idle slots shrink with the
+// items.  The reference has no counterpart (its cost per op is proportional to the sites, partials.c:177-213).
+// Each segment is a plan of its own (order, slots, header records); reload sources, pair tables and character rows
+// are numbered across the segments.  pllhip_fused_segments is host logic (CPU tests: tests/test_host.py).
+struct FusedSeg
+{
+  unsigned int rec_first;   // the segment's two header records begin here (in records)
+  unsigned int nops;
+  unsigned int first_batch; // the batch of character rows its first ops use
+  unsigned int pad;
+};
+#define PLLHIP_FUSED_MAX_SEGS 8u
+
 // what the offsets of a FusedRec are relative to (kernel argument)
 struct FusedBases
 {
   const double * pmat;
   const double * pairtab;
   const unsigned long long * rowtab; // [batch][64]: the address each lane fetches its 16 bytes of tip characters from (+ site)
+  const struct FusedSrc * srcs;      // reload sources, numbered across the segments
+  const FusedSeg * segs;             // [nsegs] (nsegs == 1: not read, the kernel's own arguments say it all)
+  unsigned int nsegs;
 };
 
 // (The planner is host logic and needs no device: what it must know of the partition is here.)
@@ -126,7 +147,14 @@ int pllhip_fused_plan(const FusedGeom & geom, const pllhip_op_t * ops, const Par
                       const int * kinds, unsigned int count, unsigned int nslots,
                       std::vector<FusedOp> & plan, unsigned int * reloads);
 unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int workgroups_per_cu);
-int pllhip_launch_fused(pllhip_ctx * c, const std::vector<FusedOp> & plan, unsigned int nslots);
+// The list as up to `max_segments` independent sub-lists of at least two ops each: seg_of[i] = segment of op i
+// (segment 0 the longest; ops keep their relative order within a segment).  Components -- ops connected through a
+// buffer one of them writes -- are dealt to the segments longest first, each to the segment that is shortest then.
+// Returns the number of segments (1: the list does not split).
+unsigned int pllhip_fused_segments(const FusedGeom & geom, const pllhip_op_t * ops, unsigned int count,
+                                   unsigned int max_segments, std::vector<unsigned int> & seg_of);
+// one plan per segment (pllhip_fused_plan of its sub-list)
+int pllhip_launch_fused(pllhip_ctx * c, const std::vector<std::vector<FusedOp>> & plans, unsigned int nslots);
 int pllhip_relaunch_fused(pllhip_ctx * c); // the same op list as in the previous whole-list call of this context
 
 #endif

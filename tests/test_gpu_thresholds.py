@@ -178,3 +178,52 @@ def test_lookup_table_budget(gpu, monkeypatch, budget_mb):
     assert same(observe(gpu, plan, seqs, 20), want)
     monkeypatch.setenv("PLLHIP_AA_TT_PAIRS", "0")      # (tip-tip ops of the list over the two tip tables, as in round 3)
     assert same(observe(gpu, plan, seqs, 20), want)
+
+
+def observe_all(gpu, plan, seqs, states, every=1):
+    """every op's CLV and scale buffer, per-site lnL, and the same after a branch-length change + partial traversal"""
+    p = W.setup_partition(gpu, plan, seqs, states, 4, ATTRIB_PATTERN_TIP)
+    p.update_partials(plan.ops)
+    lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
+    clvs = [p.get_clv(int(op["parent_clv_index"])) for op in plan.ops[::every]]
+    scs = [p.get_scaler(int(op["parent_scaler_index"])) for op in plan.ops]
+    p.update_partials(plan.ops)                 # (the kept plan)
+    lnl2, ps2 = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
+    n = max(2, len(plan.ops) // 3)
+    p.update_prob_matrices([0] * 4, [int(plan.ops[-n]["child1_matrix_index"])], [0.27])
+    p.update_partials(plan.ops[-n:])
+    lnl3, ps3 = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
+    p.destroy()
+    return (lnl, ps, clvs, scs, lnl2, ps2, lnl3, ps3)
+
+
+@pytest.mark.parametrize("states,shape,taxa,sites", [(4, "balanced", 64, 3_000), (4, "balanced", 64, 50_000),
+                                                     (4, "random", 40, 62_500), (4, "balanced", 16, 200_000),
+                                                     (4, "balanced", 8, 400_000), (4, "caterpillar", 30, 20_000),
+                                                     (20, "balanced", 64, 3_000), (20, "random", 40, 25_000),
+                                                     (20, "balanced", 16, 70_000), (20, "caterpillar", 30, 9_000)])
+def test_segments_threshold(gpu, monkeypatch, states, shape, taxa, sites):
+    """Round 5: the two sides of the root edge (any sets of ops that share no written buffer) as SEGMENTS of one
+    whole-list launch -- (tile, segment) work items, handed out while the tiles alone do not fill the chip eight
+    times over.  Never / two / up to eight / the size rule: every CLV, every scale buffer and the per-site lnL are
+    the same bits, also through the kept plan and a partial traversal (one segment again)."""
+    monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
+    monkeypatch.setenv("PLLHIP_FUSED", "2")
+    plan = {"balanced": W.balanced_tree, "random": W.random_tree, "caterpillar": W.caterpillar_tree}[shape](taxa, seed=9)
+    seqs = W.random_alignment(taxa, sites, states, seed=sites)
+    res = {}
+    for mode in ("0", "2", "8", "default"):
+        if mode == "default":
+            monkeypatch.delenv("PLLHIP_FUSED_SEGMENTS", raising=False)
+        else:
+            monkeypatch.setenv("PLLHIP_FUSED_SEGMENTS", mode)
+        res[mode] = observe_all(gpu, plan, seqs, states, every=1 if sites <= 70_000 else 7)
+    want = res["0"]
+    for mode, got in res.items():
+        assert got[0] == want[0] and got[4] == want[4] and got[6] == want[6], mode
+        assert bits_equal(got[1], want[1]) and bits_equal(got[5], want[5]) and bits_equal(got[7], want[7]), mode
+        assert got[0] == got[4] and bits_equal(got[1], got[5]), mode
+        for a, b in zip(got[2], want[2]):
+            assert bits_equal(a, b), mode
+        for a, b in zip(got[3], want[3]):
+            assert (a == b).all(), mode

@@ -333,6 +333,83 @@ def test_fused_planner_on_random_op_sequences(amd):
     assert _plan_dry(amd, bad, 8, 6, 6, 1, 5)[0] == -1
 
 
+def _segments_dry(amd, ops, tips, clv_buffers, scale_buffers, pattern_tip, max_segments=8):
+    ops = np.ascontiguousarray(ops)
+    n = len(ops)
+    seg = (C.c_uint * n)()
+    amd.lib.pllhip_fused_segments_dry.restype = C.c_uint
+    ns = amd.lib.pllhip_fused_segments_dry(C.c_uint(tips), C.c_uint(clv_buffers), C.c_uint(scale_buffers),
+                                           C.c_int(pattern_tip), ops.ctypes.data_as(C.c_void_p), C.c_uint(n),
+                                           C.c_uint(max_segments), seg)
+    return ns, list(seg)
+
+
+def _segments_are_independent(ops, seg):
+    """No buffer written by an op of one segment is touched by an op of another."""
+    writes, touches = {}, {}
+    for i, op in enumerate(ops):
+        w = [("clv", int(op["parent_clv_index"]))] + ([("sc", int(op["parent_scaler_index"]))] if op["parent_scaler_index"] >= 0 else [])
+        t = w + [("clv", int(op["child1_clv_index"])), ("clv", int(op["child2_clv_index"]))] + \
+            [("sc", int(x)) for x in (op["child1_scaler_index"], op["child2_scaler_index"]) if x >= 0]
+        for b in w:
+            writes.setdefault(b, set()).add(seg[i])
+        for b in t:
+            touches.setdefault(b, set()).add(seg[i])
+    return all(len(touches[b]) == 1 for b in writes)
+
+
+def test_fused_segments(amd):
+    """pllhip_fused_segments (round 5; host logic of the whole-list kernels' (tile, segment) work items): a full
+    traversal of an unrooted tree is the two sides of its root edge -- two segments of 31 ops for BASELINE config 2's
+    64 taxa, the longer side first; a partial traversal (a path to the root) is one; random lists with heavy buffer
+    reuse split only into sets that share no written buffer; every segment has two ops at least."""
+    plan = W.balanced_tree(64)
+    ns, seg = _segments_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 1)
+    assert ns == 2 and sorted(seg.count(k) for k in range(ns)) == [31, 31]
+    assert _segments_are_independent(plan.ops, seg)
+    # tips as CLVs (nobody writes a tip): the same split
+    ns0, seg0 = _segments_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 0)
+    assert ns0 == 2 and seg0 == seg
+    # the sides of a random tree are unequal: segment 0 is the longer one
+    plan = W.random_tree(200, seed=42)
+    ns, seg = _segments_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 1)
+    assert ns == 2 and seg.count(0) >= seg.count(1) >= 2 and _segments_are_independent(plan.ops, seg)
+    # max_segments = 1 and lists that do not split
+    assert _segments_dry(amd, plan.ops, plan.tips, plan.clv_buffers, plan.scale_buffers, 1, max_segments=1)[0] == 1
+    cat = W.caterpillar_tree(40)
+    ns, seg = _segments_dry(amd, cat.ops, cat.tips, cat.clv_buffers, cat.scale_buffers, 1)
+    assert (ns == 1 and set(seg) == {0}) or min(seg.count(k) for k in range(ns)) >= 2
+    view = W.UnrootedView(W.balanced_tree(64))
+    ops_r, _ = view.traversal(view.root)
+    part = view.partial(ops_r, [view.edges()[5]], view.root)
+    assert _segments_dry(amd, part, 64, 62, 62, 1)[0] == 1
+    # random lists: whatever the split, it is one into independent sets of >= 2 ops; many components are dealt
+    # to at most eight segments
+    from helpers import random_op_sequence
+    split = 0
+    for seed in range(60):
+        rng = np.random.default_rng(seed)
+        tips, inner, scalers = 12, 14, 14
+        ops = random_op_sequence(rng, tips, inner, scalers, 2 * tips - 3, 30 + seed)
+        for pattern_tip in (0, 1):
+            ns, seg = _segments_dry(amd, ops, tips, inner, scalers, pattern_tip)
+            assert 1 <= ns <= 8 and set(seg) == set(range(ns))
+            assert _segments_are_independent(ops, seg), seed
+            if ns > 1:
+                split += 1
+                assert min(seg.count(k) for k in range(ns)) >= 2
+    # sixteen cherries: sixteen components, eight segments of two
+    cher = np.zeros(16, dtype=W.balanced_tree(8).ops.dtype)
+    for i in range(16):
+        cher[i]["parent_clv_index"] = 32 + i
+        cher[i]["parent_scaler_index"] = i
+        cher[i]["child1_clv_index"], cher[i]["child2_clv_index"] = 2 * i, 2 * i + 1
+        cher[i]["child1_scaler_index"] = cher[i]["child2_scaler_index"] = -1
+        cher[i]["child1_matrix_index"], cher[i]["child2_matrix_index"] = 2 * i, 2 * i + 1
+    ns, seg = _segments_dry(amd, cher, 32, 16, 16, 1)
+    assert ns == 8 and all(seg.count(k) == 2 for k in range(8))
+
+
 @pytest.mark.parametrize("rate_cats", [1, 2, 4, 8])
 def test_tip_character_batches_of_the_whole_list_kernel(amd, rate_cats):
     """pllhip_fused_char_batches (host logic of partials_fused.hip): a wave fetches the characters of its tile's

@@ -51,11 +51,13 @@ def run(states, sites):
 def parse(d):
     import csv
     import glob
+    import re
     import numpy as np
     rows = []
     for path in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
-            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"].split("(")[0][:40]))
+            m = re.search(r"k_\w+", row["Kernel_Name"])
+            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), m.group(0) if m else row["Kernel_Name"][:40]))
     for path in glob.glob(os.path.join(d, "**", "*_memory_copy_trace.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
             rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), "copy " + row.get("Direction", "")))
