@@ -703,9 +703,17 @@ def main():
         gp.destroy()
 
     lnl_ref_total = None
-    if shard_ref_lnl is not None:
-        # N > 1: sum of the reference's per-range values (torch.distributed; the product's own sum went through its
-        # RCCL all-reduce, or -- one process, library-sharded partition -- through the host sum of the shards)
+    # N > 1: sum of the reference's per-range values (torch.distributed; the product's own sum went through its
+    # RCCL all-reduce, or -- one process, library-sharded partition -- through the host sum of the shards).  Every
+    # rank enters the collectives, whether it has a value or not (a rank whose reference library did not load would
+    # otherwise leave the others waiting in the SUM: ADVICE r4) -- first a MIN over "I have one", as the config-4
+    # section does.
+    have_ref = shard_ref_lnl is not None
+    if world > 1:
+        flag = torch.tensor([1.0 if have_ref else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        have_ref = flag.item() >= 1.0
+    if have_ref:
         lnl_ref_total = shard_ref_lnl
         if world > 1:
             t = torch.tensor([shard_ref_lnl], dtype=torch.float64, device="cuda")

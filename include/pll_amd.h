@@ -617,9 +617,12 @@ PLL_EXPORT void pll_amd_core_release(void);
 /* Device the NEXT pll_partition_create OF THE CALLING THREAD binds to.  Kept per thread, like pll_errno
  * (pll.c:24-25) -- distinct threads may create partitions on distinct devices concurrently, as the reference lets
  * threads create partitions concurrently -- WITH a process-wide default: a thread that has not set a device uses what
- * any thread set last (a client that selects its device once on the main thread and creates partitions from workers
- * gets that device there), then env PLL_AMD_DEVICE, else LOCAL_RANK, else 0.  pll_amd_get_device() = what a partition
- * created now by the calling thread would get.  pll_amd_set_devices() below follows the same rule. */
+ * the thread that selected a device FIRST in this process set last (a client that selects its device once on the main
+ * thread and creates partitions from workers gets that device there; a worker that selects a device of its own moves
+ * nobody else's), then env PLL_AMD_DEVICE, else LOCAL_RANK, else 0.  Mixed use -- some threads select, others rely
+ * on the default -- is therefore deterministic as long as the thread that owns the default selects before the others
+ * create.  pll_amd_get_device() = what a partition created now by the calling thread would get.
+ * pll_amd_set_devices() below follows the same rule. */
 PLL_EXPORT int pll_amd_set_device(int device);
 PLL_EXPORT int pll_amd_get_device(void);
 PLL_EXPORT int pll_amd_device_count(void);

@@ -466,6 +466,9 @@ __global__ __launch_bounds__(256) void k_derivatives_dna(DerivArgs a)
     // Everything the round needs is requested up front, unclamped (the table, the
     // weights and the invariant array carry PLLHIP_TAIL_SITES of slack): W KiB of table
     // plus the weight of the one site the lane finishes.
+    // (Round 5 measured TWO rounds in flight per wave -- the next round's W KiB requested before this round's
+    // arithmetic: 15.4 against 14.5 us per launch on BASELINE config 5's table, profiles/r5_result_calls_ab.txt; the
+    // copies and the registers cost more than the overlap gains with ~4 rounds per wave.  Not kept.)
     const size_t n_own = r * 64 + (size_t)(lane & (W - 1)) * SPS + lane / W;
     const unsigned int pw_own = a.pattern_weights[n_own];
     const int inv_raw = inv_site[has_inv ? n_own : 0];

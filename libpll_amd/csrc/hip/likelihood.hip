@@ -98,10 +98,12 @@ static bool pllhip_host_partials_landed(const pllhip_ctx * c, unsigned long long
   const size_t n = (size_t)c->hostsum_grid * c->hostsum_ncomp;
   for (size_t i = from ? *from : 0; i < n; ++i)
   {
-    const double y = part[i].y;
-    unsigned long long got;
+    // (tag = PLLHIP_SEQ_TAG(seq) ^ bits(value), lnl_common.hpp: holds whichever half the host happens to see first)
+    const double y = part[i].y, x = part[i].x;
+    unsigned long long got, val;
     memcpy(&got, &y, sizeof(got));
-    if (got != seq)
+    memcpy(&val, &x, sizeof(val));
+    if ((got ^ val) != PLLHIP_SEQ_TAG(seq))
     {
       if (from) *from = i;
       return false;
@@ -459,6 +461,10 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
       const int src = (int)(j * SPS + lane / W);
       return (size_t)(unsigned int)__shfl((int)rows_of_round, src, 64) * W + (lane & (W - 1));
     };
+    // (Round 5 measured TWO sub-steps' operands in flight per lane, and the next round's first two requested before
+    // this round's last two are evaluated: at 126 registers -- four waves per SIMD instead of five -- the launch took
+    // 61.5 against 55.5 us on BASELINE config 2 with the full grid and the same 55-56 us with a persistent grid of 1024
+    // workgroups, profiles/r5_result_calls_ab.txt: bytes in flight are not what holds this kernel at 0.62.  Not kept.)
     double2 p_next = ld16<NT>(P2 + granule(0, pi_round)), c_next = make_double2(0.0, 0.0);
     if (KIND == EDGE_II) c_next = ld16<NT>(C2 + granule(0, ci_round));
     auto substep = [&](unsigned int j, const double2 p, const double2 c) {
@@ -1004,6 +1010,14 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
     grid = s4 ? pllhip_stream_grid(c, ((size_t)a.sites + 63) / 64 * 64, 256)
               : pllhip_stream_grid(c, (size_t)a.sites * R, 256);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
+    // (round 5) no more workgroups than the host adds sums of (PLLHIP_HOSTSUM_MAX): beyond that a one-workgroup
+    // k_final_sum launch followed every call -- BASELINE config 4 whole on one GPU, 31,250 workgroups; the waves
+    // then walk several rounds each.  PLLHIP_LNL_GRID: measurements.
+    {
+      const char * e = getenv("PLLHIP_LNL_GRID");
+      const unsigned int cap = e && atoi(e) > 0 ? (unsigned int)atoi(e) : (unsigned int)PLLHIP_HOSTSUM_MAX;
+      if (grid > cap) grid = cap;
+    }
     a.reduce = pllhip_reduce_out(c, grid);
     size_t lds = 0;
     if (kind == EDGE_II && !s4) lds = (size_t)R * S * S * sizeof(double);

@@ -24,6 +24,11 @@ struct ReduceOut
                            // k_final_sum's order once every entry carries this call's seq: no second launch
 };
 
+// the tag of a host-summed workgroup entry {value, tag}: tag = PLLHIP_SEQ_TAG(seq) ^ bits(value).  The odd
+// multiplier makes the tags of any two calls differ in about half of their bits, so a value of one call next to the
+// tag half of another would have to differ from its own call's value in exactly those bits to pass.
+#define PLLHIP_SEQ_TAG(seq) ((unsigned long long)(seq) * 0x9E3779B97F4A7C15ull)
+
 struct LnlArgs
 {
   const double * __restrict__ parent;   // CLV carrying the frequencies side
@@ -109,9 +114,11 @@ __device__ __forceinline__ void grid_sum(const double (&v_in)[NCOMP], const Redu
       {
         if (ro.host_partials)
         {
-          // value and sequence number travel together (a lane's 16 aligned bytes are one write): the host never
-          // sees one without the other, and nobody waits for anybody on the device
-          const pll_v2d e = {t, __longlong_as_double((long long)ro.seq)};
+          // value and tag travel in ONE 16-byte store, and nobody waits for anybody on the device.  Nothing promises
+          // the host that the two halves become visible together, so the tag does not depend on it: it is
+          // the call's sequence number, spread over all 64 bits, XOR the value's own bits -- an entry whose halves
+          // are of different calls matches neither call's tag (PLLHIP_SEQ_TAG; the host: pllhip_host_partials_landed)
+          const pll_v2d e = {t, __longlong_as_double((long long)(PLLHIP_SEQ_TAG(ro.seq) ^ (unsigned long long)__double_as_longlong(t)))};
           *reinterpret_cast<pll_v2d *>(ro.host_partials + (size_t)cidx * nparts + blockIdx.x) = e;
         }
         else

@@ -657,9 +657,12 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   const size_t fused_tile_sites = (size_t)PLLHIP_FUSED_J * 64 / (2 * c->sh.rate_cats);
   static const bool small_rule = !(getenv("PLLHIP_FUSED_SMALL") && atoi(getenv("PLLHIP_FUSED_SMALL")) == 0);
   const bool whole_list_kind = (dna_fast && (c->sh.rate_cats <= 4 || c->sh.rate_cats == 8)) || (aa_fast && c->sh.rate_cats == 4);
-  // (asked only below the sizes from which the whole-list kernels always pay: 16,384 sites, see below)
+  // (asked only below the sizes from which the whole-list kernels always pay -- the two rules below, in THIS device's
+  // compute units: 16,384 sites on an MI355X's 256; derived, not a constant of its own, so that no size falls
+  // between the two rules on another part.  The cost constants of the estimate are this part's, measured.)
+  const size_t always_pays_from = dna_fast ? fused_tile_sites * (size_t)c->num_cus * 4 : (size_t)32 * c->num_cus * 2;
   const bool small_pays = small_rule && whole_list_kind && !c->no_fused && !c->force_fused && c->rows.empty() && count >= 2 &&
-                          c->sh.sites < 16384 && whole_list_pays_when_small(c, ops, count);
+                          (size_t)c->sh.sites < always_pays_from && whole_list_pays_when_small(c, ops, count);
   const bool fused_pays = (size_t)c->sh.sites / fused_tile_sites >= (size_t)c->num_cus * 4 || c->force_fused || small_pays;
   // (8 rate categories: a tile is 8 sites, a P-matrix a whole 1 KB block per wave, a site's lanes a DPP row of 16.
   // Round 1's first attempt spilled and lost -- 5.6 against 10.2 G site-updates/s per level; the rebuilt kernel

@@ -57,10 +57,24 @@ int pll_amd_device_count(void)
   return n;
 }
 
+/* The process-wide defaults (device, device list) belong to the thread that selected a device FIRST -- the client that
+ * picks its device once on the main thread and creates partitions from workers -- : only that thread's later calls move
+ * them.  A worker that selects a device of its own changes its own choice and nobody else's (as
+ * last-writer-wins, partitions created concurrently by threads that had set nothing landed on whichever device a
+ * sibling had just chosen). */
+static __thread char g_thread_tag;      /* (its address names the calling thread) */
+static const char * g_default_owner = NULL;
+static int owns_defaults(void)
+{
+  const char * none = NULL;
+  if (__atomic_compare_exchange_n(&g_default_owner, &none, &g_thread_tag, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) return 1;
+  return none == &g_thread_tag;
+}
+
 int pll_amd_set_device(int device)
 {
   g_device = device;
-  __atomic_store_n(&g_device_default, device, __ATOMIC_RELAXED);
+  if (owns_defaults()) __atomic_store_n(&g_device_default, device, __ATOMIC_RELAXED);
   return PLL_SUCCESS;
 }
 
@@ -91,10 +105,13 @@ int pll_amd_set_devices(const int * devices, unsigned int count)
   }
   for (i = 0; i < count; ++i) g_devices[i] = devices[i];
   g_ndevices = count ? (int)count : -1; /* an empty list: back to the process default / the environment's */
-  devices_lock();
-  for (i = 0; i < count; ++i) g_devices_default[i] = devices[i];
-  g_ndevices_default = count ? (int)count : -1;
-  devices_unlock();
+  if (owns_defaults())
+  {
+    devices_lock();
+    for (i = 0; i < count; ++i) g_devices_default[i] = devices[i];
+    g_ndevices_default = count ? (int)count : -1;
+    devices_unlock();
+  }
   return PLL_SUCCESS;
 }
 

@@ -467,9 +467,11 @@ def test_whole_list_kernel_keeps_out_of_the_slot_registers():
 
 
 def test_device_selection_per_thread_with_a_process_wide_default(amd):
-    """pll_amd_set_device: a thread that has set a device uses its own; a thread that has not uses what any thread
-    set last (round 3 made the setting thread-local only: a client that selects its device once on the main thread
-    and creates partitions from worker threads silently fell back to the environment there)."""
+    """pll_amd_set_device: a thread that has set a device uses its own; a thread that has not uses the process-wide
+    default, which belongs to the thread that selected a device first -- here the main thread (round 3 made the
+    setting thread-local only: a client that selects its device once on the main thread and creates partitions from
+    worker threads silently fell back to the environment there; round 4 let ANY thread move the default:
+    last writer wins, partitions of threads that had set nothing landed where a sibling had just pointed)."""
     import ctypes
     import threading
     lib = amd.lib
@@ -491,7 +493,11 @@ def test_device_selection_per_thread_with_a_process_wide_default(amd):
     assert lib.pll_amd_get_device() == 3           # the main thread keeps its own value ...
     t = threading.Thread(target=worker, args=("later", None))
     t.start(); t.join()
-    assert seen["later"] == 1                       # ... a thread without one sees the LAST setting of any thread
+    assert seen["later"] == 3                       # ... and so does the default: a worker's choice is its own
+    lib.pll_amd_set_device(2)                       # the owner of the default moves it
+    t = threading.Thread(target=worker, args=("after the owner's change", None))
+    t.start(); t.join()
+    assert seen["after the owner's change"] == 2
     lib.pll_amd_set_device(0)
 
 

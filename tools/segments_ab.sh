@@ -5,7 +5,8 @@ line() { python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; a=d['api_calls']
 print('states %2d sites %7d %-26s step %8.1f us  update_partials %8.1f us (events)  frac %.3f' % ($1, $2, '$3', d['ms_per_step']*1e3, a['update_partials_ms_hip_events']['median']*1e3, r['frac']))"; }
-for cfg in ${@:-"4 20000" "4 31250" "4 50000" "4 62500" "4 100000" "4 125000" "4 250000" "4 1000000"}; do
+if [ $# -eq 0 ]; then set -- "4 20000" "4 31250" "4 50000" "4 62500" "4 100000" "4 125000" "4 250000" "4 1000000"; fi
+for cfg in "$@"; do
   set -- $cfg
   for rep in 1 2; do
     for v in 0 8; do
