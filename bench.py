@@ -138,7 +138,25 @@ def cpu_all_cores(ref_path, plan, sample, S, R, attrs, cores, reps):
     return len(plan.ops) * n * reps / max(out) / 1e6
 
 
+def launcher_command(gpus, argv, port):
+    """The command line and environment bench.py --gpus N (N > 1, no launcher above it) starts the ranks with: a
+    FRESH child process -- this one has not touched a GPU and never replaces itself (an exec from a process that has
+    initialised the GPU takes the machine down on this pool).  Host logic: tests/test_host.py checks it on CPU."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return cmd, env
+
+
 def main():
+    t_process = time.perf_counter()
+    sections = {}
+
+    def section(name):
+        """wall-clock seconds since the process started, by section: what a run that times out was doing"""
+        sections[name] = round(time.perf_counter() - t_process, 2)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -206,11 +224,7 @@ def main():
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
             sock.close()
-            env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-            env.setdefault("OMP_NUM_THREADS", "1")
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                   "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            cmd, env = launcher_command(args.gpus, sys.argv[1:], port)
             raise SystemExit(subprocess.run(cmd, env=env).returncode)
     inproc = args.gpus if (args.in_process and args.gpus > 1 and not launched) else 1
 
@@ -248,6 +262,7 @@ def main():
     fi = [0] * R
     ops_per_eval = len(plan.ops)
 
+    section("alignment generated")
     # ---- N > 1: the reference's lnL of THIS rank's range (all of it, in chunks through one small CPU partition),
     # before anything touches the GPU; the ranks' values are summed after the timed region and compared with the
     # lnL the product's all-reduce returned (lnl_rel_err_vs_reference).  One evaluation of 62 ops x 1 M sites
@@ -256,6 +271,7 @@ def main():
     if (world > 1 or inproc > 1) and args.cpu_sites > 0 and ref is not None:
         shard_ref_lnl, _ = W.reference_lnl(ref, plan, seqs, S, R, attrs | ATTRIB_ARCH_AVX2)
 
+    section("reference lnL of this rank's range")
     # ---- CPU baseline (rank 0, N=1 only), BEFORE anything touches the GPU (its
     # multi-core leg forks workers): the reference library's AVX2-flag path on a
     # bounded sample of the same workload, same tree / ops / model.
@@ -315,6 +331,7 @@ def main():
         if not amd.lib.pll_amd_set_devices((ctypes.c_int * len(devs))(*devs), len(devs)):
             raise SystemExit("pll_amd_set_devices failed: " + amd.errmsg())
 
+    section("cpu baseline")
     part = W.setup_partition(amd, plan, seqs, S, R,
                              attrs | (ATTRIB_SITE_REPEATS if args.site_repeats else 0))
     if use_comm:
@@ -338,6 +355,7 @@ def main():
 
     # the very first traversal also pays one-off costs (with --site-repeats: the class
     # identification on the host); reported apart, never part of the timed steps
+    section("partition on the device")
     t_first = time.perf_counter()
     lnl = step()
     sync()
@@ -411,6 +429,7 @@ def main():
     value = site_updates / elapsed / 1e6
     untimed_steps = 1 + len(ramp_steps) + args.warmup   # what really ran before the timed region
 
+    section("warm-up + timed region")
     # ---- the spread the K-step region cannot show (boxes of the pool differ by 10-20 %, processes on one
     # box by several per cent): every step synchronised and timed on its own, for at least 20 steps
     # and half a second.  (Each step then pays its own launch + completion latency: the median reads
@@ -566,6 +585,7 @@ def main():
     api = {"update_partials_ms_hip_events": spread(ev_up), "update_partials_ms_wall": spread(wall_up),
            "edge_loglikelihood_ms_wall": spread(wall_lnl)}
 
+    section("spread, roofline and api legs")
     # ---- op lists that CHANGE from call to call: what the reference's real callers do (tree search:
     # test/src/partial-traversal.c:17-58 re-roots and prunes; examples/newton).  Every figure above
     # replays one list, which the library recognises (memcmp) and relaunches from its kept plan; here
@@ -670,6 +690,7 @@ def main():
     per_kernel = {k: {"launches": v[0], "avg_us": round(v[1] / v[0] * 1e3, 2) if v[0] else None}
                   for k, v in prof.items() if v[0]}
 
+    section("varying lists")
     # ---- optional: the branch-length optimisation inner loop at the root edge
     newton = None
     if args.newton > 0:
@@ -727,6 +748,7 @@ def main():
         repeats = {"rows_computed_per_evaluation": int(sum(rows)),
                    "rows_plain": ops_per_eval * (hi - lo),
                    "ops_stored_by_class": int(sum(1 for r in rows if r < hi - lo))}
+    section("newton, profile, lnL checks")
     # ---- N > 1: BASELINE config 4 as a strong-scaling job (fixed 8,000,000 sites x 128 taxa
     # divided over the GPUs), next to the weak-scaling headline above
     c4 = None
@@ -906,6 +928,7 @@ def main():
                       "speedup_vs_one_gpu": round(base_ms / ms4, 3) if base_ms else None}
                 if one_lnl and not c4["lnl_consistent"]:
                     c4["error"] = "lnL of the divided alignment differs from the one-GPU evaluation of the same alignment"
+    section("config 4 section")
     rccl_path = None
     if use_comm:
         import ctypes
@@ -942,6 +965,9 @@ def main():
                               "the reference's lnL of the CPU-baseline sample, against a product partition of the same sample")
                              if lnl_rel_err is not None else None,
             "first_evaluation_ms": round(first_ms, 2),
+            # wall-clock seconds since this process (rank 0) started, at the end of each section: a first multi-GPU run
+            # that times out says where it was
+            "sections_s": sections,
             "ramp": ramp,
             "roofline": roofline, "api_calls": api, "kernels": per_kernel, "cpu_baseline": cpu,
             "varying_lists": varying, "newton": newton, "c4_strong": c4,

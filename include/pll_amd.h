@@ -632,7 +632,10 @@ PLL_EXPORT int pll_amd_device_count(void);
  * the client: pll_update_partials runs every range's op list on its device,
  * pll_compute_edge_loglikelihood / pll_compute_likelihood_derivatives return the sum over the
  * ranges (added on the host in range order: deterministic), the pll_amd_sync_* mirrors and
- * persite_lnl are gathered.  Not combined with PLL_ATTRIB_SITE_REPEATS or pll_amd_comm_init.  The
+ * persite_lnl are gathered.  PLL_ATTRIB_SITE_REPEATS composes with it (every range identifies its own
+ * classes); pll_amd_comm_init does not.  The hot calls (P-matrices, op lists, sumtables, the calls that return
+ * a sum) are enqueued on the devices by one host thread per range (round 5; PLLHIP_SHARD_THREADS=0: by the
+ * calling thread, range after range) and their results are polled in host-mapped memory.  The
  * list belongs to the calling thread; calls on such a partition leave the caller's current HIP
  * device as they found it. */
 PLL_EXPORT int pll_amd_set_devices(const int * devices, unsigned int count);

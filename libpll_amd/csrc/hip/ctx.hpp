@@ -32,7 +32,14 @@ struct pllhip_ctx
   // enqueue everything and return without waiting (pllhip_result_wait fetches).
   std::vector<pllhip_ctx *> shards;
   std::vector<size_t> shard_lo;
+  struct pllhip_shard_pool * pool = nullptr; // (round 5) the group's enqueueing threads, one per shard but the first (shard.hip)
   bool defer = false;
+  // (round 5) what the group needs to wait for a shard's enqueued result the way an unsharded context waits for its
+  // own -- polling the word / the workgroup sums in host-mapped memory instead of one hipStreamSynchronize per
+  // shard after the other: the call's sequence number, whether the host adds the workgroup
+  // sums, whether a word is published, whether copies follow the kernel (then the stream is waited for)
+  unsigned long long pending_seq = 0;
+  bool pending_hostsum = false, pending_spin = false, pending_stream_work = false;
 
   size_t span = 0;         // states * rate_cats doubles per site
   size_t clv_elems = 0;    // sites * span
@@ -68,6 +75,7 @@ struct pllhip_ctx
   // whole-list kernel (partials_fused.hip): the plan's device copy and two pinned staging buffers
   void * d_plan = nullptr;
   void * d_sink = nullptr; // 1 KB that the stores of lanes past the last site go to
+  unsigned int tile_counter_phase = 0;     // (4 states: which of the two sets of tile counters the next launch hands out from)
   unsigned int * d_tile_counter = nullptr; // whole-list kernels: next tile to hand out (PLLHIP_TILE_COUNTER_BYTES: one per
                                            // group of eight workgroups, 128 bytes apart -- partials_fused.hip)
   // the op list of the last whole-list launch (its plan is still on the device: an identical
@@ -129,7 +137,7 @@ struct pllhip_ctx
   // workgroup sums of a result-returning kernel, written by the kernel straight into host memory and added by
   // the host (likelihood.hip: pllhip_result_wait_host): {value, sequence number} per workgroup and component
   double2 * h_partials = nullptr, * h_partials_dev = nullptr;
-  unsigned int hostsum_grid = 0, hostsum_ncomp = 0; // the call in flight
+  unsigned int hostsum_grid = 0, hostsum_ncomp = 0, hostsum_width = 256; // the call in flight (width: threads of the sum it stands for)
   unsigned int * d_counter = nullptr;  // arrival counter of the reducing kernels
   double * d_persite = nullptr;        // [sites], lazily allocated
 
@@ -219,6 +227,18 @@ struct pllhip_device_guard
       }                                                         \
       return 0;                                                 \
     }                                                           \
+  } while (0)
+
+// (round 5) The same on every shard AT ONCE, from one host thread per shard (shard.hip: pllhip_group_parallel): the
+// calls of the hot path -- P-matrices, op lists, sumtables, the result-returning calls -- cost 5-15 us of launches
+// per shard, and a host thread that visits eight devices in turn starts the last one 50-100 us after the first:
+// half the run time of an eighth of BASELINE config 2 or 5.  Falls through for an ordinary context.
+#include <functional>
+int pllhip_group_parallel(pllhip_ctx * g, const std::function<int(pllhip_ctx *, size_t)> & fn);
+#define PLLHIP_ALL_SHARDS_PAR(c, expr)                                                                          \
+  do {                                                                                                          \
+    if (!(c)->shards.empty())                                                                                   \
+      return pllhip_group_parallel((c), [&](pllhip_ctx * s, size_t lo) -> int { (void)lo; return (expr); });   \
   } while (0)
 
 // shard.hip: the group forms of the calls that return sums over sites

@@ -86,7 +86,7 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
                                       int child_scaler, const unsigned int * h_params_indices,
                                       unsigned int slot)
 {
-  PLLHIP_ALL_SHARDS(c, pllhip_update_sumtable(s, parent_clv, parent_scaler, child_clv, child_scaler, h_params_indices, slot));
+  PLLHIP_ALL_SHARDS_PAR(c, pllhip_update_sumtable(s, parent_clv, parent_scaler, child_clv, child_scaler, h_params_indices, slot));
   HIP_TRY(hipSetDevice(c->sh.device));
   const unsigned int nodes = (unsigned int)c->clv.size();
   if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || parent_clv >= nodes || child_clv >= nodes ||
@@ -843,7 +843,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     grid = pllhip_stream_grid(c, a.sites, 128);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
-    a.reduce = pllhip_reduce_out(c, grid, 2);
+    a.reduce = pllhip_reduce_out(c, grid, 2, 128);
     k_derivatives_gen<<<grid, 128, 0, c->stream>>>(a);
   }
   HIP_TRY(hipGetLastError());
@@ -859,7 +859,11 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost,
                            c->stream));
   }
-  if (c->defer) return 0; // a shard of a group: the group waits for all of them
+  if (c->defer) // a shard of a group: the group waits for all of them
+  {
+    pllhip_defer_result(c, a.reduce, c->comm != nullptr);
+    return 0;
+  }
   {
     int rc = pllhip_result_wait_host(c, a.reduce, c->comm != nullptr);
     if (rc) return rc;

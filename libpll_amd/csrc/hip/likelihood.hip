@@ -33,16 +33,15 @@
 #include "lnl_common.hpp"
 
 
-ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncomp)
+ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncomp, unsigned int block)
 {
   ReduceOut r;
   r.partials = c->block_partials;
   r.counter = c->d_counter;
   r.result = c->d_result;
   r.host_result = c->comm ? nullptr : c->h_result_dev;
-  // (the word the host spins on: h_result[3]; not with a communicator -- the collective follows -- and
-  // not for a shard of a group, whose results the group collects after enqueueing everywhere)
-  r.host_seq = (c->comm || c->defer || c->no_spin) ? nullptr : reinterpret_cast<unsigned long long *>(c->h_result_dev + 3);
+  // (the word the host spins on: h_result[3]; not with a communicator -- the collective follows)
+  r.host_seq = (c->comm || c->no_spin) ? nullptr : reinterpret_cast<unsigned long long *>(c->h_result_dev + 3);
   r.seq = ++c->result_seq;
   r.extra = c->pending_extra; // set by the caller for exactly one launch
   c->pending_extra = nullptr;
@@ -54,18 +53,28 @@ ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncom
   // at 1954 workgroups against 33.9 us with the separate 6 us launch, 31.3 against 28.8 at 512
   // (tools/call_floor_ab.sh).  Small grids are latency-bound and save the launch.
   r.fused = c->fuse_forced >= 0 ? c->fuse_forced : (grid <= c->fuse_max_grid ? 1 : 0);
+  // Round 5: small grids too hand their workgroup sums to the host when they can (below) -- a kernel of eight
+  // workgroups spent its last microseconds on write-through stores, two ticket atomics, an acquire fence and the
+  // finisher's reads: the edge lnL call of a 2,000-site partition 16.2 -> 12.6 us from C (tools/step_floor.c,
+  // profiles/r5_step_floor_from_c.txt).  The host adds in the order the finishing workgroup used -- thread t of
+  // `block` takes entries t, t + block, ...; then the tree -- so the bits are those of rounds 1-4.
+  const bool small = grid <= c->fuse_max_grid;
+  const bool can_hostsum = !c->no_hostsum && !c->comm && !r.extra && (size_t)grid * ncomp <= PLLHIP_HOSTSUM_MAX;
+  if (c->fuse_forced < 0 && small && can_hostsum) r.fused = 0;
   // Larger grids (round 4): the workgroup sums go straight to host-mapped memory and the host adds them -- in
   // k_final_sum's order, so the bits are those of rounds 1-3 -- instead of a one-workgroup launch behind the kernel
   // (4.5-6.7 us per result-returning call).  Not with a communicator (the all-reduce wants the
-  // sum on the device), not for a shard of a group (collected after enqueueing everywhere), not with an
-  // ascertainment-bias term (a device value the final step adds).  PLLHIP_HOSTSUM=0 switches it off.
+  // sum on the device), not with an ascertainment-bias term (a device value the final step adds).  A shard of a
+  // group does the same since round 5: the group polls every shard's entries (pllhip_result_wait_pending).
+  // PLLHIP_HOSTSUM=0 switches it off.
   r.host_partials = nullptr;
   c->hostsum_grid = 0;
-  if (!c->no_hostsum && !r.fused && !c->comm && !c->defer && !r.extra && (size_t)grid * ncomp <= PLLHIP_HOSTSUM_MAX)
+  if (can_hostsum && !r.fused)
   {
     r.host_partials = c->h_partials_dev;
     c->hostsum_grid = grid;
     c->hostsum_ncomp = ncomp;
+    c->hostsum_width = small ? block : 256u; // (k_final_sum, which larger grids used to launch, is 256 wide)
   }
   return r;
 }
@@ -73,18 +82,18 @@ ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncom
 // the host's final sum: k_final_sum's order -- thread t of 256 adds entries t, t + 256, ..., then the tree
 static void pllhip_host_final_sum(pllhip_ctx * c)
 {
-  const unsigned int nparts = c->hostsum_grid;
+  const unsigned int nparts = c->hostsum_grid, width = c->hostsum_width;
   for (unsigned int comp = 0; comp < c->hostsum_ncomp; ++comp)
   {
     const double2 * part = c->h_partials + (size_t)comp * nparts;
     double s[256];
-    for (unsigned int t = 0; t < 256; ++t)
+    for (unsigned int t = 0; t < width; ++t)
     {
       double v = 0.0;
-      for (unsigned int i = t; i < nparts; i += 256) v += part[i].x;
+      for (unsigned int i = t; i < nparts; i += width) v += part[i].x;
       s[t] = v;
     }
-    for (unsigned int w = 128; w > 0; w >>= 1)
+    for (unsigned int w = width >> 1; w > 0; w >>= 1)
       for (unsigned int t = 0; t < w; ++t) s[t] += s[t + w];
     c->h_result[comp] = s[0];
   }
@@ -201,6 +210,25 @@ int pllhip_result_wait_host(pllhip_ctx * c, const ReduceOut & ro, bool stream_wo
     pllhip_host_final_sum(c);
   }
   return 0;
+}
+
+// a shard's result-returning call has been enqueued: remember how its group waits for it
+void pllhip_defer_result(pllhip_ctx * c, const ReduceOut & ro, bool stream_work_follows)
+{
+  c->pending_seq = ro.seq;
+  c->pending_hostsum = ro.host_partials != nullptr;
+  c->pending_spin = ro.host_seq != nullptr;
+  c->pending_stream_work = stream_work_follows;
+}
+
+int pllhip_result_wait_pending(pllhip_ctx * c)
+{
+  ReduceOut ro;
+  memset(&ro, 0, sizeof(ro));
+  ro.seq = c->pending_seq;
+  ro.host_partials = c->pending_hostsum ? c->h_partials_dev : nullptr;
+  ro.host_seq = c->pending_spin ? reinterpret_cast<unsigned long long *>(c->h_result_dev + 3) : nullptr;
+  return pllhip_result_wait_host(c, ro, c->pending_stream_work);
 }
 
 int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp)
@@ -1034,7 +1062,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   {
     grid = pllhip_stream_grid(c, a.sites, 128);
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
-    a.reduce = pllhip_reduce_out(c, grid);
+    a.reduce = pllhip_reduce_out(c, grid, 1, 128);
     if (kind == EDGE_II) k_lnl_gen<EDGE_II><<<grid, 128, 0, c->stream>>>(a);
     if (kind == EDGE_TI) k_lnl_gen<EDGE_TI><<<grid, 128, 0, c->stream>>>(a);
     if (kind == ROOT) k_lnl_gen<ROOT><<<grid, 128, 0, c->stream>>>(a);
@@ -1055,7 +1083,11 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
   if (h_persite)
     HIP_TRY(hipMemcpyAsync(h_persite, c->d_persite, (size_t)a.sites * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
-  if (c->defer) return 0; // a shard of a group: the group waits for all of them (pllhip_result_wait)
+  if (c->defer) // a shard of a group: the group waits for all of them (pllhip_result_wait_pending)
+  {
+    pllhip_defer_result(c, a.reduce, c->comm != nullptr || h_persite != nullptr);
+    return 0;
+  }
   {
     int rc = pllhip_result_wait_host(c, a.reduce, c->comm != nullptr || h_persite != nullptr);
     if (rc) return rc;

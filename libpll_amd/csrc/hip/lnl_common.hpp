@@ -218,11 +218,13 @@ __device__ __forceinline__ double site_loglk(const LnlArgs & a, double terma, si
 
 // fills a ReduceOut from the context (host_result only when no all-reduce follows);
 // pllhip_finish_reduce launches the final pass when the kernel did not fuse it
-ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncomp = 1);
+ReduceOut pllhip_reduce_out(pllhip_ctx * c, unsigned int grid, unsigned int ncomp = 1, unsigned int block = 256);
 int pllhip_finish_reduce(pllhip_ctx * c, const ReduceOut & ro, unsigned int grid, unsigned int ncomp);
 // after the launches of a result-returning call: wait until h_result holds this call's values
 // (`stream_work_follows`: copies or a collective were enqueued behind the kernel -- wait for the stream)
 int pllhip_result_wait_host(pllhip_ctx * c, const ReduceOut & ro, bool stream_work_follows);
+// a shard of a group: remember the enqueued call (pllhip_defer_result), wait for it later (ctx.hpp: pending_*)
+void pllhip_defer_result(pllhip_ctx * c, const ReduceOut & ro, bool stream_work_follows);
 
 // asc_bias.hip: launch the correction kernel (if a correction type is set) ahead of the
 // site kernel; *extra = what that kernel's final sum must add

@@ -609,7 +609,7 @@ static bool whole_list_pays_when_small(const pllhip_ctx * c, const pllhip_op_t *
 
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)
 {
-  PLLHIP_ALL_SHARDS(c, pllhip_update_partials(s, ops, count)); // (enqueued on every device; nothing waits)
+  PLLHIP_ALL_SHARDS_PAR(c, pllhip_update_partials(s, ops, count)); // (enqueued on every device; nothing waits)
   HIP_TRY(hipSetDevice(c->sh.device));
   if (!c->rows.empty())
   {

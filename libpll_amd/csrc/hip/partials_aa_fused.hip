@@ -337,6 +337,9 @@ __device__ __forceinline__ af_gptr af_base(unsigned long long uniform_address)
 // (-DPLLHIP_AF_SAVE_M0=0).  Measured late in round 4, three interleaved pairs on one box: C3 1.713-1.724 against
 // 1.710-1.713 ms, 200-taxon random tree 3.989 against 3.981 -- the scalar unit is not on the waves' critical path;
 // not worth leaning on a reserved register: the default saves.
+#ifndef PLLHIP_AF_PIPE
+#define PLLHIP_AF_PIPE 0
+#endif
 #ifndef PLLHIP_AF_SAVE_M0
 #define PLLHIP_AF_SAVE_M0 1
 #endif
@@ -468,6 +471,23 @@ __device__ __forceinline__ void af_matvec(const char * mat_lane, const char * ma
   // operands of group t + 1 ahead of the MFMAs of group t and deferred the sums -- worth 1 % then, and 32 registers,
   // which the column tail and the wider fifth-step operands need now: the kernel must stay within 128, see the slots.)
   double c5[AF_J][4];
+#if (PLLHIP_AF_PIPE & 1)
+  // (round 5, PLLHIP_AF_PIPE bit 0: the A operands of row group t + 1 requested before the eight MFMAs of group t are
+  // issued -- with eight MFMAs per group instead of round 3's sixteen the LDS round trip is a third of a group's time)
+  AfAops a_cur, a_nxt;
+  af_fetch_a(mat_lane, mat_cls, 0, a_cur);
+  af_column_tail(b, lane, c5);
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+  {
+    double acc[AF_J][4];
+    if (t < 4) af_fetch_a(mat_lane, mat_cls, t + 1, a_nxt);
+    af_group(a_cur, b, c5, acc);
+    af_sum<MUL>(acc, t, x);
+    if (t < 4) a_cur = a_nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#else
   af_column_tail(b, lane, c5);
 #pragma unroll
   for (int t = 0; t < 5; ++t)
@@ -479,6 +499,7 @@ __device__ __forceinline__ void af_matvec(const char * mat_lane, const char * ma
     af_sum<MUL>(acc, t, x);
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
 }
 
 // x[j][t] = tip factor * (P . column)[state 4q + t | 16 + q] in the order of the reference's TIP-INNER kernel
@@ -1251,7 +1272,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     HIP_TRY(hipMemsetAsync(c->fused_zero_row, 0, bytes, c->stream));
   }
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 80 * sizeof(double2)));
-  if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, PLLHIP_TILE_COUNTER_BYTES));
+  if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, 2 * PLLHIP_TILE_COUNTER_BYTES));
   k.lk_ops.clear();
   k.lk_k1.clear();
   k.lk_k2.clear();

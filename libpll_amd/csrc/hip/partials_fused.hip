@@ -115,8 +115,9 @@ __device__ __forceinline__ unsigned int rec_pcnt(const Rec & r) { return r.w[15]
 // list and read back by the list kernel with one 16-byte gather per lane and sub-step
 // (32 KB per op at 4 rate categories: L2-resident).  Table 0 is all zeros: what ops without a
 // tip gather from (every op issues the same loads).
-// (round 4: the launch also resets the tile counters of the list kernel behind it -- counter g is word 32 g, one
-// 128-byte line each -- which used to be a fill kernel of its own per call, 4.3 us)
+// (round 4: the launch also reset the tile counters of the list kernel behind it -- counter g is word 32 g, one
+// 128-byte line each -- which used to be a fill kernel of its own per call, 4.3 us; round 5: the list kernel resets
+// the set of counters of the launch BEHIND it, two sets in turn, and this launch no longer does)
 template <int RC>
 __global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedPairJob * __restrict__ jobs, unsigned int njobs,
                                                          unsigned int * __restrict__ tile_counters)
@@ -161,8 +162,14 @@ template <int RC, int J, int MODE, int NTP, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_dna_fused(const FusedRec * __restrict__ plan0, FusedBases bases,
                                                         unsigned int nops0, unsigned int sites, unsigned int nslots,
                                                         double2 * sink, unsigned int * next_tile, unsigned int dynamic_rounds,
-                                                        unsigned int site_base, unsigned int tile_groups)
+                                                        unsigned int site_base, unsigned int tile_groups,
+                                                        unsigned int * reset_tiles)
 {
+  // (round 5) Two sets of tile counters in turn: this launch hands out tiles from `next_tile` and zeroes the OTHER set
+  // for the launch behind it (stream order separates the two) -- until then a list without tip operands, which has no
+  // table launch to do it, was preceded by a 32 KB hipMemsetAsync: two fill kernels in front of every short
+  // all-inner list, the path to the root after a branch-length change (tools/step_floor.c).
+  if (reset_tiles && blockIdx.x == 0) reset_tiles[threadIdx.x * 32u] = 0u;
   static_assert(RC == 1 || RC == 2 || RC == 4 || RC == 8, "lane groups of 2, 4, 8 or 16");
   constexpr bool NT = NTP != 0;
   constexpr unsigned int W = 2 * RC, SPS = 64 / W, TS = J * SPS;
@@ -1083,7 +1090,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
-  unsigned int * tile_counter = getenv("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
+  const bool static_tiles = getenv("PLLHIP_FUSED_STATIC_TILES") != nullptr;
   // Partitions beyond 8 GB (CLVs + scale buffers): the counts are stored non-temporally like the
   // tiles (see the kernel).  8 GB is what the address-translation caches reach (4096 pages of
   // 2 MB): every shape ran at 0.59-0.64 of the HBM peak up to there and at 0.46-0.50 beyond
@@ -1117,7 +1124,10 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   const size_t btiles = (bsites + tile_sites - 1) / tile_sites;
   size_t bgrid = (btiles * nsegs + 3) / 4;
   if (bgrid > cap) bgrid = cap;
-  if (base) HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, PLLHIP_TILE_COUNTER_BYTES, c->stream));
+  // (the two sets of tile counters in turn: see the kernel)
+  unsigned int * const tile_counter = static_tiles ? nullptr : c->d_tile_counter + (size_t)c->tile_counter_phase * (PLLHIP_TILE_COUNTER_BYTES / 4);
+  unsigned int * const reset_tiles = static_tiles ? nullptr : c->d_tile_counter + (size_t)(c->tile_counter_phase ^ 1u) * (PLLHIP_TILE_COUNTER_BYTES / 4);
+  c->tile_counter_phase ^= 1u;
   const size_t rounds = btiles * nsegs / (bgrid * 4);
   const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                       : (c->fused_last_longest >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
@@ -1127,7 +1137,8 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   const unsigned int tile_groups = (unsigned int)std::min<size_t>(std::min<size_t>(want_groups, PLLHIP_TILE_COUNTER_BYTES / 128),
                                                                   std::max<size_t>(1, bgrid / 8));
 #define LAUNCH_FUSED_ARGS (unsigned int)bgrid, 256, lds, c->stream>>>( \
-      d_plan, bases, count, bsites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds, (unsigned int)base, tile_groups)
+      d_plan, bases, count, bsites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds, (unsigned int)base, tile_groups, \
+      reset_tiles)
 #define LAUNCH_FUSED(MODEV, NTV) k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<LAUNCH_FUSED_ARGS
 #define LAUNCH_FUSED_MODE(NTV)                         \
   do {                                                  \
@@ -1458,7 +1469,11 @@ int pllhip_launch_fused(pllhip_ctx * c, const std::vector<std::vector<FusedOp>> 
   HIP_TRY(hipEventRecord(c->plan_done[b], c->stream));
   c->plan_pending[b] = true;
   if (!c->d_sink) HIP_TRY(hipMalloc(&c->d_sink, (size_t)c->num_cus * 16 * 96 * sizeof(double2))); // 1536 B per wave
-  if (!c->d_tile_counter) HIP_TRY(hipMalloc((void **)&c->d_tile_counter, PLLHIP_TILE_COUNTER_BYTES));
+  if (!c->d_tile_counter)
+  {
+    HIP_TRY(hipMalloc((void **)&c->d_tile_counter, 2 * PLLHIP_TILE_COUNTER_BYTES));
+    HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, 2 * PLLHIP_TILE_COUNTER_BYTES, c->stream));
+  }
   // what a repeated call with the same op list needs (pllhip_relaunch_fused)
   c->fused_last_segs_offset = rec_bytes;
   c->fused_last_srcs_offset = rec_bytes + seg_bytes;
@@ -1482,7 +1497,6 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
   const unsigned int count = c->fused_last_count, nslots = c->fused_last_nslots, njobs = c->fused_last_jobs; // (count: segment 0's)
   const int mode = c->fused_last_mode;
   static_assert(PLLHIP_TILE_COUNTER_BYTES == 256 * 128, "one counter per thread of k_dna_pair_tables' first workgroup");
-  if (!njobs) HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, PLLHIP_TILE_COUNTER_BYTES, c->stream)); // (no table launch to do it)
   const FusedRec * d_plan = (const FusedRec *)c->d_plan;
   const FusedPairJob * d_jobs = (const FusedPairJob *)(static_cast<const char *>(c->d_plan) + c->fused_last_jobs_offset);
   const FusedBases bases = {c->pmatrix, c->d_pairtab,
@@ -1494,10 +1508,10 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
   {
     switch (c->sh.rate_cats)
     {
-      case 1: k_dna_pair_tables<1><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, c->d_tile_counter); break;
-      case 2: k_dna_pair_tables<2><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, c->d_tile_counter); break;
-      case 8: k_dna_pair_tables<8><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, c->d_tile_counter); break;
-      default: k_dna_pair_tables<4><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, c->d_tile_counter); break;
+      case 1: k_dna_pair_tables<1><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
+      case 2: k_dna_pair_tables<2><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
+      case 8: k_dna_pair_tables<8><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
+      default: k_dna_pair_tables<4><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
     }
     HIP_TRY(hipGetLastError());
   }

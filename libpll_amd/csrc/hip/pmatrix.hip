@@ -24,6 +24,7 @@ struct PmatArgs
   const unsigned int * matrix_indices; // [count]
   const double * branch_lengths;       // [count]
   unsigned int states, rate_cats;
+  unsigned int split;            // workgroups per branch: 1, or rate_cats (one per category; round 5)
   unsigned int params_indices[PLLHIP_MAX_RATE_CATS];
   // up to PMAT_INLINE branches travel as kernel arguments (used when matrix_indices is
   // null): no staging copy and, above all, no draining of the stream to reuse the
@@ -36,7 +37,12 @@ __global__ __launch_bounds__(256) void k_update_pmatrix(PmatArgs a)
 {
   extern __shared__ double s_expd[]; // [R][S]
   const unsigned int S = a.states, R = a.rate_cats;
-  const unsigned int b = blockIdx.x;
+  // Round 5: 20 states -- a workgroup per (branch, rate category) instead of per branch.  One branch's 1600 entries
+  // are twenty-term chains over strided eigenvector columns: 6 of them per thread took 9.0 us, the longest kernel
+  // of a three-op step at a few thousand sites (pll_update_prob_matrices for ONE branch + three ops + edge lnL,
+  // tools/step_floor.c); with the categories side by side every thread forms one or two.  Same arithmetic per entry.
+  const unsigned int b = blockIdx.x / a.split;
+  const unsigned int e_lo = a.split > 1 ? (blockIdx.x % a.split) : 0u, e_n = a.split > 1 ? 1u : R; // categories [e_lo, e_lo + e_n)
   const bool inl = a.matrix_indices == nullptr;
   const double t = inl ? a.bl_inline[b] : a.branch_lengths[b];
   double * const pm = a.pmatrix + (size_t)(inl ? a.mi_inline[b] : a.matrix_indices[b]) * R * S * S;
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(256) void k_update_pmatrix(PmatArgs a)
   if (t == 0.0)
   {
     // zero-length branch: exact identity (core_pmatrix.c:174-179)
-    for (unsigned int e = threadIdx.x; e < R * S * S; e += blockDim.x)
+    for (unsigned int e = e_lo * S * S + threadIdx.x; e < (e_lo + e_n) * S * S; e += blockDim.x)
     {
       const unsigned int j = (e / S) % S, k = e % S;
       pm[e] = (j == k) ? 1.0 : 0.0;
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void k_update_pmatrix(PmatArgs a)
     return;
   }
 
-  for (unsigned int e = threadIdx.x; e < R * S; e += blockDim.x)
+  for (unsigned int e = e_lo * S + threadIdx.x; e < (e_lo + e_n) * S; e += blockDim.x)
   {
     const unsigned int n = e / S, m = e % S;
     const unsigned int pi = a.params_indices[n];
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void k_update_pmatrix(PmatArgs a)
   }
   __syncthreads();
 
-  for (unsigned int e = threadIdx.x; e < R * S * S; e += blockDim.x)
+  for (unsigned int e = e_lo * S * S + threadIdx.x; e < (e_lo + e_n) * S * S; e += blockDim.x)
   {
     const unsigned int n = e / (S * S), j = (e / S) % S, k = e % S;
     const unsigned int pi = a.params_indices[n];
@@ -106,7 +112,7 @@ extern "C" int pllhip_update_pmatrices(pllhip_ctx_t * c, const unsigned int * h_
                                        const unsigned int * h_matrix_indices,
                                        const double * h_branch_lengths, unsigned int count)
 {
-  PLLHIP_ALL_SHARDS(c, pllhip_update_pmatrices(s, h_params_indices, h_matrix_indices, h_branch_lengths, count));
+  PLLHIP_ALL_SHARDS_PAR(c, pllhip_update_pmatrices(s, h_params_indices, h_matrix_indices, h_branch_lengths, count));
   if (!count) return 0;
   HIP_TRY(hipSetDevice(c->sh.device));
   for (unsigned int i = 0; i < count; ++i)
@@ -131,6 +137,9 @@ extern "C" int pllhip_update_pmatrices(pllhip_ctx_t * c, const unsigned int * h_
   a.rates = c->rates;
   a.states = c->sh.states;
   a.rate_cats = c->sh.rate_cats;
+  // (a workgroup per category from 16 states on, while the branches are few: a whole tree's matrices fill the chip
+  // either way)
+  a.split = (c->sh.states >= 16 && c->sh.rate_cats > 1 && count <= 64) ? c->sh.rate_cats : 1u;
   for (unsigned int n = 0; n < c->sh.rate_cats; ++n)
   {
     if (h_params_indices[n] >= c->sh.rate_matrices)
@@ -152,7 +161,7 @@ extern "C" int pllhip_update_pmatrices(pllhip_ctx_t * c, const unsigned int * h_
       memcpy(a.mi_inline, h_matrix_indices + done, n * sizeof(unsigned int));
       memcpy(a.bl_inline, h_branch_lengths + done, n * sizeof(double));
       pllhip_prof_scope prof(c, PLLHIP_PROF_PMATRIX);
-      k_update_pmatrix<<<n, 256, lds_small, c->stream>>>(a);
+      k_update_pmatrix<<<n * a.split, 256, lds_small, c->stream>>>(a);
       HIP_TRY(hipGetLastError());
       done += n;
     }
@@ -175,7 +184,7 @@ extern "C" int pllhip_update_pmatrices(pllhip_ctx_t * c, const unsigned int * h_
     a.branch_lengths = (const double *)c->d_stage;
     a.matrix_indices = (const unsigned int *)((const double *)c->d_stage + n);
     const size_t lds = (size_t)c->sh.rate_cats * c->sh.states * sizeof(double);
-    k_update_pmatrix<<<n, 256, lds, c->stream>>>(a);
+    k_update_pmatrix<<<n * a.split, 256, lds, c->stream>>>(a);
     HIP_TRY(hipGetLastError());
     done += n;
   }

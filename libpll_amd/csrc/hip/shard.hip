@@ -15,8 +15,134 @@
 // doubles in shard order -- deterministic, and cheaper than a collective for 8 bytes.  (The
 // one-process-per-GPU mode, pllhip_comm_init, sums the same values with one RCCL all-reduce.)
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
 
 #include "ctx.hpp"
+
+// ---- one host thread per shard (round 5) ----
+// The calling thread takes shard 0 itself; shard i > 0 has a thread of its own that sleeps on a condition variable
+// between calls (after a short spin: the calls of a likelihood evaluation come in bursts), binds its device once per
+// job and runs the same function on its shard.  Errors come back as each shard's return code and message (the
+// library's error text is per thread); the first failing shard's is the call's.  PLLHIP_SHARD_THREADS=0: the calling
+// thread visits the shards in turn, as until round 4.
+struct pllhip_shard_pool
+{
+  std::vector<std::thread> threads;
+  std::mutex m;
+  std::condition_variable cv;
+  const std::function<int(pllhip_ctx *, size_t)> * job = nullptr;
+  std::atomic<unsigned long long> generation{0};
+  std::atomic<unsigned int> remaining{0};
+  std::vector<int> rc;
+  std::vector<std::string> msg;
+  bool stop = false;
+};
+
+static void shard_worker(pllhip_ctx * g, size_t i)
+{
+  pllhip_shard_pool & p = *g->pool;
+  unsigned long long seen = 0;
+  for (;;)
+  {
+    // a short spin (the next call of a burst), then sleep
+    bool got = false;
+    for (int spin = 0; spin < 2000 && !got; ++spin)
+    {
+      got = p.generation.load(std::memory_order_acquire) != seen;
+#if defined(__x86_64__) || defined(__i386__)
+      if (!got) __builtin_ia32_pause();
+#endif
+    }
+    if (!got)
+    {
+      std::unique_lock<std::mutex> lk(p.m);
+      p.cv.wait(lk, [&] { return p.stop || p.generation.load(std::memory_order_acquire) != seen; });
+      if (p.stop) return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(p.m); // (the job pointer and the generation were published under the lock)
+      if (p.stop) return;
+      seen = p.generation.load(std::memory_order_acquire);
+    }
+    int rc = 0;
+    if (hipSetDevice(g->shards[i]->sh.device) != hipSuccess)
+    {
+      pllhip_set_error("hipSetDevice(%d) on a shard's thread", g->shards[i]->sh.device);
+      rc = -1;
+    }
+    else rc = (*p.job)(g->shards[i], g->shard_lo[i]);
+    p.rc[i] = rc;
+    if (rc) p.msg[i] = pllhip_last_error();
+    p.remaining.fetch_sub(1, std::memory_order_acq_rel);
+  }
+}
+
+int pllhip_group_parallel(pllhip_ctx * g, const std::function<int(pllhip_ctx *, size_t)> & fn)
+{
+  pllhip_device_guard guard; // (the caller's current device is put back on return)
+  const size_t n = g->shards.size();
+  static const bool threads_on = !(getenv("PLLHIP_SHARD_THREADS") && atoi(getenv("PLLHIP_SHARD_THREADS")) == 0);
+  if (n < 2 || !threads_on)
+  {
+    for (size_t i = 0; i < n; ++i)
+    {
+      if (hipSetDevice(g->shards[i]->sh.device) != hipSuccess) { pllhip_set_error("hipSetDevice"); return -1; }
+      const int rc = fn(g->shards[i], g->shard_lo[i]);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  if (!g->pool)
+  {
+    g->pool = new pllhip_shard_pool();
+    g->pool->rc.assign(n, 0);
+    g->pool->msg.assign(n, std::string());
+    for (size_t i = 1; i < n; ++i) g->pool->threads.emplace_back(shard_worker, g, i);
+  }
+  pllhip_shard_pool & p = *g->pool;
+  {
+    std::lock_guard<std::mutex> lk(p.m);
+    p.job = &fn;
+    p.remaining.store((unsigned int)(n - 1), std::memory_order_release);
+    p.generation.fetch_add(1, std::memory_order_acq_rel);
+  }
+  p.cv.notify_all();
+  int rc0 = 0;
+  if (hipSetDevice(g->shards[0]->sh.device) != hipSuccess) { pllhip_set_error("hipSetDevice"); rc0 = -1; }
+  else rc0 = fn(g->shards[0], g->shard_lo[0]);
+  // (everybody is through before `fn` -- the caller's lambda, its captures on the caller's stack -- goes away)
+  while (p.remaining.load(std::memory_order_acquire) != 0)
+  {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (rc0) return rc0;
+  for (size_t i = 1; i < n; ++i)
+    if (p.rc[i])
+    {
+      pllhip_set_error("%s", p.msg[i].c_str());
+      return p.rc[i];
+    }
+  return 0;
+}
+
+static void pool_destroy(pllhip_ctx * g)
+{
+  if (!g->pool) return;
+  {
+    std::lock_guard<std::mutex> lk(g->pool->m);
+    g->pool->stop = true;
+  }
+  g->pool->cv.notify_all();
+  for (std::thread & t : g->pool->threads) t.join();
+  delete g->pool;
+  g->pool = nullptr;
+}
 
 extern "C" int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int * devices,
                                          unsigned int ndevices, pllhip_ctx_t ** out)
@@ -64,6 +190,7 @@ extern "C" int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int
 
 void pllhip_group_destroy(pllhip_ctx * g)
 {
+  pool_destroy(g);
   pllhip_device_guard guard;
   for (pllhip_ctx * s : g->shards) pllhip_ctx_destroy(s);
   g->shards.clear();
@@ -80,11 +207,30 @@ extern "C" unsigned int pllhip_shard_first_site(pllhip_ctx_t * c, unsigned int s
   return (c->shards.empty() || shard >= c->shards.size()) ? 0u : (unsigned int)c->shard_lo[shard];
 }
 
-// wait for a shard's enqueued result-returning call and take its sums
+// Wait for a shard's enqueued result-returning call and take its sums.  Round 5: the way an unsharded context waits
+// for its own -- polling the shard's word / workgroup sums in host-mapped memory (pllhip_result_wait_host; the stream
+// itself only after 200 us, or when copies follow the kernel) -- instead of a hipStreamSynchronize per shard, one
+// after the other, each 10-20 us of runtime whether the shard had finished or not: eight shards of 125,000 sites
+// are 0.2 ms each.  PLLHIP_SHARD_POLL=0: the stream waits again.
+int pllhip_result_wait_pending(pllhip_ctx * c);
 static int result_wait(pllhip_ctx * s, unsigned int count, double * out)
 {
+  static const bool poll = !(getenv("PLLHIP_SHARD_POLL") && atoi(getenv("PLLHIP_SHARD_POLL")) == 0);
   HIP_TRY(hipSetDevice(s->sh.device));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (poll)
+  {
+    const int rc = pllhip_result_wait_pending(s);
+    if (rc) return rc;
+  }
+  else
+  {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->pending_hostsum)
+    {
+      const int rc = pllhip_result_wait_pending(s); // (the stream is drained: this only adds the sums)
+      if (rc) return rc;
+    }
+  }
   for (unsigned int i = 0; i < count; ++i) out[i] = s->h_result[i];
   return 0;
 }
@@ -96,14 +242,12 @@ template <typename Enqueue>
 int fan_out_and_sum(pllhip_ctx * g, unsigned int ncomp, double * sums, Enqueue enqueue)
 {
   pllhip_device_guard guard; // (the caller's current device is put back on return)
-  int rc = 0;
-  for (size_t i = 0; i < g->shards.size() && !rc; ++i)
-  {
-    pllhip_ctx * s = g->shards[i];
+  int rc = pllhip_group_parallel(g, [&](pllhip_ctx * s, size_t lo) -> int {
     s->defer = true;
-    rc = enqueue(s, g->shard_lo[i]);
+    const int r = enqueue(s, lo);
     s->defer = false;
-  }
+    return r;
+  });
   for (unsigned int k = 0; k < ncomp; ++k) sums[k] = 0.0;
   // (also after a failure: nothing may still be writing into the caller's per-site buffer)
   for (pllhip_ctx * s : g->shards)

@@ -280,11 +280,14 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
   if ((attributes & PLL_ATTRIB_SITE_REPEATS) &&
       ((states != 4 && states != 20) || !(attributes & PLL_ATTRIB_PATTERN_TIP) ||
        (attributes & (PLL_ATTRIB_AB_MASK | PLL_ATTRIB_AB_FLAG)) ||
-       !(rate_cats == 1 || rate_cats == 2 || rate_cats == 4 || (rate_cats == 8 && states == 4))))
+       /* (20 states with other category counts than 1, 2, 4 -- their ops run in chunks of the categories, which do
+        * not follow row maps -- take the attribute since round 5 and store every CLV per site: the client's code
+        * path is the same, the results are the plain partition's) */
+       !(states == 20 || rate_cats == 1 || rate_cats == 2 || rate_cats == 4 || rate_cats == 8)))
   {
     pll_amd_set_error(PLL_ERROR_HIP_UNSUPPORTED,
-                      "PLL_ATTRIB_SITE_REPEATS needs 4 states (1/2/4/8 rate categories) or 20 states "
-                      "(1/2/4), PLL_ATTRIB_PATTERN_TIP and no ascertainment-bias attribute.");
+                      "PLL_ATTRIB_SITE_REPEATS needs 4 states (1/2/4/8 rate categories) or 20 states, "
+                      "PLL_ATTRIB_PATTERN_TIP and no ascertainment-bias attribute.");
     return NULL;
   }
   if (!states || !sites || !rate_cats || !rate_matrices || (tips + clv_buffers) == 0)

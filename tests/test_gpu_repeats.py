@@ -181,9 +181,24 @@ def test_repeats_attribute_contract(gpu, monkeypatch):
     same_state(p, q, aa["plan"])
     p.destroy()
     q.destroy()
+    # 20 states x 8 (or 6, 3) rate categories on the default path (round 5; until then pll_errno 202): the ops run in
+    # chunks of the categories, which follow no row maps -- accepted, stored per site, the plain partition's bits
+    monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
+    for cats in (8, 6, 3):
+        aa = make_case(20, "random", 10, 300, rate_cats=cats, seed=cats)
+        p = build_partition(gpu, aa, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)
+        q = build_partition(gpu, aa, ATTRIB_PATTERN_TIP)
+        ea, eb = evaluate(p, aa["plan"], cats), evaluate(q, aa["plan"], cats)
+        assert all(p.repeats_classes(int(op["parent_clv_index"])) == 0 for op in aa["plan"].ops)
+        same_state(p, q, aa["plan"])
+        assert ea[0] == eb[0] and bits_equal(ea[1], eb[1]) and bits_equal(ea[2], eb[2]) and ea[3] == eb[3]
+        p.destroy()
+        q.destroy()
     dna = make_case(4, "balanced", 8, 50, seed=3)
     with pytest.raises(PllError):
         build_partition(gpu, dna, ATTRIB_SITE_REPEATS)                           # tip CLVs
+    with pytest.raises(PllError):
+        gpu.partition_create(8, 6, 4, 50, 1, 14, 3, 6, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)   # 4 states x 3 categories
     with pytest.raises(PllError):
         build_partition(gpu, dna, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS | ATTRIB_AB_LEWIS)
 

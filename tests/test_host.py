@@ -6,6 +6,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -499,6 +500,54 @@ def test_device_selection_per_thread_with_a_process_wide_default(amd):
     t.start(); t.join()
     assert seen["after the owner's change"] == 2
     lib.pll_amd_set_device(0)
+
+
+def test_bench_multi_gpu_launcher_branch(monkeypatch):
+    """bench.py --gpus N (N > 1, nobody launched the ranks): the branch the driver's scaling run relies on, on CPU
+    (VERDICT r4 item 7b).  The ranks are started as a FRESH child -- python -m torch.distributed.run, one node, N
+    processes, rendezvous on 127.0.0.1, dmabuf IPC -- with this process's own arguments, before anything here has
+    initialised a GPU and without this process replacing itself (no os.exec*); the child's exit code is the run's.
+    Without devices the branch refuses with a message instead of launching."""
+    import subprocess
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd, env = bench.launcher_command(8, ["--gpus", "8", "--steps", "3"], 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-5] == os.path.join(root, "bench.py") and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "OMP_NUM_THREADS" in env
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "os.exec" not in src.replace("os.exec*", "") and "execv" not in src
+    # the branch itself: eight devices "visible", the child's exit code handed on, nothing else run in this process
+    seen = {}
+
+    def fake_run(c, env=None, **kw):
+        seen["cmd"], seen["env"] = c, env
+        return subprocess.CompletedProcess(c, 7)
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    assert seen["cmd"][-6:] == ["--gpus", "8", "--steps", "2", "--warmup", "1"] and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    # fewer devices than ranks: refused before anything is launched
+    seen.clear()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "device(s) visible" in str(e.value.code) and not seen
+    # a launched rank whose WORLD_SIZE disagrees with --gpus is refused too
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE" in str(e.value.code)
 
 
 def test_bench_alignment_blocks():
