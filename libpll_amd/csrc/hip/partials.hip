@@ -584,16 +584,42 @@ extern "C" int pllhip_small_partition_estimate(unsigned int states, unsigned int
     }
     else ++launches;
   }
+  // Round 5: a list that splits into independent segments (partials_fused.hpp) is walked segment by segment by
+  // different waves at these sizes -- the walk that counts is the longest segment's (a full traversal: the longer side
+  // of the root edge), and a list seen for the first time pays its planning on this path (4 states: 0.16 us per op;
+  // 20 states: the fixed term 32 -> 40 us).  A three-op list on the 4-state whole-list path is one launch since the tile
+  // counters come in two sets (no table launch, no memset): 49 against 55-58 us per step from Python.  Measured again with the segments in (profiles/r5_small_partitions_ab.txt): 4 states x 64 taxa x
+  // 12,000 sites 64 (per level) against 54 us, 20 states x 64 taxa x 2,000 sites 115 against 106.
+  double walk = 1.0;
+  {
+    unsigned int nsc = 0;
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      const pllhip_op_t & op = ops[i];
+      for (int sc : {op.parent_scaler, op.child1_scaler, op.child2_scaler})
+        if (sc >= 0 && (unsigned int)sc + 1 > nsc) nsc = (unsigned int)sc + 1;
+    }
+    const FusedGeom geom = {nclv, nsc, tips, pattern_tip != 0};
+    static thread_local std::vector<unsigned int> seg_of;
+    const unsigned int nsegs = pllhip_fused_segments(geom, ops, count, PLLHIP_FUSED_MAX_SEGS, seg_of);
+    if (nsegs > 1)
+    {
+      unsigned int longest = 0;
+      for (unsigned int sg = 0; sg < nsegs; ++sg)
+        longest = std::max(longest, (unsigned int)std::count(seg_of.begin(), seg_of.end(), sg));
+      walk = (double)longest / count;
+    }
+  }
   double whole_us, level_us;
   if (states == 4)
   {
-    whole_us = 14.0 + 0.70 * count;
+    whole_us = 12.0 + 0.16 * count + 0.70 * count * walk; // (fixed + planning a list of this length + the walk)
     level_us = 5.5 * launches + (double)count * sites * 265.0 / 8.5e6;
   }
   else
   {
     // (20 states: the per-level path adds table launches per level -- tip tables, the lookup ops' tables and kernels)
-    whole_us = 32.0 + 1.6 * n_tt + 2.0 * n_lookup + 3.2 * n_ii + 3.4 * n_ti;
+    whole_us = 40.0 + (1.6 * n_tt + 2.0 * n_lookup + 3.2 * n_ii + 3.4 * n_ti) * walk;
     level_us = 7.5 * 2.2 * launches + (double)count * sites * 1300.0 / 7.0e6;
   }
   if (whole_us_out) *whole_us_out = whole_us;

@@ -585,32 +585,38 @@ def _small_choice(amd, states, sites, plan, pattern_tip=1, ops=None):
 def test_small_partition_path_choice(amd):
     """Below 16,384 sites the library chooses between the whole-list kernel and the per-level launches from the op
     list (partials.hip, whole_list_pays_when_small).  The choices measured on the device
-    (profiles/r4_small_partitions_ab.txt: the default matched the faster path in every row) are pinned here."""
+    (profiles/r5_small_partitions_ab.txt, round 4: r4_small_partitions_ab.txt -- the default matches the faster path
+    in every row) are pinned here."""
     from libpll_amd import workload as W
     bal64, rnd200, rnd64, bal128 = (W.balanced_tree(64, seed=42), W.random_tree(200, seed=42),
                                     W.random_tree(64, seed=42), W.balanced_tree(128, seed=42))
     ladder = W.caterpillar_tree(100, seed=42)
-    # 20 states
-    assert _small_choice(amd, 20, 2000, bal64)[0] == 0      # six levels: per level (120 against 167 us)
-    assert _small_choice(amd, 20, 4000, bal64)[0] == 0
-    assert _small_choice(amd, 20, 6000, bal64)[0] == 1      # 185 -> 170 us
-    assert _small_choice(amd, 20, 12000, bal64)[0] == 1     # 289 -> 184
-    assert _small_choice(amd, 20, 6000, rnd200)[0] == 1     # 767 -> 570
-    assert _small_choice(amd, 20, 3000, rnd64)[0] == 1      # 287 -> 200
-    assert _small_choice(amd, 20, 3000, bal128)[0] == 0     # 224 against 321
-    assert _small_choice(amd, 20, 10000, bal128)[0] == 1    # 456 -> 357
-    assert _small_choice(amd, 20, 3000, ladder)[0] == 1     # 1857 -> 407: a launch per op on the per-level path
+    # 20 states (round 5: the whole-list kernel walks the two sides of the root edge side by side -- segments --, which
+    # moved every crossover down; profiles/r5_small_partitions_ab.txt: the default matches the faster path in every row)
+    assert _small_choice(amd, 20, 2000, bal64)[0] == 1      # 108 against 116 us per step (round 4: 167 against 120)
+    assert _small_choice(amd, 20, 6000, bal64)[0] == 1      # 119 against 186
+    assert _small_choice(amd, 20, 12000, bal64)[0] == 1     # 175 against 286
+    assert _small_choice(amd, 20, 2000, rnd200)[0] == 1     # 519 against 541
+    assert _small_choice(amd, 20, 6000, rnd200)[0] == 1     # 518 against 771
+    assert _small_choice(amd, 20, 3000, rnd64)[0] == 1      # 191 against 277
+    assert _small_choice(amd, 20, 3000, bal128)[0] == 1     # 193-200 against 220 (round 4: 321 against 224)
+    assert _small_choice(amd, 20, 10000, bal128)[0] == 1    # 330 against 456
+    assert _small_choice(amd, 20, 3000, ladder)[0] == 1     # 402 against 1877: a launch per op on the per-level path
     # 4 states
-    assert _small_choice(amd, 4, 2000, bal64)[0] == 0       # 46 against 67 us
-    assert _small_choice(amd, 4, 12000, bal64)[0] == 0
-    assert _small_choice(amd, 4, 6000, rnd200)[0] == 1      # 200 -> 175
-    assert _small_choice(amd, 4, 3000, rnd64)[0] == 1       # 108 -> 71
-    assert _small_choice(amd, 4, 3000, bal128)[0] == 0      # 75 against 119
-    assert _small_choice(amd, 4, 3000, ladder)[0] == 1      # 717 -> 106
-    # a partial traversal -- the path from a changed branch to the root: one op per level -- always takes the whole list
-    chain = ladder.ops[-7:]
-    assert _small_choice(amd, 20, 2000, ladder, ops=chain)[0] == 1
-    assert _small_choice(amd, 4, 2000, ladder, ops=chain)[0] == 1
+    assert _small_choice(amd, 4, 2000, bal64)[0] == 0       # 45 against 48 us: six launches still win here
+    assert _small_choice(amd, 4, 6000, bal64)[0] == 1       # 52-53 against 56
+    assert _small_choice(amd, 4, 12000, bal64)[0] == 1      # 56 against 66 (round 4: per level, 67 against 76)
+    assert _small_choice(amd, 4, 6000, rnd200)[0] == 1      # 166 against 195
+    assert _small_choice(amd, 4, 3000, rnd64)[0] == 1       # 70 against 105
+    assert _small_choice(amd, 4, 3000, bal128)[0] == 0      # 72 against 76
+    assert _small_choice(amd, 4, 10000, bal128)[0] == 1     # 81 against 95
+    assert _small_choice(amd, 4, 3000, ladder)[0] == 1      # 107 against 663
+    # a partial traversal -- the path from a changed branch to the root: one op per level -- takes the whole list, from
+    # three ops on (4 states: one launch since round 5, 49 against 55-58 us)
+    for n in (3, 7, 15):
+        chain = ladder.ops[-n:]
+        assert _small_choice(amd, 20, 2000, ladder, ops=chain)[0] == 1
+        assert _small_choice(amd, 4, 2000, ladder, ops=chain)[0] == 1
     # estimates are positive and finite; a bad index is reported, not dereferenced
     rc, whole, level = _small_choice(amd, 20, 8000, rnd200)
     assert rc == 1 and 0 < whole < level < 1e6
