@@ -32,6 +32,7 @@ struct pllhip_ctx
   // enqueue everything and return without waiting (pllhip_result_wait fetches).
   std::vector<pllhip_ctx *> shards;
   std::vector<size_t> shard_lo;
+  bool shard_threads = true, shard_poll = true; // env PLLHIP_SHARD_THREADS / PLLHIP_SHARD_POLL = 0 (read at creation)
   struct pllhip_shard_pool * pool = nullptr; // (round 5) the group's enqueueing threads, one per shard but the first (shard.hip)
   bool defer = false;
   // (round 5) what the group needs to wait for a shard's enqueued result the way an unsharded context waits for its

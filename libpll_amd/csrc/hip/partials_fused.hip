@@ -1199,7 +1199,10 @@ unsigned int pllhip_fused_segments(const FusedGeom & geom, const pllhip_op_t * o
   seg_of.assign(count, 0u);
   if (max_segments > PLLHIP_FUSED_MAX_SEGS) max_segments = PLLHIP_FUSED_MAX_SEGS;
   if (count < 4 || max_segments < 2) return 1;
-  std::vector<unsigned int> parent(count);
+  // (every new list passes here: the work arrays are the thread's, not the heap's)
+  static thread_local std::vector<unsigned int> parent, size, roots, load, seg_of_root;
+  static thread_local std::vector<int> clv_first, sc_first;
+  parent.resize(count);
   for (unsigned int i = 0; i < count; ++i) parent[i] = i;
   auto find = [&](unsigned int x) {
     while (parent[x] != x) x = parent[x] = parent[parent[x]];
@@ -1211,7 +1214,8 @@ unsigned int pllhip_fused_segments(const FusedGeom & geom, const pllhip_op_t * o
     if (a != b) parent[a > b ? a : b] = a < b ? a : b;
   };
   // first op that touches each WRITTEN buffer (-1: not written in this list, -2: written, nobody met yet)
-  std::vector<int> clv_first(geom.nclv, -1), sc_first(geom.nsc, -1);
+  clv_first.assign(geom.nclv, -1);
+  sc_first.assign(geom.nsc, -1);
   for (unsigned int i = 0; i < count; ++i)
   {
     if (ops[i].parent_clv >= geom.nclv || ops[i].child1_clv >= geom.nclv || ops[i].child2_clv >= geom.nclv ||
@@ -1235,16 +1239,16 @@ unsigned int pllhip_fused_segments(const FusedGeom & geom, const pllhip_op_t * o
     touch(sc_first, ops[i].child2_scaler);
   }
   // components by size, longest first (ties: the one that begins first)
-  std::vector<unsigned int> size(count, 0u);
+  size.assign(count, 0u);
   for (unsigned int i = 0; i < count; ++i) ++size[find(i)];
-  std::vector<unsigned int> roots;
+  roots.clear();
   for (unsigned int i = 0; i < count; ++i)
     if (size[i]) roots.push_back(i);
   if (roots.size() < 2) return 1;
   std::stable_sort(roots.begin(), roots.end(), [&](unsigned int a, unsigned int b) { return size[a] > size[b]; });
   // as many segments as have two ops each at least, and no more than shorten the longest
   unsigned int nsegs = (unsigned int)std::min<size_t>(max_segments, roots.size());
-  std::vector<unsigned int> load, seg_of_root(count, 0u);
+  seg_of_root.assign(count, 0u);
   for (;; --nsegs)
   {
     load.assign(nsegs, 0u);

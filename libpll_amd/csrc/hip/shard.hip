@@ -85,8 +85,7 @@ int pllhip_group_parallel(pllhip_ctx * g, const std::function<int(pllhip_ctx *, 
 {
   pllhip_device_guard guard; // (the caller's current device is put back on return)
   const size_t n = g->shards.size();
-  static const bool threads_on = !(getenv("PLLHIP_SHARD_THREADS") && atoi(getenv("PLLHIP_SHARD_THREADS")) == 0);
-  if (n < 2 || !threads_on)
+  if (n < 2 || !g->shard_threads)
   {
     for (size_t i = 0; i < n; ++i)
     {
@@ -161,6 +160,9 @@ extern "C" int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int
   std::vector<size_t> lo;
   for (size_t b = 0; b < ordinary; b += per) lo.push_back(b);
   pllhip_ctx * g = new pllhip_ctx();
+  // (read when the group is created, like every other switch)
+  g->shard_threads = !(getenv("PLLHIP_SHARD_THREADS") && atoi(getenv("PLLHIP_SHARD_THREADS")) == 0);
+  const bool shard_poll = !(getenv("PLLHIP_SHARD_POLL") && atoi(getenv("PLLHIP_SHARD_POLL")) == 0);
   g->sh = *shape;
   g->sh.device = devices[0];
   g->span = (size_t)shape->states * shape->rate_cats;
@@ -180,6 +182,7 @@ extern "C" int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int
       pllhip_group_destroy(g);
       return rc;
     }
+    s->shard_poll = shard_poll;
     g->shards.push_back(s);
     g->shard_lo.push_back(lo[i]);
   }
@@ -215,9 +218,8 @@ extern "C" unsigned int pllhip_shard_first_site(pllhip_ctx_t * c, unsigned int s
 int pllhip_result_wait_pending(pllhip_ctx * c);
 static int result_wait(pllhip_ctx * s, unsigned int count, double * out)
 {
-  static const bool poll = !(getenv("PLLHIP_SHARD_POLL") && atoi(getenv("PLLHIP_SHARD_POLL")) == 0);
   HIP_TRY(hipSetDevice(s->sh.device));
-  if (poll)
+  if (s->shard_poll)
   {
     const int rc = pllhip_result_wait_pending(s);
     if (rc) return rc;

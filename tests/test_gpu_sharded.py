@@ -204,6 +204,33 @@ def test_sharded_refusals(gpu):
             build_partition(gpu, case, ATTRIB_PATTERN_TIP)
 
 
+@pytest.mark.parametrize("threads", ["1", "0"])
+def test_sharded_errors_come_back_from_the_shards_threads(gpu, monkeypatch, threads):
+    """Round 5: the hot calls on a sharded partition are enqueued by one host thread per shard (shard.hip,
+    pllhip_group_parallel).  An error raised on a shard's thread -- an op that names a CLV the partition does not have,
+    a negative branch length -- comes back to the caller with its text (the library's error state is per thread), and the
+    partition works on afterwards; the same with the calling thread visiting the shards in turn (PLLHIP_SHARD_THREADS=0)."""
+    monkeypatch.setenv("PLLHIP_SHARD_THREADS", threads)
+    case = make_case(4, "balanced", 8, 1500, seed=5)
+    plan, R = case["plan"], case["rate_cats"]
+    with devices(gpu, [0, 0, 0]):
+        p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    assert gpu.lib.pll_amd_shard_count(p.ptr) == 3
+    p.update_partials(plan.ops)
+    want = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    bad = plan.ops.copy()
+    bad["child1_clv_index"][2] = 10_000
+    with pytest.raises(PllError) as e:
+        p.update_partials(bad)
+    assert str(e.value)                               # (a message, whichever shard's)
+    with pytest.raises(PllError):
+        p.update_prob_matrices([0] * R, [0], [-1.0])
+    for _ in range(20):                               # many calls in a row: the threads' hand-over
+        p.update_partials(plan.ops)
+    assert p.compute_edge_loglikelihood(*plan.root_edge, [0] * R) == want
+    p.destroy()
+
+
 def test_environment_device_list(gpu, monkeypatch):
     case = make_case(4, "balanced", 8, 1024, seed=2)
     monkeypatch.setenv("PLL_AMD_DEVICES", "0,0-0,0")      # three entries: ranges of 512 sites, so two shards

@@ -7,7 +7,7 @@
 # gpurun_out/<tag>/summary/ (what gets copied into profiles/) and writes the index bench.py reads
 # `roofline.traffic` from.
 set -u
-tag=${1:-r4}
+tag=${1:-r5}
 root=$(pwd)
 out=$root/gpurun_out/$tag
 sum=$out/summary
@@ -110,7 +110,10 @@ workloads
 # times) -- lnL checked against the reference and against the one-GPU evaluation of the same alignment --, and the
 # RCCL path (communicator, lnL all-reduce) on one rank
 (cd "$root" && python3 bench.py --gpus 4 --in-process --devices 0,0,0,0 --sites 250000 --steps 10 > "$sum/${tag}_bench_in_process_4_shards.json" 2> "$out/bench_inproc4.err")
+(cd "$root" && python3 bench.py --gpus 8 --in-process --devices 0,0,0,0,0,0,0,0 --total-sites 1000000 --steps 10 --cpu-sites 0 --no-vary > "$sum/${tag}_bench_in_process_8_shards_of_c2.json" 2> "$out/bench_inproc8.err")
 (cd "$root" && python3 bench.py --force-comm --no-c4 --steps 10 > "$sum/${tag}_bench_force_comm.json" 2> "$out/bench_forcecomm.err")
+# the sizes an 8-way split of the BASELINE configs leaves a GPU (round 5: segments)
+(cd "$root" && bash tools/size_sweep2.sh > "$sum/${tag}_size_sweep.txt" 2>&1)
 # site repeats on the C5 shape
 (cd "$root" && python3 bench.py --sites 500000 --taxa 200 --tree random --site-repeats --cpu-sites 0 > "$sum/${tag}_bench_c5_shape_site_repeats.json" 2> "$out/bench_c5rep.err")
 ls -la "$sum"
