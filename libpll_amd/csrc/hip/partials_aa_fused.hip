@@ -143,7 +143,6 @@ __device__ __forceinline__ double af_masksum20(const double (&r)[20], unsigned i
   return a;
 }
 
-constexpr unsigned int AF_PREP_C1 = 4u; // first characters per workgroup of a pair / lookup table job
 __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict__ mj, unsigned int nmat,
                                                     const AfTipJob * __restrict__ tj, unsigned int ntip,
                                                     char * aorder, char * titab,
@@ -153,7 +152,6 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
                                                     const AaLookupJob * __restrict__ lj, unsigned int nlk)
 {
   const unsigned int b = blockIdx.x;
-  const unsigned int cgroups = (ms + AF_PREP_C1 - 1u) / AF_PREP_C1; // workgroups per pair / lookup table
   __shared__ double sh_m1[1600], sh_m2[1600]; // a job's matrices (pair and lookup tables)
   __shared__ double sh_left[80];              // the row of character 1
   __shared__ double sh_child[32 * 80];        // a lookup table's child over (c1, every c2)
@@ -207,15 +205,17 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
       out[t] = masksum_seq(lmat + (size_t)ki * 20, tipmap[code], 20);
     }
   }
-  else if (b - nmat - ntip < npair * cgroups)
+  else if (b - nmat - ntip < npair * ms)
   {
-    // one workgroup per (op, AF_PREP_C1 first characters): row (c1 ms + c2) = left factor of c1 (.) right factor of c2
-    // -- the two masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds.
-    // The matrices come through LDS (coalesced loads); a thread keeps ITS row of the right matrix in registers and
+    // (round 5 measured four first characters per workgroup -- the 25.6 KB of matrices fetched once instead of four
+    // times: 34.1 against 26.7 us per launch at C3, profiles/r5_aa_prepare_ab.txt; the jobs are bound by their own
+    // serial arithmetic, not by the matrices.  Not kept.)
+    // one workgroup per (op, character 1): row (c1 ms + c2) = left factor of c1 (.) right factor of c2 -- the two
+    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds.  The
+    // matrices come through LDS (coalesced loads); a thread keeps ITS row of the right matrix in registers and
     // walks the second characters (a masked sum = the row's selected entries added in ascending order; adding +0.0
-    // for the others changes no bit).  (Round 5: four first characters per workgroup instead of one -- the
-    // 25.6 KB of matrices were what a workgroup spent its time on, 23 times per table: 27 -> see DESIGN 2.2c.)
-    const unsigned int job = (b - nmat - ntip) / cgroups, cg = (b - nmat - ntip) - job * cgroups;
+    // for the others changes no bit).
+    const unsigned int job = (b - nmat - ntip) / ms, c1 = (b - nmat - ntip) - job * ms;
     const AfPairJob & j = pj[job];
     for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x)
     {
@@ -223,38 +223,33 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
       sh_m2[t] = j.rmat[t];
     }
     __syncthreads();
-    const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u;
-    double r[20];
+    if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
+    __syncthreads();
+    double * out = reinterpret_cast<double *>(pairtab + j.dst_off) + (size_t)c1 * ms * 80;
     if (threadIdx.x < 240)
+    {
+      const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u;
+      double r[20];
 #pragma unroll
       for (int jj = 0; jj < 20; ++jj) r[jj] = sh_m2[ki * 20 + jj];
-    for (unsigned int c1 = cg * AF_PREP_C1; c1 < ms && c1 < (cg + 1u) * AF_PREP_C1; ++c1)
-    {
-      if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
-      __syncthreads();
-      double * out = reinterpret_cast<double *>(pairtab + j.dst_off) + (size_t)c1 * ms * 80;
-      if (threadIdx.x < 240)
-      {
-        const double l = sh_left[ki];
-        for (unsigned int c2 = g; c2 < ms; c2 += 3)
-          out[c2 * 80 + ki] = l * af_masksum20(r, tipmap[c2]);
-      }
-      __syncthreads(); // (sh_left is rewritten for the next first character)
+      const double l = sh_left[ki];
+      for (unsigned int c2 = g; c2 < ms; c2 += 3)
+        out[c2 * 80 + ki] = l * af_masksum20(r, tipmap[c2]);
     }
   }
-  else if (b - nmat - ntip - npair * cgroups < nlk * cgroups)
+  else if (b - nmat - ntip - npair * ms < nlk * ms)
   {
-    // (round 4) a lookup op's table, one workgroup per (table, AF_PREP_C1 first characters): rows (c1 ms + c2) = P x
-    // child over the character pairs the child -- a tip-tip result -- can be: the child as the branch above makes it,
-    // then the mat-vec in the order of the kernel the op would have run (AaLookupJob, ctx.hpp).  Until then six
-    // launches of those kernels ahead of every list (tip tables, tip-tip over all pairs, inner-inner x "ones"): 60 us.
-    const unsigned int job = (b - nmat - ntip - npair * cgroups) / cgroups, cg = (b - nmat - ntip - npair * cgroups) - job * cgroups;
+    // (round 4) a lookup op's table, one workgroup per (table, character 1): rows (c1 ms + c2) = P x child over the
+    // character pairs the child -- a tip-tip result -- can be: the child as the branch above makes it, then the
+    // mat-vec in the order of the kernel the op would have run (AaLookupJob, ctx.hpp).  Until then six launches of
+    // those kernels ahead of every list (tip tables, tip-tip over all pairs, inner-inner x "ones"): 60 us.
+    const unsigned int job = (b - nmat - ntip - npair * ms) / ms, c1 = (b - nmat - ntip - npair * ms) - job * ms;
     const AaLookupJob & j = lj[job];
+    double * out = j.dst + (size_t)c1 * ms * 80;
     if (j.mode == 2u)
     {
       // the tip's own factor: row (c1, 0) is its table's row c1 (the op's second character row is all zeros)
-      for (unsigned int c1 = cg * AF_PREP_C1; c1 < ms && c1 < (cg + 1u) * AF_PREP_C1; ++c1)
-        if (threadIdx.x < 80) j.dst[(size_t)c1 * ms * 80 + threadIdx.x] = masksum_seq(j.kl + (size_t)threadIdx.x * 20, tipmap[c1], 20);
+      if (threadIdx.x < 80) out[threadIdx.x] = masksum_seq(j.kl + (size_t)threadIdx.x * 20, tipmap[c1], 20);
       return;
     }
     for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x)
@@ -263,38 +258,31 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
       sh_m2[t] = j.kr[t];
     }
     __syncthreads();
+    if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
+    __syncthreads();
     const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u; // (threads 240..255: no row)
-    double r[20], prow[20];
     if (threadIdx.x < 240)
     {
+      double r[20];
 #pragma unroll
       for (int jj = 0; jj < 20; ++jj) r[jj] = sh_m2[ki * 20 + jj];
-      // the thread's row of P in registers (straight from memory: 160 contiguous bytes per thread, once per workgroup)
-#pragma unroll
-      for (int jj = 0; jj < 20; ++jj) prow[jj] = j.pm[ki * 20 + jj];
+      const double l = sh_left[ki];
+      for (unsigned int c2 = g; c2 < ms; c2 += 3) sh_child[c2 * 80 + ki] = l * af_masksum20(r, tipmap[c2]);
     }
-    const unsigned int kk = ki / 20u;
-    for (unsigned int c1 = cg * AF_PREP_C1; c1 < ms && c1 < (cg + 1u) * AF_PREP_C1; ++c1)
+    for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x) sh_m1[t] = j.pm[t]; // (the left tip matrix is done with)
+    __syncthreads();
+    if (threadIdx.x < 240)
     {
-      if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
-      __syncthreads();
-      if (threadIdx.x < 240)
+      // the thread's row of P in registers, the children of its second characters out of LDS
+      double prow[20];
+#pragma unroll
+      for (int jj = 0; jj < 20; ++jj) prow[jj] = sh_m1[ki * 20 + jj];
+      const unsigned int kk = ki / 20u;
+      for (unsigned int c2 = g; c2 < ms; c2 += 3)
       {
-        const double l = sh_left[ki];
-        for (unsigned int c2 = g; c2 < ms; c2 += 3) sh_child[c2 * 80 + ki] = l * af_masksum20(r, tipmap[c2]);
+        const double * v = sh_child + c2 * 80 + kk * 20;
+        out[c2 * 80 + ki] = j.mode == 0u ? dot_strided4<true>(prow, v, 20u) : dot_strided4<false>(prow, v, 20u);
       }
-      __syncthreads();
-      double * out = j.dst + (size_t)c1 * ms * 80;
-      if (threadIdx.x < 240)
-      {
-        // the children of the thread's second characters out of LDS
-        for (unsigned int c2 = g; c2 < ms; c2 += 3)
-        {
-          const double * v = sh_child + c2 * 80 + kk * 20;
-          out[c2 * 80 + ki] = j.mode == 0u ? dot_strided4<true>(prow, v, 20u) : dot_strided4<false>(prow, v, 20u);
-        }
-      }
-      __syncthreads(); // (sh_left and sh_child are rewritten for the next first character)
     }
   }
 }
@@ -1073,7 +1061,7 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
   const char * plan = static_cast<const char *>(k.d_plan);
   if (k.nmat + k.ntip + k.npair + k.nlk)
   {
-    k_af_prepare<<<k.nmat + k.ntip + (k.npair + k.nlk) * ((c->maxstates + AF_PREP_C1 - 1u) / AF_PREP_C1), 256, 0, c->stream>>>(
+    k_af_prepare<<<k.nmat + k.ntip + (k.npair + k.nlk) * c->maxstates, 256, 0, c->stream>>>(
         (const AfMatJob *)(plan + k.off_mat), k.nmat, (const AfTipJob *)(plan + k.off_tip), k.ntip, k.d_aorder,
         k.d_titab, c->tipmap, c->maxstates, c->d_tile_counter, (const AfPairJob *)(plan + k.off_pair), k.npair,
         k.d_pairtab, (const AaLookupJob *)(plan + k.off_lk), k.nlk);
