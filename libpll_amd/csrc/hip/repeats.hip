@@ -11,6 +11,13 @@
 //   site_id[n_i] = class[i];  at heads: lrow[class] = key / nb, rrow[class] = key % nb
 //
 // Classes are numbered in key order, which is as good as any: every result is per site.
+// (Round 5 built the identification WITHOUT the sort -- a hash table of (key, smallest site that shows it): 64-bit
+// compare-and-swap with linear probing, atomicMin of the site, classes numbered by first occurrence with an inclusive
+// sum in site order; correct (tests/test_gpu_repeats.py) and twice as slow: 2.4 against 1.1 ms for a four-op partial
+// traversal after a subtree swap at 1 M sites, 154 against 55 ms for the first evaluation of BASELINE config 5's
+// shape (profiles/r5_repeats_hash_ab.txt).  Where repeats pay there are few keys for many sites -- a million atomics
+// on a few hundred addresses -- and where they do not, a million atomics on a million random lines run at a
+// seventeenth of the streaming rate (MI355X_MICROARCH.md, global atomics); the radix sort streams.  Not kept.)
 // The class count goes back to the host (one 4-byte copy), which needs it to size the
 // launches and to decide whether the node is worth storing by class at all.
 #include <hipcub/hipcub.hpp>
@@ -24,82 +31,7 @@ struct pllhip_rep_work
   void * temp = nullptr;
   size_t temp_bytes = 0;
   unsigned int * h_count = nullptr; // pinned
-  // round 5: the hash table of the sort-free identification -- `slots` keys (a power of two >= 2 x sites) and, behind
-  // them, the smallest site that showed each key
-  unsigned long long * tab_keys = nullptr;
-  unsigned int * tab_first = nullptr;
-  size_t slots = 0;
 };
-
-// ---- round 5: classes without a sort (a topology change re-identified at 1.08 ms for a 4-op
-// partial traversal against 0.27 ms plain -- a radix sort of a million (key, site) pairs per op costs more than the op).
-// The distinct (row of child 1, row of child 2) pairs are found with a hash table instead: every site inserts its key
-// (64-bit compare-and-swap, linear probing, a table of at least two slots per site) and leaves its index with an
-// atomicMin, so each key ends up knowing the FIRST site that shows it; the classes are numbered in the order of those
-// first sites -- an inclusive sum over "I am the first of my key" in site order --, which does not depend on who won
-// which race: the same numbering every run.  (The sort numbered them in key order; nothing observable depends on
-// the numbering: every result is per site.)  PLLHIP_REPEATS_SORT=1: the sort again.
-#define REP_EMPTY 0xffffffffffffffffull
-__device__ __forceinline__ unsigned long long rep_key(const unsigned int * __restrict__ id1, const unsigned char * __restrict__ tip1,
-                                                      const unsigned int * __restrict__ id2, const unsigned char * __restrict__ tip2,
-                                                      unsigned int nb, unsigned int tip_mask, size_t n)
-{
-  const unsigned int a = tip1 ? (tip1[n] & tip_mask) : id1[n];
-  const unsigned int b = tip2 ? (tip2[n] & tip_mask) : id2[n];
-  return (unsigned long long)a * nb + b;
-}
-
-__global__ __launch_bounds__(256) void k_rep_insert(const unsigned int * __restrict__ id1, const unsigned char * __restrict__ tip1,
-                                                    const unsigned int * __restrict__ id2, const unsigned char * __restrict__ tip2,
-                                                    unsigned int nb, unsigned int tip_mask, unsigned int sites,
-                                                    unsigned long long * __restrict__ tab_keys, unsigned int * __restrict__ tab_first,
-                                                    unsigned int log2_slots, unsigned int * __restrict__ slot_of)
-{
-  const unsigned int mask = (1u << log2_slots) - 1u;
-  for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < sites; n += (size_t)gridDim.x * blockDim.x)
-  {
-    const unsigned long long key = rep_key(id1, tip1, id2, tip2, nb, tip_mask, n);
-    unsigned int h = (unsigned int)((key * 0x9E3779B97F4A7C15ull) >> (64u - log2_slots));
-    for (;;)
-    {
-      const unsigned long long seen = atomicCAS(tab_keys + h, REP_EMPTY, key);
-      if (seen == REP_EMPTY || seen == key) break;
-      h = (h + 1u) & mask;
-    }
-    atomicMin(tab_first + h, (unsigned int)n);
-    slot_of[n] = h;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_rep_first_flags(const unsigned int * __restrict__ slot_of, const unsigned int * __restrict__ tab_first,
-                                                         unsigned int sites, unsigned int * __restrict__ flag)
-{
-  for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < sites; n += (size_t)gridDim.x * blockDim.x)
-    flag[n] = tab_first[slot_of[n]] == (unsigned int)n ? 1u : 0u;
-}
-
-// cls: inclusive sums of the flags (site order)
-__global__ __launch_bounds__(256) void k_rep_assign(const unsigned int * __restrict__ slot_of, const unsigned int * __restrict__ tab_first,
-                                                    const unsigned long long * __restrict__ tab_keys, const unsigned int * __restrict__ cls,
-                                                    unsigned int nb, unsigned int sites, unsigned int * __restrict__ site_id,
-                                                    unsigned int * __restrict__ lrow, unsigned int * __restrict__ rrow,
-                                                    unsigned int classes, unsigned int slack)
-{
-  // (the slack behind the row lists is zero, so that lanes past the last row gather row 0)
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < slack; i += (size_t)gridDim.x * blockDim.x)
-    lrow[classes + i] = rrow[classes + i] = 0u;
-  for (size_t n = blockIdx.x * (size_t)blockDim.x + threadIdx.x; n < sites; n += (size_t)gridDim.x * blockDim.x)
-  {
-    const unsigned int h = slot_of[n], first = tab_first[h], c = cls[first] - 1u;
-    site_id[n] = c;
-    if (first == (unsigned int)n)
-    {
-      const unsigned long long key = tab_keys[h];
-      lrow[c] = (unsigned int)(key / nb);
-      rrow[c] = (unsigned int)(key % nb);
-    }
-  }
-}
 
 __global__ __launch_bounds__(256) void k_rep_keys(const unsigned int * __restrict__ id1,
                                                   const unsigned char * __restrict__ tip1,
@@ -171,11 +103,6 @@ static int rep_work(pllhip_ctx * c, pllhip_rep_work ** out)
   w->temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
   HIP_TRY(hipMalloc(&w->temp, w->temp_bytes));
   HIP_TRY(hipHostMalloc((void **)&w->h_count, sizeof(unsigned int), hipHostMallocDefault));
-  w->slots = 1024;
-  while (w->slots < 2 * N) w->slots <<= 1;
-  // (one allocation, one memset to all ones per identification: the keys, then the first sites)
-  HIP_TRY(hipMalloc((void **)&w->tab_keys, w->slots * (sizeof(unsigned long long) + sizeof(unsigned int))));
-  w->tab_first = reinterpret_cast<unsigned int *>(w->tab_keys + w->slots);
   c->rep_work = w;
   *out = w;
   return 0;
@@ -186,7 +113,7 @@ void pllhip_rep_work_free(pllhip_ctx * c)
   pllhip_rep_work * w = c->rep_work;
   if (!w) return;
   for (void * p : {(void *)w->keys_in, (void *)w->keys_out, (void *)w->vals_in, (void *)w->vals_out,
-                   (void *)w->cls, w->temp, (void *)w->tab_keys})
+                   (void *)w->cls, w->temp})
     if (p) (void)hipFree(p);
   if (w->h_count) (void)hipHostFree(w->h_count);
   delete w;
@@ -254,46 +181,6 @@ extern "C" int pllhip_identify_repeats(pllhip_ctx_t * c, unsigned int parent, un
   pllhip_rep_work * w;
   if (rep_work(c, &w)) return -1;
   const unsigned int grid = pllhip_stream_grid(c, N, 256);
-  static const bool by_sort = getenv("PLLHIP_REPEATS_SORT") && atoi(getenv("PLLHIP_REPEATS_SORT")) != 0;
-  if (!by_sort)
-  {
-    unsigned int log2_slots = 0;
-    while (((size_t)1 << log2_slots) < w->slots) ++log2_slots;
-    HIP_TRY(hipMemsetAsync(w->tab_keys, 0xff, w->slots * (sizeof(unsigned long long) + sizeof(unsigned int)), c->stream));
-    k_rep_insert<<<grid, 256, 0, c->stream>>>(t1 ? nullptr : c->rows[child1].site_id, t1 ? pllhip_tip_ptr(c, child1) : nullptr,
-                                              t2 ? nullptr : c->rows[child2].site_id, t2 ? pllhip_tip_ptr(c, child2) : nullptr,
-                                              nb, tip_rows - 1u, N, w->tab_keys, w->tab_first, log2_slots, w->vals_in);
-    k_rep_first_flags<<<grid, 256, 0, c->stream>>>(w->vals_in, w->tab_first, N, w->cls);
-    HIP_TRY(hipGetLastError());
-    size_t tb = w->temp_bytes;
-    HIP_TRY(hipcub::DeviceScan::InclusiveSum(w->temp, tb, w->cls, w->cls, (int)N, c->stream));
-    HIP_TRY(hipMemcpyAsync(w->h_count, w->cls + (N - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const unsigned int classes = *w->h_count;
-    if (classes > max_classes) return 0;
-    const size_t slack = PLLHIP_TAIL_SITES;
-    if (!r.site_id)
-    {
-      HIP_TRY(hipMalloc((void **)&r.site_id, ((size_t)N + slack) * sizeof(unsigned int)));
-      HIP_TRY(hipMemsetAsync(r.site_id, 0, ((size_t)N + slack) * sizeof(unsigned int), c->stream));
-    }
-    if (r.row_cap < classes)
-    {
-      if (r.lrow) HIP_TRY(hipFree(r.lrow)); // (the stream is idle: synchronised above)
-      if (r.rrow) HIP_TRY(hipFree(r.rrow));
-      r.lrow = r.rrow = nullptr;
-      HIP_TRY(hipMalloc((void **)&r.lrow, (classes + slack) * sizeof(unsigned int)));
-      HIP_TRY(hipMalloc((void **)&r.rrow, (classes + slack) * sizeof(unsigned int)));
-      r.row_cap = classes;
-    }
-    // (rows below `classes` are all written by k_rep_assign, which also zeroes the slack behind them)
-    k_rep_assign<<<grid, 256, 0, c->stream>>>(w->vals_in, w->tab_first, w->tab_keys, w->cls, nb, N, r.site_id, r.lrow, r.rrow,
-                                              classes, (unsigned int)slack);
-    HIP_TRY(hipGetLastError());
-    r.classes = classes;
-    *classes_out = classes;
-    return 0;
-  }
   k_rep_keys<<<grid, 256, 0, c->stream>>>(t1 ? nullptr : c->rows[child1].site_id,
                                           t1 ? pllhip_tip_ptr(c, child1) : nullptr,
                                           t2 ? nullptr : c->rows[child2].site_id,
