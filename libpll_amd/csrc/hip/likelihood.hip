@@ -492,7 +492,11 @@ __global__ __launch_bounds__(256) void k_lnl_dna(LnlArgs a)
     // (Round 5 measured TWO sub-steps' operands in flight per lane, and the next round's first two requested before
     // this round's last two are evaluated: at 126 registers -- four waves per SIMD instead of five -- the launch took
     // 61.5 against 55.5 us on BASELINE config 2 with the full grid and the same 55-56 us with a persistent grid of 1024
-    // workgroups, profiles/r5_result_calls_ab.txt: bytes in flight are not what holds this kernel at 0.62.  Not kept.)
+    // workgroups, profiles/r5_result_calls_ab.txt: bytes in flight are not what holds this kernel at 0.62.  Not kept.
+    // Nor is the opposite extreme, every operand of the round requested up front as k_dna_partials does -- 162
+    // registers, three waves per SIMD, 192 KB in flight per CU: 58-59 against 55-56 us, r5_lnl_unroll_ab.txt.  The
+    // same kernel reads BASELINE config 4's 2.1 GB in 323 us = 6.6 TB/s, 0.83 of the peak: what a 1 M-site launch
+    // lacks is length -- ~13 us of its 54 are not streaming.)
     double2 p_next = ld16<NT>(P2 + granule(0, pi_round)), c_next = make_double2(0.0, 0.0);
     if (KIND == EDGE_II) c_next = ld16<NT>(C2 + granule(0, ci_round));
     auto substep = [&](unsigned int j, const double2 p, const double2 c) {
