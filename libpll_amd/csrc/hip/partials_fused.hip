@@ -125,14 +125,27 @@ __global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedPairJob * __
   const unsigned int i = blockIdx.x;
   if (i == 0 && tile_counters) tile_counters[threadIdx.x * 32u] = 0u;
   if (i >= njobs) return;
+  // Round 5: the two matrices through LDS, the table written in address order.  (A thread per character pair that
+  // read its 2 x 16 rows of 4 straight from memory and wrote 128 contiguous bytes of its own took 10.6 us per launch
+  // -- sixteen dependent trips to L1 per thread --, a fifth of pll_update_partials at 20,000 sites.)  Same products,
+  // same order: masksum4 of a row, times masksum4 of a row.
+  __shared__ double s_lm[RC * 16], s_rm[RC * 16];
   const double * lm = jobs[i].lmat, * rm = jobs[i].rmat;
   double * tab = jobs[i].tab;
-  const unsigned int pair = threadIdx.x, c1 = pair >> 4, c2 = pair & 15u;
   // (tip-inner ops: the tip's factor alone, in the entries [code 1][0] the kernel's index
   // (code 1 << 4 | character of an absent tip = 0) reaches; x * 1.0 is x)
   const bool tt = jobs[i].tip_tip != 0;
-  for (unsigned int ki = 0; ki < RC * 4u; ++ki)
-    tab[pair * RC * 4u + ki] = masksum4(lm + ki * 4u, c1) * (tt ? masksum4(rm + ki * 4u, c2) : 1.0);
+  for (unsigned int t = threadIdx.x; t < RC * 16u; t += blockDim.x)
+  {
+    s_lm[t] = lm[t];
+    s_rm[t] = tt ? rm[t] : 0.0;
+  }
+  __syncthreads();
+  for (unsigned int e = threadIdx.x; e < 256u * RC * 4u; e += blockDim.x)
+  {
+    const unsigned int pair = e / (RC * 4u), ki = e - pair * (RC * 4u), c1 = pair >> 4, c2 = pair & 15u;
+    tab[e] = masksum4(s_lm + ki * 4u, c1) * (tt ? masksum4(s_rm + ki * 4u, c2) : 1.0);
+  }
 }
 
 // what a lane requests for an op ahead of its use
