@@ -114,11 +114,17 @@ int pllhip_group_parallel(pllhip_ctx * g, const std::function<int(pllhip_ctx *, 
   if (hipSetDevice(g->shards[0]->sh.device) != hipSuccess) { pllhip_set_error("hipSetDevice"); rc0 = -1; }
   else rc0 = fn(g->shards[0], g->shard_lo[0]);
   // (everybody is through before `fn` -- the caller's lambda, its captures on the caller's stack -- goes away)
-  while (p.remaining.load(std::memory_order_acquire) != 0)
+  for (unsigned int spins = 0; p.remaining.load(std::memory_order_acquire) != 0; ++spins)
   {
+    // (the others enqueue a few launches each: microseconds; a shard that takes longer -- a first call that allocates,
+    // a stream it must drain -- is waited for without a core)
+    if (spins < 20000u)
+    {
 #if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
+      __builtin_ia32_pause();
 #endif
+    }
+    else std::this_thread::yield();
   }
   if (rc0) return rc0;
   for (size_t i = 1; i < n; ++i)
