@@ -156,6 +156,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   HIP_TRY(hipGetDeviceProperties(&prop, shape->device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
+  if (const char * e = getenv("PLLHIP_AA_TI_MFMA")) c->aa_ti_mfma = atoi(e) != 0;
   if (const char * e = getenv("PLLHIP_SPIN")) c->no_spin = atoi(e) == 0;
   if (const char * e = getenv("PLLHIP_HOSTSUM")) c->no_hostsum = atoi(e) == 0;
   if (const char * e = getenv("PLLHIP_FUSE_REDUCE")) c->fuse_forced = atoi(e) ? 1 : 0;

@@ -184,6 +184,11 @@ struct pllhip_ctx
   // 0 = matrix-core kernels where they exist (last-bit differences, see
   // partials_aa_mfma.hip)
   int aa_exact = 0;
+  // (round 5, opt-in, env PLLHIP_AA_TI_MFMA=1) 20-state whole-list kernel: the ONE mat-vec of a tip-inner op on the
+  // matrix cores (fused chains) instead of the vector unit in the reference's non-fused order -- ~7 % on trees with
+  // many tip-inner ops, at the price of tip-inner CLVs that agree with the reference's to ~1e-15 instead of bit for
+  // bit (and of scaler counts that are then equal "unless an entry lies within that of 2^-256").  Default off.
+  bool aa_ti_mfma = false;
 
   // optional per-launch timing (pllhip_profile_*): one event pair per launch
   bool profiling = false;

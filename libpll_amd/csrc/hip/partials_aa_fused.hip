@@ -98,13 +98,14 @@ constexpr unsigned int AF_SYNC_LEFT = 2048u;   // an inner-inner op behind a loo
 constexpr unsigned int AF_ZERO_COUNTS = 1024u; // (bits 8-9: the next op's kind) a tip-tip op inside the list: never
                                                // scales, but clears its scale buffer (core_partials_avx.c:598-599)
 constexpr unsigned int AF_ONE_TABLE = 4096u;   // a lookup with ONE table (round 4: a tip-tip op's pair table): nothing to multiply
-// (round 5) The records of a segment are LINKED: bits 14.. of `flags` name the record of the op that runs next -- the
+// (round 5) The records of a segment are LINKED: bits 15.. of `flags` name the record of the op that runs next -- the
 // last op's names op 0's again, AF_LAST set --, the header's `yoff` the segment's last record.  The kernel then
 // carries neither an op count nor an op number through the op loop: with segments both would be values of the
 // item instead of kernel arguments, two scalar registers more in a loop that has none to spare (the two records in
 // flight are 56 of them).
+constexpr unsigned int AF_TI_MFMA = 16384u;   // (opt-in, PLLHIP_AA_TI_MFMA=1) a tip-inner op whose mat-vec runs on the matrix cores
 constexpr unsigned int AF_LAST = 8192u;
-constexpr unsigned int AF_NEXT_SHIFT = 14u;
+constexpr unsigned int AF_NEXT_SHIFT = 15u;
 
 struct AfMatJob
 {
@@ -1384,7 +1385,8 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     if (kind <= 1)
     {
       r.yoff = (unsigned int)(mj.size() * AF_MAT_B);
-      mj.push_back(AfMatJob{f.rmat, (unsigned long long)r.yoff, kind == 1 ? 1ull : 0ull});
+      mj.push_back(AfMatJob{f.rmat, (unsigned long long)r.yoff, (kind == 1 && !c->aa_ti_mfma) ? 1ull : 0ull});
+      if (kind == 1 && c->aa_ti_mfma) r.flags |= AF_TI_MFMA;
     }
     if (kind == 1)
     {

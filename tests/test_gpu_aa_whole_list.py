@@ -210,3 +210,37 @@ def test_whole_list_repeats_itself_at_size(gpu, monkeypatch):
             got = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
             assert got[0] == ref[0] and bits_equal(got[1], ref[1]), "partition %d, evaluation %d" % (fresh, again)
         p.destroy()
+
+
+def test_tip_inner_on_the_matrix_cores_is_opt_in(gpu, orc, monkeypatch):
+    """Round 5, PLLHIP_AA_TI_MFMA=1 (default off): the ONE mat-vec of a tip-inner op of the whole-list
+    kernel on the matrix cores (fused chains) instead of the vector unit in the reference's non-fused order
+    (core_partials_avx.c:1229-1284).  The opt-in path is NOT bit-exact: tip-inner CLVs -- and everything above them --
+    agree with the default path's (= the reference's) to 1e-13 relative on a 150-tip ladder (errors of ~1e-16 per op,
+    carried up the tree), the scale buffers are equal here (an entry within that distance of 2^-256 could differ), lnL
+    to 1e-12.  The default path stays what tests/test_gpu_aa_whole_list.py pins everywhere else: the oracle's bits."""
+    from helpers import make_case, build_partition, bits_equal, rel_err
+    from libpll_amd.pllapi import ATTRIB_PATTERN_TIP
+    monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
+    monkeypatch.setenv("PLLHIP_FUSED", "2")
+    for shape, tips, sites in (("caterpillar", 150, 700), ("random", 60, 2100)):
+        case = make_case(20, shape, tips, sites, seed=tips)
+        case["rates"], case["freqs"] = gpu.aa_model("lg")
+        plan, R = case["plan"], case["rate_cats"]
+        out = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("PLLHIP_AA_TI_MFMA", flag)
+            p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+            p.update_partials(plan.ops)
+            lnl, ps = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
+            clvs = [p.get_clv(int(op["parent_clv_index"])) for op in plan.ops[::7]]
+            scs = [p.get_scaler(int(op["parent_scaler_index"])) for op in plan.ops]
+            out[flag] = (lnl, ps, clvs, scs)
+            p.destroy()
+        a, b = out["0"], out["1"]
+        assert any(not bits_equal(x, y) for x, y in zip(a[2], b[2])), "the opt-in path should differ in the last bits"
+        for x, y in zip(a[2], b[2]):
+            assert rel_err(y, x) < 1e-13
+        for x, y in zip(a[3], b[3]):
+            assert (x == y).all()
+        assert rel_err(b[1], a[1]) < 1e-11 and abs(b[0] - a[0]) <= 1e-12 * abs(a[0])
