@@ -396,7 +396,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   pllhip_rep_work_free(c);
   pllhip_level_cache_free(c);
   for (pllhip_ctx::node_rows & r : c->rows)
-    for (void * p : {(void *)r.site_id, (void *)r.lrow, (void *)r.rrow})
+    for (void * p : {(void *)r.site_id, (void *)r.perm, (void *)r.perm_class, (void *)r.lrow, (void *)r.rrow})
       if (p) (void)hipFree(p);
   if (c->h_result) (void)hipHostFree(c->h_result);
   if (c->h_partials) (void)hipHostFree(c->h_partials);

@@ -168,6 +168,8 @@ struct pllhip_ctx
   {
     unsigned int classes = 0;
     unsigned int * site_id = nullptr; // [sites + slack]
+    unsigned int * perm = nullptr;    // [sites]: the sites in class order (what a parent's identification starts from)
+    unsigned int * perm_class = nullptr; // [sites]: the class of perm[i] (read in order instead of gathered from site_id)
     unsigned int * lrow = nullptr;    // [classes + slack]
     unsigned int * rrow = nullptr;
     size_t row_cap = 0;
@@ -351,6 +353,15 @@ struct PartialsArgs
 // element, so that a wave working on the last (partial) round of 64 sites may load
 // unconditionally and unclamped; what it computes there is masked out of every result.
 #define PLLHIP_TAIL_SITES 64
+
+// one turn of a host spin loop (the bounded polls of host-mapped result words)
+#if defined(__x86_64__) || defined(__i386__)
+#define PLLHIP_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define PLLHIP_CPU_RELAX() asm volatile("yield" ::: "memory")
+#else
+#define PLLHIP_CPU_RELAX() asm volatile("" ::: "memory")
+#endif
 #define PLLHIP_TILE_COUNTER_BYTES (256 * 128)
 
 #define PLLHIP_BATCH_MAX 24

@@ -153,13 +153,7 @@ __global__ __launch_bounds__(256) void k_final_sum(ReduceOut ro, unsigned int np
 // kernel).  The spin is for the short kernels behind a result-returning call (a 15 us derivative kernel, a 50 us
 // lnL kernel: the stream wait costs 6 us more than the spin); after 200 us -- a long kernel, a profiler in
 // between, memory that is not coherent after all -- the stream's own completion is waited for, as before round 3.
-#if defined(__x86_64__) || defined(__i386__)
-#define PLLHIP_CPU_RELAX() __builtin_ia32_pause()
-#elif defined(__aarch64__)
-#define PLLHIP_CPU_RELAX() asm volatile("yield" ::: "memory")
-#else
-#define PLLHIP_CPU_RELAX() asm volatile("" ::: "memory")
-#endif
+// (PLLHIP_CPU_RELAX: ctx.hpp)
 int pllhip_result_wait_host(pllhip_ctx * c, const ReduceOut & ro, bool stream_work_follows)
 {
   const bool hostsum = ro.host_partials != nullptr;

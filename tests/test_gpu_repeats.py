@@ -274,3 +274,44 @@ def test_repeats_with_invariant_sites_and_weights(gpu, monkeypatch, states):
         p.destroy()
     a, b = res
     assert a[0] == b[0] and bits_equal(a[1], b[1]) and bits_equal(a[2], b[2]) and a[3] == b[3]
+
+
+@pytest.mark.parametrize("tips,sites", [(16, 70), (16, 700), (16, 140_000), (64, 600_000)])
+def test_identification_on_every_sort_path(gpu, tips, sites):
+    """repeats.hip sorts (row at the major child, row at the minor child) keys: a merge sort up to 2^17 sites, Onesweep
+    above; 32-bit keys while both parts fit, 64-bit beyond (both children above 2^16 rows: the 600 k case); class
+    numbers from per-wave head counts whose prefixes take one pass up to 2^19 sites and a carry beyond.  Whatever the
+    path, every observable equals the plain partition's."""
+    case = make_case(4, "balanced", tips, sites, rate_cats=4, seed=sites)
+    rng = np.random.default_rng(sites)
+    pool = rng.integers(0, sites, size=sites // 6 + 1)
+    pick = pool[rng.integers(0, len(pool), size=sites)]
+    case["seqs"] = [bytes(np.frombuffer(s, dtype=np.uint8)[pick]) for s in case["seqs"]]
+    plan = case["plan"]
+    plain = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+    rep = build_partition(gpu, case, ATTRIB_PATTERN_TIP | ATTRIB_SITE_REPEATS)
+    a, b = evaluate(plain, plan, 4), evaluate(rep, plan, 4)
+    rows = {int(op["parent_clv_index"]): rep.repeats_classes(int(op["parent_clv_index"])) for op in plan.ops}
+    assert sum(1 for r in rows.values() if r) >= len(plan.ops) // 2, rows
+    if sites == 600_000:
+        top = plan.ops[-1]
+        assert min(rows[int(top["child1_clv_index"])], rows[int(top["child2_clv_index"])]) > 65536, rows
+    assert a[0] == b[0] and bits_equal(a[1], b[1])
+    assert bits_equal(a[2], b[2]) and a[3] == b[3]
+    for op in plan.ops[-3:]:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        assert bits_equal(plain.get_clv(node), rep.get_clv(node)), "CLV %d" % node
+        if sc >= 0:
+            assert (plain.get_scaler(sc) == rep.get_scaler(sc)).all(), "scaler %d" % sc
+    # a subtree swap below the root: the classes of the ops above it are identified again, from the kept orders
+    ops = plan.ops.copy()
+    i, j = len(ops) - 3, len(ops) - 2
+    for f in ("child2_clv_index", "child2_matrix_index", "child2_scaler_index"):
+        ops[i][f], ops[j][f] = ops[j][f], ops[i][f]
+    for p in (plain, rep):
+        p.update_partials(ops[-3:])
+    la = plain.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
+    lb = rep.compute_edge_loglikelihood(*plan.root_edge, [0] * 4, persite=True)
+    assert la[0] == lb[0] and bits_equal(la[1], lb[1]) and la[0] != a[0]
+    plain.destroy()
+    rep.destroy()
