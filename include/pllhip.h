@@ -169,6 +169,13 @@ PLLHIP_EXPORT unsigned int pllhip_fused_segments_dry(unsigned int tips, unsigned
                                                      const pllhip_op_t * ops, unsigned int count,
                                                      unsigned int max_segments, unsigned int * seg_out);
 
+/* Environment switches (round 5).  1: `name` is one of the switches a client may set (INTEGRATION.md section 6 lists
+ * them), read as it stands; 0: a developer's knob -- tile shapes, grid caps, experiments -- which the library reads
+ * only under PLLHIP_DEVELOPER=1, so that a stray variable cannot move a production run off the tested configuration. */
+PLLHIP_EXPORT int pllhip_env_is_user_switch(const char * name);
+/* 1: `name` is set in the environment and the library would act on it right now; 0: unset, or ignored. */
+PLLHIP_EXPORT int pllhip_env_is_honoured(const char * name);
+
 /* Host logic, no device: which path a partition below 16,384 sites takes for this op list (4 or 20 states) -- 1: the
  * whole-list kernel, 0: the per-level launches, -1: an index out of range -- and, if the pointers are not NULL, the
  * two estimated times in microseconds (partials.hip: a launch per dependency level and op kind plus the bytes, against

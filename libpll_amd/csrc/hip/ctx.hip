@@ -36,6 +36,47 @@ void pllhip_set_error(const char * fmt, ...)
 
 extern "C" const char * pllhip_last_error(void) { return g_err; }
 
+// the switches a client may set (everything else: PLLHIP_DEVELOPER=1)
+static const char * const pllhip_user_switches[] = {
+  "PLLHIP_AA_EXACT",         // 20 states: the bit-exact vector kernels everywhere (no matrix cores, no whole-list kernel)
+  "PLLHIP_AA_TI_MFMA",       // 20 states, opt-in: tip-inner mat-vecs of the whole-list kernel on the matrix cores
+  "PLLHIP_FUSED",            // 0: one launch per tree level instead of the whole-list kernels
+  "PLLHIP_HOSTSUM",          // 0: workgroup sums added on the device (k_final_sum / tickets) instead of by the host
+  "PLLHIP_FUSE_REDUCE",      // 0 / 1: force the ticketed in-kernel final sum off / on
+  "PLLHIP_SPIN",             // 0: wait for the stream instead of polling host-mapped result words
+  "PLLHIP_SHARD_THREADS",    // 0: a sharded partition is driven by the calling thread alone
+  "PLLHIP_SHARD_POLL",       // 0: a sharded partition waits for its shards' streams one after another
+  "PLLHIP_FUSED_DEBUG",      // diagnostics on stderr
+  "PLLHIP_RCCL_DEBUG",       // diagnostics on stderr
+  "PLLHIP_DEVELOPER",
+};
+
+const char * pllhip_env(const char * name)
+{
+  for (const char * u : pllhip_user_switches)
+    if (!strcmp(u, name)) return getenv(name);
+  const char * dev = getenv("PLLHIP_DEVELOPER");
+  if (dev && atoi(dev) != 0) return getenv(name);
+  static bool said = false;
+  if (!said && getenv(name))
+  {
+    said = true;
+    fprintf(stderr, "libpll_amd: %s is a developer's switch and is ignored without PLLHIP_DEVELOPER=1\n", name);
+  }
+  return nullptr;
+}
+
+// what the library sees of a variable right now: 1 set and honoured, 0 unset or ignored (tests/test_host.py)
+extern "C" int pllhip_env_is_honoured(const char * name) { return pllhip_env(name) != nullptr; }
+
+// 1: the variable is read as it stands; 0: only under PLLHIP_DEVELOPER=1 (tests/test_host.py)
+extern "C" int pllhip_env_is_user_switch(const char * name)
+{
+  for (const char * u : pllhip_user_switches)
+    if (!strcmp(u, name)) return 1;
+  return 0;
+}
+
 extern "C" int pllhip_device_count(int * count)
 {
   int n = 0;
@@ -81,7 +122,7 @@ static void pllhip_fence_mark(void * flag)
 
 static void pllhip_stream_quiesce(hipStream_t stream)
 {
-  static const bool off = getenv("PLLHIP_QUIESCE") && atoi(getenv("PLLHIP_QUIESCE")) == 0; // (A/B of the crash hunt)
+  static const bool off = pllhip_env("PLLHIP_QUIESCE") && atoi(pllhip_env("PLLHIP_QUIESCE")) == 0; // (A/B of the crash hunt)
   (void)hipStreamSynchronize(stream);
   if (off) return;
   // (the flag must outlive a callback that fires after the timeout: leaked on that path only)
@@ -111,7 +152,7 @@ static void pllhip_stream_quiesce(hipStream_t stream)
 static void pllhip_exit_drain()
 {
   (void)hipDeviceSynchronize();
-  if (const char * e = getenv("PLLHIP_EXIT_GRACE_US")) // (experiment knob of the crash hunt)
+  if (const char * e = pllhip_env("PLLHIP_EXIT_GRACE_US")) // (experiment knob of the crash hunt)
     if (atoi(e) > 0) usleep((useconds_t)atoi(e));
 }
 
@@ -155,20 +196,20 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, shape->device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char * e = getenv("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
-  if (const char * e = getenv("PLLHIP_AA_TI_MFMA")) c->aa_ti_mfma = atoi(e) != 0;
-  if (const char * e = getenv("PLLHIP_SPIN")) c->no_spin = atoi(e) == 0;
-  if (const char * e = getenv("PLLHIP_HOSTSUM")) c->no_hostsum = atoi(e) == 0;
-  if (const char * e = getenv("PLLHIP_FUSE_REDUCE")) c->fuse_forced = atoi(e) ? 1 : 0;
-  if (const char * e = getenv("PLLHIP_FUSE_MAX_GRID")) c->fuse_max_grid = (unsigned int)atoi(e);
-  if (const char * e = getenv("PLLHIP_NT")) c->nt_override = atoi(e); // 0 / 1; 2: the whole-list kernel's counts too
-  if (const char * e = getenv("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
-  if (const char * e = getenv("PLLHIP_FUSED"))
+  if (const char * e = pllhip_env("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
+  if (const char * e = pllhip_env("PLLHIP_AA_TI_MFMA")) c->aa_ti_mfma = atoi(e) != 0;
+  if (const char * e = pllhip_env("PLLHIP_SPIN")) c->no_spin = atoi(e) == 0;
+  if (const char * e = pllhip_env("PLLHIP_HOSTSUM")) c->no_hostsum = atoi(e) == 0;
+  if (const char * e = pllhip_env("PLLHIP_FUSE_REDUCE")) c->fuse_forced = atoi(e) ? 1 : 0;
+  if (const char * e = pllhip_env("PLLHIP_FUSE_MAX_GRID")) c->fuse_max_grid = (unsigned int)atoi(e);
+  if (const char * e = pllhip_env("PLLHIP_NT")) c->nt_override = atoi(e); // 0 / 1; 2: the whole-list kernel's counts too
+  if (const char * e = pllhip_env("PLLHIP_NO_BATCH")) c->no_batch = atoi(e) != 0;
+  if (const char * e = pllhip_env("PLLHIP_FUSED"))
   {
     c->no_fused = atoi(e) == 0;
     c->force_fused = atoi(e) == 2;
   }
-  if (const char * e = getenv("PLLHIP_BLOCKS_PER_CU"))
+  if (const char * e = pllhip_env("PLLHIP_BLOCKS_PER_CU"))
     if (atoi(e) > 0) c->blocks_per_cu = atoi(e);
 
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -303,7 +344,7 @@ static int rccl_load()
     snprintf(g_rccl_path, sizeof(g_rccl_path), "%s (%s)", info.dli_fname, how);
   else
     snprintf(g_rccl_path, sizeof(g_rccl_path), "? (%s)", how);
-  if (getenv("PLLHIP_RCCL_DEBUG")) fprintf(stderr, "pllhip: RCCL bound to %s\n", g_rccl_path);
+  if (pllhip_env("PLLHIP_RCCL_DEBUG")) fprintf(stderr, "pllhip: RCCL bound to %s\n", g_rccl_path);
   g_rccl.handle = h;
   return 0;
 }
@@ -406,7 +447,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
-  if (const char * e = getenv("PLLHIP_DESTROY_GRACE_US"))
+  if (const char * e = pllhip_env("PLLHIP_DESTROY_GRACE_US"))
     if (atoi(e) > 0) usleep((useconds_t)atoi(e));
 }
 

@@ -212,6 +212,13 @@ struct pllhip_prof_scope
 
 void pllhip_set_error(const char * fmt, ...);
 
+// Environment switches.  The ones a client may rely on are the table in ctx.hip (pllhip_user_switches; INTEGRATION.md
+// section 6 documents each one); every other PLLHIP_* variable is a developer's knob -- tile shapes, grid caps,
+// experiments whose A/B results are in DESIGN.md -- and is read only under PLLHIP_DEVELOPER=1: a stray variable cannot
+// move a production run off the configuration the test suite covers, and the library says so once on stderr when it
+// ignores one.  (forty switches, each a configuration nobody crosses with the others.)
+const char * pllhip_env(const char * name);
+
 // Run `expr` on every shard of a group context and return (inside `expr`: s = the shard, lo =
 // its first site within the group); falls through for an ordinary context.
 // (A call on a group visits every device of the group; the caller's current device is put back

@@ -748,7 +748,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     // sum 512 values instead of 1954 and the launch less to dispatch: 33.9 -> 28.8 us per call at
     // 500 k sites; PLLHIP_DERIV_GRID for measurements)
     {
-      const char * e = getenv("PLLHIP_DERIV_GRID");
+      const char * e = pllhip_env("PLLHIP_DERIV_GRID");
       const unsigned int cap = e && atoi(e) > 0 ? (unsigned int)atoi(e) : (unsigned int)c->num_cus * 2;
       if (grid > cap) grid = cap;
     }
@@ -758,7 +758,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     // nothing will touch again)
     const size_t table_bytes = (size_t)c->sh.sites * R * S * sizeof(double);
     bool nt = pllhip_use_nt(c) && table_bytes > ((size_t)128 << 20);
-    if (const char * e = getenv("PLLHIP_DERIV_NT")) nt = atoi(e) != 0; // (measurements)
+    if (const char * e = pllhip_env("PLLHIP_DERIV_NT")) nt = atoi(e) != 0; // (measurements)
 #define DERIV_DNA(RCV)                                                        \
     do {                                                                      \
       if (nt) k_derivatives_dna<RCV, true><<<grid, 256, 0, c->stream>>>(a);   \
@@ -777,7 +777,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     const size_t tiles = ((size_t)a.sites + 15) / 16;
     size_t blocks = (tiles + 3) / 4;
-    const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 3; // 47 KB of LDS per workgroup (env: tests)
+    const size_t cap = pllhip_env("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(pllhip_env("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 3; // 47 KB of LDS per workgroup (env: tests)
     if (blocks > cap) blocks = cap;
     grid = (unsigned int)blocks;
     a.reduce = pllhip_reduce_out(c, grid, 2);
@@ -804,7 +804,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
     const size_t region = rc == 4 ? aa_geom<4>::REGION_B : (rc == 2 ? aa_geom<2>::REGION_B : aa_geom<1>::REGION_B);
     const size_t lds = (size_t)R * 102 * sizeof(double) + 4 * region;
     const size_t per_cu = lds <= 48 * 1024 ? 3 : (lds <= 76 * 1024 ? 2 : 1);
-    const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * per_cu;
+    const size_t cap = pllhip_env("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(pllhip_env("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * per_cu;
     if (blocks > cap) blocks = cap;
     grid = (unsigned int)blocks;
     a.reduce = pllhip_reduce_out(c, grid, 2);

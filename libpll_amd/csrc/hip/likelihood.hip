@@ -1040,7 +1040,7 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
     // k_final_sum launch followed every call -- BASELINE config 4 whole on one GPU, 31,250 workgroups; the waves
     // then walk several rounds each.  PLLHIP_LNL_GRID: measurements.
     {
-      const char * e = getenv("PLLHIP_LNL_GRID");
+      const char * e = pllhip_env("PLLHIP_LNL_GRID");
       const unsigned int cap = e && atoi(e) > 0 ? (unsigned int)atoi(e) : (unsigned int)PLLHIP_HOSTSUM_MAX;
       if (grid > cap) grid = cap;
     }

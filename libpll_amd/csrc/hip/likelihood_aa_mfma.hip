@@ -249,7 +249,7 @@ static int launch_lnl_rc(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int * g
   using G = aa_geom<RC>;
   const size_t tiles = ((size_t)a.sites + 15) / 16;
   size_t blocks = (tiles + 3) / 4;
-  const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per wave)
+  const size_t cap = pllhip_env("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(pllhip_env("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per wave)
   if (blocks > cap) blocks = cap;
   const size_t head = (kind == EDGE_II) ? (size_t)RC * 400
                                         : (kind == EDGE_TI ? (size_t)a.maxstates * RC * 20 : 0);
@@ -456,7 +456,7 @@ static int launch_lnl_chunks(pllhip_ctx * c, LnlArgs & a, int kind, unsigned int
   if (lds > 150 * 1024) return 1;
   // (two workgroups per CU while their LDS allows)
   const size_t per_cu = lds <= 80 * 1024 ? 2 : 1;
-  const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * per_cu;
+  const size_t cap = pllhip_env("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(pllhip_env("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * per_cu;
   if (blocks > cap) blocks = cap;
   const bool nt = pllhip_use_nt(c);
   const dim3 grid((unsigned int)blocks), block(256);

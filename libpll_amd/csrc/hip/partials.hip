@@ -681,7 +681,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // whole list vs per level: 8 k sites 74 vs 63 us, 16 k 78 vs 79, 24 k 84 vs 93, 33 k 100 vs 121,
   // 50 k 118 vs 164.  A property of the device -- tiles against SIMDs -- not a tuned number.)
   const size_t fused_tile_sites = (size_t)PLLHIP_FUSED_J * 64 / (2 * c->sh.rate_cats);
-  static const bool small_rule = !(getenv("PLLHIP_FUSED_SMALL") && atoi(getenv("PLLHIP_FUSED_SMALL")) == 0);
+  static const bool small_rule = !(pllhip_env("PLLHIP_FUSED_SMALL") && atoi(pllhip_env("PLLHIP_FUSED_SMALL")) == 0);
   const bool whole_list_kind = (dna_fast && (c->sh.rate_cats <= 4 || c->sh.rate_cats == 8)) || (aa_fast && c->sh.rate_cats == 4);
   // (asked only below the sizes from which the whole-list kernels always pay -- the two rules below, in THIS device's
   // compute units: 16,384 sites on an MI355X's 256; derived, not a constant of its own, so that no size falls
@@ -700,7 +700,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // round 3 they lost -- 3 ops 260 vs 200 us -- to the tile counter, not to their reloads: see the kernel.)
   if (dna_fast && (c->sh.rate_cats <= 4 || c->sh.rate_cats == 8) && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
   {
-    if (c->fused_last_ops.size() == count && !getenv("PLLHIP_FUSED_DEBUG") &&
+    if (c->fused_last_ops.size() == count && !pllhip_env("PLLHIP_FUSED_DEBUG") &&
         c->fused_last_epoch == c->layout_epoch &&
         memcmp(c->fused_last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
     {
@@ -723,13 +723,13 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     // written together with their CLV -- runs per level.
     const FusedGeom geom = {c->clv.size(), c->sh.scale_buffers, c->sh.tips, c->sh.pattern_tip != 0};
     // (PLLHIP_FUSED_WGS=2: the 8-wave, 7-slot configuration at once -- tests run both)
-    const unsigned int first_wgs = getenv("PLLHIP_FUSED_WGS") && atoi(getenv("PLLHIP_FUSED_WGS")) == 2 ? 2u : 3u;
+    const unsigned int first_wgs = pllhip_env("PLLHIP_FUSED_WGS") && atoi(pllhip_env("PLLHIP_FUSED_WGS")) == 2 ? 2u : 3u;
     // Round 5: independent sub-lists (the two sides of the root edge of a full traversal) as SEGMENTS of one launch
     // -- (tile, segment) work items -- while the tiles alone do not fill the chip's wave slots eight times over:
     // below that a launch's time is quantised by rounds of the list's length (partials_fused.hpp).
     // PLLHIP_FUSED_SEGMENTS=0 / n: never / up to n whatever the size.
     unsigned int max_segs = (size_t)c->sh.sites / fused_tile_sites < (size_t)c->num_cus * 12 * 8 ? PLLHIP_FUSED_MAX_SEGS : 1u;
-    if (const char * e = getenv("PLLHIP_FUSED_SEGMENTS")) max_segs = (unsigned int)std::max(1, atoi(e));
+    if (const char * e = pllhip_env("PLLHIP_FUSED_SEGMENTS")) max_segs = (unsigned int)std::max(1, atoi(e));
     std::vector<unsigned int> seg_of;
     unsigned int nsegs = pllhip_fused_segments(geom, ops, count, max_segs, seg_of);
     std::vector<std::vector<FusedOp>> fplans;

@@ -1071,16 +1071,16 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
   else HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
   const size_t tiles = (((size_t)c->sh.sites + AF_WGS - 1) / AF_WGS) * k.nsegs; // (work items: (tile, segment) pairs)
   size_t grid = tiles;
-  const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per workgroup)
+  const size_t cap = pllhip_env("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(pllhip_env("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // (tests: many tiles per workgroup)
   if (grid > cap) grid = cap;
   const size_t rounds = tiles / grid;
-  const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
+  const unsigned int dynamic_rounds = pllhip_env("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(pllhip_env("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                                                             : (unsigned int)std::max<size_t>(2, rounds / 3);
   const unsigned int static_rounds = rounds > dynamic_rounds ? (unsigned int)(rounds - dynamic_rounds) : 1u;
-  unsigned int * counter = getenv("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
+  unsigned int * counter = pllhip_env("PLLHIP_FUSED_STATIC_TILES") ? nullptr : c->d_tile_counter;
 #ifdef PLLHIP_AF_TIMING
   {
-    const unsigned int m = getenv("PLLHIP_AF_EXP") ? (unsigned int)atoi(getenv("PLLHIP_AF_EXP")) : 0u;
+    const unsigned int m = pllhip_env("PLLHIP_AF_EXP") ? (unsigned int)atoi(pllhip_env("PLLHIP_AF_EXP")) : 0u;
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(af_exp_mask), &m, sizeof(m), 0, hipMemcpyHostToDevice, c->stream));
   }
 #endif
@@ -1126,7 +1126,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   if (!c->aa_fused) c->aa_fused = new pllhip_aa_fused_cache();
   pllhip_aa_fused_cache & k = *c->aa_fused;
   // (PLLHIP_FUSED_DEBUG=3: where the host's time goes when a list is new)
-  const bool host_times = getenv("PLLHIP_FUSED_DEBUG") && atoi(getenv("PLLHIP_FUSED_DEBUG")) == 3;
+  const bool host_times = pllhip_env("PLLHIP_FUSED_DEBUG") && atoi(pllhip_env("PLLHIP_FUSED_DEBUG")) == 3;
   auto t_host = std::chrono::steady_clock::now();
   auto lap = [&](const char * what) {
     if (!host_times) return;
@@ -1135,7 +1135,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     t_host = now;
   };
   if (k.last_ops.size() == count && k.epoch == c->layout_epoch && k.maxstates == c->maxstates &&
-      !getenv("PLLHIP_FUSED_DEBUG") && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
+      !pllhip_env("PLLHIP_FUSED_DEBUG") && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
     return aa_fused_launch(c, false);
   k.last_ops.clear();
 
@@ -1159,7 +1159,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   // edges): a list with no or one operand reloaded from HBM gains 4-5 % (2.09-2.11 against 2.19 ms), the two
   // lists with three reloads lose 10 % (2.47 against 2.25) -- so a list with more than one reload is planned again
   // with the tip-tip ops ahead of it (a rule from five lists, not a law).  PLLHIP_AA_TT_INSIDE=0 / 1: never / always.
-  const char * tt_env = getenv("PLLHIP_AA_TT_INSIDE");
+  const char * tt_env = pllhip_env("PLLHIP_AA_TT_INSIDE");
   const bool tt_inside = c->sh.pattern_tip && (tt_env ? atoi(tt_env) != 0 : tt_wanted);
   for (unsigned int i = 0; i < count; ++i)
   {
@@ -1230,7 +1230,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   // not fill the device's workgroup slots eight times over (partials_fused.hpp); PLLHIP_FUSED_SEGMENTS=0 / n: never /
   // up to n whatever the size.
   unsigned int max_segs = ((size_t)c->sh.sites + AF_WGS - 1) / AF_WGS < (size_t)c->num_cus * 2 * 8 ? PLLHIP_FUSED_MAX_SEGS : 1u;
-  if (const char * e = getenv("PLLHIP_FUSED_SEGMENTS")) max_segs = (unsigned int)std::max(1, atoi(e));
+  if (const char * e = pllhip_env("PLLHIP_FUSED_SEGMENTS")) max_segs = (unsigned int)std::max(1, atoi(e));
   std::vector<unsigned int> seg_of, seg_first, seg_n;
   const unsigned int nsegs = pllhip_fused_segments(geom, rops.data(), n, max_segs, seg_of);
   int rc = 0;
@@ -1300,7 +1300,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   std::vector<AaLookupTables> tabs(k.lk_ops.size());
   // (round 4: the tables are made by k_af_prepare, AaLookupJob; PLLHIP_AA_LOOKUP_DIRECT=0: by launches of the
   // tabulating kernels ahead of it, as in round 3)
-  const bool lk_direct = !(getenv("PLLHIP_AA_LOOKUP_DIRECT") && atoi(getenv("PLLHIP_AA_LOOKUP_DIRECT")) == 0);
+  const bool lk_direct = !(pllhip_env("PLLHIP_AA_LOOKUP_DIRECT") && atoi(pllhip_env("PLLHIP_AA_LOOKUP_DIRECT")) == 0);
   std::vector<AaLookupJob> lj(lk_direct ? 2 * k.lk_ops.size() : 0);
   if (!k.lk_ops.empty())
   {
@@ -1321,7 +1321,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   const size_t tip_tab_b = (size_t)c->maxstates * 80 * sizeof(double);
   const size_t pair_tab_b = (size_t)c->maxstates * tip_tab_b;
   // (the pool of the pair tables shares the lookup tables' budget: what the lookups of this list left of it)
-  const bool pairs_on = !(getenv("PLLHIP_AA_TT_PAIRS") && atoi(getenv("PLLHIP_AA_TT_PAIRS")) == 0);
+  const bool pairs_on = !(pllhip_env("PLLHIP_AA_TT_PAIRS") && atoi(pllhip_env("PLLHIP_AA_TT_PAIRS")) == 0);
   const size_t lookup_tab_b = 4 * ((size_t)c->maxstates * c->maxstates + PLLHIP_TAIL_SITES) * 80 * sizeof(double);
   const size_t pair_budget_b = !pairs_on ? 0 : (size_t)(lookups_max > lookups ? lookups_max - lookups : 0) * lookup_tab_b;
   const unsigned long long zero_row = (unsigned long long)(uintptr_t)c->fused_zero_row;
@@ -1529,7 +1529,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   k.nmat = (unsigned int)mj.size();
   k.ntip = (unsigned int)tj.size();
   k.nops = n;
-  if (getenv("PLLHIP_FUSED_DEBUG"))
+  if (pllhip_env("PLLHIP_FUSED_DEBUG"))
   {
     fprintf(stderr, "pllhip 20-state list kernel: %u ops = %zu tip-tip ahead + %zu tip-tip in the list + %zu lookups + %zu on the matrix cores "
                     "(%u of them behind a lookup: a barrier more), %u operands reloaded, %u segment(s)\n",

@@ -483,7 +483,7 @@ static int launch_rc(pllhip_ctx * c, const PartialsBatch & b, unsigned int count
   size_t blocks = (tiles + wpb - 1) / wpb;
   // the P-matrix staging per workgroup is amortised over several tiles per wave
   // (PLLHIP_AA_GRID_CAP: tests make every wave walk many tiles of a small partition)
-  const size_t cap = getenv("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(getenv("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2;
+  const size_t cap = pllhip_env("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(pllhip_env("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2;
   if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned int)blocks, count), block(64 * wpb);
   const size_t lds = fixed + wpb * (size_t)G::REGION_B;
@@ -650,8 +650,8 @@ __global__ __launch_bounds__(256) void k_aa_cherry_rounds(CherryBatch batch)
 
 bool pllhip_aa_chunks_enabled()
 {
-  static const bool on = !(getenv("PLLHIP_AA_CHUNKS") && atoi(getenv("PLLHIP_AA_CHUNKS")) == 0) &&
-                         !(getenv("PLLHIP_AA_RC8") && atoi(getenv("PLLHIP_AA_RC8")) == 0);
+  static const bool on = !(pllhip_env("PLLHIP_AA_CHUNKS") && atoi(pllhip_env("PLLHIP_AA_CHUNKS")) == 0) &&
+                         !(pllhip_env("PLLHIP_AA_RC8") && atoi(pllhip_env("PLLHIP_AA_RC8")) == 0);
   return on;
 }
 
@@ -832,7 +832,7 @@ static int launch_ti_with_tables(pllhip_ctx * c, const PartialsBatch & b, unsign
 // (characters and matrices are taken from them).  mode: SCALE_NONE or SCALE_SITE.
 bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode)
 {
-  const char * e = getenv("PLLHIP_AA_CHERRY"); // 0: never, 2: whatever the partition's size (tests)
+  const char * e = pllhip_env("PLLHIP_AA_CHERRY"); // 0: never, 2: whatever the partition's size (tests)
   const bool off = e && atoi(e) == 0;
   return !off && !c->cherry_pool_failed && c->sh.states == 20 && (c->sh.rate_cats == 1 || c->sh.rate_cats == 2 || c->sh.rate_cats == 4) && pllhip_aa_fast_covers(c, 0) && pllhip_aa_fast_covers(c, 2) &&
          c->rows.empty() && mode != SCALE_RATE && c->maxstates >= 1 && c->maxstates <= 32 && !c->sh.asc_states;
@@ -841,7 +841,7 @@ bool pllhip_aa_cherry_covers(const pllhip_ctx * c, int mode)
 // Do `lookups` lookup ops on `levels` tree levels pay for their tables?  (partials.hip: the model)
 bool pllhip_aa_cherry_pays(const pllhip_ctx * c, unsigned int lookups, unsigned int levels)
 {
-  const char * e = getenv("PLLHIP_AA_CHERRY");
+  const char * e = pllhip_env("PLLHIP_AA_CHERRY");
   if (e && atoi(e) == 2) return true;
   const double saved_us = (double)lookups * c->sh.sites * (1932.0 - 646.0) / 5.5e6; // bytes / (bytes per us)
   const double cost_us = 8.0 * 6.0 * levels;
@@ -1069,7 +1069,7 @@ unsigned int pllhip_aa_lookup_budget(const pllhip_ctx * c)
   const size_t rows = (size_t)c->maxstates * c->maxstates + PLLHIP_TAIL_SITES;
   const size_t per_op = 4 * rows * (size_t)c->sh.rate_cats * 20 * sizeof(double);
   size_t budget = (size_t)1 << 30;
-  if (const char * e = getenv("PLLHIP_AA_LOOKUP_MB"))
+  if (const char * e = pllhip_env("PLLHIP_AA_LOOKUP_MB"))
     if (atoi(e) >= 0) budget = (size_t)atoi(e) << 20;
   const size_t share = c->clv_arena_bytes / 16 + ((size_t)64 << 20);
   if (budget > share) budget = share;

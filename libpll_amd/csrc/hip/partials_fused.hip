@@ -1013,10 +1013,10 @@ int pllhip_fused_plan(const FusedGeom & geom, const pllhip_op_t * ops, const Par
 
   const int rc = assign_slots_reload(geom, ops, args, kinds, count, nslots, order, pos_of, node, plan, reloads_out, &pool);
   if (rc) return rc;
-  if (getenv("PLLHIP_FUSED_DEBUG"))
+  if (pllhip_env("PLLHIP_FUSED_DEBUG"))
   {
     fprintf(stderr, "pllhip fused plan: %u ops, %u slots, %u operands reloaded from HBM\n", count, nslots, *reloads_out);
-    if (atoi(getenv("PLLHIP_FUSED_DEBUG")) > 1)
+    if (atoi(pllhip_env("PLLHIP_FUSED_DEBUG")) > 1)
       for (unsigned int pos = 0; pos < count; ++pos)
       {
         const FusedOp & f = plan[pos];
@@ -1103,7 +1103,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
-  const bool static_tiles = getenv("PLLHIP_FUSED_STATIC_TILES") != nullptr;
+  const bool static_tiles = pllhip_env("PLLHIP_FUSED_STATIC_TILES") != nullptr;
   // Partitions beyond 8 GB (CLVs + scale buffers): the counts are stored non-temporally like the
   // tiles (see the kernel).  8 GB is what the address-translation caches reach (4096 pages of
   // 2 MB): every shape ran at 0.59-0.64 of the HBM peak up to there and at 0.46-0.50 beyond
@@ -1126,7 +1126,7 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   // characters, not on the footprint of a launch (profiles/r3_footprint.txt).
   size_t block_sites = sites;
   {
-    const char * e = getenv("PLLHIP_FUSED_BLOCK_SITES");
+    const char * e = pllhip_env("PLLHIP_FUSED_BLOCK_SITES");
     if (e) block_sites = atoi(e) > 0 ? (size_t)atoi(e) : sites;
     block_sites = (block_sites + 255) / 256 * 256; // (whole tiles, whole rounds)
     if (block_sites > sites) block_sites = sites;
@@ -1142,11 +1142,11 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   unsigned int * const reset_tiles = static_tiles ? nullptr : c->d_tile_counter + (size_t)(c->tile_counter_phase ^ 1u) * (PLLHIP_TILE_COUNTER_BYTES / 4);
   c->tile_counter_phase ^= 1u;
   const size_t rounds = btiles * nsegs / (bgrid * 4);
-  const unsigned int dynamic_rounds = getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(getenv("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
+  const unsigned int dynamic_rounds = pllhip_env("PLLHIP_FUSED_DYNAMIC_ROUNDS") ? (unsigned int)atoi(pllhip_env("PLLHIP_FUSED_DYNAMIC_ROUNDS"))
                                       : (c->fused_last_longest >= 32 ? (unsigned int)std::max<size_t>(7, rounds / 3) : 2u);
   // (eight counters, or what PLLHIP_FUSED_TILE_GROUPS says -- but never more than there are groups of eight
   // workgroups, or a counter's tiles would have no takers; and no more than the counter buffer holds)
-  const size_t want_groups = getenv("PLLHIP_FUSED_TILE_GROUPS") ? (size_t)std::max(1, atoi(getenv("PLLHIP_FUSED_TILE_GROUPS"))) : 8;
+  const size_t want_groups = pllhip_env("PLLHIP_FUSED_TILE_GROUPS") ? (size_t)std::max(1, atoi(pllhip_env("PLLHIP_FUSED_TILE_GROUPS"))) : 8;
   const unsigned int tile_groups = (unsigned int)std::min<size_t>(std::min<size_t>(want_groups, PLLHIP_TILE_COUNTER_BYTES / 128),
                                                                   std::max<size_t>(1, bgrid / 8));
 #define LAUNCH_FUSED_ARGS (unsigned int)bgrid, 256, lds, c->stream>>>( \

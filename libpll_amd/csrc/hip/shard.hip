@@ -167,8 +167,8 @@ extern "C" int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int
   for (size_t b = 0; b < ordinary; b += per) lo.push_back(b);
   pllhip_ctx * g = new pllhip_ctx();
   // (read when the group is created, like every other switch)
-  g->shard_threads = !(getenv("PLLHIP_SHARD_THREADS") && atoi(getenv("PLLHIP_SHARD_THREADS")) == 0);
-  const bool shard_poll = !(getenv("PLLHIP_SHARD_POLL") && atoi(getenv("PLLHIP_SHARD_POLL")) == 0);
+  g->shard_threads = !(pllhip_env("PLLHIP_SHARD_THREADS") && atoi(pllhip_env("PLLHIP_SHARD_THREADS")) == 0);
+  const bool shard_poll = !(pllhip_env("PLLHIP_SHARD_POLL") && atoi(pllhip_env("PLLHIP_SHARD_POLL")) == 0);
   g->sh = *shape;
   g->sh.device = devices[0];
   g->span = (size_t)shape->states * shape->rate_cats;

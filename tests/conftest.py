@@ -15,6 +15,10 @@ import sys
 
 import pytest
 
+# tests set tile shapes, grid caps and the like to reach code paths at small sizes: developer's switches, which the
+# library honours only under this one (tests/test_host.py::test_developer_switches_are_gated)
+os.environ.setdefault("PLLHIP_DEVELOPER", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

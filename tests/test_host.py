@@ -623,3 +623,47 @@ def test_small_partition_path_choice(amd):
     bad = bal64.ops.copy()
     bad["child1_clv_index"][3] = 10 ** 6
     assert _small_choice(amd, 4, 2000, bal64, ops=bad)[0] == -1
+
+
+def test_developer_switches_are_gated(amd, monkeypatch):
+    """Environment switches (round 5): the ones a client may set are a short table in the library (ctx.hip) and in
+    INTEGRATION.md section 6; every other PLLHIP_* variable the sources read is a developer's knob, honoured only
+    under PLLHIP_DEVELOPER=1 -- a stray variable cannot move a production run off the tested configuration."""
+    lib = amd.lib
+    lib.pllhip_env_is_user_switch.argtypes = [C.c_char_p]
+    lib.pllhip_env_is_honoured.argtypes = [C.c_char_p]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    src = os.path.join(root, "libpll_amd", "csrc", "hip")
+    for name in os.listdir(src):
+        text = open(os.path.join(src, name)).read()
+        read |= set(re.findall(r'pllhip_env\("([A-Z_0-9]+)"', text))
+        # nothing in the device layer reads a PLLHIP_ variable past the gate
+        assert not [m for m in re.findall(r'[^_]getenv\("(PLLHIP_[A-Z_0-9]+)"', text) if m != "PLLHIP_DEVELOPER"], name
+    assert len(read) > 30
+    user = {n for n in read if lib.pllhip_env_is_user_switch(n.encode())}
+    assert user == {"PLLHIP_AA_EXACT", "PLLHIP_AA_TI_MFMA", "PLLHIP_FUSED", "PLLHIP_HOSTSUM", "PLLHIP_FUSE_REDUCE",
+                    "PLLHIP_SPIN", "PLLHIP_SHARD_THREADS", "PLLHIP_SHARD_POLL", "PLLHIP_FUSED_DEBUG",
+                    "PLLHIP_RCCL_DEBUG"}
+    # INTEGRATION.md: the first table holds the client's switches, the second every developer's one
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 6. Environment switches"):]
+    client, developer = sec.split("**Developer's switches")
+    in_client = set(re.findall(r"`(PLLHIP_[A-Z_0-9]+)", "\n".join(l for l in client.splitlines() if l.startswith("| `"))))
+    in_developer = set(re.findall(r"`(PLLHIP_[A-Z_0-9]+)", "\n".join(l for l in developer.splitlines() if l.startswith("| `"))))
+    assert in_client - {"PLLHIP_DEVELOPER"} == user
+    assert read - user <= in_developer, sorted(read - user - in_developer)
+    assert not (in_developer & user)
+    # the gate itself
+    dev = sorted(read - user)[0]
+    monkeypatch.setenv(dev, "1")
+    monkeypatch.setenv("PLLHIP_SPIN", "0")
+    monkeypatch.setenv("PLLHIP_DEVELOPER", "1")
+    assert lib.pllhip_env_is_honoured(dev.encode()) == 1 and lib.pllhip_env_is_honoured(b"PLLHIP_SPIN") == 1
+    monkeypatch.delenv("PLLHIP_DEVELOPER")
+    assert lib.pllhip_env_is_honoured(dev.encode()) == 0 and lib.pllhip_env_is_honoured(b"PLLHIP_SPIN") == 1
+    monkeypatch.setenv("PLLHIP_DEVELOPER", "0")
+    assert lib.pllhip_env_is_honoured(dev.encode()) == 0
+    monkeypatch.delenv(dev)
+    monkeypatch.setenv("PLLHIP_DEVELOPER", "1")
+    assert lib.pllhip_env_is_honoured(dev.encode()) == 0

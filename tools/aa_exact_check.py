@@ -2,6 +2,7 @@
 """developer tool: which 20-state ops of the DEFAULT (matrix-core) path are bit-identical to the oracle.
 Runs random / balanced / caterpillar trees with tips as characters and as CLVs, both scaling modes."""
 import os
+os.environ.setdefault("PLLHIP_DEVELOPER", "1")  # the switches set below are developer's ones (INTEGRATION.md section 6)
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -2,6 +2,7 @@
 """developer tool: the 20-state whole-list kernel (PLLHIP_FUSED=2) against the per-level launches
 (PLLHIP_FUSED=0) and the oracle: every CLV and scale buffer bit for bit."""
 import os
+os.environ.setdefault("PLLHIP_DEVELOPER", "1")  # the switches set below are developer's ones (INTEGRATION.md section 6)
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

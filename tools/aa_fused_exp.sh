@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # On the GPU box: the 20-state list kernel with parts switched off (tool build -DPLLHIP_AF_TIMING -DPLLHIP_AF_NOTICKS,
 # PLLHIP_AF_EXP bits: 1 no matrix-core products, 2 no stores, 4 no gathers, 8 no block staging, 16 no barriers):
 # what the time of an update is made of.  Results are wrong by construction.

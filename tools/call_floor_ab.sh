@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # On the GPU box: the floor of a result-returning call (C5 shape: 500 k sites, 200-taxon random tree): how the
 # sum is finished (PLLHIP_FUSE_REDUCE), how the host waits (PLLHIP_SPIN), the derivative kernel's grid and cache hint
 for env in "PLLHIP_SPIN=1 PLLHIP_FUSE_REDUCE=0" "PLLHIP_SPIN=1 PLLHIP_FUSE_REDUCE=0 PLLHIP_DERIV_NT=1" "PLLHIP_SPIN=1 PLLHIP_FUSE_REDUCE=0 PLLHIP_DERIV_GRID=1024" "PLLHIP_SPIN=1 PLLHIP_FUSE_REDUCE=0 PLLHIP_DERIV_GRID=512" \

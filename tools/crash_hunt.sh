@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # a crash of a reference test program seen once in a full test run: repeat it with a backtrace handler preloaded
 export PLLHIP_AA_EXACT=1
 n=0

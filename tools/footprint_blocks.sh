@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # On the GPU box: partitions beyond 32 GB (BASELINE config 4 whole on one GPU: 8 M sites x 128 taxa, 133 GB;
 # 2 M sites x 256 taxa, 67 GB) with the whole-list launch walking the alignment in blocks of sites.
 #   bash tools/footprint_blocks.sh          timings per block size

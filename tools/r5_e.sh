@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 mkdir -p gpurun_out/r5e
 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_api.py tests/test_gpu_core_api.py tests/test_gpu_thresholds.py -x -q -k "not full_size" > gpurun_out/r5e/tests.txt 2>&1; tail -3 gpurun_out/r5e/tests.txt
 bash tools/segments_ab.sh "20 12500" "20 25000" "20 50000" "20 100000" "20 200000" > gpurun_out/r5e/segments_ab_20.txt 2>&1; cat gpurun_out/r5e/segments_ab_20.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # 20 states x R rate categories (R != 1, 2, 4): chunk launches of the matrix-core kernels (default) against the
 # all-vector kernels (PLLHIP_AA_CHUNKS=0), three shapes, one box; then the kernel statistics of the first shape.
 # Run through gpurun from the repo root:  bash tools/rc8_ab.sh [R]

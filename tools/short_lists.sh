@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # On the GPU box: short op lists (partial traversals) at 1 M sites x 64 taxa -- per level, whole list with
 # one launch
 sites=${1:-1000000}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # BASELINE config 2's shape (and config 3's) at smaller site counts: where the fixed cost of a call shows.
 #   bash tools/size_sweep.sh
 for st in 4 20; do

@@ -4,6 +4,7 @@ written more than once) on 20-state partitions with a number of rate categories 
 launches of partials_aa_mfma.hip on the DEFAULT path -- against the oracle, CLVs and scaler counts bit for bit.
 python3 tools/soak_aa_chunks.py [first] [count]"""
 import os, sys
+os.environ.setdefault("PLLHIP_DEVELOPER", "1")  # the switches set below are developer's ones (INTEGRATION.md section 6)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 os.environ.pop("PLLHIP_AA_EXACT", None)

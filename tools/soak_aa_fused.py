@@ -5,6 +5,7 @@ changes, every CLV and scale buffer bitwise against the per-level launches (PLLH
 CLVs and counts the test suite pins to the oracle.
 python tools/soak_aa_fused.py [first seed] [count]"""
 import os, sys
+os.environ.setdefault("PLLHIP_DEVELOPER", "1")  # the switches set below are developer's ones (INTEGRATION.md section 6)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 os.environ["PLLHIP_AA_EXACT"] = "0"

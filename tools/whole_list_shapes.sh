@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # On the GPU box: the 4-state whole-list launch across the partition shapes of BASELINE configs 2, 4 (shard and
 # whole), 5 and a 256-taxon list: launch time, rate on the launch's own bytes, fraction of the 8 TB/s peak.
 line() { python3 -c "
