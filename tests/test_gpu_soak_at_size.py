@@ -69,3 +69,13 @@ def test_environment_switches_crossed(gpu, monkeypatch, states):
         assert rel_err(d, base[2]) < 1e-10, key
         for a, b in zip(scs, base[3]):
             assert (a == b).all(), "scale buffers under HOSTSUM=%s FUSED=%s AA_EXACT=%s" % key
+
+
+def test_repeat_identification_at_size(gpu, monkeypatch):
+    """Site-repeat classes (repeats.hip) at 100 k - 800 k sites, where the sort changes from a merge sort to Onesweep,
+    the keys from 32 to 64 bits and the prefix kernel starts to carry: 24 random trees / column pools, a partition with
+    the attribute bitwise against one without it, through two subtree swaps and a replaced tip
+    (tools/soak_repeats_at_size.py; profiles/r5_soak_repeats_at_size.log: 120 seeds)."""
+    monkeypatch.setenv("PLLHIP_AA_EXACT", "0")   # (20 states: the matrix-core kernels follow row maps; the tool sets it too)
+    import soak_repeats_at_size as soak
+    assert soak.run(31_000, 24, log=lambda *a: None, amd=gpu) == 0
