@@ -18,8 +18,8 @@
 // shape (profiles/r5_repeats_hash_ab.txt).  Where repeats pay there are few keys for many sites -- a million atomics
 // on a few hundred addresses -- and where they do not, a million atomics on a million random lines run at a
 // seventeenth of the streaming rate (MI355X_MICROARCH.md, global atomics); the radix sort streams.  Not kept.)
-// The class count goes back to the host (one 4-byte copy), which needs it to size the
-// launches and to decide whether the node is worth storing by class at all.
+// The class count goes back to the host (a tagged word in host-mapped memory, polled), which needs it to size the
+// launches and to decide whether the node is worth storing by class at all; nothing on the stream waits for that.
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
