@@ -175,6 +175,8 @@ PLLHIP_EXPORT unsigned int pllhip_fused_segments_dry(unsigned int tips, unsigned
 PLLHIP_EXPORT int pllhip_env_is_user_switch(const char * name);
 /* 1: `name` is set in the environment and the library would act on it right now; 0: unset, or ignored. */
 PLLHIP_EXPORT int pllhip_env_is_honoured(const char * name);
+/* PLLHIP_DEVELOPER is read once per process; this reads it again (for tests that change it). */
+PLLHIP_EXPORT void pllhip_env_reload(void);
 
 /* Host logic, no device: which path a partition below 16,384 sites takes for this op list (4 or 20 states) -- 1: the
  * whole-list kernel, 0: the per-level launches, -1: an index out of range -- and, if the pointers are not NULL, the

@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "ctx.hpp"
@@ -51,31 +52,49 @@ static const char * const pllhip_user_switches[] = {
   "PLLHIP_DEVELOPER",
 };
 
-const char * pllhip_env(const char * name)
+static bool pllhip_is_user_switch(const char * name)
 {
   for (const char * u : pllhip_user_switches)
-    if (!strcmp(u, name)) return getenv(name);
+    if (!strcmp(u, name)) return true;
+  return false;
+}
+
+// PLLHIP_DEVELOPER is read once (and again by pllhip_env_reload): a developer's switch costs one flag test per read in
+// a production run -- several are read per launch -- and the environment is searched for ignored ones only then.
+static int g_developer = -1;
+extern char ** environ;
+
+extern "C" void pllhip_env_reload(void)
+{
   const char * dev = getenv("PLLHIP_DEVELOPER");
-  if (dev && atoi(dev) != 0) return getenv(name);
+  const int on = dev && atoi(dev) != 0;
   static bool said = false;
-  if (!said && getenv(name))
-  {
-    said = true;
-    fprintf(stderr, "libpll_amd: %s is a developer's switch and is ignored without PLLHIP_DEVELOPER=1\n", name);
-  }
-  return nullptr;
+  if (!on && !said)
+    for (char ** e = environ; e && *e; ++e)
+    {
+      if (strncmp(*e, "PLLHIP_", 7)) continue;
+      const char * eq = strchr(*e, '=');
+      const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+      if (pllhip_is_user_switch(name.c_str())) continue;
+      said = true;
+      fprintf(stderr, "libpll_amd: %s is a developer's switch and is ignored without PLLHIP_DEVELOPER=1\n", name.c_str());
+      break;
+    }
+  g_developer = on;
+}
+
+const char * pllhip_env(const char * name)
+{
+  if (pllhip_is_user_switch(name)) return getenv(name);
+  if (g_developer < 0) pllhip_env_reload();
+  return g_developer ? getenv(name) : nullptr;
 }
 
 // what the library sees of a variable right now: 1 set and honoured, 0 unset or ignored (tests/test_host.py)
 extern "C" int pllhip_env_is_honoured(const char * name) { return pllhip_env(name) != nullptr; }
 
 // 1: the variable is read as it stands; 0: only under PLLHIP_DEVELOPER=1 (tests/test_host.py)
-extern "C" int pllhip_env_is_user_switch(const char * name)
-{
-  for (const char * u : pllhip_user_switches)
-    if (!strcmp(u, name)) return 1;
-  return 0;
-}
+extern "C" int pllhip_env_is_user_switch(const char * name) { return pllhip_is_user_switch(name) ? 1 : 0; }
 
 extern "C" int pllhip_device_count(int * count)
 {

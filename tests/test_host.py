@@ -658,12 +658,23 @@ def test_developer_switches_are_gated(amd, monkeypatch):
     dev = sorted(read - user)[0]
     monkeypatch.setenv(dev, "1")
     monkeypatch.setenv("PLLHIP_SPIN", "0")
-    monkeypatch.setenv("PLLHIP_DEVELOPER", "1")
-    assert lib.pllhip_env_is_honoured(dev.encode()) == 1 and lib.pllhip_env_is_honoured(b"PLLHIP_SPIN") == 1
-    monkeypatch.delenv("PLLHIP_DEVELOPER")
-    assert lib.pllhip_env_is_honoured(dev.encode()) == 0 and lib.pllhip_env_is_honoured(b"PLLHIP_SPIN") == 1
-    monkeypatch.setenv("PLLHIP_DEVELOPER", "0")
-    assert lib.pllhip_env_is_honoured(dev.encode()) == 0
-    monkeypatch.delenv(dev)
-    monkeypatch.setenv("PLLHIP_DEVELOPER", "1")
-    assert lib.pllhip_env_is_honoured(dev.encode()) == 0
+    # (PLLHIP_DEVELOPER is read once per process -- several developer's switches are read per launch --
+    # and again by pllhip_env_reload)
+    try:
+        monkeypatch.setenv("PLLHIP_DEVELOPER", "1")
+        lib.pllhip_env_reload()
+        assert lib.pllhip_env_is_honoured(dev.encode()) == 1 and lib.pllhip_env_is_honoured(b"PLLHIP_SPIN") == 1
+        monkeypatch.delenv("PLLHIP_DEVELOPER")
+        assert lib.pllhip_env_is_honoured(dev.encode()) == 1          # not read again yet
+        lib.pllhip_env_reload()
+        assert lib.pllhip_env_is_honoured(dev.encode()) == 0 and lib.pllhip_env_is_honoured(b"PLLHIP_SPIN") == 1
+        monkeypatch.setenv("PLLHIP_DEVELOPER", "0")
+        lib.pllhip_env_reload()
+        assert lib.pllhip_env_is_honoured(dev.encode()) == 0
+        monkeypatch.delenv(dev)
+        monkeypatch.setenv("PLLHIP_DEVELOPER", "1")
+        lib.pllhip_env_reload()
+        assert lib.pllhip_env_is_honoured(dev.encode()) == 0
+    finally:
+        monkeypatch.undo()
+        lib.pllhip_env_reload()
