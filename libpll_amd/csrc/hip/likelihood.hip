@@ -1038,10 +1038,15 @@ static int run_lnl(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite, do
     if (grid > PLLHIP_REDUCE_BLOCKS) grid = PLLHIP_REDUCE_BLOCKS;
     // (round 5) no more workgroups than the host adds sums of (PLLHIP_HOSTSUM_MAX): beyond that a one-workgroup
     // k_final_sum launch followed every call -- BASELINE config 4 whole on one GPU, 31,250 workgroups; the waves
-    // then walk several rounds each.  PLLHIP_LNL_GRID: measurements.
+    // then walk several rounds each.  4 states: four workgroups per CU at most -- 1 M sites 54.7 -> 50.6 us for the
+    // kernel and 64.9 -> 58.3 us for the call (a quarter of the sums for the host to wait for and add), 2 M sites 92 ->
+    // 85 / 106 -> 95, 500 k 30.2 -> 27.5 / 39.1 -> 36.2, no difference at 8 M sites or below 250 k
+    // (profiles/r5_lnl_grid_cap_ab.txt).  PLLHIP_LNL_GRID: measurements.
     {
       const char * e = pllhip_env("PLLHIP_LNL_GRID");
-      const unsigned int cap = e && atoi(e) > 0 ? (unsigned int)atoi(e) : (unsigned int)PLLHIP_HOSTSUM_MAX;
+      unsigned int cap = (unsigned int)PLLHIP_HOSTSUM_MAX;
+      if (s4 && (unsigned int)c->num_cus * 4u < cap) cap = (unsigned int)c->num_cus * 4u;
+      if (e && atoi(e) > 0) cap = (unsigned int)atoi(e);
       if (grid > cap) grid = cap;
     }
     a.reduce = pllhip_reduce_out(c, grid);
