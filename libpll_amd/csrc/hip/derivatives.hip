@@ -777,7 +777,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   {
     const size_t tiles = ((size_t)a.sites + 15) / 16;
     size_t blocks = (tiles + 3) / 4;
-    const size_t cap = pllhip_env("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(pllhip_env("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 3; // 47 KB of LDS per workgroup (env: tests)
+    const size_t cap = pllhip_env("PLLHIP_AA_GRID_CAP") ? (size_t)atoi(pllhip_env("PLLHIP_AA_GRID_CAP")) : (size_t)c->num_cus * 2; // two workgroups per CU (three fit the LDS, 47 KB each, and were the default until round 5: 38.4-39.7 -> 35.0-37.6 us per call at 200 k sites, 58 -> 54.5 at 400 k, equal at 50 k; profiles/r5_newton_floor_from_c.txt) (env: tests)
     if (blocks > cap) blocks = cap;
     grid = (unsigned int)blocks;
     a.reduce = pllhip_reduce_out(c, grid, 2);
