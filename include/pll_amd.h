@@ -702,6 +702,18 @@ PLL_EXPORT int pll_amd_profile_enable(pll_partition_t * partition, int on);
 PLL_EXPORT int pll_amd_profile_read(pll_partition_t * partition, unsigned int * launches,
                                     double * total_ms);
 
+/* The scaling certificate of 20-state partitions (pllhip.h: pllhip_cert_stats).  The whole-list kernel
+ * runs the mat-vec of tip-inner ops on the matrix cores; those CLVs -- and what is computed from them -- agree with
+ * the reference's (src/core_partials_avx.c:1229-1284) to ~1e-15 per op instead of bit for bit, and every scaling
+ * decision taken on such a value (src/core_partials_avx2.c:752-800) is checked: a largest entry within a window of
+ * 2^-256 far wider than the accumulated difference makes the library run the op list again in the reference's
+ * order before anything reads its results.  stats[0] = op lists that ran with the check, [1] = flags raised,
+ * [2] = lists run again, [3] = uncertified decisions (a partial traversal in the reference's order over CLVs an
+ * earlier call left approximate, within 6e-11 of the threshold).  While stats[3] == 0 every scaler count of the
+ * partition is the reference's.  PLLHIP_AA_TI_MFMA=0 (environment, read when a partition is created): reference
+ * order everywhere, every CLV bit for bit. */
+PLL_EXPORT int pll_amd_scaling_certificate(pll_partition_t * partition, unsigned long long * stats4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,6 +186,16 @@ PLLHIP_EXPORT int pllhip_small_partition_estimate(unsigned int states, unsigned 
                                                   unsigned int clv_buffers, int pattern_tip, const pllhip_op_t * ops,
                                                   unsigned int count, double * whole_us_out, double * level_us_out);
 
+/* The scaling certificate (20 states; libpll_amd/csrc/hip/ctx.hpp).  The whole-list kernel runs
+ * the mat-vec of tip-inner ops on the matrix cores (fused multiply-adds; the reference rounds products and sums
+ * separately, core_partials_avx.c:1229-1284), so those CLVs agree with the reference's to ~1e-15 per op -- and every
+ * scaling decision taken on such a value is certified: a largest entry within a window of 2^-256 far wider than the
+ * accumulated difference raises a flag, and the list is run again in the reference's order before anything reads
+ * its results.  out4 = {op lists launched with the test, flags raised, lists run again, uncertified}: while
+ * out4[3] == 0 every scaler count of the partition is the reference's (core_partials_avx2.c:752-800).
+ * PLLHIP_AA_TI_MFMA=0: reference order everywhere, every CLV bit for bit, nothing to certify. */
+PLLHIP_EXPORT int pllhip_cert_stats(pllhip_ctx_t * ctx, unsigned long long * out4);
+
 /* Host logic of the same planner, no device: where the 4-state whole-list kernel keeps each op's tip characters.
  * tips[i]: bit 0 / 1 = op i (in the PLANNED order) has a left / right tip row.  chars_out[i]: bits 0-7 / 8-15 the
  * first lane of the left / right row in the wave's character registers, bit 16 / 17 = has a left / right tip;

@@ -40,7 +40,7 @@ extern "C" const char * pllhip_last_error(void) { return g_err; }
 // the switches a client may set (everything else: PLLHIP_DEVELOPER=1)
 static const char * const pllhip_user_switches[] = {
   "PLLHIP_AA_EXACT",         // 20 states: the bit-exact vector kernels everywhere (no matrix cores, no whole-list kernel)
-  "PLLHIP_AA_TI_MFMA",       // 20 states, opt-in: tip-inner mat-vecs of the whole-list kernel on the matrix cores
+  "PLLHIP_AA_TI_MFMA",       // 20 states, 0: tip-inner mat-vecs of the whole-list kernel on the vector unit in the reference's order
   "PLLHIP_FUSED",            // 0: one launch per tree level instead of the whole-list kernels
   "PLLHIP_HOSTSUM",          // 0: workgroup sums added on the device (k_final_sum / tickets) instead of by the host
   "PLLHIP_FUSE_REDUCE",      // 0 / 1: force the ticketed in-kernel final sum off / on
@@ -282,6 +282,10 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   HIP_TRY(hipHostMalloc((void **)&c->h_partials, PLLHIP_HOSTSUM_MAX * sizeof(double2), hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void **)&c->h_partials_dev, c->h_partials, 0));
   memset(c->h_partials, 0, PLLHIP_HOSTSUM_MAX * sizeof(double2));
+  // (the scaling certificate's flag: a word the list kernels raise, read by the host -- ctx.hpp)
+  HIP_TRY(hipHostMalloc((void **)&c->h_cert, 64, hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void **)&c->h_cert_dev, c->h_cert, 0));
+  memset(c->h_cert, 0, 64);
   // (arrival tickets of the reducing kernels: one word per group of 64 workgroups + one)
   if ((rc = dev_alloc(&c->d_counter, (size_t)(PLLHIP_REDUCE_BLOCKS / 64 + 4) * sizeof(unsigned int), true, c->stream))) goto fail;
 
@@ -460,6 +464,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
       if (p) (void)hipFree(p);
   if (c->h_result) (void)hipHostFree(c->h_result);
   if (c->h_partials) (void)hipHostFree(c->h_partials);
+  if (c->h_cert) (void)hipHostFree(c->h_cert);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -473,6 +478,7 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
 extern "C" int pllhip_wait(pllhip_ctx_t * c)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_wait(s));
+  PLLHIP_CERT_FIRST(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -498,6 +504,7 @@ static int d2h(pllhip_ctx * c, void * dst, const void * src, size_t bytes)
 extern "C" int pllhip_put_tipchars(pllhip_ctx_t * c, unsigned int tip, const unsigned char * h)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_put_tipchars(s, tip, h + lo));
+  PLLHIP_CERT_FIRST(c);
   if (!c->sh.pattern_tip || tip >= c->sh.tips)
   {
     pllhip_set_error("pllhip_put_tipchars: tip %u invalid", tip);
@@ -510,6 +517,7 @@ extern "C" int pllhip_put_tipmap(pllhip_ctx_t * c, const unsigned int * h, unsig
 {
   if (!c->shards.empty()) c->maxstates = maxstates;
   PLLHIP_ALL_SHARDS(c, pllhip_put_tipmap(s, h, maxstates));
+  PLLHIP_CERT_FIRST(c);
   if (maxstates > 256) { pllhip_set_error("tipmap too large"); return -1; }
   c->maxstates = maxstates;
   return h2d(c, c->tipmap, h, maxstates * sizeof(unsigned int));
@@ -518,11 +526,13 @@ extern "C" int pllhip_put_tipmap(pllhip_ctx_t * c, const unsigned int * h, unsig
 extern "C" int pllhip_put_clv(pllhip_ctx_t * c, unsigned int idx, const double * h)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_put_clv(s, idx, h + lo * c->span));
+  PLLHIP_CERT_FIRST(c);
   if (idx >= c->clv.size() || !c->clv[idx])
   {
     pllhip_set_error("pllhip_put_clv: index %u has no CLV", idx);
     return -1;
   }
+  pllhip_cert_mark_clv(c, idx, 0.0); // (the caller's values: nothing of ours in them)
   return h2d(c, c->clv[idx], h, c->clv_elems * sizeof(double));
 }
 
@@ -544,11 +554,13 @@ extern "C" int pllhip_put_tip_clv_persite(pllhip_ctx_t * c, unsigned int idx,
                                           const double * h, unsigned int stride)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_put_tip_clv_persite(s, idx, h + lo * stride, stride));
+  PLLHIP_CERT_FIRST(c);
   if (idx >= c->clv.size() || !c->clv[idx])
   {
     pllhip_set_error("pllhip_put_tip_clv_persite: index %u has no CLV", idx);
     return -1;
   }
+  pllhip_cert_mark_clv(c, idx, 0.0);
   const size_t S = c->sh.states, N = c->sh.sites;
   // stage the compact [sites][states] vectors in the tail of the parent CLV's
   // own storage?  No: use a temporary so partially written CLVs never alias.
@@ -633,6 +645,7 @@ extern "C" int pllhip_put_model(pllhip_ctx_t * c, unsigned int pi, const double 
 extern "C" int pllhip_put_pmatrix(pllhip_ctx_t * c, unsigned int idx, const double * h)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_put_pmatrix(s, idx, h));
+  PLLHIP_CERT_FIRST(c);
   if (idx >= c->sh.prob_matrices) { pllhip_set_error("pllhip_put_pmatrix: index %u", idx); return -1; }
   return h2d(c, pllhip_pmat_ptr(c, idx), h, c->pmat_elems * sizeof(double));
 }
@@ -640,6 +653,7 @@ extern "C" int pllhip_put_pmatrix(pllhip_ctx_t * c, unsigned int idx, const doub
 extern "C" int pllhip_put_scaler(pllhip_ctx_t * c, unsigned int idx, const unsigned int * h)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_put_scaler(s, idx, h + lo * (c->sh.rate_scalers ? c->sh.rate_cats : 1)));
+  PLLHIP_CERT_FIRST(c);
   if (idx >= c->sh.scale_buffers) { pllhip_set_error("pllhip_put_scaler: index %u", idx); return -1; }
   return h2d(c, pllhip_scaler_ptr(c, (int)idx), h, c->scaler_elems * sizeof(unsigned int));
 }
@@ -667,12 +681,14 @@ extern "C" int pllhip_partial_tt_from_lookup(pllhip_ctx_t * c, unsigned int pare
                                              size_t rows, unsigned int log2_maxstates)
 {
   if (!c->shards.empty()) { pllhip_set_error("pllhip_partial_tt_from_lookup: not for a sharded context"); return -1; }
+  PLLHIP_CERT_FIRST(c);
   if (parent_clv >= c->clv.size() || !c->clv[parent_clv] || !c->sh.pattern_tip || tip1 >= c->sh.tips ||
       tip2 >= c->sh.tips || parent_scaler >= (int)c->sh.scale_buffers)
   {
     pllhip_set_error("pllhip_partial_tt_from_lookup: bad arguments");
     return -1;
   }
+  pllhip_cert_mark_clv(c, parent_clv, 0.0);
   HIP_TRY(hipSetDevice(c->sh.device));
   double * d_lookup = nullptr;
   HIP_TRY(hipMalloc((void **)&d_lookup, rows * c->span * sizeof(double)));
@@ -732,6 +748,7 @@ static int shard_scaler_per_site(pllhip_ctx * s, unsigned int idx, unsigned int 
 extern "C" int pllhip_get_clv(pllhip_ctx_t * c, unsigned int idx, double * h)
 {
   PLLHIP_ALL_SHARDS(c, shard_clv_per_site(s, idx, h + lo * c->span));
+  PLLHIP_CERT_FIRST(c);
   if (idx >= c->clv.size() || !c->clv[idx])
   {
     pllhip_set_error("pllhip_get_clv: index %u has no CLV", idx);
@@ -743,6 +760,7 @@ extern "C" int pllhip_get_clv(pllhip_ctx_t * c, unsigned int idx, double * h)
 extern "C" int pllhip_get_scaler(pllhip_ctx_t * c, unsigned int idx, unsigned int * h)
 {
   PLLHIP_ALL_SHARDS(c, shard_scaler_per_site(s, idx, h + lo * (c->sh.rate_scalers ? c->sh.rate_cats : 1)));
+  PLLHIP_CERT_FIRST(c);
   if (idx >= c->sh.scale_buffers) { pllhip_set_error("pllhip_get_scaler: index %u", idx); return -1; }
   return d2h(c, h, pllhip_scaler_ptr(c, (int)idx), c->scaler_elems * sizeof(unsigned int));
 }
@@ -812,6 +830,7 @@ extern "C" int pllhip_release_sumtable(pllhip_ctx_t * c, unsigned int slot)
 extern "C" void * pllhip_dev_clv(pllhip_ctx_t * c, unsigned int idx)
 {
   if (!c->shards.empty()) return nullptr; // (one CLV lives on several devices)
+  if (c->cert_pending && pllhip_cert_resolve(c)) return nullptr;
   return idx < c->clv.size() ? (void *)c->clv[idx] : nullptr;
 }
 

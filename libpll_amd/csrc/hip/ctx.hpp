@@ -186,11 +186,29 @@ struct pllhip_ctx
   // 0 = matrix-core kernels where they exist (last-bit differences, see
   // partials_aa_mfma.hip)
   int aa_exact = 0;
-  // (round 5, opt-in, env PLLHIP_AA_TI_MFMA=1) 20-state whole-list kernel: the ONE mat-vec of a tip-inner op on the
-  // matrix cores (fused chains) instead of the vector unit in the reference's non-fused order -- ~7 % on trees with
-  // many tip-inner ops, at the price of tip-inner CLVs that agree with the reference's to ~1e-15 instead of bit for
-  // bit (and of scaler counts that are then equal "unless an entry lies within that of 2^-256").  Default off.
-  bool aa_ti_mfma = false;
+  // 20-state whole-list kernel: the ONE mat-vec of a tip-inner op on the matrix cores (fused chains) instead of the
+  // vector unit in the reference's non-fused order -- +6 % on a 200-taxon random tree, +42 % on a ladder.  Round 5:
+  // opt-in, because tip-inner CLVs (and what is computed from them) then agree with the reference's to ~1e-15 per op
+  // instead of bit for bit, and a scaler count could differ when an entry lies within that of 2^-256.  Round 6: the
+  // DEFAULT (env PLLHIP_AA_TI_MFMA=0: off), behind the scaling certificate below, which keeps the counts the reference's.
+  bool aa_ti_mfma = true;
+  // ---- the scaling certificate (round 6; partials.hip: pllhip_cert_resolve)
+  // clv_err[i]: a bound on the relative difference, entry by entry, between CLV i and the reference's (0: bit for
+  // bit; > 0: written by a matrix-core tip-inner op, or computed from such a CLV -- PLLHIP_CERT_OP_ERR per op plus
+  // the operands' bounds); n_inexact: how many are > 0 (0: nothing below costs anything).  An op that scales such a
+  // value also tests whether its largest entry lies within a window of the threshold eight times wider than the
+  // bound: outside it, the decision -- hence the count -- is the reference's.  Inside it, the kernel raises *h_cert
+  // (host memory); the host looks at the word before anything else reads or changes what the list read or wrote:
+  // cert_kind 1 (the list ran tip-inner ops on the matrix cores) -- the list (cert_ops) is run again in the
+  // reference's order; cert_kind 2 (reference order on marked operands, nothing to run again), a second trip of a
+  // re-run whose operands were marked, and a bound too large for any window count as `uncertified`.
+  std::vector<double> clv_err;
+  unsigned int n_inexact = 0;
+  unsigned int * h_cert = nullptr, * h_cert_dev = nullptr;
+  bool cert_pending = false, cert_force_exact = false;
+  int cert_kind = 0;
+  std::vector<pllhip_op_t> cert_ops;
+  unsigned long long cert_stats[4] = {0, 0, 0, 0}; // lists launched with the test, trips, re-runs, uncertified
 
   // optional per-launch timing (pllhip_profile_*): one event pair per launch
   bool profiling = false;
@@ -351,7 +369,11 @@ struct PartialsArgs
   // 20 states, a launch over a CHUNK of the rate categories (partials_aa_mfma.hip, SPLIT): its first category;
   // rate_cats stays the CLV's count, lmat / rmat / ltab are the chunk's, lidx is the per-site verdict buffer
   unsigned int rate_first, pad_;
+  // (round 6) the scaling certificate: not null = the op's scaling test also looks for a largest entry within
+  // 2^-pad_ (relative) of the threshold and raises this word (host memory) -- k_aa_ii_mfma only
+  unsigned int * cert;
 };
+static_assert(sizeof(PartialsArgs) * 24 <= 3900, "a batch of ops travels as kernel arguments (4 KB)");
 
 // Several mutually independent ops (one tree level) run in ONE launch:
 // blockIdx.y selects the op.  The op descriptors travel as kernel arguments
@@ -425,6 +447,36 @@ int pllhip_aa_lookup_tables(pllhip_ctx * c, const PartialsArgs * ops, const Part
 // partials_aa_fused.hip: a 20-state op list in one site-blocked launch; returns 1 if the list (or
 // the partition) is not one it takes -- the caller then launches per level
 int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count);
+// The scaling certificate (see pllhip_ctx::clv_err).  What one op adds to the bound: either summation order
+// (core_partials_avx2.c:632-750 fused, core_partials_avx.c:1229-1284 not) rounds a sum of 20 non-negative products at
+// most 8 times per term, the product of the two factors once: both results lie within 17 units of roundoff (2^-53) of
+// the exact value, which moves with the operands by the sum of THEIR bounds -- 34 units per op, 40 taken.  The
+// window of a list: 8 x the largest bound of its testing ops, at least 2^-44 (a 200-taxon tree: ~4e-12 -- one trip
+// in a million evaluations); at most 2^-21 (the kernels' two-instruction pre-test looks at the high word only: 2^-20)
+// -- a bound beyond that (only an op list that feeds one CLV to both sides of an op, again and again, doubles it
+// that fast: never a tree) cannot be certified.
+#define PLLHIP_CERT_OP_ERR (40.0 * 0x1p-53)
+#define PLLHIP_CERT_WINDOW_MIN 0x1p-44
+#define PLLHIP_CERT_WINDOW_MAX 0x1p-21
+// Looks at the flag of the last certified list, if one is pending (waits for the stream unless `drained` says a
+// result of a later launch has already arrived); *rerun: the list was run again -- results computed from its CLVs
+// since are stale.  Called at the top of every entry point that reads or changes what a list read or wrote.
+int pllhip_cert_resolve(pllhip_ctx * c, bool * rerun = nullptr, bool drained = false);
+// The scaling certificate (ctx.hpp): an entry point that reads or changes what the last certified op list read or wrote
+// looks at that list's flag first -- and runs the list again in the reference's order if it was raised.
+#define PLLHIP_CERT_FIRST(c)                       \
+  do {                                             \
+    if ((c)->cert_pending) {                       \
+      const int rc_cert_ = pllhip_cert_resolve(c); \
+      if (rc_cert_) return rc_cert_;               \
+    }                                              \
+  } while (0)
+// per-level path (partials.hip) and whole-list kernel (partials_aa_fused.hip): marks after the list, which ops test
+void pllhip_cert_mark_clv(pllhip_ctx * c, unsigned int clv_index, double err);
+static inline double pllhip_cert_err(const pllhip_ctx * c, unsigned int clv_index)
+{
+  return (c->n_inexact && clv_index < c->clv_err.size()) ? c->clv_err[clv_index] : 0.0;
+}
 // partials.hip: one op resolved into kernel arguments (kind 0 inner-inner, 1 tip-inner, 2 tip-tip)
 int pllhip_resolve_op(pllhip_ctx * c, const pllhip_op_t & op, PartialsArgs & a, int & kind, int & mode);
 void pllhip_aa_fused_free(pllhip_ctx * c);

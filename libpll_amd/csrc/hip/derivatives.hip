@@ -88,6 +88,7 @@ extern "C" int pllhip_update_sumtable(pllhip_ctx_t * c, unsigned int parent_clv,
 {
   PLLHIP_ALL_SHARDS_PAR(c, pllhip_update_sumtable(s, parent_clv, parent_scaler, child_clv, child_scaler, h_params_indices, slot));
   HIP_TRY(hipSetDevice(c->sh.device));
+  PLLHIP_CERT_FIRST(c);
   const unsigned int nodes = (unsigned int)c->clv.size();
   if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || parent_clv >= nodes || child_clv >= nodes ||
       parent_scaler >= (int)c->sh.scale_buffers || child_scaler >= (int)c->sh.scale_buffers)
@@ -679,6 +680,7 @@ extern "C" int pllhip_likelihood_derivatives(pllhip_ctx_t * c, unsigned int slot
   if (!c->shards.empty())
     return pllhip_group_likelihood_derivatives(c, slot, parent_scaler, child_scaler, h_params_indices, h_diagptable, h_d_f, h_dd_f);
   HIP_TRY(hipSetDevice(c->sh.device));
+  if (!c->defer) PLLHIP_CERT_FIRST(c); // (reads scaler counts; the sumtable call before it has normally looked already.  A shard of a group: shard.hip looks)
   if (slot >= PLLHIP_SUMTABLE_MAX_SLOTS || !c->sumtable[slot])
   {
     pllhip_set_error("pllhip_likelihood_derivatives: sumtable slot %u empty", slot);

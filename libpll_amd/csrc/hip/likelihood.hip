@@ -1113,6 +1113,23 @@ static int fill_freqs_indices(pllhip_ctx * c, LnlArgs & a, const unsigned int * 
   return 0;
 }
 
+// The scaling certificate (ctx.hpp) without a bubble: the lnL kernel is enqueued right behind the op list, and the
+// list's flag is looked at when the result has arrived -- a word in host memory, written before the lnL kernel
+// started.  Raised (rare): the list runs again in the reference's order, and the evaluation once more.  A shard of a
+// group (defer) returns without waiting: its group looks at the flags when it has collected (shard.hip).
+static int run_lnl_certified(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite_lnl, double * h_lnl)
+{
+  for (;;)
+  {
+    LnlArgs aa = a;
+    int rc = run_lnl(c, aa, kind, h_persite_lnl, h_lnl);
+    if (rc || c->defer || !c->cert_pending) return rc;
+    bool again = false;
+    rc = pllhip_cert_resolve(c, &again, h_persite_lnl == nullptr);
+    if (rc || !again) return rc;
+  }
+}
+
 extern "C" int pllhip_edge_loglikelihood(pllhip_ctx_t * c, unsigned int parent_clv,
                                          int parent_scaler, unsigned int child_clv,
                                          int child_scaler, unsigned int matrix_index,
@@ -1167,7 +1184,7 @@ extern "C" int pllhip_edge_loglikelihood(pllhip_ctx_t * c, unsigned int parent_c
       if (c->rows[child_clv].classes) a.cidx = c->rows[child_clv].site_id;
     }
   }
-  return run_lnl(c, a, kind, h_persite_lnl, h_lnl);
+  return run_lnl_certified(c, a, kind, h_persite_lnl, h_lnl);
 }
 
 extern "C" int pllhip_root_loglikelihood(pllhip_ctx_t * c, unsigned int clv_index,
@@ -1189,5 +1206,5 @@ extern "C" int pllhip_root_loglikelihood(pllhip_ctx_t * c, unsigned int clv_inde
   a.pscaler = c->root_scaler_override ? c->root_scaler_override : pllhip_scaler_ptr(c, scaler_index);
   a.pscaler_by_site = c->root_scaler_override != nullptr;
   if (!c->rows.empty() && c->rows[clv_index].classes) a.pidx = c->rows[clv_index].site_id;
-  return run_lnl(c, a, ROOT, h_persite_lnl, h_lnl);
+  return run_lnl_certified(c, a, ROOT, h_persite_lnl, h_lnl);
 }

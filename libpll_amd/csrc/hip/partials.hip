@@ -633,10 +633,82 @@ static bool whole_list_pays_when_small(const pllhip_ctx * c, const pllhip_op_t *
                                          c->sh.pattern_tip ? 1 : 0, ops, count, nullptr, nullptr) == 1;
 }
 
+// ---- the scaling certificate (round 6; ctx.hpp) ----
+// The whole-list 20-state kernel runs the mat-vec of a tip-inner op on the matrix cores: fused multiply-adds where the
+// reference (core_partials_avx.c:1229-1284) rounds products and sums separately -- 1e-15 per op, and from then on
+// everything computed from that CLV.  north_star asks for scaler counts bit for bit.  A count can only differ where
+// a scaling decision does, and a decision -- "every entry of the site (or of its rate block) below 2^-256",
+// core_partials_avx2.c:752-800 -- only where the largest entry lies within the accumulated difference of the
+// threshold.  So every op that scales a marked value tests for a largest entry within a window 170 (reference order:
+// 2.6) times wider than the bound on that difference, and raises a word in host memory.  The host looks at the word
+// before anything else reads or changes what the list read or wrote, and on a raised flag runs the list again with
+// every op in the reference's order.  Then: no flag => every count of the call is the reference's; flag => the list
+// as the round-5 default ran it.  What is left is a list of reference-order arithmetic on operands that an EARLIER
+// call left marked (a partial traversal): nothing to run again; a largest entry within the narrow window there is
+// counted as "uncertified" (pllhip_cert_stats; never seen: the window is 6e-11 relative).
+void pllhip_cert_mark_clv(pllhip_ctx * c, unsigned int idx, double err)
+{
+  if (!(err > 0.0) && !c->n_inexact) return;
+  if (c->clv_err.size() != c->clv.size()) c->clv_err.assign(c->clv.size(), 0.0);
+  if (idx >= c->clv_err.size()) return;
+  if (c->clv_err[idx] > 0.0 && !(err > 0.0)) --c->n_inexact;
+  if (!(c->clv_err[idx] > 0.0) && err > 0.0) ++c->n_inexact;
+  c->clv_err[idx] = err > 0.0 ? err : 0.0;
+}
+
+int pllhip_cert_resolve(pllhip_ctx * c, bool * rerun, bool drained)
+{
+  if (rerun) *rerun = false;
+  if (!c->cert_pending) return 0;
+  HIP_TRY(hipSetDevice(c->sh.device));
+  if (!drained) HIP_TRY(hipStreamSynchronize(c->stream));
+  c->cert_pending = false;
+  const unsigned int flag = *(volatile unsigned int *)c->h_cert;
+  if (!flag) return 0;
+  *(volatile unsigned int *)c->h_cert = 0u;
+  ++c->cert_stats[1];
+  if (c->cert_kind != 1)
+  {
+    ++c->cert_stats[3];
+    return 0;
+  }
+  // the list again, every op in the reference's order (its operands from earlier calls are as they were: a list
+  // that overwrites one of them never runs on the matrix cores' tip-inner path, partials_aa_fused.hip)
+  ++c->cert_stats[2];
+  if (pllhip_env("PLLHIP_FUSED_DEBUG")) fprintf(stderr, "pllhip: scaling certificate raised, %zu ops run again in the reference's order\n", c->cert_ops.size());
+  const std::vector<pllhip_op_t> again(c->cert_ops);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->cert_force_exact = true;
+  int rc = pllhip_update_partials(c, again.data(), (unsigned int)again.size());
+  c->cert_force_exact = false;
+  if (rc) return rc;
+  if (rerun) *rerun = true;
+  if (c->cert_pending) rc = pllhip_cert_resolve(c); // (operands marked by earlier calls: the narrow window)
+  return rc;
+}
+
+extern "C" int pllhip_cert_stats(pllhip_ctx_t * c, unsigned long long * out4)
+{
+  for (int t = 0; t < 4; ++t) out4[t] = 0;
+  if (!c->shards.empty())
+  {
+    for (pllhip_ctx * s : c->shards)
+      for (int t = 0; t < 4; ++t) out4[t] += s->cert_stats[t];
+    return 0;
+  }
+  for (int t = 0; t < 4; ++t) out4[t] = c->cert_stats[t];
+  return 0;
+}
+
 extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count)
 {
   PLLHIP_ALL_SHARDS_PAR(c, pllhip_update_partials(s, ops, count)); // (enqueued on every device; nothing waits)
   HIP_TRY(hipSetDevice(c->sh.device));
+  if (c->cert_pending)
+  {
+    const int rc = pllhip_cert_resolve(c);
+    if (rc) return rc;
+  }
   if (!c->rows.empty())
   {
     // (site repeats: which CLV each scale buffer belongs to -- a shard of a group expands its own mirrors, ctx.hip)
@@ -903,6 +975,37 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   }
   } // !plan_kept
 
+  // The scaling certificate on this path: its kernels work in the reference's order, so a value is marked only when
+  // an operand is; the marks are walked in list order, and an op that scales a marked value tests (k_aa_ii_mfma).
+  std::vector<unsigned char> op_marked;
+  unsigned int cert_log2 = 0; // the window of this call: 2^-cert_log2, relative
+  if (c->n_inexact)
+  {
+    op_marked.assign(count, 0);
+    double worst = 0.0;
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      const pllhip_op_t & op = ops[i];
+      const double in = (pllhip_is_tip(c, op.child1_clv) ? 0.0 : pllhip_cert_err(c, op.child1_clv)) +
+                        (pllhip_is_tip(c, op.child2_clv) ? 0.0 : pllhip_cert_err(c, op.child2_clv));
+      const double e = in > 0.0 ? in + PLLHIP_CERT_OP_ERR : 0.0;
+      pllhip_cert_mark_clv(c, op.parent_clv, e);
+      op_marked[i] = e > 0.0 && op.parent_scaler >= 0;
+      if (op_marked[i] && e > worst) worst = e;
+    }
+    if (worst > 0.0)
+    {
+      c->cert_pending = true;
+      c->cert_kind = 2;
+      ++c->cert_stats[0];
+      double w = 8.0 * worst;
+      if (w > PLLHIP_CERT_WINDOW_MAX) ++c->cert_stats[3]; // (no window is wide enough: uncertified as it stands)
+      w = std::min(std::max(w, PLLHIP_CERT_WINDOW_MIN), PLLHIP_CERT_WINDOW_MAX);
+      int ex = 0;
+      (void)frexp(w, &ex);           // w = m 2^ex, m in [0.5, 1): 2^ex >= w
+      cert_log2 = (unsigned int)(-ex);
+    }
+  }
   PartialsBatch b;
   for (unsigned int i = 0; i < count;)
   {
@@ -930,7 +1033,14 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
       continue;
     }
     unsigned int nb = 0;
-    while (i < count && plan[i].key == key && nb < PLLHIP_BATCH_MAX) b.op[nb++] = plan[i++].a;
+    while (i < count && plan[i].key == key && nb < PLLHIP_BATCH_MAX)
+    {
+      b.op[nb] = plan[i].a;
+      b.op[nb].cert = (!op_marked.empty() && op_marked[plan[i].order]) ? c->h_cert_dev : nullptr;
+      if (b.op[nb].cert) b.op[nb].pad_ = cert_log2;
+      ++nb;
+      ++i;
+    }
     pllhip_prof_scope prof(c, PLLHIP_PROF_PARTIALS_II + kind);
     int rc = dna_fast ? pllhip_launch_dna_batch(c, b, nb, kind, mode)
              : aa_fast ? pllhip_launch_aa_batch(c, b, nb, kind, mode)

@@ -105,7 +105,11 @@ constexpr unsigned int AF_ONE_TABLE = 4096u;   // a lookup with ONE table (round
 // flight are 56 of them).
 constexpr unsigned int AF_TI_MFMA = 16384u;   // (opt-in, PLLHIP_AA_TI_MFMA=1) a tip-inner op whose mat-vec runs on the matrix cores
 constexpr unsigned int AF_LAST = 8192u;
-constexpr unsigned int AF_NEXT_SHIFT = 15u;
+// (round 6) the scaling certificate: an op whose scaling test also looks for a largest entry within rounding distance of
+// the threshold (partials_aa_fused_op.inc); the segment's HEADER record carries what the rare path needs -- `parent`:
+// the address of the call's flag word (host memory), `pscaler`: the window as a double, 2^-256 x its relative half-width
+constexpr unsigned int AF_CERT = 32768u;
+constexpr unsigned int AF_NEXT_SHIFT = 16u;
 
 struct AfMatJob
 {
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
   auto cls32_of = [](unsigned int l) __attribute__((always_inline)) { return ((l >> 4) * 4u + ((l >> 2) & 3u)) * 32u; };
   // the lane's column in a stage
   auto coloff_of = [](unsigned int l) __attribute__((always_inline)) { return (l & 3u) * 640u + ((l >> 2) & 3u) * 160u; };
-  const unsigned long long sink_a = (unsigned long long)(uintptr_t)(sink + ((size_t)blockIdx.x * 4u + wave) * 4u);
+  const unsigned long long sink_a = (unsigned long long)(uintptr_t)(sink + ((size_t)blockIdx.x * 4u + wave) * 8u); // (128 bytes per wave)
   const unsigned long long aorder_a = (unsigned long long)(uintptr_t)aorder;
 
 
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
     }
     const size_t site0 = tile * AF_WGS + (size_t)wave * AF_WS;
     const unsigned long long clv_off = (unsigned long long)site0 * 640u;
-    const unsigned long long cnt_off = (unsigned long long)site0 * 4u;
+    const unsigned long long cnt_off = (unsigned long long)site0 * (MODE == SCALE_RATE ? 16u : 4u);
 
     // an operand without a slot: from HBM through stage 1 into a slot (AF_RELOAD_TAKE)
     auto reload_issue = [&](unsigned long long src) __attribute__((always_inline)) {
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
       for (int j = 0; j < AF_J; ++j)
       {
         cj[j] = 0u;
-        unsigned int o = (4u * j + n) * 4u;
+        unsigned int o = MODE == SCALE_RATE ? ((4u * j + n) * 4u + rate) * 4u : (4u * j + n) * 4u;
         asm volatile("" : "+v"(o));
         if (MODE != SCALE_NONE && cnt) cj[j] = *(const unsigned int PLL_GLOBAL *)(af_base(cnt + cnt_off) + o);
       }
@@ -1021,6 +1025,12 @@ struct pllhip_aa_fused_cache
   unsigned int nlk = 0;
   size_t off_seg = 0;                  // (round 5) the segment table: {first record, ops} per segment
   unsigned int nsegs = 1;
+  // (round 6) the scaling certificate: the plan was made for these marks of the operands it reads from earlier calls
+  // (index, mark) and in this mode; what it leaves marked; whether any op tests, and what a trip means (ctx.hpp)
+  bool ti_mfma = false;
+  std::vector<std::pair<unsigned int, double>> ext_marks, out_marks;
+  int cert_kind = 0;
+  bool cert_too_wide = false; // the bounds outgrew the widest window: every launch counts as uncertified
 };
 
 void pllhip_aa_fused_free(pllhip_ctx * c)
@@ -1094,9 +1104,19 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
         c->maxstates, (double2 *)c->d_sink, counter, static_rounds);                                                   \
   } while (0)
   if (k.mode == SCALE_NONE) { if (nt) AF_LAUNCH(SCALE_NONE, true); else AF_LAUNCH(SCALE_NONE, false); }
+  else if (k.mode == SCALE_RATE) { if (nt) AF_LAUNCH(SCALE_RATE, true); else AF_LAUNCH(SCALE_RATE, false); }
   else { if (nt) AF_LAUNCH(SCALE_SITE, true); else AF_LAUNCH(SCALE_SITE, false); }
 #undef AF_LAUNCH
   HIP_TRY(hipGetLastError());
+  // the scaling certificate: what the list leaves marked, and whether its flag has to be looked at
+  for (const auto & m : k.out_marks) pllhip_cert_mark_clv(c, m.first, m.second);
+  if (k.cert_kind)
+  {
+    c->cert_pending = true;
+    c->cert_kind = k.cert_kind;
+    ++c->cert_stats[0];
+    if (k.cert_too_wide) ++c->cert_stats[3];
+  }
   return 0;
 }
 
@@ -1119,7 +1139,7 @@ int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
 
 static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count, bool tt_wanted)
 {
-  if (c->sh.states != 20 || c->sh.rate_cats != 4 || c->sh.rate_scalers || c->sh.asc_states || !c->rows.empty() ||
+  if (c->sh.states != 20 || c->sh.rate_cats != 4 || c->sh.asc_states || !c->rows.empty() ||
       c->aa_exact || count > PLLHIP_FUSED_MAX_OPS)
     return 1;
   if (c->sh.pattern_tip && (c->maxstates < 1 || c->maxstates > 32)) return 1;
@@ -1134,9 +1154,21 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     fprintf(stderr, "pllhip 20-state list, host: %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_host).count());
     t_host = now;
   };
-  if (k.last_ops.size() == count && k.epoch == c->layout_epoch && k.maxstates == c->maxstates &&
+  // Tip-inner mat-vecs on the matrix cores (the default, round 6) -- unless the list is being run again after its
+  // certificate tripped, or could not be run again: a list that overwrites an operand it has read from an earlier
+  // call (slot reuse across calls) is not idempotent, and keeps to the reference's order.
+  const bool ti_mfma = c->aa_ti_mfma && !c->cert_force_exact && !c->no_batch;
+  if (k.last_ops.size() == count && k.epoch == c->layout_epoch && k.maxstates == c->maxstates && k.ti_mfma == ti_mfma &&
       !pllhip_env("PLLHIP_FUSED_DEBUG") && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
-    return aa_fused_launch(c, false);
+  {
+    bool same_marks = true;
+    for (const auto & m : k.ext_marks) same_marks = same_marks && pllhip_cert_err(c, m.first) == m.second;
+    if (same_marks)
+    {
+      if (k.cert_kind == 1) c->cert_ops.assign(ops, ops + count);
+      return aa_fused_launch(c, false);
+    }
+  }
   k.last_ops.clear();
 
   // ---- classify.  Tip-tip ops run ahead of the list: allowed only if nothing earlier in the list
@@ -1192,6 +1224,80 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     if (op.child2_scaler >= 0) sc_touched[op.child2_scaler] = 1;
   }
 
+  // ---- the scaling certificate (ctx.hpp): a bound on every op's relative difference from the reference's value --
+  // its operands' bounds plus PLLHIP_CERT_OP_ERR when anything below it ran on the matrix cores' tip-inner path --, which
+  // ops therefore test, and the window they test with
+  std::vector<unsigned char> op_inexact(count, 0);
+  bool list_ti_mfma = ti_mfma;
+  double cert_window = PLLHIP_CERT_WINDOW_MIN;
+  bool cert_too_wide = false;
+  k.ext_marks.clear();
+  k.out_marks.clear();
+  {
+    bool rerunnable = true;
+    std::vector<unsigned char> written(nclv, 0), sc_written(nsc, 0), ext_read(nclv, 0), sc_ext_read(nsc, 0);
+    for (unsigned int i = 0; i < count && ti_mfma; ++i)
+    {
+      const pllhip_op_t & op = ops[i];
+      for (unsigned int ch : {op.child1_clv, op.child2_clv})
+        if (!written[ch]) ext_read[ch] = 1;
+      for (int sc : {op.child1_scaler, op.child2_scaler})
+        if (sc >= 0 && !sc_written[sc]) sc_ext_read[sc] = 1;
+      if (ext_read[op.parent_clv] || (op.parent_scaler >= 0 && sc_ext_read[op.parent_scaler])) rerunnable = false;
+      written[op.parent_clv] = 1;
+      if (op.parent_scaler >= 0) sc_written[op.parent_scaler] = 1;
+    }
+    list_ti_mfma = ti_mfma && rerunnable;
+    std::vector<double> err(nclv, 0.0);
+    std::vector<unsigned char> local(nclv, 0);
+    bool any_ti = false;
+    double worst = 0.0;
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+      // (first with the tip-inner mat-vecs on the matrix cores; if the bounds then outgrow every window -- operands
+      // that earlier calls left with large bounds -- once more with every op in the reference's order)
+      std::fill(local.begin(), local.end(), 0);
+      k.ext_marks.clear();
+      any_ti = false;
+      worst = 0.0;
+      for (unsigned int i = 0; i < count; ++i)
+      {
+        const pllhip_op_t & op = ops[i];
+        const bool source = kinds[i] == 1 && list_ti_mfma;
+        any_ti = any_ti || source;
+        double in = 0.0;
+        for (unsigned int ch : {op.child1_clv, op.child2_clv})
+        {
+          if (pllhip_is_tip(c, ch)) continue;
+          if (!local[ch])
+          {
+            // an operand from an earlier call: the plan holds for THIS bound of it
+            const double m = pllhip_cert_err(c, ch);
+            bool seen = false;
+            for (const auto & e : k.ext_marks) seen = seen || e.first == ch;
+            if (!seen) k.ext_marks.push_back({ch, m});
+            in += m;
+          }
+          else in += err[ch];
+        }
+        const double out = (source || in > 0.0) ? in + PLLHIP_CERT_OP_ERR : 0.0;
+        err[op.parent_clv] = out;
+        local[op.parent_clv] = 1;
+        op_inexact[i] = out > 0.0 && op.parent_scaler >= 0;
+        if (op_inexact[i] && out > worst) worst = out;
+      }
+      if (!(list_ti_mfma && 8.0 * worst > PLLHIP_CERT_WINDOW_MAX)) break;
+      list_ti_mfma = false;
+    }
+    for (unsigned int i = 0; i < nclv; ++i)
+      if (local[i]) k.out_marks.push_back({i, err[i]});
+    k.cert_kind = !(worst > 0.0) ? 0 : (any_ti ? 1 : 2);
+    cert_too_wide = 8.0 * worst > PLLHIP_CERT_WINDOW_MAX;
+    cert_window = std::min(std::max(8.0 * worst, PLLHIP_CERT_WINDOW_MIN), PLLHIP_CERT_WINDOW_MAX);
+    k.cert_too_wide = cert_too_wide;
+    if (k.cert_kind == 1) c->cert_ops.assign(ops, ops + count);
+  }
+  k.ti_mfma = ti_mfma;
   lap("resolve + classify");
   // ---- the list the kernel walks: everything but the tip-tip ops, ordered and given slots by the
   // planner of the 4-state kernel (a lookup has no inner operands: a "tip-tip" op to the planner)
@@ -1325,7 +1431,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   const size_t lookup_tab_b = 4 * ((size_t)c->maxstates * c->maxstates + PLLHIP_TAIL_SITES) * 80 * sizeof(double);
   const size_t pair_budget_b = !pairs_on ? 0 : (size_t)(lookups_max > lookups ? lookups_max - lookups : 0) * lookup_tab_b;
   const unsigned long long zero_row = (unsigned long long)(uintptr_t)c->fused_zero_row;
-  k.mode = any_scaler ? SCALE_SITE : SCALE_NONE;
+  k.mode = !any_scaler ? SCALE_NONE : (c->sh.rate_scalers ? SCALE_RATE : SCALE_SITE);
   auto slot4 = [](int s) { return (unsigned int)(s > 0 ? s : 0) & 15u; };
   auto reloads_of = [&](AaRec & r, const FusedOp & f) {
     // what is done during the op before `f` for it
@@ -1373,6 +1479,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     o.flags = (unsigned int)kind;
     if (f.pslot >= 0) r.flags |= AF_HAS_PSLOT;
     if (f.pscaler) r.flags |= tt_op ? AF_ZERO_COUNTS : AF_SCALING;
+    if (f.pscaler && op_inexact[oi] && kind <= 1) r.flags |= AF_CERT;
     if (kind == 0 && f.lsc_slot >= 0) r.flags |= AF_LCNT;
     if (kind <= 1 && f.rsc_slot >= 0) r.flags |= AF_RCNT;
     r.slots = slot4(f.lslot) | slot4(f.rslot) << 4 | slot4(f.pslot) << 8;
@@ -1385,8 +1492,8 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     if (kind <= 1)
     {
       r.yoff = (unsigned int)(mj.size() * AF_MAT_B);
-      mj.push_back(AfMatJob{f.rmat, (unsigned long long)r.yoff, (kind == 1 && !c->aa_ti_mfma) ? 1ull : 0ull});
-      if (kind == 1 && c->aa_ti_mfma) r.flags |= AF_TI_MFMA;
+      mj.push_back(AfMatJob{f.rmat, (unsigned long long)r.yoff, (kind == 1 && !list_ti_mfma) ? 1ull : 0ull});
+      if (kind == 1 && list_ti_mfma) r.flags |= AF_TI_MFMA;
     }
     if (kind == 1)
     {
@@ -1454,6 +1561,12 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     if (pos == m) r.flags |= AF_LAST;
   }
   R[0].yoff = (unsigned int)(base + m); // (the segment's last record: the prologue takes op 1's rows from it)
+  // (the scaling certificate's rare path reads these two from the header: the flag's address, the window)
+  R[0].parent = (unsigned long long)(uintptr_t)c->h_cert_dev;
+  {
+    const double w = PLLHIP_SCALE_THRESHOLD * cert_window;
+    memcpy(&R[0].pscaler, &w, sizeof(w));
+  }
   } // segments
   if (recs.size() >= (1u << (32 - AF_NEXT_SHIFT))) return 1;
   if ((mj.size() + 1) * (size_t)AF_MAT_B > 0xffffffffull) return 1;

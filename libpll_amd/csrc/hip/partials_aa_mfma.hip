@@ -321,6 +321,24 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     right_rate(std::integral_constant<int, 1>{});
     right_rate(std::integral_constant<int, 2>{});
     right_rate(std::integral_constant<int, 3>{});
+    // (round 6) the scaling certificate (ctx.hpp): this kernel works in the reference's order, but a child may carry
+    // the matrix cores' rounding of a tip-inner op of the whole-list kernel; then a decision is the reference's for
+    // certain only while no block's largest entry lies within rounding distance of the threshold.  Two integer
+    // instructions on the high word per category (a window of 2^-20); the exact window only behind that.
+    if (MODE != SCALE_NONE && SPLIT == 0 && a.cert)
+    {
+      bool wide = false, inside = false;
+#pragma unroll
+      for (int k = 0; k < RC; ++k)
+      {
+        const double mx = fmax(fmax(fmax(x[k][0], x[k][1]), fmax(x[k][2], x[k][3])), x[k][4]);
+        const bool w = ((unsigned int)__double2hiint(mx) - 0x2FEFFFFFu) < 2u;
+        wide = wide || w;
+        inside = inside || (w && fabs(mx - PLLHIP_SCALE_THRESHOLD) < __hiloint2double((int)((767u - a.pad_) << 20), 0));
+      }
+      if (__ballot(wide))
+        if (__ballot(inside && site0 + s < sites) && lane == 0u) *a.cert = 1u;
+    }
     if (MODE == SCALE_SITE && (SPLIT == 1 || SPLIT == 3))
     {
       // not the last chunk of the categories: no decision yet -- the verdict so far goes to the verdict buffer (the

@@ -115,6 +115,7 @@ extern "C" int pllhip_update_pmatrices(pllhip_ctx_t * c, const unsigned int * h_
   PLLHIP_ALL_SHARDS_PAR(c, pllhip_update_pmatrices(s, h_params_indices, h_matrix_indices, h_branch_lengths, count));
   if (!count) return 0;
   HIP_TRY(hipSetDevice(c->sh.device));
+  PLLHIP_CERT_FIRST(c); // (a list that may have to run again must find the matrices it ran with)
   for (unsigned int i = 0; i < count; ++i)
   {
     if (h_matrix_indices[i] >= c->sh.prob_matrices)

@@ -18,7 +18,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <signal.h>
 #include <string>
+#include <system_error>
 #include <thread>
 
 #include "ctx.hpp"
@@ -81,6 +83,8 @@ static void shard_worker(pllhip_ctx * g, size_t i)
   }
 }
 
+static void pool_destroy(pllhip_ctx * g);
+
 int pllhip_group_parallel(pllhip_ctx * g, const std::function<int(pllhip_ctx *, size_t)> & fn)
 {
   pllhip_device_guard guard; // (the caller's current device is put back on return)
@@ -97,10 +101,31 @@ int pllhip_group_parallel(pllhip_ctx * g, const std::function<int(pllhip_ctx *, 
   }
   if (!g->pool)
   {
+    // (the workers inherit a mask with every signal blocked: a client's handlers run on the client's threads.  A
+    // thread that cannot be created must not end the process inside a C API: the calling thread then visits the
+    // shards itself, now and from now on -- ADVICE r5)
+    sigset_t all, old;
+    sigfillset(&all);
+    pthread_sigmask(SIG_BLOCK, &all, &old);
     g->pool = new pllhip_shard_pool();
     g->pool->rc.assign(n, 0);
     g->pool->msg.assign(n, std::string());
-    for (size_t i = 1; i < n; ++i) g->pool->threads.emplace_back(shard_worker, g, i);
+    bool ok = true;
+    try
+    {
+      for (size_t i = 1; i < n; ++i) g->pool->threads.emplace_back(shard_worker, g, i);
+    }
+    catch (const std::system_error &)
+    {
+      ok = false;
+    }
+    pthread_sigmask(SIG_SETMASK, &old, nullptr);
+    if (!ok)
+    {
+      pool_destroy(g);
+      g->shard_threads = false;
+      return pllhip_group_parallel(g, fn);
+    }
   }
   pllhip_shard_pool & p = *g->pool;
   {
@@ -250,22 +275,61 @@ template <typename Enqueue>
 int fan_out_and_sum(pllhip_ctx * g, unsigned int ncomp, double * sums, Enqueue enqueue)
 {
   pllhip_device_guard guard; // (the caller's current device is put back on return)
-  int rc = pllhip_group_parallel(g, [&](pllhip_ctx * s, size_t lo) -> int {
-    s->defer = true;
-    const int r = enqueue(s, lo);
-    s->defer = false;
-    return r;
-  });
-  for (unsigned int k = 0; k < ncomp; ++k) sums[k] = 0.0;
-  // (also after a failure: nothing may still be writing into the caller's per-site buffer)
-  for (pllhip_ctx * s : g->shards)
+  for (;;)
   {
-    double v[2] = {0.0, 0.0};
-    const int rw = result_wait(s, ncomp, v);
-    if (!rc) rc = rw;
-    for (unsigned int k = 0; k < ncomp; ++k) sums[k] += v[k];
+    const size_t n = g->shards.size();
+    std::vector<int> enq(n, 0);
+    std::vector<std::string> enq_msg(n);
+    int rc = pllhip_group_parallel(g, [&](pllhip_ctx * s, size_t lo) -> int {
+      // (a shard that fails before it has enqueued a result must not be waited for as if it had: the previous
+      // call's sequence number and "host adds the sums" would be polled -- ADVICE r5)
+      s->pending_seq = 0;
+      s->pending_hostsum = s->pending_spin = s->pending_stream_work = false;
+      s->defer = true;
+      const int r = enqueue(s, lo);
+      s->defer = false;
+      size_t i = 0;
+      while (i + 1 < n && g->shards[i] != s) ++i;
+      enq[i] = r;
+      if (r) enq_msg[i] = pllhip_last_error();
+      return r;
+    });
+    for (unsigned int k = 0; k < ncomp; ++k) sums[k] = 0.0;
+    // (also after a failure: nothing may still be writing into the caller's per-site buffer)
+    for (size_t i = 0; i < n; ++i)
+    {
+      pllhip_ctx * s = g->shards[i];
+      if (enq[i])
+      {
+        // nothing of this call's to collect from this shard: its stream only, and the first error's text is kept
+        if (hipSetDevice(s->sh.device) == hipSuccess) (void)hipStreamSynchronize(s->stream);
+        if (!rc) rc = enq[i];
+        continue;
+      }
+      double v[2] = {0.0, 0.0};
+      const int rw = result_wait(s, ncomp, v);
+      if (!rc) rc = rw;
+      for (unsigned int k = 0; k < ncomp; ++k) sums[k] += v[k];
+    }
+    if (rc)
+    {
+      for (size_t i = 0; i < n; ++i)
+        if (enq[i] && !enq_msg[i].empty()) { pllhip_set_error("%s", enq_msg[i].c_str()); break; }
+      return rc;
+    }
+    // the scaling certificate (ctx.hpp): every shard's result is in, so every shard's list is through and its flag can
+    // be read; a shard that runs its list again makes the whole evaluation stale
+    bool again = false;
+    for (pllhip_ctx * s : g->shards)
+      if (s->cert_pending)
+      {
+        bool r = false;
+        const int rr = pllhip_cert_resolve(s, &r);
+        if (rr) return rr;
+        again = again || r;
+      }
+    if (!again) return 0;
   }
-  return rc;
 }
 }
 
@@ -351,7 +415,10 @@ int pllhip_group_root_loglikelihood(pllhip_ctx * g, unsigned int clv_index, int 
   if (g->sh.rate_scalers && scaler_index >= 0 && scaler_index < (int)g->sh.scale_buffers)
   {
     pllhip_device_guard guard;
-    rc = gather_root_counts(g, scaler_index);
+    // (the counts gathered below must be final: the scaling certificate of every shard's last list first)
+    for (pllhip_ctx * s : g->shards)
+      if (s->cert_pending && !rc) rc = pllhip_cert_resolve(s);
+    if (!rc) rc = gather_root_counts(g, scaler_index);
   }
   if (!rc)
     rc = fan_out_and_sum(g, 1, h_lnl, [&](pllhip_ctx * s, size_t lo) {

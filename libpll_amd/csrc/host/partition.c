@@ -797,6 +797,13 @@ int pll_amd_profile_enable(pll_partition_t * p, int on)
   return PLL_SUCCESS;
 }
 
+int pll_amd_scaling_certificate(pll_partition_t * p, unsigned long long * stats4)
+{
+  int rc = pllhip_cert_stats(pll_amd_priv(p)->ctx, stats4);
+  if (rc) return pll_amd_fail_hip(rc, "scaling certificate");
+  return PLL_SUCCESS;
+}
+
 int pll_amd_profile_read(pll_partition_t * p, unsigned int * launches, double * total_ms)
 {
   int rc = pllhip_profile_read(pll_amd_priv(p)->ctx, launches, total_ms);

@@ -158,6 +158,8 @@ class PllLibrary:
             lib.pll_amd_comm_init.argtypes = [_PP, C.c_int, C.c_int, C.c_void_p]
             lib.pll_amd_profile_enable.argtypes = [_PP, C.c_int]
             lib.pll_amd_profile_read.argtypes = [_PP, _up, _dp]
+            if hasattr(lib, "pll_amd_scaling_certificate"):
+                lib.pll_amd_scaling_certificate.argtypes = [_PP, C.POINTER(C.c_ulonglong)]
             lib.pll_amd_eigen_decompose.argtypes = [C.c_uint, _dp, _dp, _dp, _dp, _dp]
 
     # -- library-level helpers -------------------------------------------------
@@ -398,6 +400,12 @@ class Partition:
         names = ("partials_ii", "partials_ti", "partials_tt", "lnl", "sumtable", "derivatives",
                  "pmatrix")
         return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(names)}
+
+    def scaling_certificate(self):
+        """{lists, raised, rerun, uncertified} of the 20-state scaling certificate (pll_amd.h)."""
+        buf = (C.c_ulonglong * 4)()
+        self._check(self.lib.pll_amd_scaling_certificate(self.ptr, buf), "pll_amd_scaling_certificate")
+        return dict(zip(("lists", "raised", "rerun", "uncertified"), (int(v) for v in buf)))
 
     def comm_init(self, rank, nranks, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)

@@ -88,11 +88,14 @@ def ref_tree():
     return _L
 
 
-@pytest.fixture(params=["exact", "mfma"])
+@pytest.fixture(params=["exact", "mfma", "mfma-reference-order"])
 def aa_mode(request, monkeypatch):
-    """20-state kernels: bit-exact vector kernels (PLLHIP_AA_EXACT=1) or the
-    default matrix-core kernels.  Read when a partition is created."""
+    """20-state kernels: bit-exact vector kernels (PLLHIP_AA_EXACT=1), the default matrix-core kernels (round 6: the
+    whole-list kernel's tip-inner mat-vecs on the matrix cores too -- CLVs to rounding below such an op, scaler counts
+    bit for bit behind the scaling certificate), or the matrix-core kernels with those mat-vecs in the reference's
+    order (PLLHIP_AA_TI_MFMA=0: every CLV bit for bit).  Read when a partition is created."""
     monkeypatch.setenv("PLLHIP_AA_EXACT", "1" if request.param == "exact" else "0")
+    monkeypatch.setenv("PLLHIP_AA_TI_MFMA", "1" if request.param == "mfma" else "0")
     # the table-lookup ops (used from 32 k sites on) also for the small test partitions
     monkeypatch.setenv("PLLHIP_AA_CHERRY", "2")
     return request.param

@@ -164,6 +164,38 @@ def bits_equal(a, b):
     return a.shape == b.shape and bool((a.view(np.uint64) == b.view(np.uint64)).all())
 
 
+def clvs_bitwise(states):
+    """Does the configuration the environment selects promise every CLV bit for bit?  Not 20 states on the default
+    path: PLLHIP_AA_TI_MFMA (default on) runs tip-inner mat-vecs of the whole-list kernel on the matrix cores."""
+    import os
+    return not (states == 20 and os.environ.get("PLLHIP_AA_TI_MFMA", "1") != "0" and
+                os.environ.get("PLLHIP_AA_EXACT", "0") != "1")
+
+
+def clv_err(a, b):
+    """Largest difference of two CLVs [sites][rates][states], entry by entry, relative to the entry -- or to 1e-150 x
+    the site's largest entry, if that is more.  The floor is for entries that were DENORMAL on the way (a block whose
+    largest entry is kept above 2^-256 by the scaling can hold entries 200 orders of magnitude below it): they were
+    rounded to a multiple of 2^-1074 there, so two summation orders that differ in the last bit of a normal number
+    differ by 1e-12 relative in such an entry (seen: 6.4e-235 in a block with 2.4e-67 -- exactly 2^-1074 x 2^256
+    apart).  Such entries weigh nothing in any likelihood."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if not a.size:
+        return 0.0
+    floor = 1e-150 * np.abs(b).reshape(b.shape[0], -1).max(axis=1).reshape((-1,) + (1,) * (b.ndim - 1))
+    return float(np.max(np.abs(a - b) / np.maximum(np.maximum(np.abs(b), floor), 1e-300)))
+
+
+def clv_ok(a, b, exact=True, tol=1e-12):
+    """A CLV against the oracle's / the reference's: bit for bit, or -- 20 states on the default path, where the
+    whole-list kernel runs the mat-vec of tip-inner ops on the matrix cores (round 6) -- to rounding, entry by entry
+    (clv_err; ~6e-16 per op of depth measured on a 300-tip ladder: 1e-13 for the trees of the BASELINE configs, which
+    tests/test_gpu_baseline_configs.py asks for, 1e-12 by default -- 400-tip ladders).
+    (Scaler counts are compared bit for bit either way: the scaling certificate, tests/test_gpu_cert.py.)"""
+    return bits_equal(a, b) if exact else clv_err(a, b) <= tol
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

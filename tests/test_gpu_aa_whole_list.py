@@ -2,11 +2,14 @@
 products (round 3), through the C-ABI against the oracle and against the per-level launches.
 
 What is asserted:
-  * EVERY CLV update on the DEFAULT path equals the oracle bit for bit: inner-inner ops on the matrix cores --
+  * with PLLHIP_AA_TI_MFMA=0 EVERY CLV update equals the oracle bit for bit: inner-inner ops on the matrix cores --
     core_partials_avx2.c:632-750's four FMA chains and pairwise tree, reproduced with the MFMA's own
     accumulation order (tools/mfma_order_probe.hip) --, tip-inner ops (round 4) with their one mat-vec on the
     vector unit in the non-fused order of core_partials_avx.c:1229-1284, tip-tip ops and the table lookups
     that replace ops over tip-tip results; scaler counts equal everywhere;
+  * on the DEFAULT path (round 6: the whole-list kernel runs the mat-vec of tip-inner ops on the matrix cores, behind
+    the scaling certificate of tests/test_gpu_cert.py) every scaler count still equals the oracle's bit for bit, every
+    CLV to 1e-13 entry by entry -- and bit for bit wherever no tip-inner op lies below it;
   * the whole-list kernel (PLLHIP_FUSED=2) and the per-level launches (PLLHIP_FUSED=0) give the same
     bits for every CLV and scale buffer: full traversals, partial traversals on top of them (operands
     from earlier calls), tips as characters and as CLVs, trees that need evictions, ragged site
@@ -18,7 +21,7 @@ What is asserted:
 import numpy as np
 import pytest
 
-from helpers import make_case, build_partition, oracle_run, bits_equal
+from helpers import make_case, build_partition, oracle_run, bits_equal, clv_ok
 from libpll_amd.pllapi import ATTRIB_PATTERN_TIP, SCALE_BUFFER_NONE
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +42,10 @@ def _kinds(plan, tips, attrs):
     return out
 
 
-def _evaluate(gpu, case, attrs, monkeypatch, fused, partial=True):
+def _evaluate(gpu, case, attrs, monkeypatch, fused, partial=True, ti_mfma="0"):
+    """ti_mfma: "0" = tip-inner mat-vecs of the whole-list kernel in the reference's order (every CLV bit for bit),
+    "1" = on the matrix cores, the default."""
+    monkeypatch.setenv("PLLHIP_AA_TI_MFMA", ti_mfma)
     monkeypatch.setenv("PLLHIP_AA_EXACT", "0")
     monkeypatch.setenv("PLLHIP_AA_CHERRY", "2")
     monkeypatch.setenv("PLLHIP_FUSED", fused)
@@ -73,21 +79,30 @@ def test_whole_list_equals_per_level_and_oracle(gpu, orc, monkeypatch, shape, ti
     plan = case["plan"]
     pf, cf, sf, lf = _evaluate(gpu, case, attrs, monkeypatch, "2")
     pf.destroy()
+    pd, cd, sd, ld = _evaluate(gpu, case, attrs, monkeypatch, "2", ti_mfma="1")   # the default
+    cert = pd.scaling_certificate()
+    pd.destroy()
     pl, cl, sl, ll = _evaluate(gpu, case, attrs, monkeypatch, "0")
     o = oracle_run(orc, gpu, pl, case, attrs)
     o.update_partials()
     pl.destroy()
     kinds = _kinds(plan, tips, attrs)
-    for op, kind, a, b, x, y in zip(plan.ops, kinds, cf, cl, sf, sl):
+    for op, kind, a, b, x, y, ad, xd in zip(plan.ops, kinds, cf, cl, sf, sl, cd, sd):
         node = int(op["parent_clv_index"])
         assert bits_equal(a, b), "CLV %d: whole list != per level" % node
         assert (x == y).all(), "scale buffer of CLV %d: whole list != per level" % node
         assert (x == o.scalers[int(op["parent_scaler_index"])]).all(), "scaler counts of CLV %d != oracle" % node
         # round 4: tip-inner ops too (their one mat-vec runs on the vector unit in the reference's non-fused order)
         assert bits_equal(a, o.clv[node]), "CLV %d (%s) != oracle" % (node, kind)
+        # round 6, the default: counts bit for bit, CLVs to rounding
+        assert (xd == x).all(), "default path: scaler counts of CLV %d != oracle" % node
+        assert clv_ok(ad, o.clv[node], exact=False), "default path: CLV %d (%s)" % (node, kind)
     assert lf == ll
     ref = o.edge_loglikelihood(*plan.root_edge)
-    assert abs(lf - ref) <= 1e-11 * abs(ref)
+    assert abs(lf - ref) <= 1e-11 * abs(ref) and abs(ld - ref) <= 1e-11 * abs(ref)
+    assert cert["uncertified"] == 0
+    if "ti" in kinds and attrs:
+        assert cert["lists"] >= 1 or all(int(op["parent_scaler_index"]) < 0 for op in plan.ops), cert
 
 
 @pytest.mark.parametrize("tips,sites", [(24, 900), (40, 130)])
@@ -102,6 +117,10 @@ def test_whole_list_with_another_character_map(gpu, orc, monkeypatch, tips, site
     pf, cf, sf, lf = _evaluate(gpu, case, attrs, monkeypatch, "2")
     assert pf.s.maxstates != 23
     pf.destroy()
+    pd, cd, sd, ld = _evaluate(gpu, case, attrs, monkeypatch, "2", ti_mfma="1")   # the default
+    pd.destroy()
+    for a, ad, x, xd in zip(cf, cd, sf, sd):
+        assert clv_ok(ad, a, exact=False) and (x == xd).all()
     pl, cl, sl, ll = _evaluate(gpu, case, attrs, monkeypatch, "0")
     o = oracle_run(orc, gpu, pl, case, attrs)
     o.update_partials()
@@ -143,20 +162,22 @@ def test_many_tiles_per_wave_on_a_tree_that_scales(gpu, orc, monkeypatch, attrs,
     monkeypatch.setenv("PLLHIP_AA_GRID_CAP", "1")
     case = _case(gpu, "caterpillar", 300, 300, seed=5)
     plan = case["plan"]
-    p, clvs, scs, lnl = _evaluate(gpu, case, attrs, monkeypatch, fused, partial=False)
-    o = oracle_run(orc, gpu, p, case, attrs)
-    o.update_partials()
-    p.destroy()
-    top = 0
-    kinds = _kinds(plan, 300, attrs)
-    for op, kind, a, x in zip(plan.ops, kinds, clvs, scs):
-        sc = o.scalers[int(op["parent_scaler_index"])]
-        assert (x == sc).all(), "scaler counts of CLV %d" % int(op["parent_clv_index"])
-        top = max(top, int(sc.max()))
-        assert bits_equal(a, o.clv[int(op["parent_clv_index"])]), kind
-    assert top >= 3, "the tree was meant to scale (highest count %d)" % top
-    ref = o.edge_loglikelihood(*plan.root_edge)
-    assert abs(lnl - ref) <= 1e-11 * abs(ref)
+    for ti_mfma in ("0", "1"):
+        p, clvs, scs, lnl = _evaluate(gpu, case, attrs, monkeypatch, fused, partial=False, ti_mfma=ti_mfma)
+        o = oracle_run(orc, gpu, p, case, attrs)
+        o.update_partials()
+        assert p.scaling_certificate()["uncertified"] == 0
+        p.destroy()
+        top = 0
+        kinds = _kinds(plan, 300, attrs)
+        for op, kind, a, x in zip(plan.ops, kinds, clvs, scs):
+            sc = o.scalers[int(op["parent_scaler_index"])]
+            assert (x == sc).all(), "scaler counts of CLV %d" % int(op["parent_clv_index"])
+            top = max(top, int(sc.max()))
+            assert clv_ok(a, o.clv[int(op["parent_clv_index"])], exact=ti_mfma == "0"), kind
+        assert top >= 3, "the tree was meant to scale (highest count %d)" % top
+        ref = o.edge_loglikelihood(*plan.root_edge)
+        assert abs(lnl - ref) <= 1e-11 * abs(ref)
 
 
 def test_default_path_against_the_bit_exact_kernels_at_size(gpu, monkeypatch):
@@ -204,21 +225,30 @@ def test_whole_list_repeats_itself_at_size(gpu, monkeypatch):
     p.destroy()
     monkeypatch.setenv("PLLHIP_FUSED", "1")
     for fresh in range(2):
+        # (fresh 0: tip-inner mat-vecs in the reference's order -- the per-level launches' bits; fresh 1: the default, on
+        # the matrix cores -- the same value every time, and the per-level launches' to rounding)
+        monkeypatch.setenv("PLLHIP_AA_TI_MFMA", str(fresh))
         p = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP)
+        first = None
         for again in range(4):
             p.update_partials(plan.ops)
             got = p.compute_edge_loglikelihood(*plan.root_edge, [0] * R, persite=True)
-            assert got[0] == ref[0] and bits_equal(got[1], ref[1]), "partition %d, evaluation %d" % (fresh, again)
+            if fresh == 0:
+                assert got[0] == ref[0] and bits_equal(got[1], ref[1]), "partition %d, evaluation %d" % (fresh, again)
+            else:
+                first = first or got
+                assert got[0] == first[0] and bits_equal(got[1], first[1]), "evaluation %d differs from the first" % again
+                assert abs(got[0] - ref[0]) <= 1e-12 * abs(ref[0]) and np.abs(got[1] - ref[1]).max() <= 1e-9
+        assert p.scaling_certificate()["uncertified"] == 0
         p.destroy()
 
 
-def test_tip_inner_on_the_matrix_cores_is_opt_in(gpu, orc, monkeypatch):
-    """Round 5, PLLHIP_AA_TI_MFMA=1 (default off): the ONE mat-vec of a tip-inner op of the whole-list
-    kernel on the matrix cores (fused chains) instead of the vector unit in the reference's non-fused order
-    (core_partials_avx.c:1229-1284).  The opt-in path is NOT bit-exact: tip-inner CLVs -- and everything above them --
-    agree with the default path's (= the reference's) to 1e-13 relative on a 150-tip ladder (errors of ~1e-16 per op,
-    carried up the tree), the scale buffers are equal here (an entry within that distance of 2^-256 could differ), lnL
-    to 1e-12.  The default path stays what tests/test_gpu_aa_whole_list.py pins everywhere else: the oracle's bits."""
+def test_tip_inner_on_the_matrix_cores_against_the_reference_order(gpu, orc, monkeypatch):
+    """PLLHIP_AA_TI_MFMA (round 5: opt-in; round 6: the default, behind the scaling certificate): the ONE mat-vec of a
+    tip-inner op of the whole-list kernel on the matrix cores (fused chains) instead of the vector unit in the
+    reference's non-fused order (core_partials_avx.c:1229-1284).  Tip-inner CLVs -- and everything above them --
+    agree with the reference-order path's (= the reference's bits) to 1e-13 relative on a 150-tip ladder (errors of
+    ~1e-16 per op, carried up the tree), the scale buffers are equal (the certificate), lnL to 1e-12."""
     from helpers import make_case, build_partition, bits_equal, rel_err
     from libpll_amd.pllapi import ATTRIB_PATTERN_TIP
     monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
@@ -238,9 +268,9 @@ def test_tip_inner_on_the_matrix_cores_is_opt_in(gpu, orc, monkeypatch):
             out[flag] = (lnl, ps, clvs, scs)
             p.destroy()
         a, b = out["0"], out["1"]
-        assert any(not bits_equal(x, y) for x, y in zip(a[2], b[2])), "the opt-in path should differ in the last bits"
+        assert any(not bits_equal(x, y) for x, y in zip(a[2], b[2])), "the matrix-core path should differ in the last bits"
         for x, y in zip(a[2], b[2]):
-            assert rel_err(y, x) < 1e-13
+            assert clv_ok(y, x, exact=False, tol=1e-13)
         for x, y in zip(a[3], b[3]):
             assert (x == y).all()
         assert rel_err(b[1], a[1]) < 1e-11 and abs(b[0] - a[0]) <= 1e-12 * abs(a[0])

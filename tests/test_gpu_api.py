@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import (make_case, build_partition, oracle_run, bits_equal, rel_err,
+from helpers import (make_case, build_partition, oracle_run, bits_equal, rel_err, clv_ok, clvs_bitwise,
                      random_op_sequence, random_sequence_case)
 from libpll_amd.pllapi import (ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, OPS_DTYPE, SCALE_BUFFER_NONE,
                                PllError)
@@ -216,6 +216,10 @@ def test_random_op_sequences(gpu, orc, seed, monkeypatch):
     only ops that are independent on CLV *and* scale-buffer indices.  Bitwise
     against the oracle's strictly sequential execution."""
     monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)   # (the default path: 20 states on the matrix cores)
+    # (20 states: tip-inner mat-vecs of the whole-list kernel in the reference's order for the bitwise part -- these
+    # sequences feed one CLV to BOTH sides of an op, again and again, which no tree does and which doubles any last-bit
+    # difference each time; what the default path makes of them comes last)
+    monkeypatch.setenv("PLLHIP_AA_TI_MFMA", "0")
     case, attrs, ops, rng = random_sequence_case(seed)
     plan = case["plan"]
     p = build_partition(gpu, case, attrs)
@@ -236,6 +240,23 @@ def test_random_op_sequences(gpu, orc, seed, monkeypatch):
         assert bits_equal(p2.get_clv(node), p.get_clv(node))
     p.destroy()
     p2.destroy()
+    if case["states"] == 20:
+        # The default path (tip-inner mat-vecs on the matrix cores behind the scaling certificate): the bound it keeps
+        # per CLV doubles wherever a CLV meets itself; lists whose bounds would outgrow every window run in the
+        # reference's order, and a decision taken on operands that already carry such a bound is REPORTED as
+        # uncertified instead of silently trusted.  Counts still equal the oracle's here; CLVs to the bound's order.
+        monkeypatch.setenv("PLLHIP_AA_TI_MFMA", "1")
+        for pieces in (False, True):
+            q = build_partition(gpu, case, attrs)
+            for lo, hi in (zip([0] + cut, cut + [len(ops)]) if pieces else [(0, len(ops))]):
+                if hi > lo:
+                    q.update_partials(ops[lo:hi])
+            for sc in range(plan.scale_buffers):
+                assert (q.get_scaler(sc) == o.scalers[sc]).all(), "default path: scale buffer %d" % sc
+            cert = q.scaling_certificate()
+            worst = max(rel_err(q.get_clv(node), o.clv[node]) for node in sorted(set(int(x) for x in ops["parent_clv_index"])))
+            assert worst < 1e-4 and (worst < 1e-9 or cert["uncertified"] > 0), (worst, cert)
+            q.destroy()
 
 
 @pytest.mark.parametrize("states,rate_cats", [(2, 4), (5, 4), (5, 3), (13, 2), (13, 3), (24, 4), (61, 2), (7, 64)])
@@ -288,7 +309,7 @@ def test_same_list_again_after_branch_lengths_changed(gpu, orc, states, monkeypa
     o = oracle_run(orc, gpu, q, case, ATTRIB_PATTERN_TIP)
     o.update_partials()
     last = int(plan.ops[-1]["parent_clv_index"])
-    assert bits_equal(p.get_clv(last), o.clv[last])
+    assert clv_ok(p.get_clv(last), o.clv[last], clvs_bitwise(states))
     p.destroy()
     q.destroy()
 
@@ -364,11 +385,13 @@ def test_partial_traversal_after_branch_change(gpu, orc, states, shape, monkeypa
         o = oracle_run(orc, gpu, fresh, case, ATTRIB_PATTERN_TIP)
         fresh.update_partials(plan.ops)
         o.update_partials()
-        assert lnl_inc == fresh.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+        exact = clvs_bitwise(states)   # (20 states, default path: a one-op list runs in the reference's order, a
+        lnl_fresh = fresh.compute_edge_loglikelihood(*plan.root_edge, [0] * R)   # longer one on the matrix cores)
+        assert lnl_inc == lnl_fresh if exact else abs(lnl_inc - lnl_fresh) <= 1e-12 * abs(lnl_fresh)
         assert lnl_inc != lnl_before
         for op in plan.ops:
             node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
-            assert bits_equal(p.get_clv(node), o.clv[node]), node
+            assert clv_ok(p.get_clv(node), o.clv[node], exact), node
             assert (p.get_scaler(sc) == o.scalers[sc]).all()
         assert abs(lnl_inc - o.edge_loglikelihood(*plan.root_edge)) <= 1e-12 * abs(lnl_inc)
         fresh.destroy()
@@ -404,7 +427,7 @@ def test_one_rate_matrix_per_category(gpu, ref, aa_mode, states, pinv):
     eigen-decomposition, frequencies, weight (and +I proportion).  P-matrices, CLVs,
     lnL, sumtable and derivatives against the genuine reference."""
     from libpll_amd.pllapi import ATTRIB_ARCH_AVX2
-    if states == 4 and aa_mode == "mfma":
+    if states == 4 and aa_mode != "exact":
         pytest.skip("mode only affects 20-state kernels")
     exact = states == 4 or aa_mode == "exact"
     rng = np.random.default_rng(states + int(100 * pinv))

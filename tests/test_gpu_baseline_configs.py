@@ -14,7 +14,7 @@ Reference shapes: test/src/scaling.c:263-367 (deep tree + scalers + sumtable/der
 import numpy as np
 import pytest
 
-from helpers import bits_equal, rel_err
+from helpers import bits_equal, clv_ok, rel_err
 from libpll_amd import workload as W
 from libpll_amd.pllapi import ATTRIB_ARCH_AVX2, ATTRIB_PATTERN_TIP, ATTRIB_RATE_SCALERS, ATTRIB_SITE_REPEATS, PllError
 
@@ -181,18 +181,20 @@ def c3_data(request, gpu):
 
 
 @pytest.mark.parametrize("scale_attr", [0, ATTRIB_RATE_SCALERS], ids=["per-site-scalers", "per-rate-scalers"])
-@pytest.mark.parametrize("path", ["whole-list", "levels"])
+@pytest.mark.parametrize("path", ["whole-list", "whole-list-reference-order", "levels"])
 def test_config3_slice_against_reference(gpu, ref, c3_data, monkeypatch, path, scale_attr):
     """50,000 sites of C3 -- and of an LG alignment on a 200-taxon random tree: tip-inner ops, scaling events,
     evictions -- through the genuine reference (AVX2 flag) and through the product's DEFAULT 20-state path, whole
-    list and per level: the scale buffer of EVERY op bitwise, CLVs bitwise (every fifth op and the last five: a
-    CLV is 32 MB), per-site lnL to 1e-11 (the edge kernel on the matrix cores sums a row in one fused chain),
-    lnL to 1e-12."""
+    list and per level: the scale buffer of EVERY op bitwise, CLVs (every fifth op and the last five: a CLV is 32 MB)
+    bitwise -- on the default whole-list path (round 6: tip-inner mat-vecs on the matrix cores behind the scaling
+    certificate) to 1e-13 wherever a tip-inner op lies below; with PLLHIP_AA_TI_MFMA=0 bitwise everywhere --,
+    per-site lnL to 1e-11 (the edge kernel on the matrix cores sums a row in one fused chain), lnL to 1e-12.
+    Per-rate scale buffers (round 6) on the whole-list kernel too."""
     name, plan, seqs = c3_data
     monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
-    monkeypatch.setenv("PLLHIP_FUSED", "2" if path == "whole-list" else "0")
-    if scale_attr and path == "whole-list":
-        pytest.skip("per-rate scale buffers: the 20-state whole-list kernel does not take them (per-level launches, the other case)")
+    monkeypatch.setenv("PLLHIP_FUSED", "0" if path == "levels" else "2")
+    monkeypatch.setenv("PLLHIP_AA_TI_MFMA", "0" if path == "whole-list-reference-order" else "1")
+    exact = path != "whole-list"
     a = W.setup_partition(gpu, plan, seqs, 20, R, ATTRIB_PATTERN_TIP | scale_attr)
     r = W.setup_partition(ref, plan, seqs, 20, R, ATTRIB_PATTERN_TIP | scale_attr | ATTRIB_ARCH_AVX2)
     a.update_partials(plan.ops)
@@ -205,9 +207,11 @@ def test_config3_slice_against_reference(gpu, ref, c3_data, monkeypatch, path, s
         assert (a.get_scaler(sc) == rs).all(), "%s: scale buffer of op %d" % (name, i)
         top = max(top, int(rs.max()))
         if i % 5 == 0 or i >= len(plan.ops) - 5:
-            assert bits_equal(a.get_clv(node), r.get_clv(node)), "%s: CLV of op %d" % (name, i)
+            assert clv_ok(a.get_clv(node), r.get_clv(node), exact, tol=1e-13), "%s: CLV of op %d" % (name, i)
     if name == "random-200":
         assert top >= 1, "the 200-taxon tree was meant to scale"
+    cert = a.scaling_certificate()
+    assert cert["uncertified"] == 0 and (cert["lists"] >= 1) == (path == "whole-list" and name == "random-200"), cert
     la, pa = a.compute_edge_loglikelihood(*plan.root_edge, FI, persite=True)
     lr, pr = r.compute_edge_loglikelihood(*plan.root_edge, FI, persite=True)
     assert rel_err(pa, pr) < 1e-11

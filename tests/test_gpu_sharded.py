@@ -276,6 +276,9 @@ def test_sharded_with_site_repeats(gpu, monkeypatch, states, shape, tips, sites,
     client can observe -- expanded CLVs and scale buffers, per-site lnL, sumtable bitwise; lnL, derivatives --
     equals the unsharded PLAIN partition.  Repeated columns make most nodes stored by class on every shard."""
     monkeypatch.delenv("PLLHIP_AA_EXACT", raising=False)
+    # (site repeats run per level, the plain partition may take the whole-list kernel: bit for bit only with its
+    # tip-inner mat-vecs in the reference's order too -- the default's rounding is tests/test_gpu_cert.py's subject)
+    monkeypatch.setenv("PLLHIP_AA_TI_MFMA", "0")
     case = make_case(states, shape, tips, sites, seed=tips + sites, gap_frac=0.02)
     rng = np.random.default_rng(sites)
     pool = rng.integers(0, sites, size=sites // 6 + 1)

@@ -13,7 +13,7 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 os.environ.pop("PLLHIP_AA_EXACT", None)
 import numpy as np
 import libpll_amd
-from helpers import bits_equal
+from helpers import bits_equal, clv_err
 from libpll_amd import workload as W
 from libpll_amd.pllapi import ATTRIB_PATTERN_TIP
 
@@ -36,6 +36,7 @@ def run(first=0, count=200, sites=100_000, T=200, states=20, rate_scalers=False,
         os.environ.pop("PLLHIP_FUSED", None)
     else:
         os.environ["PLLHIP_FUSED"] = saved
+    loose = states == 20 and os.environ.get("PLLHIP_AA_TI_MFMA", "1") != "0"
     bad, t0 = 0, time.time()
     for seed in range(first, first + count):
         plan = W.random_tree(T, seed=1000 + seed)
@@ -56,18 +57,31 @@ def run(first=0, count=200, sites=100_000, T=200, states=20, rate_scalers=False,
             clvs = [p.get_clv(int(op["parent_clv_index"])) for op in plan.ops[-3:]] if seed % 50 == 0 else []
             out[fused] = (a, b, c, scs, clvs)
         x, y = out["2"], out["0"]
-        ok = all(x[k][0] == y[k][0] and bits_equal(x[k][1], y[k][1]) for k in range(3)) and \
-            x[0][0] == x[1][0] and bits_equal(x[0][1], x[1][1]) and \
-            all((s == t).all() for s, t in zip(x[3], y[3])) and all(bits_equal(s, t) for s, t in zip(x[4], y[4]))
+        if loose:
+            # 20 states, default path (round 6): the whole-list kernel's tip-inner mat-vecs run on the matrix cores --
+            # scale buffers bit for bit (the scaling certificate), everything else to rounding; the kept plan's
+            # evaluation still repeats the first one's bits
+            ok = all(abs(x[k][0] - y[k][0]) <= 1e-12 * abs(y[k][0]) and np.abs(x[k][1] - y[k][1]).max() <= 1e-9 for k in range(3)) and \
+                x[0][0] == x[1][0] and bits_equal(x[0][1], x[1][1]) and \
+                all((s == t).all() for s, t in zip(x[3], y[3])) and all(clv_err(s, t) <= 1e-13 for s, t in zip(x[4], y[4]))
+        else:
+            ok = all(x[k][0] == y[k][0] and bits_equal(x[k][1], y[k][1]) for k in range(3)) and \
+                x[0][0] == x[1][0] and bits_equal(x[0][1], x[1][1]) and \
+                all((s == t).all() for s, t in zip(x[3], y[3])) and all(bits_equal(s, t) for s, t in zip(x[4], y[4]))
         if not ok:
             bad += 1
             print("MISMATCH seed", seed, [x[k][0] for k in range(3)], [y[k][0] for k in range(3)], flush=True)
         if (seed - first) % 500 == 499 and not quiet:
             print("  ... %d seeds, %d mismatches, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
+    cert = parts["2"].scaling_certificate() if states == 20 else None
     for p in parts.values():
         p.destroy()
     print("soak_aa_fused_at_size: %d seeds from %d at %d sites x %d taxa, %d states%s, %d mismatches, %.0f s"
           % (count, first, sites, T, states, ", per-rate scale buffers" if rate_scalers else "", bad, time.time() - t0))
+    if cert is not None:
+        print("  scaling certificate of the whole-list partition: %s%s" % (cert, "" if loose else " (tip-inner mat-vecs in the reference's order)"))
+        if cert["uncertified"]:
+            bad += 1
     return bad
 
 

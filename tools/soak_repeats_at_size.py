@@ -30,6 +30,7 @@ def run(first, count, log=print, amd=None):
         case["seqs"] = [bytes(np.frombuffer(s, dtype=np.uint8)[pick]) for s in case["seqs"]]
         plan = case["plan"]
         os.environ["PLLHIP_AA_EXACT"] = "0"
+        os.environ["PLLHIP_AA_TI_MFMA"] = "0"   # (plain against repeats bit for bit: the reference's order on both)
         plain = build_partition(amd, case, attrs)
         rep = build_partition(amd, case, attrs | ATTRIB_SITE_REPEATS)
         ops = plan.ops.copy()
