@@ -60,6 +60,19 @@ import time
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# FP64 on the matrix cores, for the instruction form the 20-state kernels use: v_mfma_f64_4x4x4_4b_f64 is 512 flop per
+# wave instruction (4 blocks x 4x4x4 x 2) at 16 cycles -> 32 flop / clk / SIMD x 1024 SIMDs x 2.4 GHz.  Measured on this
+# part (tools/mfma_f64_bench.hip): 17 cycles per instruction = 65 TFLOP/s for this form, 33-43 TFLOP/s for
+# v_mfma_f64_16x16x4_f64 (136 cycles), whose 20-row operands would also be 37.5 % padding.
+MFMA_F64_PEAK_TFLOPS = 78.6
+MFMA_F64_MEASURED_TFLOPS = 65.0
+# floating-point operations per site-update of the reference's algorithm, 20 states x 4 rate categories: an
+# inner-inner op is two 20x20 mat-vecs (400 multiplications + 380 additions each) and 20 products per category
+# (core_partials_avx2.c:632-750); a tip-inner op one mat-vec and the product with the tip's table row
+# (core_partials_avx.c:1229-1284); a tip-tip op the product of two table rows (core_partials_avx.c:241-249)
+FLOPS_PER_SITE_UPDATE_20 = {"ii": 4 * (2 * 780 + 20), "ti": 4 * (780 + 20), "tt": 4 * 20}
+# ... of which on the matrix cores as this library runs them: four of a chain's five steps (columns 0-15 of the 20)
+MFMA_FLOPS_PER_MATVEC_20 = 4 * 20 * 16 * 2
 # `roofline.traffic`: HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes
 # (FETCH_SIZE x 2 -- gfx950 counts 128-B requests at 64 B -- + WRITE_SIZE, separate passes),
 # looked up in profiles/pmc_traffic.json, which tools/summarize_rocprof.py writes from the
@@ -72,7 +85,8 @@ def pmc_traffic(root, **key):
     for entry in index:
         if all(entry["workload"].get(k) == v for k, v in key.items()):
             return {"bytes_per_launch": entry["hbm_MB_per_launch"] * 1e6, "kernel": entry["kernel"],
-                    "source": entry["source"], "ops_per_launch": entry.get("ops_per_launch")}
+                    "source": entry["source"], "ops_per_launch": entry.get("ops_per_launch"),
+                    "mfma_busy": entry.get("mfma_busy_frac"), "mfma_source": entry.get("mfma_source")}
     return None
 
 
@@ -520,10 +534,55 @@ def main():
                     "avg_op_us": round(launch_s * 1e6 / len(plan.ops), 2),
                     "note": "one launch runs the whole op list site-blocked and keeps children on chip: its "
                             "algorithmic bytes are one write per CLV entry and count + one read per tip character "
-                            "(algorithmic_bytes_per_site; traffic = PMC agrees), a write stream (a bare one with the "
-                            "same addresses reaches 5.5-6.9 TB/s on this part).  Counting SURVEY 8(d)'s per-op bytes (396/265/134 B per "
-                            "site-update, per_op_algorithm_bytes_per_site) the same launch is worth "
-                            "per_op_algorithm_equivalent_GBs"}
+                            "(algorithmic_bytes_per_site; traffic = PMC agrees), a write stream -- box_ceiling is what "
+                            "nothing but these stores reaches on this device in this run.  Counting SURVEY 8(d)'s per-op "
+                            "bytes (%s B per inner-inner / tip-inner / tip-tip site-update, per_op_algorithm_bytes_per_site) "
+                            "the same launch is worth per_op_algorithm_equivalent_GBs"
+                            % "/".join(str(BYTES_PER_SITE[k][S]) for k in ("ii", "ti", "tt"))}
+        if inproc == 1 and not args.site_repeats:
+            # ---- the box's own ceiling, in THIS run: nothing but the stores of this op list --
+            # the list kernel's parents, tile walk and cache policy, no loads, no arithmetic -- for about 50 ms
+            reps_c = max(3, int(round(0.05 / launch_s)))
+            ms_c, bytes_c = part.write_ceiling(plan.ops, reps_c)
+            part.update_partials(plan.ops)          # (the ceiling pass overwrote every CLV of the list)
+            part.wait()
+            ceiling = bytes_c / (ms_c / 1e3) / 1e9
+            roofline["box_ceiling"] = {"GBs": round(ceiling, 1), "frac_of_peak": round(ceiling / HBM_PEAK_GBS, 4),
+                                       "ms_per_pass": round(ms_c, 4), "passes": reps_c, "bytes_per_pass": bytes_c,
+                                       "what": "pll_amd_write_ceiling: the %d parents' CLVs and scale buffers stored tile by "
+                                               "tile in the list kernel's order by a kernel that does nothing else, HIP events "
+                                               "on the partition's stream, after the timed region" % len(plan.ops)}
+            roofline["frac_of_box_ceiling"] = round(achieved / ceiling, 4)
+        if S == 20:
+            # ---- the other ceiling north_star names for 20 states: the FP64 matrix cores
+            kinds = part.list_kinds()
+            n_sites = hi - lo
+            F = FLOPS_PER_SITE_UPDATE_20
+            ref_flops = n_sites * (n_ii * F["ii"] + n_ti * F["ti"] + n_tt * F["tt"])
+            # as run: an op over tip-tip results is a table lookup (one product per entry), a tip-tip op of the list one
+            # gather from its pair table (nothing); the rest multiply by their matrices
+            ti_run = kinds["tip_inner_matrix_cores"] + kinds["tip_inner_vector_unit"]
+            run_flops = n_sites * (kinds["inner_inner_matrix_cores"] * F["ii"] + ti_run * F["ti"] +
+                                   (kinds["lookups"] + kinds["tip_tip_ahead"]) * F["tt"])
+            mfma_flops = n_sites * MFMA_FLOPS_PER_MATVEC_20 * (2 * kinds["inner_inner_matrix_cores"] +
+                                                              kinds["tip_inner_matrix_cores"])
+            roofline["matrix_cores"] = {
+                "flops_per_launch_reference_algorithm": ref_flops, "flops_per_launch_as_run": run_flops,
+                "flops_per_launch_on_matrix_cores": mfma_flops,
+                "tflops_reference_algorithm": round(ref_flops / launch_s / 1e12, 2),
+                "tflops_as_run": round(run_flops / launch_s / 1e12, 2),
+                "tflops_on_matrix_cores": round(mfma_flops / launch_s / 1e12, 2),
+                "peak_tflops": MFMA_F64_PEAK_TFLOPS, "instruction": "v_mfma_f64_4x4x4_4b_f64",
+                "peak_note": "512 flop per wave instruction / 16 cycles x 1024 SIMDs x 2.4 GHz; measured for this form: %.0f "
+                             "TFLOP/s (17 cycles), 33-43 for v_mfma_f64_16x16x4_f64 (tools/mfma_f64_bench.hip)" % MFMA_F64_MEASURED_TFLOPS,
+                "frac_of_peak": round(mfma_flops / launch_s / 1e12 / MFMA_F64_PEAK_TFLOPS, 4),
+                "mfma_busy": pmc.get("mfma_busy") if pmc else None,
+                "mfma_busy_source": pmc.get("mfma_source") if pmc else None,
+                "list": kinds,
+                "note": "the list is bound by neither ceiling: most of its ops need no matrix (list: tip-tip ops are "
+                        "one gather, ops over tip-tip results a table lookup), and a matrix op runs at the wave's own "
+                        "serial path (DESIGN.md 2.2c); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 "
+                        "SIMDs) of the list kernel from the rocprofv3 PMC pass named in mfma_busy_source"}
     elif len(ii_ops):
         # how many kernel launches the library makes for this op list (independent
         # ops of one tree level are batched into one launch, blockIdx.y = op)

@@ -714,6 +714,14 @@ PLL_EXPORT int pll_amd_profile_read(pll_partition_t * partition, unsigned int * 
  * order everywhere, every CLV bit for bit. */
 PLL_EXPORT int pll_amd_scaling_certificate(pll_partition_t * partition, unsigned long long * stats4);
 
+/* Measurement only (bench.py's roofline.box_ceiling; pllhip.h: pllhip_write_ceiling): nothing but the stores of an op
+ * list with the whole-list kernels' own address pattern, `reps` times, timed with HIP events.  OVERWRITES the CLVs and
+ * scale buffers the list's ops write: call pll_update_partials with the list again before reading anything.
+ * pll_amd_list_kinds: what the 20-state whole-list kernel made of the last list it planned (pllhip_aa_list_kinds). */
+PLL_EXPORT int pll_amd_write_ceiling(pll_partition_t * partition, const pll_operation_t * operations, unsigned int count,
+                                     unsigned int reps, float * ms_per_pass, double * bytes_per_pass);
+PLL_EXPORT int pll_amd_list_kinds(pll_partition_t * partition, unsigned int * kinds8);
+
 #ifdef __cplusplus
 }
 #endif

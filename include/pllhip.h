@@ -317,6 +317,18 @@ PLLHIP_EXPORT int pllhip_profile_enable(pllhip_ctx_t * ctx, int on);
 PLLHIP_EXPORT int pllhip_profile_read(pllhip_ctx_t * ctx, unsigned int * launches /*[KINDS]*/,
                                       double * total_ms /*[KINDS]*/);
 
+/* Measurement only (bench.py: roofline.box_ceiling): NOTHING BUT the stores of an op list -- every parent CLV and scale
+ * buffer of `ops`, a wave's tile of each in turn, the tile walk and cache policy of the whole-list kernels, no loads, no
+ * arithmetic -- `reps` times behind one untimed pass, timed with HIP events on the context's stream: what a write
+ * stream with the list kernel's own addresses reaches on THIS device now.  OVERWRITES those CLVs and scale buffers:
+ * run the list again before reading anything.  Not for sharded contexts. */
+PLLHIP_EXPORT int pllhip_write_ceiling(pllhip_ctx_t * ctx, const pllhip_op_t * h_ops, unsigned int count,
+                                       unsigned int reps, float * ms_per_pass, double * bytes_per_pass);
+/* What the last op list planned by the 20-state whole-list kernel is made of: {ops, tip-tip ops ahead of the list,
+ * tip-tip ops in the list (one gather each), table lookups, inner-inner ops on the matrix cores, tip-inner ops on
+ * the matrix cores, tip-inner ops on the vector unit, operands reloaded from HBM}; zeros if none was planned. */
+PLLHIP_EXPORT int pllhip_aa_list_kinds(pllhip_ctx_t * ctx, unsigned int * out8);
+
 /* raw device pointer of a CLV (for tools that share HBM buffers, e.g. a
  * torch tensor wrapped around it); NULL if out of range */
 PLLHIP_EXPORT void * pllhip_dev_clv(pllhip_ctx_t * ctx, unsigned int clv_index);

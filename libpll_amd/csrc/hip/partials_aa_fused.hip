@@ -1031,6 +1031,10 @@ struct pllhip_aa_fused_cache
   std::vector<std::pair<unsigned int, double>> ext_marks, out_marks;
   int cert_kind = 0;
   bool cert_too_wide = false; // the bounds outgrew the widest window: every launch counts as uncertified
+  // what the kept plan is made of (pllhip_aa_list_kinds: bench.py's flop count): ops, tip-tip ahead of the list,
+  // tip-tip in the list, lookups, inner-inner on the matrix cores, tip-inner on the matrix cores, tip-inner on the
+  // vector unit, operands reloaded
+  unsigned int kinds_of_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 void pllhip_aa_fused_free(pllhip_ctx * c)
@@ -1117,6 +1121,16 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
     ++c->cert_stats[0];
     if (k.cert_too_wide) ++c->cert_stats[3];
   }
+  return 0;
+}
+
+// what the last op list the 20-state whole-list kernel planned is made of (0: nothing planned on this context)
+extern "C" int pllhip_aa_list_kinds(pllhip_ctx_t * c, unsigned int * out8)
+{
+  for (int t = 0; t < 8; ++t) out8[t] = 0;
+  pllhip_ctx * s = c->shards.empty() ? c : c->shards[0];
+  if (!s->aa_fused || s->aa_fused->last_ops.empty()) return 0;
+  memcpy(out8, s->aa_fused->kinds_of_plan, 8 * sizeof(unsigned int));
   return 0;
 }
 
@@ -1642,6 +1656,17 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   k.nmat = (unsigned int)mj.size();
   k.ntip = (unsigned int)tj.size();
   k.nops = n;
+  {
+    unsigned int n_ii = 0, n_ti = 0;
+    for (unsigned int i = 0; i < count; ++i)
+    {
+      n_ii += kinds[i] == 0;
+      n_ti += kinds[i] == 1;
+    }
+    const unsigned int v[8] = {count, (unsigned int)k.tt_ops.size(), (unsigned int)(tt_inside_rec.size() + tt_pair_rec.size()),
+                               (unsigned int)k.lk_ops.size(), n_ii, list_ti_mfma ? n_ti : 0u, list_ti_mfma ? 0u : n_ti, reloads};
+    memcpy(k.kinds_of_plan, v, sizeof(v));
+  }
   if (pllhip_env("PLLHIP_FUSED_DEBUG"))
   {
     fprintf(stderr, "pllhip 20-state list kernel: %u ops = %zu tip-tip ahead + %zu tip-tip in the list + %zu lookups + %zu on the matrix cores "

@@ -804,6 +804,21 @@ int pll_amd_scaling_certificate(pll_partition_t * p, unsigned long long * stats4
   return PLL_SUCCESS;
 }
 
+int pll_amd_write_ceiling(pll_partition_t * p, const pll_operation_t * operations, unsigned int count, unsigned int reps,
+                          float * ms_per_pass, double * bytes_per_pass)
+{
+  int rc = pllhip_write_ceiling(pll_amd_priv(p)->ctx, (const pllhip_op_t *)operations, count, reps, ms_per_pass, bytes_per_pass);
+  if (rc) return pll_amd_fail_hip(rc, "write ceiling");
+  return PLL_SUCCESS;
+}
+
+int pll_amd_list_kinds(pll_partition_t * p, unsigned int * kinds8)
+{
+  int rc = pllhip_aa_list_kinds(pll_amd_priv(p)->ctx, kinds8);
+  if (rc) return pll_amd_fail_hip(rc, "list kinds");
+  return PLL_SUCCESS;
+}
+
 int pll_amd_profile_read(pll_partition_t * p, unsigned int * launches, double * total_ms)
 {
   int rc = pllhip_profile_read(pll_amd_priv(p)->ctx, launches, total_ms);

@@ -160,6 +160,9 @@ class PllLibrary:
             lib.pll_amd_profile_read.argtypes = [_PP, _up, _dp]
             if hasattr(lib, "pll_amd_scaling_certificate"):
                 lib.pll_amd_scaling_certificate.argtypes = [_PP, C.POINTER(C.c_ulonglong)]
+                lib.pll_amd_write_ceiling.argtypes = [_PP, C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_float),
+                                                      C.POINTER(C.c_double)]
+                lib.pll_amd_list_kinds.argtypes = [_PP, _up]
             lib.pll_amd_eigen_decompose.argtypes = [C.c_uint, _dp, _dp, _dp, _dp, _dp]
 
     # -- library-level helpers -------------------------------------------------
@@ -406,6 +409,21 @@ class Partition:
         buf = (C.c_ulonglong * 4)()
         self._check(self.lib.pll_amd_scaling_certificate(self.ptr, buf), "pll_amd_scaling_certificate")
         return dict(zip(("lists", "raised", "rerun", "uncertified"), (int(v) for v in buf)))
+
+    def write_ceiling(self, ops, reps):
+        """(ms per pass, bytes per pass) of nothing but the stores of `ops` -- OVERWRITES their CLVs (pll_amd.h)."""
+        ops = np.ascontiguousarray(ops, dtype=OPS_DTYPE)
+        ms, nbytes = C.c_float(), C.c_double()
+        self._check(self.lib.pll_amd_write_ceiling(self.ptr, C.c_void_p(ops.ctypes.data), len(ops), reps,
+                                                   C.byref(ms), C.byref(nbytes)), "pll_amd_write_ceiling")
+        return ms.value, nbytes.value
+
+    def list_kinds(self):
+        """what the 20-state whole-list kernel made of the last list it planned (pll_amd.h)"""
+        v = np.zeros(8, dtype=np.uint32)
+        self._check(self.lib.pll_amd_list_kinds(self.ptr, _u(v)), "pll_amd_list_kinds")
+        return dict(zip(("ops", "tip_tip_ahead", "tip_tip_in_list", "lookups", "inner_inner_matrix_cores",
+                         "tip_inner_matrix_cores", "tip_inner_vector_unit", "reloads"), (int(x) for x in v)))
 
     def comm_init(self, rank, nranks, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)

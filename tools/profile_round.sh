@@ -88,10 +88,10 @@ cat > "$sum/pmc_spec.json" <<EOF
  {"csv": "${tag}_pmc_hbm_traffic_c2_per_level.csv", "kernel_match": "k_dna_partials<4, 1, true, 0", "kernel_class": "inner-inner",
   "bench_json": "$out/pmcpass_c2_per_level.json",
   "workload": {"states": 4, "rate_cats": 4, "sites": 1000000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
- {"csv": "${tag}_pmc_hbm_traffic_c3.csv", "kernel_match": "k_aa_fused", "kernel_class": "whole-list", "sum_call": true,
+ {"csv": "${tag}_pmc_hbm_traffic_c3.csv", "kernel_match": "k_aa_fused", "kernel_class": "whole-list", "sum_call": true, "mfma_csv": "${tag}_pmc_mfma_c3.csv",
   "exclude": ["k_lnl", "k_update_pmatrix", "fillBuffer", "copyBuffer", "k_final_sum"],
   "workload": {"states": 20, "rate_cats": 4, "sites": 200000, "taxa": 64, "tree": "balanced", "tip_clv": false, "rate_scalers": false}},
- {"csv": "${tag}_pmc_hbm_traffic_c3_random_200.csv", "kernel_match": "k_aa_fused", "kernel_class": "whole-list", "sum_call": true,
+ {"csv": "${tag}_pmc_hbm_traffic_c3_random_200.csv", "kernel_match": "k_aa_fused", "kernel_class": "whole-list", "sum_call": true, "mfma_csv": "${tag}_pmc_mfma_c3_random_200.csv",
   "exclude": ["k_lnl", "k_update_pmatrix", "fillBuffer", "copyBuffer", "k_final_sum"],
   "workload": {"states": 20, "rate_cats": 4, "sites": 100000, "taxa": 200, "tree": "random", "tip_clv": false, "rate_scalers": false}},
  {"csv": "${tag}_pmc_hbm_traffic_c3_per_level.csv", "kernel_match": "k_aa_ii_mfma<4, 1", "kernel_class": "inner-inner",

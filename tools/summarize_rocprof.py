@@ -121,6 +121,19 @@ def cmd_index(spec_path, out):
         entry = {"workload": dict(e["workload"], kernel_class=e["kernel_class"]), "kernel": name,
                  "dispatches": int(best[1]), "hbm_MB_per_launch": mb,
                  "source": "profiles/" + os.path.basename(path)}
+        mc = e.get("mfma_csv")
+        if mc:
+            # SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) against the launch's duration in shader-engine cycles:
+            # GRBM_GUI_ACTIVE is counted per XCD (8), a SIMD's share of the chip is 1 / 1024
+            mc = mc if os.path.isabs(mc) else os.path.join(base, mc)
+            try:
+                with open(mc, newline="") as f:
+                    mrows = [r for r in csv.reader(l for l in f if not l.startswith("#"))]
+                val = {r[1]: float(r[3]) for r in mrows[1:] if e["kernel_match"] in r[0]}
+                entry["mfma_busy_frac"] = round(val["SQ_VALU_MFMA_BUSY_CYCLES"] / (val["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+                entry["mfma_source"] = "profiles/" + os.path.basename(mc)
+            except (OSError, KeyError, ValueError, ZeroDivisionError):
+                pass
         bj = e.get("bench_json")
         if bj:
             bj = bj if os.path.isabs(bj) else os.path.join(base, bj)
