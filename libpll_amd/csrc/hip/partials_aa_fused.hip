@@ -109,7 +109,12 @@ constexpr unsigned int AF_LAST = 8192u;
 // the threshold (partials_aa_fused_op.inc); the segment's HEADER record carries what the rare path needs -- `parent`:
 // the address of the call's flag word (host memory), `pscaler`: the window as a double, 2^-256 x its relative half-width
 constexpr unsigned int AF_CERT = 32768u;
-constexpr unsigned int AF_NEXT_SHIFT = 16u;
+// (round 6) a value that a later op of the SAME list copies back from HBM (the planner gave its slot away): stored with
+// the default cache policy instead of the non-temporal one, so that the copy -- which the reading op waits for with
+// everything else in flight -- comes out of L2 / the memory-side cache a few ops later instead of out of DRAM behind
+// the write stream (profiles/r6_replay_counters_c3.txt: a list with three such copies sees twice the read latency)
+constexpr unsigned int AF_KEEP = 65536u;
+constexpr unsigned int AF_NEXT_SHIFT = 17u;
 
 struct AfMatJob
 {
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
 
 #ifdef PLLHIP_AF_TIMING
 // (tool build: PLLHIP_AF_EXP=mask switches parts of the kernel off -- wrong results, for timing only:
-// 1 no matrix-core products, 2 no stores, 4 no gathers, 8 no block staging, 16 no barriers)
+// 1 no matrix-core products, 2 no stores, 4 no gathers, 8 no block staging, 16 no barriers, 32 no wait for the
+// operands copied back from HBM, 64 no such copies at all)
 __device__ unsigned int af_exp_mask;
 #define AF_EXP(bit) (exp_mask & (bit))
 #else
@@ -809,6 +815,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
 
     // an operand without a slot: from HBM through stage 1 into a slot (AF_RELOAD_TAKE)
     auto reload_issue = [&](unsigned long long src) __attribute__((always_inline)) {
+      if (AF_EXP(64u)) return; // (tool build, bit 64: nothing is copied back at all)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the stage's last readers are done)
       af_dma_run<4>(st1_b, src + clv_off, lane16);
       af_dma_run<1>(st1_b + 4096u, src + clv_off + 4096u, lane16);
@@ -820,14 +827,14 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
         cj[j] = 0u;
         unsigned int o = MODE == SCALE_RATE ? ((4u * j + n) * 4u + rate) * 4u : (4u * j + n) * 4u;
         asm volatile("" : "+v"(o));
-        if (MODE != SCALE_NONE && cnt) cj[j] = *(const unsigned int PLL_GLOBAL *)(af_base(cnt + cnt_off) + o);
+        if (MODE != SCALE_NONE && cnt && !AF_EXP(64u)) cj[j] = *(const unsigned int PLL_GLOBAL *)(af_base(cnt + cnt_off) + o);
       }
     };
     // (a macro, not a lambda: a lambda would capture the slot variables by reference, and
     // variables whose address is taken anywhere stay in memory)
 #define AF_RELOAD_TAKE(slot, cj)                                   \
   {                                                                \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
+    if (!AF_EXP(32u | 64u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* (tool build, bit 32: no wait for a reload) */ \
     AfSlot tmp;                                                    \
     af_read_tile(st1 + boff, st1 + boff5, tmp.v);                  \
     tmp.c[0] = cj[0];                                              \
@@ -947,13 +954,13 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
 
 #ifdef PLLHIP_AF_TIMING
     // (tool build, tools/aa_fused_timing.sh: where a wave's cycles go, by op kind and phase)
-    unsigned long long seg[3][11] = {};
+    unsigned long long phase_cycles[3][11] = {};
     unsigned int nkind_ops[3] = {};
     unsigned long long t_last = __builtin_readcyclecounter();
 #ifdef PLLHIP_AF_NOTICKS
 #define AF_TICK(ph)
 #else
-#define AF_TICK(ph) { const unsigned long long t_now = __builtin_readcyclecounter(); seg[kind][ph] += t_now - t_last; t_last = t_now; }
+#define AF_TICK(ph) { const unsigned long long t_now = __builtin_readcyclecounter(); phase_cycles[kind][ph] += t_now - t_last; t_last = t_now; }
 #endif
 #else
 #define AF_TICK(ph)
@@ -988,9 +995,9 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
         if (nkind_ops[kd])
           printf("kind %d: %u ops: first half %llu, wait A %llu, barrier A %llu, [slot read %llu, products %llu] rest of second half %llu, barrier B %llu, "
                  "[lds wait %llu, blocks %llu, gathers %llu] characters + stores %llu cycles per op\n",
-                 kd, nkind_ops[kd], seg[kd][0] / nkind_ops[kd], seg[kd][1] / nkind_ops[kd], seg[kd][2] / nkind_ops[kd],
-                 seg[kd][6] / nkind_ops[kd], seg[kd][7] / nkind_ops[kd], seg[kd][3] / nkind_ops[kd], seg[kd][4] / nkind_ops[kd],
-                 seg[kd][8] / nkind_ops[kd], seg[kd][9] / nkind_ops[kd], seg[kd][10] / nkind_ops[kd], seg[kd][5] / nkind_ops[kd]);
+                 kd, nkind_ops[kd], phase_cycles[kd][0] / nkind_ops[kd], phase_cycles[kd][1] / nkind_ops[kd], phase_cycles[kd][2] / nkind_ops[kd],
+                 phase_cycles[kd][6] / nkind_ops[kd], phase_cycles[kd][7] / nkind_ops[kd], phase_cycles[kd][3] / nkind_ops[kd], phase_cycles[kd][4] / nkind_ops[kd],
+                 phase_cycles[kd][8] / nkind_ops[kd], phase_cycles[kd][9] / nkind_ops[kd], phase_cycles[kd][10] / nkind_ops[kd], phase_cycles[kd][5] / nkind_ops[kd]);
 #endif
   }
 }
@@ -1549,6 +1556,15 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     }
     if (pos + 1 < m) reloads_of(r, fplan[first + pos + 1]);
   }
+  if (!(pllhip_env("PLLHIP_AA_KEEP") && atoi(pllhip_env("PLLHIP_AA_KEEP")) == 0))
+    for (unsigned int pos = 0; pos < m; ++pos)
+    {
+      // (the writer of a value that op `pos` reloads, if it is an earlier op of this segment)
+      const FusedOp & f = fplan[first + pos];
+      for (const double * src : {(f.dma_flags & 1) ? f.left_hbm : nullptr, (f.dma_flags & 2) ? f.right_hbm : nullptr})
+        for (unsigned int w = 0; src && w < pos; ++w)
+          if (fplan[first + w].parent == src) R[w + 1].flags |= AF_KEEP;
+    }
   // The left block of op i is staged by the four waves, a part each, while they run op i - 2, and the barrier that
   // tells a wave that everybody's part has landed is barrier A of op i - 1 -- which a lookup does not have.  Until
   // the tip-tip ops joined the list (runs of tens of barrier-free ops, over which the waves drift apart by whole

@@ -938,9 +938,19 @@ int pllhip_fused_plan(const FusedGeom & geom, const pllhip_op_t * ops, const Par
   {
     const pllhip_op_t & op = ops[i];
     Node & nd = node[i];
-    auto hard = [&](int p) { if (p >= 0 && (unsigned int)p != i) hard_of[i].push_back((unsigned int)p); };
     nd.raw[0] = clv_w[op.child1_clv];
     nd.raw[1] = clv_w[op.child2_clv];
+    // (round 6: a predecessor that is one of the op's two PRODUCERS is no hazard of its own -- the usual case: a
+    // child's scale buffer was written by the op that wrote the child -- and must not be walked ahead of the
+    // "heavier child first" rule below.  Until then every list with scale buffers was walked child 1 first, whatever the
+    // subtrees' sizes: a traversal directed at a deep edge of a balanced 64-taxon tree needed 4 operands copied back
+    // from HBM with five slots and ended in a run of seven matrix ops; now none, and at most three in a row.)
+    // (PLLHIP_FUSED_ORDER=0, a developer's switch: the old walk, for A/B measurements)
+    static const bool producers_are_no_hazards = !(pllhip_env("PLLHIP_FUSED_ORDER") && atoi(pllhip_env("PLLHIP_FUSED_ORDER")) == 0);
+    auto hard = [&](int p) {
+      if (p >= 0 && (unsigned int)p != i && !(producers_are_no_hazards && (p == nd.raw[0] || p == nd.raw[1])))
+        hard_of[i].push_back((unsigned int)p);
+    };
     nd.sraw[0] = op.child1_scaler >= 0 ? sc_w[op.child1_scaler] : -1;
     nd.sraw[1] = op.child2_scaler >= 0 ? sc_w[op.child2_scaler] : -1;
     hard(clv_w[op.parent_clv]);
