@@ -622,6 +622,10 @@ PLL_EXPORT void pll_amd_core_release(void);
  * nobody else's), then env PLL_AMD_DEVICE, else LOCAL_RANK, else 0.  Mixed use -- some threads select, others rely
  * on the default -- is therefore deterministic as long as the thread that owns the default selects before the others
  * create.  pll_amd_get_device() = what a partition created now by the calling thread would get.
+ * pll_amd_set_device(-1): the calling thread has no device of its own any more (it follows the default again), and
+ * if it was the thread that owns the process-wide default it gives that ownership up -- the next thread that selects
+ * a device becomes the owner (the owner is named by its kernel thread id; an owner that exits without this call keeps
+ * the default it set, which other threads can then only override for themselves).
  * pll_amd_set_devices() below follows the same rule. */
 PLL_EXPORT int pll_amd_set_device(int device);
 PLL_EXPORT int pll_amd_get_device(void);

@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
 #include "ctx.hpp"
 
 static thread_local char g_err[512] = "";
@@ -47,6 +48,7 @@ static const char * const pllhip_user_switches[] = {
   "PLLHIP_SPIN",             // 0: wait for the stream instead of polling host-mapped result words
   "PLLHIP_SHARD_THREADS",    // 0: a sharded partition is driven by the calling thread alone
   "PLLHIP_SHARD_POLL",       // 0: a sharded partition waits for its shards' streams one after another
+  "PLLHIP_SHARD_PIN",        // 0: the shards' threads are not bound to the cores next to their devices
   "PLLHIP_FUSED_DEBUG",      // diagnostics on stderr
   "PLLHIP_RCCL_DEBUG",       // diagnostics on stderr
   "PLLHIP_DEVELOPER",
@@ -61,33 +63,35 @@ static bool pllhip_is_user_switch(const char * name)
 
 // PLLHIP_DEVELOPER is read once (and again by pllhip_env_reload): a developer's switch costs one flag test per read in
 // a production run -- several are read per launch -- and the environment is searched for ignored ones only then.
-static int g_developer = -1;
+// (atomics: partitions may be created by several threads at once, and the shards' worker threads look switches up on
+// every launch -- ADVICE r5)
+static std::atomic<int> g_developer{-1};
 extern char ** environ;
 
 extern "C" void pllhip_env_reload(void)
 {
   const char * dev = getenv("PLLHIP_DEVELOPER");
   const int on = dev && atoi(dev) != 0;
-  static bool said = false;
-  if (!on && !said)
+  static std::atomic<bool> said{false};
+  if (!on && !said.load(std::memory_order_relaxed))
     for (char ** e = environ; e && *e; ++e)
     {
       if (strncmp(*e, "PLLHIP_", 7)) continue;
       const char * eq = strchr(*e, '=');
       const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
       if (pllhip_is_user_switch(name.c_str())) continue;
-      said = true;
+      if (said.exchange(true)) break; // (another thread has said it meanwhile)
       fprintf(stderr, "libpll_amd: %s is a developer's switch and is ignored without PLLHIP_DEVELOPER=1\n", name.c_str());
       break;
     }
-  g_developer = on;
+  g_developer.store(on, std::memory_order_release);
 }
 
 const char * pllhip_env(const char * name)
 {
   if (pllhip_is_user_switch(name)) return getenv(name);
-  if (g_developer < 0) pllhip_env_reload();
-  return g_developer ? getenv(name) : nullptr;
+  if (g_developer.load(std::memory_order_acquire) < 0) pllhip_env_reload();
+  return g_developer.load(std::memory_order_acquire) ? getenv(name) : nullptr;
 }
 
 // what the library sees of a variable right now: 1 set and honoured, 0 unset or ignored (tests/test_host.py)
@@ -216,6 +220,7 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   HIP_TRY(hipGetDeviceProperties(&prop, shape->device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char * e = pllhip_env("PLLHIP_AA_EXACT")) c->aa_exact = atoi(e) != 0;
+  if (const char * e = pllhip_env("PLLHIP_FUSED_DEBUG")) c->fused_debug = atoi(e) ? atoi(e) : 1;
   if (const char * e = pllhip_env("PLLHIP_AA_TI_MFMA")) c->aa_ti_mfma = atoi(e) != 0;
   if (const char * e = pllhip_env("PLLHIP_SPIN")) c->no_spin = atoi(e) == 0;
   if (const char * e = pllhip_env("PLLHIP_HOSTSUM")) c->no_hostsum = atoi(e) == 0;

@@ -33,6 +33,7 @@ struct pllhip_ctx
   std::vector<pllhip_ctx *> shards;
   std::vector<size_t> shard_lo;
   bool shard_threads = true, shard_poll = true; // env PLLHIP_SHARD_THREADS / PLLHIP_SHARD_POLL = 0 (read at creation)
+  bool shard_pin = false; // a shard's thread runs on the cores of its device's NUMA node (more than one distinct device; env PLLHIP_SHARD_PIN=0: never)
   struct pllhip_shard_pool * pool = nullptr; // (round 5) the group's enqueueing threads, one per shard but the first (shard.hip)
   bool defer = false;
   // (round 5) what the group needs to wait for a shard's enqueued result the way an unsharded context waits for its
@@ -119,6 +120,8 @@ struct pllhip_ctx
   bool plan_pending[2] = {false, false};
   size_t plan_cap = 0;
   int plan_next = 0;
+  int fused_debug = 0;   // env PLLHIP_FUSED_DEBUG (read when the context is created, like every other client's switch:
+                         // the hot path looked it up in the environment several times per call -- ADVICE r5)
   bool no_fused = false; // env PLLHIP_FUSED=0: one launch per dependency level instead
   bool force_fused = false; // env PLLHIP_FUSED=2: also for partitions too small for it to pay (tests)
 

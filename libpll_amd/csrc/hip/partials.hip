@@ -675,7 +675,7 @@ int pllhip_cert_resolve(pllhip_ctx * c, bool * rerun, bool drained)
   // the list again, every op in the reference's order (its operands from earlier calls are as they were: a list
   // that overwrites one of them never runs on the matrix cores' tip-inner path, partials_aa_fused.hip)
   ++c->cert_stats[2];
-  if (pllhip_env("PLLHIP_FUSED_DEBUG")) fprintf(stderr, "pllhip: scaling certificate raised, %zu ops run again in the reference's order\n", c->cert_ops.size());
+  if (c->fused_debug) fprintf(stderr, "pllhip: scaling certificate raised, %zu ops run again in the reference's order\n", c->cert_ops.size());
   const std::vector<pllhip_op_t> again(c->cert_ops);
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->cert_force_exact = true;
@@ -772,7 +772,7 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
   // round 3 they lost -- 3 ops 260 vs 200 us -- to the tile counter, not to their reloads: see the kernel.)
   if (dna_fast && (c->sh.rate_cats <= 4 || c->sh.rate_cats == 8) && !c->no_fused && fused_pays && c->rows.empty() && count >= 2)
   {
-    if (c->fused_last_ops.size() == count && !pllhip_env("PLLHIP_FUSED_DEBUG") &&
+    if (c->fused_last_ops.size() == count && !c->fused_debug &&
         c->fused_last_epoch == c->layout_epoch &&
         memcmp(c->fused_last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
     {

@@ -1167,7 +1167,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   if (!c->aa_fused) c->aa_fused = new pllhip_aa_fused_cache();
   pllhip_aa_fused_cache & k = *c->aa_fused;
   // (PLLHIP_FUSED_DEBUG=3: where the host's time goes when a list is new)
-  const bool host_times = pllhip_env("PLLHIP_FUSED_DEBUG") && atoi(pllhip_env("PLLHIP_FUSED_DEBUG")) == 3;
+  const bool host_times = c->fused_debug == 3;
   auto t_host = std::chrono::steady_clock::now();
   auto lap = [&](const char * what) {
     if (!host_times) return;
@@ -1180,7 +1180,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   // call (slot reuse across calls) is not idempotent, and keeps to the reference's order.
   const bool ti_mfma = c->aa_ti_mfma && !c->cert_force_exact && !c->no_batch;
   if (k.last_ops.size() == count && k.epoch == c->layout_epoch && k.maxstates == c->maxstates && k.ti_mfma == ti_mfma &&
-      !pllhip_env("PLLHIP_FUSED_DEBUG") && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
+      !c->fused_debug && memcmp(k.last_ops.data(), ops, (size_t)count * sizeof(pllhip_op_t)) == 0)
   {
     bool same_marks = true;
     for (const auto & m : k.ext_marks) same_marks = same_marks && pllhip_cert_err(c, m.first) == m.second;
@@ -1683,7 +1683,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
                                (unsigned int)k.lk_ops.size(), n_ii, list_ti_mfma ? n_ti : 0u, list_ti_mfma ? 0u : n_ti, reloads};
     memcpy(k.kinds_of_plan, v, sizeof(v));
   }
-  if (pllhip_env("PLLHIP_FUSED_DEBUG"))
+  if (c->fused_debug)
   {
     fprintf(stderr, "pllhip 20-state list kernel: %u ops = %zu tip-tip ahead + %zu tip-tip in the list + %zu lookups + %zu on the matrix cores "
                     "(%u of them behind a lookup: a barrier more), %u operands reloaded, %u segment(s)\n",

@@ -1284,7 +1284,18 @@ unsigned int pllhip_fused_segments(const FusedGeom & geom, const pllhip_op_t * o
     if (nsegs == 1 || *std::min_element(load.begin(), load.end()) >= 2) break;
   }
   if (nsegs == 1) return 1;
-  for (unsigned int i = 0; i < count; ++i) seg_of[i] = seg_of_root[find(i)];
+  // segment 0 the longest, as the header says and the kernels' segment-major order wants (every tile of the longest
+  // segment first): the greedy dealing above does not give that by itself once components outnumber segments --
+  // components of 5, 4 and 4 ops over two segments are loads of 5 and 8 -- so the segments are numbered by
+  // descending load afterwards (tests/test_host.py)
+  std::vector<unsigned int> rank_of(nsegs);
+  {
+    std::vector<unsigned int> by_load(nsegs);
+    for (unsigned int k = 0; k < nsegs; ++k) by_load[k] = k;
+    std::stable_sort(by_load.begin(), by_load.end(), [&](unsigned int a, unsigned int b) { return load[a] > load[b]; });
+    for (unsigned int r = 0; r < nsegs; ++r) rank_of[by_load[r]] = r;
+  }
+  for (unsigned int i = 0; i < count; ++i) seg_of[i] = rank_of[seg_of_root[find(i)]];
   return nsegs;
 }
 

@@ -18,6 +18,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <ctype.h>
+#include <pthread.h>
+#include <sched.h>
 #include <signal.h>
 #include <string>
 #include <system_error>
@@ -44,10 +47,66 @@ struct pllhip_shard_pool
   bool stop = false;
 };
 
+// (round 6) A shard's thread runs on the cores next to its device: the launches of a shard are a
+// few microseconds of host work per call, and a thread on the other socket pays the interconnect for every doorbell
+// and every poll of the shard's host-mapped result words.  The device's PCI address names its NUMA node
+// (/sys/bus/pci/devices/<address>/numa_node), the node its cores (/sys/devices/system/node/node<n>/cpulist); the thread's
+// affinity becomes those cores that the PROCESS may use at all (a cgroup or taskset mask is never widened; nothing in
+// common, no node, no sysfs: the thread stays where it is).  Only with more than one distinct device, and not with
+// PLLHIP_SHARD_PIN=0.  The calling thread (shard 0) is the client's: never touched.
+static void pin_near_device(int device)
+{
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess || !bus[0]) return;
+  for (char * q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  int node = -1;
+  if (FILE * f = fopen(path, "r"))
+  {
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+  }
+  if (node < 0) return;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  char list[4096] = "";
+  if (FILE * f = fopen(path, "r"))
+  {
+    if (!fgets(list, (int)sizeof(list), f)) list[0] = 0;
+    fclose(f);
+  }
+  cpu_set_t allowed, want;
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+  CPU_ZERO(&want);
+  int any = 0;
+  for (char * q = list; *q;)
+  {
+    char * end = nullptr;
+    const long a = strtol(q, &end, 10);
+    if (end == q) break;
+    long b = a;
+    q = end;
+    if (*q == '-')
+    {
+      b = strtol(q + 1, &end, 10);
+      q = end;
+    }
+    for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; ++cpu)
+      if (cpu >= 0 && CPU_ISSET((int)cpu, &allowed))
+      {
+        CPU_SET((int)cpu, &want);
+        any = 1;
+      }
+    while (*q == ',' || *q == ' ' || *q == '\n') ++q;
+  }
+  if (any) (void)pthread_setaffinity_np(pthread_self(), sizeof(want), &want);
+}
+
 static void shard_worker(pllhip_ctx * g, size_t i)
 {
   pllhip_shard_pool & p = *g->pool;
   unsigned long long seen = 0;
+  if (g->shard_pin) pin_near_device(g->shards[i]->sh.device);
   for (;;)
   {
     // a short spin (the next call of a burst), then sleep
@@ -218,6 +277,12 @@ extern "C" int pllhip_ctx_create_sharded(const pllhip_shape_t * shape, const int
     g->shard_lo.push_back(lo[i]);
   }
   g->shard_lo.push_back(shape->sites);
+  {
+    // (threads next to their devices: only when there is more than one device to be next to)
+    bool distinct = false;
+    for (pllhip_ctx * s : g->shards) distinct = distinct || s->sh.device != g->shards[0]->sh.device;
+    g->shard_pin = distinct && !(pllhip_env("PLLHIP_SHARD_PIN") && atoi(pllhip_env("PLLHIP_SHARD_PIN")) == 0);
+  }
   *out = g;
   return 0;
 }

@@ -62,17 +62,39 @@ int pll_amd_device_count(void)
  * them.  A worker that selects a device of its own changes its own choice and nobody else's (as
  * last-writer-wins, partitions created concurrently by threads that had set nothing landed on whichever device a
  * sibling had just chosen). */
-static __thread char g_thread_tag;      /* (its address names the calling thread) */
-static const char * g_default_owner = NULL;
+/* (round 6, ADVICE r5: the owner used to be named by the address of a thread-local variable -- an address the next
+ * thread may be given once the owner has exited, which then silently became the owner, while nobody else could ever
+ * change the defaults again.  Now: the kernel's thread id, unique among the live threads of the process, and an explicit
+ * way to give the ownership up -- pll_amd_set_device(-1) from the owner; the next thread that selects becomes the owner.
+ * An owner that exits without doing so keeps the defaults it set; they can then only be overridden per thread.) */
+#include <sys/syscall.h>
+#include <unistd.h>
+static long g_default_owner = 0; /* 0: nobody yet */
+static long this_thread(void)
+{
+  static __thread long tid = 0;
+  if (!tid) tid = (long)syscall(SYS_gettid);
+  return tid;
+}
 static int owns_defaults(void)
 {
-  const char * none = NULL;
-  if (__atomic_compare_exchange_n(&g_default_owner, &none, &g_thread_tag, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) return 1;
-  return none == &g_thread_tag;
+  long none = 0;
+  const long me = this_thread();
+  if (__atomic_compare_exchange_n(&g_default_owner, &none, me, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) return 1;
+  return none == me;
 }
 
 int pll_amd_set_device(int device)
 {
+  if (device < 0)
+  {
+    /* back to "not set by this thread"; the owner of the process-wide defaults also gives the ownership up (the
+     * defaults themselves stay as they are until the next owner selects) */
+    long me = this_thread();
+    g_device = -1;
+    (void)__atomic_compare_exchange_n(&g_default_owner, &me, 0, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+    return PLL_SUCCESS;
+  }
   g_device = device;
   if (owns_defaults()) __atomic_store_n(&g_device_default, device, __ATOMIC_RELAXED);
   return PLL_SUCCESS;

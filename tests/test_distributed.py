@@ -1,10 +1,11 @@
-"""world_size-2 run of the site-sharding scheme on CPU (gloo).
+"""world_size-2 and world_size-8 runs of the site-sharding scheme on CPU (gloo).
 
 The multi-GPU path shards alignment columns across ranks with no data-path
 collective; the only exchange is a sum of per-shard lnL (and of d/dd).  Here
-two processes each evaluate their shard -- through the oracle, since there is no
-GPU -- using the same shard_bounds / site_range code bench.py and the product
-use, all-reduce the scalar over gloo and must reproduce the unsharded value.
+two -- and, as the driver's scaling bench does, eight -- processes each evaluate
+their shard -- through the oracle, since there is no GPU -- using the same
+shard_bounds / site_range code bench.py and the product use, all-reduce the
+scalar over gloo and must reproduce the unsharded value.
 """
 import os
 import socket
@@ -31,7 +32,8 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 orc = Oracle(os.path.join(sys.argv[1], "oracle", "liboracle.so"))
 amd = PllLibrary(os.path.join(sys.argv[1], "libpll_amd", "libpll_amd.so"))
-case = make_case(4, "random", 10, 1000, seed=11)
+TOTAL = int(sys.argv[2])
+case = make_case(4, "random", 10, TOTAL, seed=11)
 S, R, plan = 4, 4, case["plan"]
 dp = lambda a: a.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))
 vals, vecs, inv = np.zeros(S), np.zeros((S, S)), np.zeros((S, S))
@@ -52,10 +54,11 @@ def evaluate(lo, hi):
     d, dd = o.derivatives(o.sumtable(e[0], e[2], e[1], e[3]), 0.1)
     return np.array([lnl, d, dd])
 
-b = W.shard_bounds(1000, world, granule=256)
+b = W.shard_bounds(TOTAL, world, granule=256)
+assert len(b) == world + 1 and all(x < y for x, y in zip(b, b[1:]))
 mine = torch.from_numpy(evaluate(b[rank], b[rank + 1]))
 dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-full = evaluate(0, 1000)
+full = evaluate(0, TOTAL)
 err = float(np.max(np.abs(mine.numpy() - full) / np.abs(full)))
 assert err < 1e-13, (mine, full)
 if rank == 0:
@@ -72,16 +75,23 @@ def free_port():
     return port
 
 
-def test_site_sharding_two_ranks_gloo(tmp_path, orc, amd):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER)
+def launch(script, nproc, *args):
+    """`nproc` ranks of `script` the way the driver launches bench.py (torch.distributed.run, 127.0.0.1)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
-                          str(free_port()), str(script), ROOT],
-                         capture_output=True, text=True, env=env, timeout=600)
+                          "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1", "--master-port",
+                          str(free_port()), str(script), ROOT] + [str(a) for a in args],
+                         capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "SHARDED_OK" in out.stdout
+    return out.stdout
+
+
+# (world_size 8: what SCALE_rNN runs -- VERDICT r5 item 6a; eight ranges on multiples of 256 need a few thousand sites)
+@pytest.mark.parametrize("nproc,total", [(2, 1000), (8, 4000)], ids=["two-ranks", "eight-ranks"])
+def test_site_sharding_gloo(tmp_path, orc, amd, nproc, total):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    assert "SHARDED_OK" in launch(script, nproc, total)
 
 
 # ---------------------------------------------------------------- the product's HOST logic per rank
@@ -118,6 +128,37 @@ try:
 except ValueError:
     refused = True
 assert refused
+# the site counts of the BASELINE configs, split `world` ways (what each rank of the driver's scaling runs derives:
+# C2 weak = world x 1,000,000; C4 = 8,000,000; C5 = 500,000; C3 = 200,000): whole, contiguous, nobody empty, every
+# inner boundary on a multiple of 256, the same everywhere -- and a split that would leave a rank empty is refused
+# on EVERY rank (a rank that went on alone would hang the others in the first collective)
+for t in (world * 1_000_000, 8_000_000, 500_000, 200_000, 256 * world):
+    bb = W.shard_bounds(t, world)
+    assert bb[0] == 0 and bb[-1] == t and len(bb) == world + 1 and all(x < y for x, y in zip(bb, bb[1:])), (t, bb)
+    assert all(x % 256 == 0 for x in bb[1:-1])
+    assert max(y - x for x, y in zip(bb, bb[1:])) - min(y - x for x, y in zip(bb, bb[1:])) <= 256 * world, (t, bb)
+    tb = torch.tensor(bb, dtype=torch.int64)
+    lo_, hi_ = tb.clone(), tb.clone()
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN); dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    assert torch.equal(lo_, hi_)
+verdicts = []
+for t in (256 * (world - 1), 256 * world + 1, world - 1):
+    try:
+        W.shard_bounds(t, world)
+        verdicts.append(0)
+    except ValueError:
+        verdicts.append(1)
+v = torch.tensor(verdicts, dtype=torch.int64)
+vmin = v.clone()
+dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+assert torch.equal(v, vmin) and (world == 1 or verdicts[-1] == 1), verdicts
+# "everybody has a value" (bench.py's reference check: a rank without the reference build must make ALL ranks skip
+# the comparison, not sum a partial value): the agreement is an all-reduce of a flag, MIN
+for someone_lacks_it in (False, True):
+    have = 0 if (someone_lacks_it and rank == world - 1) else 1
+    flag = torch.tensor([have], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    assert int(flag.item()) == (0 if someone_lacks_it else 1)
 
 # (2) the PRODUCT's planner (pllhip_fused_plan_dry: pure host logic) on the op list every rank is
 # handed: the same order, slots and reloads on every rank -- the ranks then launch the same kernels
@@ -155,19 +196,14 @@ dist.destroy_process_group()
 '''
 
 
-def test_product_host_logic_two_ranks_gloo(tmp_path, amd):
+@pytest.mark.parametrize("nproc", [2, 8], ids=["two-ranks", "eight-ranks"])
+def test_product_host_logic_gloo(tmp_path, amd, nproc):
     """What each rank of the one-process-per-GPU mode does on the HOST, with the product library (no
-    device needed): its site range, the op-list planner's dry run (identical plans on all ranks),
-    pattern compression of its own columns."""
+    device needed): its site range -- also at the BASELINE configs' site counts split 2 and 8 ways --, the
+    op-list planner's dry run (identical plans on all ranks), pattern compression of its own columns."""
     script = tmp_path / "host_worker.py"
     script.write_text(HOST_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
-                          str(free_port()), str(script), ROOT],
-                         capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "HOST_OK" in out.stdout
+    assert "HOST_OK" in launch(script, nproc)
 
 
 # ---------------------------------------------------------------- bench.py's alignment: one, indexed by global site
@@ -186,7 +222,7 @@ rank, world = dist.get_rank(), dist.get_world_size()
 ref = PllLibrary(os.path.join(sys.argv[1], "oracle", "_ref", "libpll_ref.so"))
 plan = W.balanced_tree(16, seed=42)
 cat = ref.compute_gamma_cats(W.GAMMA_ALPHA, 4)
-total, block = 5000, 700      # (ranges that begin and end inside blocks)
+total, block = int(sys.argv[2]), 700      # (ranges that begin and end inside blocks)
 b = W.shard_bounds(total, world)
 lo, hi = b[rank], b[rank + 1]
 mine = W.global_alignment(plan, lo, hi, W.GTR_RATES, W.GTR_FREQS, cat, seed=42, block=block)
@@ -217,19 +253,15 @@ dist.destroy_process_group()
 '''
 
 
-def test_bench_alignment_is_one_alignment_two_ranks_gloo(tmp_path, ref):
+@pytest.mark.parametrize("nproc", [2, 8], ids=["two-ranks", "eight-ranks"])
+def test_bench_alignment_is_one_alignment_gloo(tmp_path, ref, nproc):
     """bench.py at N > 1: every rank makes its own columns of ONE alignment
     (W.global_alignment), so the N-GPU lnL has something to be compared with; the per-rank reference
-    values sum to the reference's value of the whole."""
+    values sum to the reference's value of the whole.  With 2 ranks and with the 8 the driver's scaling bench starts."""
     script = tmp_path / "align_worker.py"
     script.write_text(ALIGN_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
-                          str(free_port()), str(script), ROOT],
-                         capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "ALIGN_OK" in out.stdout
+    # (5,000 sites split two ways; eight ranges on multiples of 256 sites need more than 8 x 512)
+    assert "ALIGN_OK" in launch(script, nproc, 5000 if nproc == 2 else 12000)
 
 
 # ---------------------------------------------------------------- the product, one rank per GPU

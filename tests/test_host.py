@@ -409,6 +409,30 @@ def test_fused_segments(amd):
         cher[i]["child1_matrix_index"], cher[i]["child2_matrix_index"] = 2 * i, 2 * i + 1
     ns, seg = _segments_dry(amd, cher, 32, 16, 16, 1)
     assert ns == 8 and all(seg.count(k) == 2 for k in range(8))
+    # more components than segments: three independent ladders of 5, 4 and 4 ops over two segments are
+    # loads of 5 and 8 -- segment 0 must still be the longest (the kernels hand its tiles out first)
+    def ladder(first_tip, first_inner, n):
+        out = np.zeros(n, dtype=cher.dtype)
+        for i in range(n):
+            out[i]["parent_clv_index"] = first_inner + i
+            out[i]["parent_scaler_index"] = first_inner + i - 32
+            out[i]["child1_clv_index"] = first_tip if i == 0 else first_inner + i - 1
+            out[i]["child2_clv_index"] = first_tip + 1 + i
+            out[i]["child1_scaler_index"] = -1 if i == 0 else first_inner + i - 1 - 32
+            out[i]["child2_scaler_index"] = -1
+            out[i]["child1_matrix_index"], out[i]["child2_matrix_index"] = 2 * (first_inner + i - 32), 2 * (first_inner + i - 32) + 1
+        return out
+    three = np.concatenate([ladder(0, 32, 5), ladder(8, 37, 4), ladder(16, 41, 4)])
+    ns, seg = _segments_dry(amd, three, 32, 16, 16, 1, max_segments=2)
+    assert ns == 2 and _segments_are_independent(three, seg)
+    assert [seg.count(0), seg.count(1)] == [8, 5], "segment 0 is the longest"
+    for seed in range(40):
+        rng = np.random.default_rng(1000 + seed)
+        ops = random_op_sequence(rng, 12, 14, 14, 21, 40 + seed)
+        for max_segments in (2, 3, 8):
+            ns, seg = _segments_dry(amd, ops, 12, 14, 14, 1, max_segments=max_segments)
+            loads = [seg.count(k) for k in range(ns)]
+            assert loads == sorted(loads, reverse=True), (seed, loads)
 
 
 @pytest.mark.parametrize("rate_cats", [1, 2, 4, 8])
@@ -499,6 +523,20 @@ def test_device_selection_per_thread_with_a_process_wide_default(amd):
     t = threading.Thread(target=worker, args=("after the owner's change", None))
     t.start(); t.join()
     assert seen["after the owner's change"] == 2
+    # (round 6) the owner is named by its thread id and can give the ownership up: pll_amd_set_device(-1);
+    # the next thread that selects a device becomes the owner -- here a worker, whose choice then IS the default
+    lib.pll_amd_set_device(-1)
+    t = threading.Thread(target=worker, args=("new owner", 1))
+    t.start(); t.join()
+    assert seen["new owner"] == 1
+    assert lib.pll_amd_get_device() == 1            # the main thread has no device of its own now: the new default
+    t = threading.Thread(target=worker, args=("follows the new owner", None))
+    t.start(); t.join()
+    assert seen["follows the new owner"] == 1
+    lib.pll_amd_set_device(2)                       # not the owner any more: its own choice only
+    t = threading.Thread(target=worker, args=("still the worker's default", None))
+    t.start(); t.join()
+    assert seen["still the worker's default"] == 1 and lib.pll_amd_get_device() == 2
     lib.pll_amd_set_device(0)
 
 
@@ -643,7 +681,7 @@ def test_developer_switches_are_gated(amd, monkeypatch):
     assert len(read) > 30
     user = {n for n in read if lib.pllhip_env_is_user_switch(n.encode())}
     assert user == {"PLLHIP_AA_EXACT", "PLLHIP_AA_TI_MFMA", "PLLHIP_FUSED", "PLLHIP_HOSTSUM", "PLLHIP_FUSE_REDUCE",
-                    "PLLHIP_SPIN", "PLLHIP_SHARD_THREADS", "PLLHIP_SHARD_POLL", "PLLHIP_FUSED_DEBUG",
+                    "PLLHIP_SPIN", "PLLHIP_SHARD_THREADS", "PLLHIP_SHARD_POLL", "PLLHIP_SHARD_PIN", "PLLHIP_FUSED_DEBUG",
                     "PLLHIP_RCCL_DEBUG"}
     # the first table holds the client's switches, the second every developer's one
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
