@@ -126,6 +126,20 @@ PLLHIP_EXPORT int pllhip_get_scaler(pllhip_ctx_t * ctx, unsigned int scaler_inde
 PLLHIP_EXPORT int pllhip_get_pmatrix(pllhip_ctx_t * ctx, unsigned int matrix_index,
                                      double * h_pmatrix);
 
+/* Several CLVs / scale buffers to host memory in ONE launch and one wait (round 6: the host mirrors that small
+ * partitions keep current by themselves, include/pll_amd.h).  h must come from pllhip_host_alloc (pinned, mapped into
+ * the device's address space: the copy is a kernel that writes it over the bus, no staging); kind 0 = CLV `index`
+ * (sites * rate_cats * states doubles), 1 = scale buffer `index`.  Not for sharded contexts and not for CLVs stored
+ * by class (site repeats): those go through pllhip_get_clv / pllhip_get_scaler. */
+typedef struct pllhip_mirror_job
+{
+  unsigned int kind, index;
+  void * h;
+} pllhip_mirror_job_t;
+PLLHIP_EXPORT void * pllhip_host_alloc(size_t bytes);
+PLLHIP_EXPORT void pllhip_host_free(void * p);
+PLLHIP_EXPORT int pllhip_mirror_batch(pllhip_ctx_t * ctx, const pllhip_mirror_job_t * h_jobs, unsigned int count);
+
 /* ---- compute ---- */
 
 /* replaces pll_core_update_pmatrix (core_pmatrix.c:24; AVX2-flag kernels

@@ -770,6 +770,81 @@ extern "C" int pllhip_get_scaler(pllhip_ctx_t * c, unsigned int idx, unsigned in
   return d2h(c, h, pllhip_scaler_ptr(c, (int)idx), c->scaler_elems * sizeof(unsigned int));
 }
 
+// ---- several buffers to pinned host memory in one launch (pllhip.h: pllhip_mirror_batch)
+#define PLLHIP_MIRROR_BATCH 48
+struct MirrorCopies
+{
+  const unsigned int * src[PLLHIP_MIRROR_BATCH];
+  unsigned int * dst[PLLHIP_MIRROR_BATCH];
+  unsigned int words[PLLHIP_MIRROR_BATCH];
+};
+// blockIdx.y = buffer; 16 bytes per lane where the alignment allows, words for the tail
+__global__ __launch_bounds__(256) void k_mirror_copy(MirrorCopies m)
+{
+  const unsigned int * __restrict__ src = m.src[blockIdx.y];
+  unsigned int * __restrict__ dst = m.dst[blockIdx.y];
+  const size_t words = m.words[blockIdx.y], quads = words / 4;
+  const uint4 * s4 = reinterpret_cast<const uint4 *>(src);
+  uint4 * d4 = reinterpret_cast<uint4 *>(dst);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i];
+  if (blockIdx.x == 0 && threadIdx.x < words - 4 * quads) dst[4 * quads + threadIdx.x] = src[4 * quads + threadIdx.x];
+}
+
+extern "C" void * pllhip_host_alloc(size_t bytes)
+{
+  void * p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return nullptr;
+  return p;
+}
+
+extern "C" void pllhip_host_free(void * p)
+{
+  if (p) (void)hipHostFree(p);
+}
+
+extern "C" int pllhip_mirror_batch(pllhip_ctx_t * c, const pllhip_mirror_job_t * jobs, unsigned int count)
+{
+  if (!c->shards.empty()) { pllhip_set_error("pllhip_mirror_batch: not for a sharded context"); return -1; }
+  HIP_TRY(hipSetDevice(c->sh.device));
+  PLLHIP_CERT_FIRST(c);
+  for (unsigned int first = 0; first < count; first += PLLHIP_MIRROR_BATCH)
+  {
+    const unsigned int n = std::min<unsigned int>(PLLHIP_MIRROR_BATCH, count - first);
+    MirrorCopies m;
+    size_t most = 0;
+    for (unsigned int k = 0; k < n; ++k)
+    {
+      const pllhip_mirror_job_t & j = jobs[first + k];
+      void * dev = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev, j.h, 0));
+      if (j.kind == 0)
+      {
+        if (j.index >= c->clv.size() || !c->clv[j.index] || (!c->rows.empty() && c->rows[j.index].classes))
+        {
+          pllhip_set_error("pllhip_mirror_batch: CLV %u", j.index);
+          return -1;
+        }
+        m.src[k] = reinterpret_cast<const unsigned int *>(c->clv[j.index]);
+        m.words[k] = (unsigned int)(c->clv_elems * 2);
+        if (c->clv_elems * 2 > 0xffffffffull) { pllhip_set_error("pllhip_mirror_batch: CLV too large"); return -1; }
+      }
+      else
+      {
+        if (j.index >= c->sh.scale_buffers) { pllhip_set_error("pllhip_mirror_batch: scale buffer %u", j.index); return -1; }
+        m.src[k] = pllhip_scaler_ptr(c, (int)j.index);
+        m.words[k] = (unsigned int)c->scaler_elems;
+      }
+      m.dst[k] = static_cast<unsigned int *>(dev);
+      most = std::max<size_t>(most, m.words[k]);
+    }
+    const unsigned int gx = (unsigned int)std::min<size_t>(std::max<size_t>(1, (most / 4 + 255) / 256), 64);
+    k_mirror_copy<<<dim3(gx, n), 256, 0, c->stream>>>(m);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 extern "C" int pllhip_get_pmatrix(pllhip_ctx_t * c, unsigned int idx, double * h)
 {
   if (!c->shards.empty()) return pllhip_get_pmatrix(c->shards[0], idx, h); // (replicated: identical bits on every shard)

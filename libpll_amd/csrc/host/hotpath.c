@@ -32,7 +32,51 @@ void pll_update_partials(pll_partition_t * p, const pll_operation_t * ops, unsig
     pll_amd_fail_hip(rc, "CLV update");
     return;
   }
-  if (pll_amd_mirror_mode)
+  if (!pll_amd_mirror_mode && q->auto_mirror && !q->rep && pllhip_shard_count(q->ctx) == 1)
+  {
+    /* the mirrors a small partition keeps current by itself: every CLV and scale buffer the list wrote, in ONE
+       launch that writes pinned host memory and one wait (the per-buffer copies below cost 25 us each: a three-op
+       step 180 us instead of 19; batched: profiles/r6_auto_mirror_step_floor.txt) */
+    pllhip_mirror_job_t jobs[64];
+    unsigned int n = 0;
+    const unsigned int nodes = p->tips + p->clv_buffers;
+    const size_t clv_b = (size_t)q->sites_alloc * p->rate_cats * p->states * sizeof(double);
+    const size_t sc_b = (size_t)q->sites_alloc * ((p->attributes & PLL_ATTRIB_RATE_SCALERS) ? p->rate_cats : 1) * sizeof(unsigned int);
+    if (!q->clv_pinned) q->clv_pinned = (unsigned char *)calloc(nodes ? nodes : 1, 1);
+    if (!q->scaler_pinned) q->scaler_pinned = (unsigned char *)calloc(p->scale_buffers ? p->scale_buffers : 1, 1);
+    for (i = 0; q->clv_pinned && q->scaler_pinned && i <= count; ++i)
+    {
+      if (i == count || n + 2 > 64)
+      {
+        if (n && (rc = pllhip_mirror_batch(q->ctx, jobs, n))) { pll_amd_fail_hip(rc, "mirror copy"); return; }
+        n = 0;
+        if (i == count) break;
+      }
+      {
+        const unsigned int node = ops[i].parent_clv_index;
+        const int sc = ops[i].parent_scaler_index;
+        if (node < nodes)
+        {
+          if (p->clv[node] && !q->clv_pinned[node]) { pll_amd_sync_clv(p, node); }   /* (allocated by an explicit sync earlier) */
+          else
+          {
+            if (!p->clv[node] && (p->clv[node] = (double *)pllhip_host_alloc(clv_b))) q->clv_pinned[node] = 1;
+            if (p->clv[node]) { jobs[n].kind = 0; jobs[n].index = node; jobs[n].h = p->clv[node]; ++n; }
+          }
+        }
+        if (sc != PLL_SCALE_BUFFER_NONE && (unsigned int)sc < p->scale_buffers)
+        {
+          if (p->scale_buffer[sc] && !q->scaler_pinned[sc]) { pll_amd_sync_scaler(p, (unsigned int)sc); }
+          else
+          {
+            if (!p->scale_buffer[sc] && (p->scale_buffer[sc] = (unsigned int *)pllhip_host_alloc(sc_b))) q->scaler_pinned[sc] = 1;
+            if (p->scale_buffer[sc]) { jobs[n].kind = 1; jobs[n].index = (unsigned int)sc; jobs[n].h = p->scale_buffer[sc]; ++n; }
+          }
+        }
+      }
+    }
+  }
+  else if (PLL_AMD_MIRRORS(p))
     for (i = 0; i < count; ++i)
     {
       pll_amd_sync_clv(p, ops[i].parent_clv_index);
@@ -197,7 +241,7 @@ int pll_update_sumtable(pll_partition_t * p, unsigned int parent_clv_index,
     q->sumtable_key[slot] = NULL;
     return pll_amd_fail_hip(rc, "sumtable update");
   }
-  if (pll_amd_mirror_mode) return pll_amd_sync_sumtable(p, sumtable);
+  if (PLL_AMD_MIRRORS(p)) return pll_amd_sync_sumtable(p, sumtable);
   /* The table lives on the device; the caller's buffer is its key and is NOT filled.  A reference client that reads
      it anyway (derivatives.c hands it to pll_core_likelihood_derivatives; a client may sum it itself) must not find
      plausible numbers there: the first site's entries become signalling NaNs (VERDICT r3 Weak 8). */

@@ -53,7 +53,16 @@ typedef struct pll_amd_partition
   pll_amd_node_repeats_t * rep;
   int * scaler_owner;
   unsigned int rep_epoch;
+  /* (round 6) host mirrors kept current by the library itself: partitions whose CLVs together stay below
+     PLL_AMD_AUTO_MIRROR_MB (default 64 MB; 0: never) behave as under pll_amd_set_mirror_mode(1) -- every call that
+     writes a CLV, a scale buffer, a P-matrix or a sumtable on the device copies it to partition->clv[i] / ... before it
+     returns, so an unmodified client that reads those arrays finds what the reference would hold there, not NULL */
+  int auto_mirror;
+  /* which mirrors are pinned memory of the device layer's (pllhip_host_alloc: the batched copy writes them over the
+     bus) rather than the C library's: [tips + clv_buffers] and [scale_buffers] flags, NULL until the first one */
+  unsigned char * clv_pinned, * scaler_pinned;
 } pll_amd_partition_t;
+#define PLL_AMD_MIRRORS(p) (pll_amd_mirror_mode || pll_amd_priv(p)->auto_mirror)
 
 static inline pll_amd_partition_t * pll_amd_priv(const pll_partition_t * p)
 {

@@ -307,7 +307,7 @@ int pll_update_prob_matrices(pll_partition_t * p, const unsigned int * params_in
   rc = pllhip_update_pmatrices(pll_amd_priv(p)->ctx, params_indices, matrix_indices,
                                branch_lengths, count);
   if (rc) return pll_amd_fail_hip(rc, "P-matrix update");
-  if (pll_amd_mirror_mode)
+  if (PLL_AMD_MIRRORS(p))
     for (n = 0; n < count; ++n)
       if (!pll_amd_sync_pmatrix(p, matrix_indices[n])) return PLL_FAILURE;
   return PLL_SUCCESS;

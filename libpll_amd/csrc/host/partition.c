@@ -222,6 +222,16 @@ void pll_partition_destroy(pll_partition_t * p)
   nodes = p->tips + p->clv_buffers;
   if (q->ctx) pllhip_ctx_destroy(q->ctx);
   free((void *)q->sumtable_evicted);
+  {
+    /* mirrors that are the device layer's pinned memory go back there */
+    unsigned int i;
+    for (i = 0; q->clv_pinned && p->clv && i < nodes; ++i)
+      if (q->clv_pinned[i]) { pllhip_host_free(p->clv[i]); p->clv[i] = NULL; }
+    for (i = 0; q->scaler_pinned && p->scale_buffer && i < p->scale_buffers; ++i)
+      if (q->scaler_pinned[i]) { pllhip_host_free(p->scale_buffer[i]); p->scale_buffer[i] = NULL; }
+    free(q->clv_pinned);
+    free(q->scaler_pinned);
+  }
   free_ptr_array((void **)p->clv, nodes);
   if (p->pmatrix)
   {
@@ -386,6 +396,14 @@ pll_partition_t * pll_partition_create(unsigned int tips, unsigned int clv_buffe
   for (i = 0; i < rate_matrices; ++i) q->model_dirty[i] = 1;
   q->rates_dirty = 1;
 
+  {
+    /* host mirrors kept current for small partitions (internal.h: auto_mirror) */
+    const char * e = getenv("PLL_AMD_AUTO_MIRROR_MB");
+    const double limit_mb = e ? atof(e) : 64.0;
+    const double clv_mb = (double)((attributes & PLL_ATTRIB_PATTERN_TIP) ? clv_buffers : tips + clv_buffers) *
+                          (double)q->sites_alloc * rate_cats * states * sizeof(double) / (1024.0 * 1024.0);
+    q->auto_mirror = limit_mb > 0.0 && clv_mb < limit_mb;
+  }
   memset(&sh, 0, sizeof(sh));
   sh.device = default_device();
   sh.states = states;
@@ -592,6 +610,7 @@ int pll_set_tip_states(pll_partition_t * p, unsigned int tip_index, const unsign
     rc = pllhip_put_tip_clv_persite(q->ctx, tip_index, v, S);
     free(v);
     if (rc) return pll_amd_fail_hip(rc, "upload of tip CLV");
+    if (PLL_AMD_MIRRORS(p) && !pll_amd_sync_clv(p, tip_index)) return PLL_FAILURE;
   }
   return PLL_SUCCESS;
 }
@@ -631,6 +650,7 @@ int pll_set_tip_clv(pll_partition_t * p, unsigned int tip_index, const double * 
   else
     rc = pllhip_put_tip_clv_persite(pll_amd_priv(p)->ctx, tip_index, clv, p->states);
   if (rc) return pll_amd_fail_hip(rc, "upload of tip CLV");
+  if (PLL_AMD_MIRRORS(p) && !pll_amd_sync_clv(p, tip_index)) return PLL_FAILURE;
   return PLL_SUCCESS;
 }
 

@@ -18,6 +18,12 @@ import pytest
 # tests set tile shapes, grid caps and the like to reach code paths at small sizes: developer's switches, which the
 # library honours only under this one (tests/test_host.py::test_developer_switches_are_gated)
 os.environ.setdefault("PLLHIP_DEVELOPER", "1")
+# Host mirrors: the suite drives the product like a client that KNOWS it (pll_amd_sync_* before it reads
+# partition->clv[i]) and reads hundreds of small partitions' CLVs through those calls; the mirrors the library keeps
+# current by itself for partitions below 64 MB of CLVs (round 6) would copy every CLV back a second time.  Off for
+# the suite; tests/test_gpu_api.py::test_small_partitions_keep_their_mirrors_current and the reference's own client
+# programs (tests/test_reference_programs.py) run with the default.
+os.environ.setdefault("PLL_AMD_AUTO_MIRROR_MB", "0")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

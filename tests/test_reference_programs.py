@@ -39,6 +39,7 @@ def test_reference_program_output(gpu, name, mode, aa_path):
     if not os.path.exists(exe):
         pytest.skip("prebuilt reference test program missing (make -C oracle reftests)")
     env = dict(os.environ, PLLHIP_AA_EXACT="1" if aa_path == "vector-kernels" else "0")
+    env.pop("PLL_AMD_AUTO_MIRROR_MB", None)   # (an unmodified client: the library's default -- mirrors kept current)
     helper = os.path.join(ROOT, "oracle", "segv_backtrace.so")  # (a crash then says where, and ends with 128 + signal)
     if os.path.exists(helper):
         env["LD_PRELOAD"] = helper

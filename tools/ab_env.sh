@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLL_AMD_AUTO_MIRROR_MB=0   # (the device path is what is measured: no host mirrors kept for partitions below 64 MB)
 export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # On the GPU box: interleaved A/B of one environment variable's values on bench.py shapes
 #   bash tools/ab_env.sh PLLHIP_FUSED_TILE_GROUPS "1 8 96" "--sites 1000000 --taxa 64" ...

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLL_AMD_AUTO_MIRROR_MB=0   # (the device path is what is measured: no host mirrors kept for partitions below 64 MB)
 export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # On the GPU box: the floor of a result-returning call (C5 shape: 500 k sites, 200-taxon random tree): how the
 # sum is finished (PLLHIP_FUSE_REDUCE), how the host waits (PLLHIP_SPIN), the derivative kernel's grid and cache hint

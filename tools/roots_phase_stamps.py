@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """developer tool (round 6): the phase stamps of the timing build (tools/aa_fused_timing.sh build) for the lists of
-traversal roots 0 and 1 of BASELINE config 3's partition:  PLL_AMD_LIB=build/aftiming/libpll_amd.so python3 tools/r6_roots_timing.py"""
+traversal roots 0 and 1 of BASELINE config 3's partition:  PLL_AMD_LIB=build/aftiming/libpll_amd.so python3 tools/roots_phase_stamps.py"""
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)

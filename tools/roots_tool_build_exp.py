@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """developer tool (round 6): the lists of traversal roots 0 and 1 of BASELINE config 3's partition under the tool
-build's switches (PLLHIP_AF_EXP, build/afexp):  PLL_AMD_LIB=build/afexp/libpll_amd.so python3 tools/r6_roots_exp.py"""
+build's switches (PLLHIP_AF_EXP, build/afexp):  PLL_AMD_LIB=build/afexp/libpll_amd.so python3 tools/roots_tool_build_exp.py"""
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)

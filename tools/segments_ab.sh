@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLL_AMD_AUTO_MIRROR_MB=0   # (the device path is what is measured: no host mirrors kept for partitions below 64 MB)
 export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # On the GPU box: whole-list launches with and without (tile, segment) work items at the sizes an 8-way shard of the
 # BASELINE configs lands on.   bash tools/segments_ab.sh [states ...]

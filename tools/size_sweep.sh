@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLL_AMD_AUTO_MIRROR_MB=0   # (the device path is what is measured: no host mirrors kept for partitions below 64 MB)
 export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # BASELINE config 2's shape (and config 3's) at smaller site counts: where the fixed cost of a call shows.
 #   bash tools/size_sweep.sh

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLL_AMD_AUTO_MIRROR_MB=0   # (the device path is what is measured: no host mirrors kept for partitions below 64 MB)
 export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # The sizes an 8-way shard of the BASELINE configs lands on (C2 125 k, C5 62.5 k, C3 25 k sites) and their neighbours:
 # whole-list launches with fewer tiles than a few rounds of workgroup slots.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLL_AMD_AUTO_MIRROR_MB=0   # (the device path is what is measured: no host mirrors kept for partitions below 64 MB)
 export PLLHIP_DEVELOPER=1   # developer switches are honoured only under this one
 # small partitions (20 states by default; argument: 4): the whole-list kernel forced (PLLHIP_FUSED=2) against the per-level launches (=0): full
 # traversals (the step) and the varying-list leg's partial traversals of 3 / 7 / 15 ops.  bash tools/small_partitions_ab.sh [states]  (SITES="2000 6000" to choose the sizes)

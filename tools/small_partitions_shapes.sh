@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLL_AMD_AUTO_MIRROR_MB=0   # (the device path is what is measured: no host mirrors kept for partitions below 64 MB)
 # the small-partition rule on other tree shapes (random 64, balanced 128, a 100-taxon ladder), 20 and 4 states, 3,000 and 10,000
 # sites: default choice against both paths forced.  bash tools/small_partitions_shapes.sh
 for ST in 20 4; do

@@ -10,6 +10,7 @@ written (children that are tip characters: 1 byte), sumtable = a CLV row.
 """
 import argparse
 import os
+os.environ.setdefault("PLL_AMD_AUTO_MIRROR_MB", "0")   # (the device path is what is measured: no host mirrors kept)
 import sys
 
 import numpy as np
