@@ -720,6 +720,10 @@ __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ 
                                                      const char * aorder, unsigned int ms, double2 * sink,
                                                      unsigned int * next_tile, unsigned int static_rounds)
 {
+  // (Round 6, measured and taken out again -- profiles/r6_aa_phase_offset_ab.txt: the second workgroup of every CU
+  // started 20 / 40 / 75 / 150 us late, so that the two workgroups of a CU would not be at the same op of the list at
+  // the same time.  C3 1.764 -> 1.784 / 1.802 / 1.834 / 1.853 ms, the 200-taxon random tree 3.401 -> 3.411 / 3.422 /
+  // 3.439 / 3.464: the delay is paid in full and buys nothing -- the workgroups of a CU are not in step to begin with.)
   extern __shared__ double2 lds_af[];
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

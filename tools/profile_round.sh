@@ -116,4 +116,9 @@ workloads
 (cd "$root" && bash tools/size_sweep2.sh > "$sum/${tag}_size_sweep.txt" 2>&1)
 # site repeats on the C5 shape
 (cd "$root" && python3 bench.py --sites 500000 --taxa 200 --tree random --site-repeats --cpu-sites 0 > "$sum/${tag}_bench_c5_shape_site_repeats.json" 2> "$out/bench_c5rep.err")
+# round 6: per-rate scale buffers on the 20-state whole-list kernel, a ladder (every op but one tip-inner), and the
+# result-returning calls from C (the Newton loop and the three-op step of the reference's examples)
+(cd "$root" && python3 bench.py --states 20 --sites 200000 --rate-scalers --cpu-sites 0 --no-vary > "$sum/${tag}_bench_c3_rate_scalers.json" 2> "$out/bench_c3_rs.err")
+(cd "$root" && python3 bench.py --states 20 --sites 100000 --taxa 100 --tree caterpillar --cpu-sites 0 --no-vary > "$sum/${tag}_bench_aa_ladder_100.json" 2> "$out/bench_ladder.err")
+(cd "$root" && { for cfg in "4 500000" "4 1000000" "20 200000"; do echo "== tools/newton_floor.bin $cfg"; tools/newton_floor.bin $cfg; done; for cfg in "4 2000" "4 12000" "20 2000" "20 12000"; do echo "== PLL_AMD_AUTO_MIRROR_MB=0 tools/step_floor.bin $cfg"; PLL_AMD_AUTO_MIRROR_MB=0 tools/step_floor.bin $cfg; done; } > "$sum/${tag}_result_calls_from_c.txt" 2>&1)
 ls -la "$sum"
