@@ -231,3 +231,41 @@ def test_partial_traversal_over_marked_clvs(gpu, orc, monkeypatch):
     assert clv_err(p.get_clv(int(last[0]["parent_clv_index"])), o.clv[int(last[0]["parent_clv_index"])]) <= 1e-13
     assert b["lists"] == a["lists"] + 1 and b["uncertified"] == 0, (a, b)
     p.destroy()
+
+
+def test_certificate_on_a_sharded_partition(gpu, orc, monkeypatch):
+    """One partition over two "devices" (ordinal 0 twice): the shard that holds the site at the threshold raises its
+    flag, the group finds it when every shard's lnL is in, that shard runs its list again, and the evaluation is
+    repeated -- the value, the counts and the CLVs the client sees are the reference's."""
+    import ctypes as C
+    monkeypatch.setenv("PLLHIP_FUSED", "2")
+    monkeypatch.delenv("PLLHIP_AA_TI_MFMA", raising=False)
+    attrs = ATTRIB_PATTERN_TIP
+    case = make_case(20, "caterpillar", 260, 700, seed=11)
+    case["rates"], case["freqs"] = gpu.aa_model("lg")
+    plan = case["plan"]
+    p0 = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p0, case, attrs)
+    p0.destroy()
+    _place_at_threshold(orc, o, case, False, +1)
+    arr = (C.c_int * 2)(0, 0)
+    assert gpu.lib.pll_amd_set_devices(arr, 2) == 1
+    try:
+        p = build_partition(gpu, case, attrs)
+    finally:
+        gpu.lib.pll_amd_set_devices(None, 0)
+    assert gpu.lib.pll_amd_shard_count(p.ptr) == 2
+    o = oracle_run(orc, gpu, p, case, attrs)
+    o.update_partials()
+    ref = o.edge_loglikelihood(*plan.root_edge)
+    p.update_partials(plan.ops)
+    lnl = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4)     # (the flags are looked at behind this call)
+    assert abs(lnl - ref) <= 1e-11 * abs(ref)
+    c = p.scaling_certificate()
+    assert c["raised"] >= 1 and c["rerun"] >= 1 and c["uncertified"] == 0, c
+    for op in plan.ops[::9]:
+        node, sc = int(op["parent_clv_index"]), int(op["parent_scaler_index"])
+        assert (p.get_scaler(sc) == o.scalers[sc]).all()
+        # (the shard that ran again holds the reference's bits; the other one its matrix-core values)
+        assert clv_err(p.get_clv(node), o.clv[node]) <= 1e-12
+    p.destroy()
