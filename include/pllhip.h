@@ -125,6 +125,8 @@ PLLHIP_EXPORT int pllhip_get_scaler(pllhip_ctx_t * ctx, unsigned int scaler_inde
                                     unsigned int * h_scaler);
 PLLHIP_EXPORT int pllhip_get_pmatrix(pllhip_ctx_t * ctx, unsigned int matrix_index,
                                      double * h_pmatrix);
+/* matrices first .. first + count - 1 in ONE copy (they are contiguous on the device and in the host mirror alike) */
+PLLHIP_EXPORT int pllhip_get_pmatrices(pllhip_ctx_t * ctx, unsigned int first, unsigned int count, double * h_pmatrices);
 
 /* Several CLVs / scale buffers to host memory in ONE launch and one wait (round 6: the host mirrors that small
  * partitions keep current by themselves, include/pll_amd.h).  h must come from pllhip_host_alloc (pinned, mapped into

@@ -23,15 +23,33 @@ struct CeilStream
 };
 
 // tile_b: bytes of one wave's tile of a CLV (a multiple of 1 KB: 64 lanes x 16 bytes per store instruction);
-// count_b: bytes of its tile of a scale buffer (4 per site, or per (site, rate))
+// count_b: bytes of its tile of a scale buffer (4 per site, or per (site, rate)).
+// The tile walk is the list kernels': a wave's first rounds by fixed stride, its last third from eight ticket counters
+// (the XCDs of a box do not write at the same rate, DESIGN 2.0 "Tile order": without the tickets this kernel ended
+// behind the kernel it is the ceiling of -- profiles/r6_bench_c2.json: 1.009).  counters: eight words, 128 bytes apart,
+// zero when the launch starts; group g of eight consecutive workgroups draws from counter g % 8, which hands out
+// tiles g % 8, g % 8 + 8, ... of the dynamic region.
 template <bool NT>
 __global__ __launch_bounds__(256) void k_write_ceiling(const CeilStream * __restrict__ streams, unsigned int K, size_t tiles,
-                                                       unsigned int tile_b, unsigned int count_b)
+                                                       unsigned int tile_b, unsigned int count_b, unsigned int static_rounds,
+                                                       unsigned int * counters)
 {
   const unsigned int lane = threadIdx.x & 63u;
   const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
   const pll_v2d one = {1.0, 1.0};
-  for (size_t t = wave; t < tiles; t += nwaves)
+  const unsigned int group = (blockIdx.x >> 3) & 7u;
+  for (unsigned int round = 0;; ++round)
+  {
+    size_t t;
+    if (round < static_rounds) t = wave + (size_t)round * nwaves;
+    else
+    {
+      unsigned int ticket = 0;
+      if (lane == 0) ticket = atomicAdd(counters + group * 32u, 1u);
+      ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+      t = (size_t)static_rounds * nwaves + group + 8u * (size_t)ticket;
+    }
+    if (t >= tiles) break;
     for (unsigned int k = 0; k < K; ++k)
     {
       const unsigned long long clv = streams[k].clv, cnt = streams[k].counts; // (wave-uniform: scalar loads)
@@ -44,6 +62,7 @@ __global__ __launch_bounds__(256) void k_write_ceiling(const CeilStream * __rest
         else *dst = one;
       }
     }
+  }
 }
 } // namespace
 
@@ -82,9 +101,19 @@ extern "C" int pllhip_write_ceiling(pllhip_ctx_t * c, const pllhip_op_t * ops, u
   const size_t tiles = ((size_t)c->sh.sites + tile_sites - 1) / tile_sites;
   const unsigned int grid = (unsigned int)std::min<size_t>((tiles + 3) / 4, (size_t)c->num_cus * (c->sh.states == 20 ? 2 : 3));
   const bool nt = pllhip_use_nt(c);
+  // the last third of a wave's rounds by ticket (two at least), as the list kernels do; a set of counters per pass
+  const size_t rounds = tiles / ((size_t)grid * 4);
+  const unsigned int dynamic_rounds = (unsigned int)std::max<size_t>(2, rounds / 3);
+  const unsigned int static_rounds = rounds > dynamic_rounds ? (unsigned int)(rounds - dynamic_rounds) : 0u;
+  unsigned int * counters = nullptr;
+  const size_t set_words = 8 * 32;
+  if (e == hipSuccess) e = hipMalloc((void **)&counters, (size_t)(reps + 1) * set_words * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemsetAsync(counters, 0, (size_t)(reps + 1) * set_words * sizeof(unsigned int), c->stream);
+  unsigned int pass = 0;
   auto launch = [&]() {
-    if (nt) k_write_ceiling<true><<<grid, 256, 0, c->stream>>>(d, count, tiles, (unsigned int)(tile_sites * site_b), (unsigned int)(tile_sites * 4 * per_count));
-    else k_write_ceiling<false><<<grid, 256, 0, c->stream>>>(d, count, tiles, (unsigned int)(tile_sites * site_b), (unsigned int)(tile_sites * 4 * per_count));
+    unsigned int * ctr = counters + (size_t)pass++ * set_words;
+    if (nt) k_write_ceiling<true><<<grid, 256, 0, c->stream>>>(d, count, tiles, (unsigned int)(tile_sites * site_b), (unsigned int)(tile_sites * 4 * per_count), static_rounds, ctr);
+    else k_write_ceiling<false><<<grid, 256, 0, c->stream>>>(d, count, tiles, (unsigned int)(tile_sites * site_b), (unsigned int)(tile_sites * 4 * per_count), static_rounds, ctr);
   };
   float ms = 0.f;
   if (e == hipSuccess)
@@ -98,6 +127,7 @@ extern "C" int pllhip_write_ceiling(pllhip_ctx_t * c, const pllhip_op_t * ops, u
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
   }
   (void)hipFree(d);
+  if (counters) (void)hipFree(counters);
   if (e != hipSuccess) { pllhip_set_error("pllhip_write_ceiling: %s", hipGetErrorString(e)); return (int)e; }
   // (kept plans hold addresses only; the CLVs they would relaunch over are simply stale until the list runs again)
   if (ms_per_pass) *ms_per_pass = ms / reps;

@@ -852,6 +852,17 @@ extern "C" int pllhip_get_pmatrix(pllhip_ctx_t * c, unsigned int idx, double * h
   return d2h(c, h, pllhip_pmat_ptr(c, idx), c->pmat_elems * sizeof(double));
 }
 
+extern "C" int pllhip_get_pmatrices(pllhip_ctx_t * c, unsigned int first, unsigned int count, double * h)
+{
+  if (!c->shards.empty()) return pllhip_get_pmatrices(c->shards[0], first, count, h); // (replicated)
+  if (!count || first >= c->sh.prob_matrices || count > c->sh.prob_matrices - first)
+  {
+    pllhip_set_error("pllhip_get_pmatrices: %u matrices from %u", count, first);
+    return -1;
+  }
+  return d2h(c, h, pllhip_pmat_ptr(c, first), (size_t)count * c->pmat_elems * sizeof(double));
+}
+
 extern "C" int pllhip_put_sumtable(pllhip_ctx_t * c, unsigned int slot, const double * h)
 {
   PLLHIP_ALL_SHARDS(c, pllhip_put_sumtable(s, slot, h + lo * c->span));

@@ -307,9 +307,19 @@ int pll_update_prob_matrices(pll_partition_t * p, const unsigned int * params_in
   rc = pllhip_update_pmatrices(pll_amd_priv(p)->ctx, params_indices, matrix_indices,
                                branch_lengths, count);
   if (rc) return pll_amd_fail_hip(rc, "P-matrix update");
-  if (PLL_AMD_MIRRORS(p))
-    for (n = 0; n < count; ++n)
-      if (!pll_amd_sync_pmatrix(p, matrix_indices[n])) return PLL_FAILURE;
+  if (PLL_AMD_MIRRORS(p) && count)
+  {
+    /* the mirrors of the matrices just computed: ONE copy of the range they span (the host block and the device
+       arena are laid out alike, partition.c; a copy per matrix is a stream wait per matrix: 126 of them are 2-3 ms) */
+    unsigned int lo = matrix_indices[0], hi = matrix_indices[0];
+    for (n = 1; n < count; ++n)
+    {
+      if (matrix_indices[n] < lo) lo = matrix_indices[n];
+      if (matrix_indices[n] > hi) hi = matrix_indices[n];
+    }
+    rc = pllhip_get_pmatrices(pll_amd_priv(p)->ctx, lo, hi - lo + 1, p->pmatrix[lo]);
+    if (rc) return pll_amd_fail_hip(rc, "P-matrix download");
+  }
   return PLL_SUCCESS;
 }
 
