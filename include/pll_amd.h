@@ -675,6 +675,10 @@ PLL_EXPORT int pll_amd_wait(pll_partition_t * partition);
 PLL_EXPORT int pll_amd_comm_unique_id(void * unique_id_128bytes);
 PLL_EXPORT int pll_amd_comm_init(pll_partition_t * partition, int rank, int nranks,
                                  const void * unique_id_128bytes);
+/* Collectives the partition has entered so far (0 without pll_amd_comm_init).  Every rank of a job counts the same
+ * number at the same point of the client's program -- also when one rank's scaling certificate (below) makes it run a
+ * list again: that happens ahead of the evaluation, never between its collectives. */
+PLL_EXPORT unsigned long long pll_amd_comm_reduces(pll_partition_t * partition);
 /* Which RCCL the process runs on: the file the collective symbols were bound to and how -- the
  * copy the host program had already mapped (PyTorch ships its own librccl.so) is used if there is
  * one, so that the process never holds two instances; "" before the first pll_amd_comm_* call. */

@@ -310,6 +310,9 @@ PLLHIP_EXPORT int pllhip_comm_unique_id(void * id128);
 PLLHIP_EXPORT const char * pllhip_rccl_path(void);
 PLLHIP_EXPORT int pllhip_comm_init(pllhip_ctx_t * ctx, int rank, int nranks,
                                    const void * id128);
+/* all-reduces this context has entered so far: the ranks of a job must agree on it at every point (a check for
+ * clients and tests; a rank whose scaling certificate trips looks at its flag BEFORE the evaluation, likelihood.hip) */
+PLLHIP_EXPORT unsigned long long pllhip_comm_reduces(pllhip_ctx_t * ctx);
 
 /* ---- HIP-event stopwatch on the context's stream ---- */
 PLLHIP_EXPORT int pllhip_timer_start(pllhip_ctx_t * ctx);

@@ -424,10 +424,13 @@ extern "C" int pllhip_comm_init(pllhip_ctx_t * c, int rank, int nranks, const vo
 int pllhip_allreduce_result(pllhip_ctx * c, unsigned int count)
 {
   if (!c->comm) return 0;
+  ++c->comm_reduces;
   NCCL_TRY(g_rccl.AllReduce(c->d_result, c->d_result, count, ncclDouble, ncclSum,
                             (ncclComm_t)c->comm, c->stream));
   return 0;
 }
+
+extern "C" unsigned long long pllhip_comm_reduces(pllhip_ctx_t * c) { return c->comm_reduces; }
 
 extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
 {

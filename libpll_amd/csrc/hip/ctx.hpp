@@ -152,6 +152,7 @@ struct pllhip_ctx
 
   ncclComm * comm = nullptr;
   int nranks = 1;
+  unsigned long long comm_reduces = 0; // all-reduces entered (pllhip_comm_reduces: every rank must count alike)
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cus = 256;

@@ -1119,6 +1119,14 @@ static int fill_freqs_indices(pllhip_ctx * c, LnlArgs & a, const unsigned int * 
 // group (defer) returns without waiting: its group looks at the flags when it has collected (shard.hip).
 static int run_lnl_certified(pllhip_ctx * c, LnlArgs & a, int kind, double * h_persite_lnl, double * h_lnl)
 {
+  // One rank of several (pllhip_comm_init): the evaluation ends in an all-reduce that every rank must enter the same
+  // number of times, and a flag is raised on ONE rank -- so the flag is looked at first (one wait for the stream, which
+  // this path pays for its result anyway) and the evaluation runs once, on every rank alike.
+  if (c->comm && c->cert_pending && !c->defer)
+  {
+    const int rc = pllhip_cert_resolve(c);
+    if (rc) return rc;
+  }
   for (;;)
   {
     LnlArgs aa = a;

@@ -162,19 +162,26 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
                                                     const AaLookupJob * __restrict__ lj, unsigned int nlk)
 {
   const unsigned int b = blockIdx.x;
-  __shared__ double sh_m1[1600], sh_m2[1600]; // a job's matrices (pair and lookup tables)
-  __shared__ double sh_left[80];              // the row of character 1
   __shared__ double sh_child[32 * 80];        // a lookup table's child over (c1, every c2)
   // (the list kernel's tile counter: reset here instead of by a fill kernel of its own, round 4)
   if (b == 0 && threadIdx.x == 0) *tile_counter = 0u;
+  // (round 6: every job asks for all it will read before it looks at any of it -- the rows of its matrices, and the
+  // state masks of the up to eleven second characters c2 = g, g + 3, ... a thread walks (maxstates <= 32): a mask
+  // fetched inside the walk was a round trip to L2 per character, eight in a row; profiles/r6_aa_prepare_ab.txt)
+  constexpr int AF_C2_MAX = 11;
   if (b < nmat)
   {
-    const double * src = mj[b].src;
+    const PLL_GLOBAL double * src = (const PLL_GLOBAL double *)mj[b].src;
     double * out = reinterpret_cast<double *>(aorder + mj[b].dst_off);
-    for (unsigned int idx = threadIdx.x; idx < AF_MAT_B / 8; idx += blockDim.x)
+    const bool plain = mj[b].plain != 0;
+    constexpr int AF_MAT_STEPS = (AF_MAT_B / 8 + 255) / 256;
+    double v[AF_MAT_STEPS];
+#pragma unroll
+    for (int k = 0; k < AF_MAT_STEPS; ++k)
     {
-      double v = 0.0;
-      if (idx < 1600 && !mj[b].plain)
+      const unsigned int idx = threadIdx.x + 256u * k;
+      unsigned int from = 0u;
+      if (!plain)
       {
         const unsigned int blk = idx >> 6, lane = idx & 63u, t = blk / 5, bb = blk - 5 * t;
         const unsigned int q = lane >> 4, i = lane & 3u;
@@ -189,9 +196,9 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
           row = t < 4 ? 4 * cq + t : 16 + cq;
           col = 16 + m;
         }
-        v = src[rate * 400 + row * 20 + col];
+        from = rate * 400 + row * 20 + col;
       }
-      else if (idx < 1600)
+      else
       {
         // Row order (the right block of a tip-inner op, af_matvec_plain): 50 pieces of 16 x 16 bytes; piece
         // (pass, t, c) holds, for lane class (q, rate), columns 4c + 2 pass and 4c + 2 pass + 1 of the row whose
@@ -199,52 +206,71 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
         const unsigned int e = idx >> 1, half = idx & 1u, piece = e >> 4, cls = e & 15u;
         const unsigned int q = cls >> 2, rate = cls & 3u, pass = piece / 25, rem = piece - 25 * pass, t = rem / 5, cc = rem - 5 * t;
         const unsigned int row = t < 4 ? 4 * q + t : 16 + q, col = 4 * cc + 2 * pass + half;
-        v = src[rate * 400 + row * 20 + col];
+        from = rate * 400 + row * 20 + col;
       }
-      out[idx] = v;
+      v[k] = src[idx < 1600 ? from : 0u]; // (unconditional: the seven requests leave together)
+    }
+#pragma unroll
+    for (int k = 0; k < AF_MAT_STEPS; ++k)
+    {
+      const unsigned int idx = threadIdx.x + 256u * k;
+      if (idx < AF_MAT_B / 8) out[idx] = idx < 1600 ? v[k] : 0.0;
     }
   }
   else if (b - nmat < ntip)
   {
-    // tab[code][k][i] = sum_{j in tipmap[code]} P[k][i][j] (core_partials_avx.c:1140-1177), as k_aa_tip_tables
-    const double * lmat = tj[b - nmat].lmat;
+    // tab[code][k][i] = sum_{j in tipmap[code]} P[k][i][j] (core_partials_avx.c:1140-1177), as k_aa_tip_tables: the
+    // row's selected entries added in ascending order (adding +0.0 for the others changes no bit)
     double * out = reinterpret_cast<double *>(titab + tj[b - nmat].dst_off);
-    for (unsigned int t = threadIdx.x; t < ms * 80; t += blockDim.x)
+    if (threadIdx.x < 240)
     {
-      const unsigned int code = t / 80, ki = t - 80 * code;
-      out[t] = masksum_seq(lmat + (size_t)ki * 20, tipmap[code], 20);
+      const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u;
+      const PLL_GLOBAL double * lm = (const PLL_GLOBAL double *)tj[b - nmat].lmat + ki * 20;
+      double r[20];
+      unsigned int msk[AF_C2_MAX];
+#pragma unroll
+      for (int jj = 0; jj < 20; ++jj) r[jj] = lm[jj];
+#pragma unroll
+      for (int k = 0; k < AF_C2_MAX; ++k) msk[k] = g + 3u * k < ms ? tipmap[g + 3u * k] : 0u;
+#pragma unroll
+      for (int k = 0; k < AF_C2_MAX; ++k)
+        if (g + 3u * k < ms) out[(g + 3u * k) * 80 + ki] = af_masksum20(r, msk[k]);
     }
   }
   else if (b - nmat - ntip < npair * ms)
   {
     // (round 5 measured four first characters per workgroup -- the 25.6 KB of matrices fetched once instead of four
     // times: 34.1 against 26.7 us per launch at C3, profiles/r5_aa_prepare_ab.txt; the jobs are bound by their own
-    // serial arithmetic, not by the matrices.  Not kept.)
+    // serial path, not by the matrices.)
     // one workgroup per (op, character 1): row (c1 ms + c2) = left factor of c1 (.) right factor of c2 -- the two
-    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds.  The
-    // matrices come through LDS (coalesced loads); a thread keeps ITS row of the right matrix in registers and
-    // walks the second characters (a masked sum = the row's selected entries added in ascending order; adding +0.0
-    // for the others changes no bit).
+    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds (a masked sum
+    // = the row's selected entries added in ascending order; adding +0.0 for the others changes no bit).
+    // Round 6: a thread reads ITS rows of the two matrices straight into registers (160 contiguous bytes each) and
+    // forms its own left factor -- three threads per row do so, which costs nothing -- instead of matrices through
+    // LDS, the left factors through LDS and two barriers in between: the launch is a chain of latencies, and with
+    // no LDS at all its workgroups are all resident at once.
     const unsigned int job = (b - nmat - ntip) / ms, c1 = (b - nmat - ntip) - job * ms;
     const AfPairJob & j = pj[job];
-    for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x)
-    {
-      sh_m1[t] = j.lmat[t];
-      sh_m2[t] = j.rmat[t];
-    }
-    __syncthreads();
-    if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
-    __syncthreads();
     double * out = reinterpret_cast<double *>(pairtab + j.dst_off) + (size_t)c1 * ms * 80;
     if (threadIdx.x < 240)
     {
       const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u;
-      double r[20];
+      // (the jobs' pointers are device memory: said so, or the loads are flat ones)
+      const PLL_GLOBAL double * lm = (const PLL_GLOBAL double *)j.lmat + ki * 20, * rm = (const PLL_GLOBAL double *)j.rmat + ki * 20;
+      double lrow[20], r[20];
+      unsigned int msk[AF_C2_MAX];
 #pragma unroll
-      for (int jj = 0; jj < 20; ++jj) r[jj] = sh_m2[ki * 20 + jj];
-      const double l = sh_left[ki];
-      for (unsigned int c2 = g; c2 < ms; c2 += 3)
-        out[c2 * 80 + ki] = l * af_masksum20(r, tipmap[c2]);
+      for (int jj = 0; jj < 20; ++jj)
+      {
+        lrow[jj] = lm[jj];
+        r[jj] = rm[jj];
+      }
+#pragma unroll
+      for (int k = 0; k < AF_C2_MAX; ++k) msk[k] = g + 3u * k < ms ? tipmap[g + 3u * k] : 0u;
+      const double l = af_masksum20(lrow, tipmap[c1]);
+#pragma unroll
+      for (int k = 0; k < AF_C2_MAX; ++k)
+        if (g + 3u * k < ms) out[(g + 3u * k) * 80 + ki] = l * af_masksum20(r, msk[k]);
     }
   }
   else if (b - nmat - ntip - npair * ms < nlk * ms)
@@ -253,6 +279,8 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
     // character pairs the child -- a tip-tip result -- can be: the child as the branch above makes it, then the
     // mat-vec in the order of the kernel the op would have run (AaLookupJob, ctx.hpp).  Until then six launches of
     // those kernels ahead of every list (tip tables, tip-tip over all pairs, inner-inner x "ones"): 60 us.
+    // Round 6: rows into registers as above; LDS holds the children only (20 KB: five workgroups per CU by their
+    // registers), one barrier, and the row of P is requested before it.
     const unsigned int job = (b - nmat - ntip - npair * ms) / ms, c1 = (b - nmat - ntip - npair * ms) - job * ms;
     const AaLookupJob & j = lj[job];
     double * out = j.dst + (size_t)c1 * ms * 80;
@@ -262,37 +290,42 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
       if (threadIdx.x < 80) out[threadIdx.x] = masksum_seq(j.kl + (size_t)threadIdx.x * 20, tipmap[c1], 20);
       return;
     }
-    for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x)
-    {
-      sh_m1[t] = j.kl[t];
-      sh_m2[t] = j.kr[t];
-    }
-    __syncthreads();
-    if (threadIdx.x < 80) sh_left[threadIdx.x] = masksum_seq(sh_m1 + threadIdx.x * 20, tipmap[c1], 20);
-    __syncthreads();
     const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u; // (threads 240..255: no row)
+    double prow[20];
     if (threadIdx.x < 240)
     {
-      double r[20];
+      const PLL_GLOBAL double * lm = (const PLL_GLOBAL double *)j.kl + ki * 20, * rm = (const PLL_GLOBAL double *)j.kr + ki * 20;
+      const PLL_GLOBAL double * pm = (const PLL_GLOBAL double *)j.pm + ki * 20;
+      double lrow[20], r[20];
 #pragma unroll
-      for (int jj = 0; jj < 20; ++jj) r[jj] = sh_m2[ki * 20 + jj];
-      const double l = sh_left[ki];
-      for (unsigned int c2 = g; c2 < ms; c2 += 3) sh_child[c2 * 80 + ki] = l * af_masksum20(r, tipmap[c2]);
+      for (int jj = 0; jj < 20; ++jj)
+      {
+        lrow[jj] = lm[jj];
+        r[jj] = rm[jj];
+      }
+      unsigned int msk[AF_C2_MAX];
+#pragma unroll
+      for (int k = 0; k < AF_C2_MAX; ++k) msk[k] = g + 3u * k < ms ? tipmap[g + 3u * k] : 0u;
+      const double l = af_masksum20(lrow, tipmap[c1]);
+#pragma unroll
+      for (int k = 0; k < AF_C2_MAX; ++k)
+        if (g + 3u * k < ms) sh_child[(g + 3u * k) * 80 + ki] = l * af_masksum20(r, msk[k]);
+#pragma unroll
+      for (int jj = 0; jj < 20; ++jj) prow[jj] = pm[jj];
     }
-    for (unsigned int t = threadIdx.x; t < 1600; t += blockDim.x) sh_m1[t] = j.pm[t]; // (the left tip matrix is done with)
     __syncthreads();
     if (threadIdx.x < 240)
     {
       // the thread's row of P in registers, the children of its second characters out of LDS
-      double prow[20];
-#pragma unroll
-      for (int jj = 0; jj < 20; ++jj) prow[jj] = sh_m1[ki * 20 + jj];
       const unsigned int kk = ki / 20u;
-      for (unsigned int c2 = g; c2 < ms; c2 += 3)
-      {
-        const double * v = sh_child + c2 * 80 + kk * 20;
-        out[c2 * 80 + ki] = j.mode == 0u ? dot_strided4<true>(prow, v, 20u) : dot_strided4<false>(prow, v, 20u);
-      }
+      const bool fused = j.mode == 0u;
+#pragma unroll
+      for (int k = 0; k < AF_C2_MAX; ++k)
+        if (g + 3u * k < ms)
+        {
+          const double * v = sh_child + (g + 3u * k) * 80 + kk * 20;
+          out[(g + 3u * k) * 80 + ki] = fused ? dot_strided4<true>(prow, v, 20u) : dot_strided4<false>(prow, v, 20u);
+        }
     }
   }
 }

@@ -813,6 +813,8 @@ int pll_amd_comm_init(pll_partition_t * p, int rank, int nranks, const void * id
   return PLL_SUCCESS;
 }
 
+unsigned long long pll_amd_comm_reduces(pll_partition_t * p) { return pllhip_comm_reduces(pll_amd_priv(p)->ctx); }
+
 int pll_amd_timer_start(pll_partition_t * p)
 {
   int rc = pllhip_timer_start(pll_amd_priv(p)->ctx);

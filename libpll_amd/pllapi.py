@@ -156,6 +156,9 @@ class PllLibrary:
             lib.pll_amd_timer_shard_ms.restype = C.c_uint
             lib.pll_amd_comm_unique_id.argtypes = [C.c_void_p]
             lib.pll_amd_comm_init.argtypes = [_PP, C.c_int, C.c_int, C.c_void_p]
+            if hasattr(lib, "pll_amd_comm_reduces"):
+                lib.pll_amd_comm_reduces.argtypes = [_PP]
+                lib.pll_amd_comm_reduces.restype = C.c_ulonglong
             lib.pll_amd_profile_enable.argtypes = [_PP, C.c_int]
             lib.pll_amd_profile_read.argtypes = [_PP, _up, _dp]
             if hasattr(lib, "pll_amd_scaling_certificate"):
@@ -424,6 +427,10 @@ class Partition:
         self._check(self.lib.pll_amd_list_kinds(self.ptr, _u(v)), "pll_amd_list_kinds")
         return dict(zip(("ops", "tip_tip_ahead", "tip_tip_in_list", "lookups", "inner_inner_matrix_cores",
                          "tip_inner_matrix_cores", "tip_inner_vector_unit", "reloads"), (int(x) for x in v)))
+
+    def comm_reduces(self):
+        """collectives entered so far (every rank of a job must count alike)"""
+        return int(self.lib.pll_amd_comm_reduces(self.ptr))
 
     def comm_init(self, rank, nranks, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)

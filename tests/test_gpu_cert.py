@@ -170,6 +170,42 @@ def test_certificate_behind_a_result_call(gpu, orc, monkeypatch):
     p.destroy()
 
 
+def test_certificate_on_a_rank_of_several(gpu, orc, monkeypatch):
+    """One rank of a multi-process job (pll_amd_comm_init): an evaluation ends in an all-reduce that every rank enters
+    once.  The flag is raised on ONE rank only, so that rank must run its list again BEFORE the evaluation -- never
+    evaluate, notice, and evaluate (and all-reduce) a second time, which its peers would answer with their NEXT
+    collective.  One rank here (a 1-GPU box): the collectives are counted."""
+    import ctypes
+    monkeypatch.setenv("PLLHIP_FUSED", "2")
+    monkeypatch.delenv("PLLHIP_AA_TI_MFMA", raising=False)
+    attrs = ATTRIB_PATTERN_TIP
+    case = make_case(20, "caterpillar", 260, 96, seed=11)
+    case["rates"], case["freqs"] = gpu.aa_model("lg")
+    plan = case["plan"]
+    p0 = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p0, case, attrs)
+    p0.destroy()
+    _place_at_threshold(orc, o, case, False, -1)
+    p = build_partition(gpu, case, attrs)
+    o = oracle_run(orc, gpu, p, case, attrs)
+    o.update_partials()
+    ref = o.edge_loglikelihood(*plan.root_edge)
+    uid = ctypes.create_string_buffer(128)
+    assert gpu.lib.pll_amd_comm_unique_id(uid), gpu.errmsg()
+    assert p.comm_reduces() == 0
+    p.comm_init(0, 1, uid.raw)
+    for k in range(3):
+        p.update_partials(plan.ops)
+        lnl = p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4)
+        assert abs(lnl - ref) <= 1e-11 * abs(ref)
+        assert p.comm_reduces() == k + 1, "an evaluation entered %d collectives" % (p.comm_reduces() - k)
+        sc = int(plan.ops[-1]["parent_scaler_index"])
+        assert (p.get_scaler(sc) == o.scalers[sc]).all()
+    c = p.scaling_certificate()
+    assert c["rerun"] == 3 and c["uncertified"] == 0, c
+    p.destroy()
+
+
 @pytest.mark.parametrize("shape,tips", [("random", 120), ("caterpillar", 150)])
 def test_default_path_counts_bitwise_clvs_to_rounding(gpu, orc, monkeypatch, shape, tips):
     """The default path on trees with many tip-inner ops: counts bit for bit, CLVs to 1e-13, lnL to 1e-12 -- and the
