@@ -122,29 +122,37 @@ template <int RC>
 __global__ __launch_bounds__(256) void k_dna_pair_tables(const FusedPairJob * __restrict__ jobs, unsigned int njobs,
                                                          unsigned int * __restrict__ tile_counters)
 {
-  const unsigned int i = blockIdx.x;
-  if (i == 0 && tile_counters) tile_counters[threadIdx.x * 32u] = 0u;
+  // (round 6: four workgroups per job, a quarter of the 256 pairs each -- the launch is a chain of latencies, and
+  // thirty-odd workgroups of sixteen rounds each left the device empty for 10 us ahead of every list; a thread reads
+  // ITS row of each matrix -- 32 bytes -- straight into registers: every pair it makes has the same (rate, state))
+  const unsigned int i = blockIdx.x >> 2, quarter = blockIdx.x & 3u;
+  if (blockIdx.x == 0 && tile_counters) tile_counters[threadIdx.x * 32u] = 0u;
   if (i >= njobs) return;
-  // Round 5: the two matrices through LDS, the table written in address order.  (A thread per character pair that
+  // Round 5: the table written in address order.  (A thread per character pair that
   // read its 2 x 16 rows of 4 straight from memory and wrote 128 contiguous bytes of its own took 10.6 us per launch
   // -- sixteen dependent trips to L1 per thread --, a fifth of pll_update_partials at 20,000 sites.)  Same products,
   // same order: masksum4 of a row, times masksum4 of a row.
-  __shared__ double s_lm[RC * 16], s_rm[RC * 16];
-  const double * lm = jobs[i].lmat, * rm = jobs[i].rmat;
+  const PLL_GLOBAL double * lm = (const PLL_GLOBAL double *)jobs[i].lmat, * rm = (const PLL_GLOBAL double *)jobs[i].rmat;
   double * tab = jobs[i].tab;
   // (tip-inner ops: the tip's factor alone, in the entries [code 1][0] the kernel's index
   // (code 1 << 4 | character of an absent tip = 0) reaches; x * 1.0 is x)
   const bool tt = jobs[i].tip_tip != 0;
-  for (unsigned int t = threadIdx.x; t < RC * 16u; t += blockDim.x)
+  constexpr unsigned int ROW = RC * 4u;                 // entries of a pair: (rate, state)
+  constexpr unsigned int PER = 256u / ROW;              // pairs a workgroup makes per round
+  constexpr unsigned int ROUNDS = 64u / PER;            // rounds of its quarter (64 pairs)
+  const unsigned int ki = threadIdx.x % ROW, sub = threadIdx.x / ROW;
+  double l[4], r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
   {
-    s_lm[t] = lm[t];
-    s_rm[t] = tt ? rm[t] : 0.0;
+    l[k] = lm[ki * 4u + k];
+    r[k] = tt ? rm[ki * 4u + k] : 0.0;
   }
-  __syncthreads();
-  for (unsigned int e = threadIdx.x; e < 256u * RC * 4u; e += blockDim.x)
+#pragma unroll
+  for (unsigned int round = 0; round < ROUNDS; ++round)
   {
-    const unsigned int pair = e / (RC * 4u), ki = e - pair * (RC * 4u), c1 = pair >> 4, c2 = pair & 15u;
-    tab[e] = masksum4(s_lm + ki * 4u, c1) * (tt ? masksum4(s_rm + ki * 4u, c2) : 1.0);
+    const unsigned int pair = quarter * 64u + round * PER + sub, c1 = pair >> 4, c2 = pair & 15u;
+    tab[pair * ROW + ki] = masksum4(l, c1) * (tt ? masksum4(r, c2) : 1.0);
   }
 }
 
@@ -1546,10 +1554,10 @@ int pllhip_relaunch_fused(pllhip_ctx * c)
   {
     switch (c->sh.rate_cats)
     {
-      case 1: k_dna_pair_tables<1><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
-      case 2: k_dna_pair_tables<2><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
-      case 8: k_dna_pair_tables<8><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
-      default: k_dna_pair_tables<4><<<njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
+      case 1: k_dna_pair_tables<1><<<4 * njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
+      case 2: k_dna_pair_tables<2><<<4 * njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
+      case 8: k_dna_pair_tables<8><<<4 * njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
+      default: k_dna_pair_tables<4><<<4 * njobs, 256, 0, c->stream>>>(d_jobs, njobs, nullptr); break;
     }
     HIP_TRY(hipGetLastError());
   }
