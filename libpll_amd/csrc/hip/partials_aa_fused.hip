@@ -153,6 +153,8 @@ __device__ __forceinline__ double af_masksum20(const double (&r)[20], unsigned i
   return a;
 }
 
+constexpr unsigned int AF_PAIR_WGS = 4;  // workgroups per pair table: a range of first characters each
+constexpr int AF_C1_MAX = 8;             // first characters of such a range at most (maxstates <= 32)
 __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict__ mj, unsigned int nmat,
                                                     const AfTipJob * __restrict__ tj, unsigned int ntip,
                                                     char * aorder, char * titab,
@@ -163,6 +165,20 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
 {
   const unsigned int b = blockIdx.x;
   __shared__ double sh_child[32 * 80];        // a lookup table's child over (c1, every c2)
+  __shared__ double sh_m0[80 * 21], sh_m1[80 * 21]; // a job's matrices, rows of 21 (a lane per row: 4-way conflicts)
+  __shared__ double sh_l[AF_C1_MAX * 80];     // left factors of a job's first character(s)
+  // a matrix [rate][row][column] = 80 rows of 20, coalesced from memory into rows of 21
+  auto af_stage_rows = [&](const PLL_GLOBAL double * m, double * sh) __attribute__((always_inline)) {
+    double v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = m[threadIdx.x + 256u * k < 1600u ? threadIdx.x + 256u * k : 0u];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+    {
+      const unsigned int e = threadIdx.x + 256u * k;
+      if (e < 1600u) sh[(e / 20u) * 21u + e % 20u] = v[k];
+    }
+  };
   // (the list kernel's tile counter: reset here instead of by a fill kernel of its own, round 4)
   if (b == 0 && threadIdx.x == 0) *tile_counter = 0u;
   // (round 6: every job asks for all it will read before it looks at any of it -- the rows of its matrices, and the
@@ -237,51 +253,66 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
         if (g + 3u * k < ms) out[(g + 3u * k) * 80 + ki] = af_masksum20(r, msk[k]);
     }
   }
-  else if (b - nmat - ntip < npair * ms)
+  else if (b - nmat - ntip < npair * AF_PAIR_WGS)
   {
-    // (round 5 measured four first characters per workgroup -- the 25.6 KB of matrices fetched once instead of four
-    // times: 34.1 against 26.7 us per launch at C3, profiles/r5_aa_prepare_ab.txt; the jobs are bound by their own
-    // serial path, not by the matrices.)
-    // one workgroup per (op, character 1): row (c1 ms + c2) = left factor of c1 (.) right factor of c2 -- the two
-    // masked row sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds (a masked sum
-    // = the row's selected entries added in ascending order; adding +0.0 for the others changes no bit).
-    // Round 6: a thread reads ITS rows of the two matrices straight into registers (160 contiguous bytes each) and
-    // forms its own left factor -- three threads per row do so, which costs nothing -- instead of matrices through
-    // LDS, the left factors through LDS and two barriers in between: the launch is a chain of latencies, and with
-    // no LDS at all its workgroups are all resident at once.
-    const unsigned int job = (b - nmat - ntip) / ms, c1 = (b - nmat - ntip) - job * ms;
+    // A tip-tip op's pair table: row (c1 ms + c2) = left factor of c1 (.) right factor of c2 -- the two masked row
+    // sums of k_aa_tip_tables / the branch above and the ONE multiplication of k_aa_tt_rounds (a masked sum = the
+    // row's selected entries added in ascending order; adding +0.0 for the others changes no bit).
+    // Round 6, third form (profiles/r6_aa_prepare_ab.txt; tools/aa_prepare_parts.sh says what each kind of job costs):
+    // a workgroup per (op, first character) that pulled its rows of both matrices straight into registers was bound
+    // by those loads -- a lane per row is sixty-four cache lines per instruction, 23 workgroups per op each fetching
+    // all of it.  Now AF_PAIR_WGS workgroups per op, each a range of first characters: the right matrix comes ONCE,
+    // coalesced, through LDS (rows of 21: a lane per row is then a 4-way bank conflict, not 16-way), the right factors
+    // of a thread's second characters are formed once and serve every first character of the range.
+    const unsigned int job = (b - nmat - ntip) / AF_PAIR_WGS, part = (b - nmat - ntip) - job * AF_PAIR_WGS;
+    const unsigned int per = (ms + AF_PAIR_WGS - 1u) / AF_PAIR_WGS, c1_0 = part * per; // (per <= AF_C1_MAX: ms <= 32)
     const AfPairJob & j = pj[job];
-    double * out = reinterpret_cast<double *>(pairtab + j.dst_off) + (size_t)c1 * ms * 80;
+    af_stage_rows((const PLL_GLOBAL double *)j.rmat, sh_m0);
+    unsigned int msk[AF_C2_MAX];
+    const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u;
+#pragma unroll
+    for (int k = 0; k < AF_C2_MAX; ++k) msk[k] = g + 3u * k < ms ? tipmap[g + 3u * k] : 0u;
+    if (threadIdx.x < 80)
+    {
+      // the left factors of the range's first characters (one thread per row: its 160 bytes straight from memory)
+      const PLL_GLOBAL double * lm = (const PLL_GLOBAL double *)j.lmat + ki * 20;
+      double lrow[20];
+#pragma unroll
+      for (int jj = 0; jj < 20; ++jj) lrow[jj] = lm[jj];
+#pragma unroll
+      for (int t = 0; t < AF_C1_MAX; ++t)
+        if (t < per && c1_0 + t < ms) sh_l[t * 80 + ki] = af_masksum20(lrow, tipmap[c1_0 + t]);
+    }
+    __syncthreads();
     if (threadIdx.x < 240)
     {
-      const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u;
-      // (the jobs' pointers are device memory: said so, or the loads are flat ones)
-      const PLL_GLOBAL double * lm = (const PLL_GLOBAL double *)j.lmat + ki * 20, * rm = (const PLL_GLOBAL double *)j.rmat + ki * 20;
-      double lrow[20], r[20];
-      unsigned int msk[AF_C2_MAX];
+      double r[20], l[AF_C1_MAX];
 #pragma unroll
-      for (int jj = 0; jj < 20; ++jj)
-      {
-        lrow[jj] = lm[jj];
-        r[jj] = rm[jj];
-      }
+      for (int jj = 0; jj < 20; ++jj) r[jj] = sh_m0[ki * 21 + jj];
 #pragma unroll
-      for (int k = 0; k < AF_C2_MAX; ++k) msk[k] = g + 3u * k < ms ? tipmap[g + 3u * k] : 0u;
-      const double l = af_masksum20(lrow, tipmap[c1]);
+      for (int t = 0; t < AF_C1_MAX; ++t) l[t] = (t < per && c1_0 + t < ms) ? sh_l[t * 80 + ki] : 0.0;
+      double * out = reinterpret_cast<double *>(pairtab + j.dst_off);
 #pragma unroll
       for (int k = 0; k < AF_C2_MAX; ++k)
-        if (g + 3u * k < ms) out[(g + 3u * k) * 80 + ki] = l * af_masksum20(r, msk[k]);
+        if (g + 3u * k < ms)
+        {
+          const double rf = af_masksum20(r, msk[k]);
+#pragma unroll
+          for (int t = 0; t < AF_C1_MAX; ++t)
+            if (t < per && c1_0 + t < ms) out[((size_t)(c1_0 + t) * ms + g + 3u * k) * 80 + ki] = l[t] * rf;
+        }
     }
   }
-  else if (b - nmat - ntip - npair * ms < nlk * ms)
+  else if (b - nmat - ntip - npair * AF_PAIR_WGS < nlk * ms)
   {
     // (round 4) a lookup op's table, one workgroup per (table, character 1): rows (c1 ms + c2) = P x child over the
     // character pairs the child -- a tip-tip result -- can be: the child as the branch above makes it, then the
     // mat-vec in the order of the kernel the op would have run (AaLookupJob, ctx.hpp).  Until then six launches of
     // those kernels ahead of every list (tip tables, tip-tip over all pairs, inner-inner x "ones"): 60 us.
-    // Round 6: rows into registers as above; LDS holds the children only (20 KB: five workgroups per CU by their
-    // registers), one barrier, and the row of P is requested before it.
-    const unsigned int job = (b - nmat - ntip - npair * ms) / ms, c1 = (b - nmat - ntip - npair * ms) - job * ms;
+    // Round 6: the child's right matrix and P come coalesced through LDS (rows of 21), the left factor of c1 from the
+    // first 80 threads (a row each, straight from memory, while the others stage); LDS: 27 KB of matrices + the
+    // children, three workgroups per CU; two barriers.
+    const unsigned int job = (b - nmat - ntip - npair * AF_PAIR_WGS) / ms, c1 = (b - nmat - ntip - npair * AF_PAIR_WGS) - job * ms;
     const AaLookupJob & j = lj[job];
     double * out = j.dst + (size_t)c1 * ms * 80;
     if (j.mode == 2u)
@@ -290,28 +321,33 @@ __global__ __launch_bounds__(256) void k_af_prepare(const AfMatJob * __restrict_
       if (threadIdx.x < 80) out[threadIdx.x] = masksum_seq(j.kl + (size_t)threadIdx.x * 20, tipmap[c1], 20);
       return;
     }
+    af_stage_rows((const PLL_GLOBAL double *)j.kr, sh_m0);
+    af_stage_rows((const PLL_GLOBAL double *)j.pm, sh_m1);
     const unsigned int ki = threadIdx.x % 80u, g = threadIdx.x / 80u; // (threads 240..255: no row)
+    unsigned int msk[AF_C2_MAX];
+#pragma unroll
+    for (int k = 0; k < AF_C2_MAX; ++k) msk[k] = g + 3u * k < ms ? tipmap[g + 3u * k] : 0u;
+    if (threadIdx.x < 80)
+    {
+      const PLL_GLOBAL double * lm = (const PLL_GLOBAL double *)j.kl + ki * 20;
+      double lrow[20];
+#pragma unroll
+      for (int jj = 0; jj < 20; ++jj) lrow[jj] = lm[jj];
+      sh_l[ki] = af_masksum20(lrow, tipmap[c1]);
+    }
+    __syncthreads();
     double prow[20];
     if (threadIdx.x < 240)
     {
-      const PLL_GLOBAL double * lm = (const PLL_GLOBAL double *)j.kl + ki * 20, * rm = (const PLL_GLOBAL double *)j.kr + ki * 20;
-      const PLL_GLOBAL double * pm = (const PLL_GLOBAL double *)j.pm + ki * 20;
-      double lrow[20], r[20];
+      double r[20];
 #pragma unroll
-      for (int jj = 0; jj < 20; ++jj)
-      {
-        lrow[jj] = lm[jj];
-        r[jj] = rm[jj];
-      }
-      unsigned int msk[AF_C2_MAX];
-#pragma unroll
-      for (int k = 0; k < AF_C2_MAX; ++k) msk[k] = g + 3u * k < ms ? tipmap[g + 3u * k] : 0u;
-      const double l = af_masksum20(lrow, tipmap[c1]);
+      for (int jj = 0; jj < 20; ++jj) r[jj] = sh_m0[ki * 21 + jj];
+      const double l = sh_l[ki];
 #pragma unroll
       for (int k = 0; k < AF_C2_MAX; ++k)
         if (g + 3u * k < ms) sh_child[(g + 3u * k) * 80 + ki] = l * af_masksum20(r, msk[k]);
 #pragma unroll
-      for (int jj = 0; jj < 20; ++jj) prow[jj] = pm[jj];
+      for (int jj = 0; jj < 20; ++jj) prow[jj] = sh_m1[ki * 21 + jj];
     }
     __syncthreads();
     if (threadIdx.x < 240)
@@ -1120,10 +1156,15 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
   const char * plan = static_cast<const char *>(k.d_plan);
   if (k.nmat + k.ntip + k.npair + k.nlk)
   {
-    k_af_prepare<<<k.nmat + k.ntip + (k.npair + k.nlk) * c->maxstates, 256, 0, c->stream>>>(
-        (const AfMatJob *)(plan + k.off_mat), k.nmat, (const AfTipJob *)(plan + k.off_tip), k.ntip, k.d_aorder,
-        k.d_titab, c->tipmap, c->maxstates, c->d_tile_counter, (const AfPairJob *)(plan + k.off_pair), k.npair,
-        k.d_pairtab, (const AaLookupJob *)(plan + k.off_lk), k.nlk);
+    // (tool switch, wrong results: PLLHIP_AF_PREP_SKIP = 1 no matrix jobs | 2 no tip tables | 4 no pair tables |
+    // 8 no lookup tables -- what each kind of job costs the launch, tools/aa_prepare_ab.sh)
+    const unsigned int skip = pllhip_env("PLLHIP_AF_PREP_SKIP") ? (unsigned int)atoi(pllhip_env("PLLHIP_AF_PREP_SKIP")) : 0u;
+    const unsigned int nmat = (skip & 1u) ? 0u : k.nmat, ntip = (skip & 2u) ? 0u : k.ntip;
+    const unsigned int npair = (skip & 4u) ? 0u : k.npair, nlk = (skip & 8u) ? 0u : k.nlk;
+    k_af_prepare<<<std::max(1u, nmat + ntip + npair * AF_PAIR_WGS + nlk * c->maxstates), 256, 0, c->stream>>>(
+        (const AfMatJob *)(plan + k.off_mat), nmat, (const AfTipJob *)(plan + k.off_tip), ntip, k.d_aorder,
+        k.d_titab, c->tipmap, c->maxstates, c->d_tile_counter, (const AfPairJob *)(plan + k.off_pair), npair,
+        k.d_pairtab, (const AaLookupJob *)(plan + k.off_lk), nlk);
     HIP_TRY(hipGetLastError());
   }
   else HIP_TRY(hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
