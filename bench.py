@@ -1024,6 +1024,9 @@ def main():
                               "the reference's lnL of the CPU-baseline sample, against a product partition of the same sample")
                              if lnl_rel_err is not None else None,
             "first_evaluation_ms": round(first_ms, 2),
+            # where the partition's CLVs lie: places in device memory tried at creation, the write rate of a zeroing pass
+            # over each, the one kept (pll_amd_placement_info; PLLHIP_PLACEMENT_TRIES=1: the first the allocator gives)
+            "placement": part.placement() if part is not None else None,
             # wall-clock seconds since this process (rank 0) started, at the end of each section: a first multi-GPU run
             # that times out says where it was
             "sections_s": sections,

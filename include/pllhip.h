@@ -343,6 +343,17 @@ PLLHIP_EXPORT int pllhip_profile_read(pllhip_ctx_t * ctx, unsigned int * launche
  * run the list again before reading anything.  Not for sharded contexts. */
 PLLHIP_EXPORT int pllhip_write_ceiling(pllhip_ctx_t * ctx, const pllhip_op_t * h_ops, unsigned int count,
                                        unsigned int reps, float * ms_per_pass, double * bytes_per_pass);
+/* Where the CLV arena lies (ctx.hip "Where an arena lies"): the speed of a partition's stores depends on where in
+ * device memory it was placed (5.7-7.3 TB/s for the same list on one device), so an arena of 1 GB or more is
+ * allocated up to PLLHIP_PLACEMENT_TRIES times (environment, default 8; 1: take the first), each place zeroed with
+ * the clock running, the fastest kept and the others freed -- never with less than another arena's worth + 4 GB of
+ * device memory left free.  Returns the number of places tried (0: no search), gbs[i] = GB/s of the zeroing pass
+ * over place i (at most `cap`), *kept = the one the partition lives in.  A sharded context: its first shard's. */
+PLLHIP_EXPORT int pllhip_placement_info(pllhip_ctx_t * ctx, double * gbs, unsigned int cap, int * kept);
+/* Measurement only: the CLV arena zeroed once more by the kernel that zeroes it at creation, timed -- GB/s of a
+ * contiguous non-temporal write stream over the partition's own memory (where an arena lies decides how fast it can be
+ * written, ctx.hip "Where an arena lies").  OVERWRITES every CLV.  Not for sharded contexts. */
+PLLHIP_EXPORT int pllhip_arena_fill_bandwidth(pllhip_ctx_t * ctx, double * gbs);
 /* What the last op list planned by the 20-state whole-list kernel is made of: {ops, tip-tip ops ahead of the list,
  * tip-tip ops in the list (one gather each), table lookups, inner-inner ops on the matrix cores, tip-inner ops on
  * the matrix cores, tip-inner ops on the vector unit, operands reloaded from HBM}; zeros if none was planned. */

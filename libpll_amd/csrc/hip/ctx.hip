@@ -25,6 +25,7 @@
 
 #include <atomic>
 #include "ctx.hpp"
+#include "numerics.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -49,6 +50,7 @@ static const char * const pllhip_user_switches[] = {
   "PLLHIP_SHARD_THREADS",    // 0: a sharded partition is driven by the calling thread alone
   "PLLHIP_SHARD_POLL",       // 0: a sharded partition waits for its shards' streams one after another
   "PLLHIP_SHARD_PIN",        // 0: the shards' threads are not bound to the cores next to their devices
+  "PLLHIP_PLACEMENT_TRIES",  // how many places in device memory a partition's CLV arena may try (1: take the first)
   "PLLHIP_FUSED_DEBUG",      // diagnostics on stderr
   "PLLHIP_RCCL_DEBUG",       // diagnostics on stderr
   "PLLHIP_DEVELOPER",
@@ -122,6 +124,112 @@ static int dev_alloc(T ** p, size_t count, bool zero, hipStream_t s)
   HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
   if (zero) HIP_TRY(hipMemsetAsync(*p, 0, count * sizeof(T), s));
   return 0;
+}
+
+// ---- Where an arena lies (round 6).  The speed of a partition's stores depends on WHERE in device memory it was
+// placed: ten partitions of BASELINE config 2 created one after the other in one process store their list at
+// 5.75-7.28 TB/s and run it in 1,398-1,484 us, each the same every time it is measured, and a new partition that gets
+// a slow one's memory back is slow again (tools/placement_probe.py, profiles/r6_placement_probe.txt) -- what rounds
+// 2-5 called "slow boxes".  k_fill_zero is the zeroing every arena gets anyway, as a kernel that can be timed:
+// contiguous non-temporal 16-byte stores, eight workgroups per CU.
+__global__ __launch_bounds__(256) void k_fill_zero(pll_v2d * __restrict__ p, size_t n16)
+{
+  const pll_v2d z = {0.0, 0.0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    __builtin_nontemporal_store(z, p + i);
+}
+
+// one timed zeroing pass over [p, p + bytes) on stream s (bytes a multiple of 16): GB/s
+static int fill_bandwidth(void * p, size_t bytes, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int cus, double * gbs)
+{
+  HIP_TRY(hipEventRecord(e0, s));
+  k_fill_zero<<<(unsigned int)cus * 8u, 256, 0, s>>>(static_cast<pll_v2d *>(p), bytes / 16);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *gbs = ms > 0.f ? (double)bytes / (ms * 1e6) : 0.0;
+  return 0;
+}
+
+// (tool: the CLV arena zeroed once more, timed -- OVERWRITES every CLV; tools/placement_probe.py)
+extern "C" int pllhip_arena_fill_bandwidth(pllhip_ctx_t * c, double * gbs)
+{
+  if (!c->shards.empty()) { pllhip_set_error("pllhip_arena_fill_bandwidth: not for a sharded context"); return -1; }
+  HIP_TRY(hipSetDevice(c->sh.device));
+  PLLHIP_CERT_FIRST(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t bytes = (c->clv_arena_alloc_bytes / 16) * 16;
+  return fill_bandwidth(c->clv_arena, bytes, c->stream, c->ev0, c->ev1, c->num_cus, gbs);
+}
+
+// The CLV arena, placed: up to `tries` allocations, each zeroed (as the arena is anyway) and zeroed twice more with
+// the clock running; the fastest is kept, the others are held until the choice is made -- a freed allocation is what
+// the next one gets -- and then freed.  An arena that reaches PLLHIP_PLACEMENT_GOOD of the HBM peak ends the search.
+// Never with less than another arena's worth (+ 4 GB) of device memory left free, never for arenas below 1 GB (the
+// write stream of a small partition is not what bounds it) -- config 4 whole (133 GB) takes what it gets, and is an
+// average over the device anyway.  Costs 3-4 ms and 8 GB of transient memory per try at config 2's size.
+#define PLLHIP_PLACEMENT_MIN_BYTES ((size_t)1 << 30)
+#define PLLHIP_PLACEMENT_GOOD_GBS 5150.0  // (k_fill_zero: 5.2-5.7 TB/s on the fast places, 4.6-4.9 on the slow ones)
+static int alloc_arena_placed(pllhip_ctx * c, double ** out, size_t count)
+{
+  *out = nullptr;
+  c->placement_tries = 0;
+  c->placement_gbs.clear();
+  const size_t bytes = count * sizeof(double);
+  int tries = 8;
+  if (const char * e = pllhip_env("PLLHIP_PLACEMENT_TRIES")) tries = atoi(e);
+  if (bytes < PLLHIP_PLACEMENT_MIN_BYTES || tries <= 1) return dev_alloc(out, count, true, c->stream);
+  std::vector<void *> held;
+  size_t best = 0;
+  for (int t = 0; t < tries; ++t)
+  {
+    if (t > 0)
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+      if (free_b < 2 * bytes + ((size_t)4 << 30)) break;
+    }
+    void * p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+    {
+      if (t == 0) { pllhip_set_error("hipMalloc of the CLV arena (%zu bytes): %s", bytes, hipGetErrorString(e)); return (int)e; }
+      (void)hipGetLastError();
+      break;
+    }
+    held.push_back(p);
+    double g[3] = {0.0, 0.0, 0.0};
+    int rc = 0;
+    for (int pass = 0; pass < 3 && !rc; ++pass) rc = fill_bandwidth(p, (bytes / 16) * 16, c->stream, c->ev0, c->ev1, c->num_cus, &g[pass]);
+    if (!rc && (bytes & 15)) rc = hipMemsetAsync((char *)p + (bytes / 16) * 16, 0, bytes & 15, c->stream) == hipSuccess ? 0 : 1;
+    if (rc)
+    {
+      for (void * h : held) (void)hipFree(h);
+      return rc;
+    }
+    // (the first pass also pays for whatever a first touch costs: the better of the two behind it)
+    c->placement_gbs.push_back(std::max(g[1], g[2]));
+    if (c->placement_gbs.back() > c->placement_gbs[best]) best = held.size() - 1;
+    if (c->placement_gbs.back() >= PLLHIP_PLACEMENT_GOOD_GBS) break;
+  }
+  for (size_t i = 0; i < held.size(); ++i)
+    if (i != best) (void)hipFree(held[i]);
+  *out = static_cast<double *>(held[best]);
+  c->placement_tries = (int)held.size();
+  c->placement_best = (int)best;
+  return 0;
+}
+
+// what the search found: the write rate (GB/s of k_fill_zero) of every place tried, in order; which one was kept.
+// Returns the number of places tried (0: no search -- a small arena, or PLLHIP_PLACEMENT_TRIES <= 1).
+extern "C" int pllhip_placement_info(pllhip_ctx_t * c, double * gbs, unsigned int cap, int * kept)
+{
+  const pllhip_ctx * x = c->shards.empty() ? c : c->shards[0];
+  for (unsigned int i = 0; i < cap && i < x->placement_gbs.size(); ++i) gbs[i] = x->placement_gbs[i];
+  if (kept) *kept = x->placement_best;
+  return x->placement_tries;
 }
 
 // ---- Quiescing the HIP runtime before anything is torn down (round 4; the crash hunt of DESIGN.md section 3).
@@ -246,6 +354,10 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   c->scaler_elems = shape->rate_scalers ? N * R : N;
   c->tip_stride = (N + 255) & ~(size_t)255;
   c->clv_stride = c->clv_elems + (size_t)PLLHIP_TAIL_SITES * c->span;
+  // (tool switch: extra sites of slack per CLV -- what the distance between the list kernels' output streams does to
+  // their stores, tools/ceiling_by_size.sh)
+  if (const char * e = pllhip_env("PLLHIP_CLV_PAD_SITES"))
+    if (atoi(e) > 0) c->clv_stride += (size_t)atoi(e) * c->span;
   c->scaler_stride = c->scaler_elems + (size_t)PLLHIP_TAIL_SITES * (shape->rate_scalers ? R : 1);
   c->pmat_elems = R * S * S;
 
@@ -254,9 +366,10 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   const size_t n_clv = nodes - first;
 
   // CLVs are zeroed like the reference's (pll.c:525-542); scalers calloc'd (pll.c:800-815)
-  if ((rc = dev_alloc(&c->clv_arena, n_clv * c->clv_stride, true, c->stream)))
+  if ((rc = alloc_arena_placed(c, &c->clv_arena, n_clv * c->clv_stride)))
     goto fail;
   c->clv_arena_bytes = n_clv * c->clv_elems * sizeof(double);
+  c->clv_arena_alloc_bytes = n_clv * c->clv_stride * sizeof(double);
   c->clv.assign(nodes, nullptr);
   for (unsigned int i = first; i < nodes; ++i)
     c->clv[i] = c->clv_arena + (size_t)(i - first) * c->clv_stride;

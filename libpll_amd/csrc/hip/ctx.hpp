@@ -183,6 +183,9 @@ struct pllhip_ctx
                                         // with a CLV stored by class is stored by class too); kept once `rows` exists
   struct pllhip_rep_work * rep_work = nullptr; // sort / scan buffers of repeats.hip
   size_t clv_arena_bytes = 0;            // all CLVs of the partition
+  size_t clv_arena_alloc_bytes = 0; // what was allocated for the arena (strides included)
+  int placement_tries = 0, placement_best = 0; // where the CLV arena lies: places tried, the one kept (ctx.hip)
+  std::vector<double> placement_gbs;          // GB/s of a zeroing pass over each place tried
   bool no_batch = false;                 // PLLHIP_NO_BATCH=1: one launch per op (measurements)
   int nt_override = -1;                  // PLLHIP_NT=0/1 forces the cache policy (measurements); 2: and the whole-list
                                          // kernel's count stores, which follow the partition's size otherwise

@@ -856,6 +856,18 @@ int pll_amd_write_ceiling(pll_partition_t * p, const pll_operation_t * operation
   return PLL_SUCCESS;
 }
 
+int pll_amd_placement_info(pll_partition_t * p, double * gbs, unsigned int cap, int * kept)
+{
+  return pllhip_placement_info(pll_amd_priv(p)->ctx, gbs, cap, kept);
+}
+
+int pll_amd_arena_fill_bandwidth(pll_partition_t * p, double * gbs)
+{
+  int rc = pllhip_arena_fill_bandwidth(pll_amd_priv(p)->ctx, gbs);
+  if (rc) return pll_amd_fail_hip(rc, "arena fill bandwidth");
+  return PLL_SUCCESS;
+}
+
 int pll_amd_list_kinds(pll_partition_t * p, unsigned int * kinds8)
 {
   int rc = pllhip_aa_list_kinds(pll_amd_priv(p)->ctx, kinds8);

@@ -156,6 +156,9 @@ class PllLibrary:
             lib.pll_amd_timer_shard_ms.restype = C.c_uint
             lib.pll_amd_comm_unique_id.argtypes = [C.c_void_p]
             lib.pll_amd_comm_init.argtypes = [_PP, C.c_int, C.c_int, C.c_void_p]
+            if hasattr(lib, "pll_amd_arena_fill_bandwidth"):
+                lib.pll_amd_arena_fill_bandwidth.argtypes = [_PP, C.POINTER(C.c_double)]
+                lib.pll_amd_placement_info.argtypes = [_PP, C.POINTER(C.c_double), C.c_uint, C.POINTER(C.c_int)]
             if hasattr(lib, "pll_amd_comm_reduces"):
                 lib.pll_amd_comm_reduces.argtypes = [_PP]
                 lib.pll_amd_comm_reduces.restype = C.c_ulonglong
@@ -427,6 +430,19 @@ class Partition:
         self._check(self.lib.pll_amd_list_kinds(self.ptr, _u(v)), "pll_amd_list_kinds")
         return dict(zip(("ops", "tip_tip_ahead", "tip_tip_in_list", "lookups", "inner_inner_matrix_cores",
                          "tip_inner_matrix_cores", "tip_inner_vector_unit", "reloads"), (int(x) for x in v)))
+
+    def placement(self):
+        """where the CLV arena lies: {"tried": n, "kept": i, "GBs": [write rate of each place tried]} (pll_amd.h)"""
+        g = (C.c_double * 32)()
+        kept = C.c_int(0)
+        n = self.lib.pll_amd_placement_info(self.ptr, g, 32, C.byref(kept))
+        return {"tried": int(n), "kept": int(kept.value), "GBs": [round(g[i], 1) for i in range(min(n, 32))]}
+
+    def arena_fill_bandwidth(self):
+        """GB/s of one timed zeroing pass over the CLV arena -- OVERWRITES every CLV (pll_amd.h)."""
+        g = C.c_double()
+        self._check(self.lib.pll_amd_arena_fill_bandwidth(self.ptr, C.byref(g)), "pll_amd_arena_fill_bandwidth")
+        return g.value
 
     def comm_reduces(self):
         """collectives entered so far (every rank of a job must count alike)"""

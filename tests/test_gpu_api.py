@@ -560,3 +560,37 @@ def test_two_threads_two_partitions(gpu, orc):
         assert got[i] == [expect[i]] * 40, i
     for p in parts:
         p.destroy()
+
+
+def test_clv_arena_is_placed_and_zeroed(gpu, monkeypatch):
+    """Round 6: a partition of 1 GB or more tries several places in device memory for its CLV arena and keeps the one it
+    can write fastest (ctx.hip "Where an arena lies"); whatever it keeps is zeroed like the reference's CLVs
+    (pll.c:525-542), results are what they are without the search, and PLLHIP_PLACEMENT_TRIES=1 switches it off."""
+    case = make_case(4, "balanced", 64, 160_000, seed=5)     # 62 inner CLVs of 20 MB: 1.3 GB
+    plan = case["plan"]
+    got = {}
+    for tries in (None, "1", "3"):
+        if tries is None:
+            monkeypatch.delenv("PLLHIP_PLACEMENT_TRIES", raising=False)
+        else:
+            monkeypatch.setenv("PLLHIP_PLACEMENT_TRIES", tries)
+        p = build_partition(gpu, case, ATTRIB_PATTERN_TIP)
+        info = p.placement()
+        if tries == "1":
+            assert info["tried"] == 0, info
+        else:
+            assert 1 <= info["tried"] <= (8 if tries is None else 3) and 0 <= info["kept"] < info["tried"], info
+            assert len(info["GBs"]) == info["tried"] and info["GBs"][info["kept"]] == max(info["GBs"]), info
+            assert min(info["GBs"]) > 500.0, info
+        inner = int(plan.ops[-1]["parent_clv_index"])
+        assert not p.get_clv(inner).any()                      # zeroed, wherever it lies
+        p.update_partials(plan.ops)
+        got[tries] = (p.get_clv(inner).copy(), p.compute_edge_loglikelihood(*plan.root_edge, [0] * 4))
+        p.destroy()
+    for tries in ("1", "3"):
+        assert bits_equal(got[tries][0], got[None][0]) and got[tries][1] == got[None][1]
+    # a small partition does not search
+    small = make_case(4, "balanced", 8, 2000, seed=5)
+    p = build_partition(gpu, small, ATTRIB_PATTERN_TIP)
+    assert p.placement()["tried"] == 0
+    p.destroy()

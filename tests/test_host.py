@@ -681,7 +681,7 @@ def test_developer_switches_are_gated(amd, monkeypatch):
     assert len(read) > 30
     user = {n for n in read if lib.pllhip_env_is_user_switch(n.encode())}
     assert user == {"PLLHIP_AA_EXACT", "PLLHIP_AA_TI_MFMA", "PLLHIP_FUSED", "PLLHIP_HOSTSUM", "PLLHIP_FUSE_REDUCE",
-                    "PLLHIP_SPIN", "PLLHIP_SHARD_THREADS", "PLLHIP_SHARD_POLL", "PLLHIP_SHARD_PIN", "PLLHIP_FUSED_DEBUG",
+                    "PLLHIP_SPIN", "PLLHIP_SHARD_THREADS", "PLLHIP_SHARD_POLL", "PLLHIP_SHARD_PIN", "PLLHIP_PLACEMENT_TRIES", "PLLHIP_FUSED_DEBUG",
                     "PLLHIP_RCCL_DEBUG"}
     # the first table holds the client's switches, the second every developer's one
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
