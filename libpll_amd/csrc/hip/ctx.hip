@@ -164,7 +164,7 @@ extern "C" int pllhip_arena_fill_bandwidth(pllhip_ctx_t * c, double * gbs)
   return fill_bandwidth(c->clv_arena, bytes, c->stream, c->ev0, c->ev1, c->num_cus, gbs);
 }
 
-// The CLV arena, placed: up to `tries` allocations, each zeroed (as the arena is anyway) and zeroed twice more with
+// The partition's per-site memory -- CLVs, tip characters, scale buffers: ONE allocation --, placed: up to `tries` allocations, each zeroed (as the arena is anyway) and zeroed twice more with
 // the clock running; the fastest is kept, the others are held until the choice is made -- a freed allocation is what
 // the next one gets -- and then freed.  An arena that reaches PLLHIP_PLACEMENT_GOOD of the HBM peak ends the search.
 // Never with less than another arena's worth (+ 4 GB) of device memory left free, never for arenas below 1 GB (the
@@ -172,15 +172,14 @@ extern "C" int pllhip_arena_fill_bandwidth(pllhip_ctx_t * c, double * gbs)
 // average over the device anyway.  Costs 3-4 ms and 8 GB of transient memory per try at config 2's size.
 #define PLLHIP_PLACEMENT_MIN_BYTES ((size_t)1 << 30)
 #define PLLHIP_PLACEMENT_GOOD_GBS 5150.0  // (k_fill_zero: 5.2-5.7 TB/s on the fast places, 4.6-4.9 on the slow ones)
-static int alloc_arena_placed(pllhip_ctx * c, double ** out, size_t count)
+static int alloc_arena_placed(pllhip_ctx * c, char ** out, size_t bytes)
 {
   *out = nullptr;
   c->placement_tries = 0;
   c->placement_gbs.clear();
-  const size_t bytes = count * sizeof(double);
   int tries = 8;
   if (const char * e = pllhip_env("PLLHIP_PLACEMENT_TRIES")) tries = atoi(e);
-  if (bytes < PLLHIP_PLACEMENT_MIN_BYTES || tries <= 1) return dev_alloc(out, count, true, c->stream);
+  if (bytes < PLLHIP_PLACEMENT_MIN_BYTES || tries <= 1) return dev_alloc(out, bytes, true, c->stream);
   std::vector<void *> held;
   size_t best = 0;
   for (int t = 0; t < tries; ++t)
@@ -216,7 +215,7 @@ static int alloc_arena_placed(pllhip_ctx * c, double ** out, size_t count)
   }
   for (size_t i = 0; i < held.size(); ++i)
     if (i != best) (void)hipFree(held[i]);
-  *out = static_cast<double *>(held[best]);
+  *out = static_cast<char *>(held[best]);
   c->placement_tries = (int)held.size();
   c->placement_best = (int)best;
   return 0;
@@ -365,20 +364,25 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
   const unsigned int first = shape->pattern_tip ? shape->tips : 0;
   const size_t n_clv = nodes - first;
 
-  // CLVs are zeroed like the reference's (pll.c:525-542); scalers calloc'd (pll.c:800-815)
-  if ((rc = alloc_arena_placed(c, &c->clv_arena, n_clv * c->clv_stride)))
-    goto fail;
+  // CLVs are zeroed like the reference's (pll.c:525-542); scalers calloc'd (pll.c:800-815).  Everything the list
+  // kernels stream per site -- CLVs, tip characters, scale buffers -- is ONE allocation, so that all of it lies where
+  // the search above found the device fast (the buffers allocated next would get the rejected places back).
+  {
+    const size_t clv_b = n_clv * c->clv_stride * sizeof(double);
+    const size_t tip_b = shape->pattern_tip ? shape->tips * c->tip_stride + PLLHIP_TAIL_SITES : 0;
+    const size_t sc_b = ((size_t)shape->scale_buffers * c->scaler_stride + PLLHIP_TAIL_SITES * R) * sizeof(unsigned int);
+    auto up = [](size_t b) { return (b + 4095) & ~(size_t)4095; };
+    char * base = nullptr;
+    if ((rc = alloc_arena_placed(c, &base, up(clv_b) + up(tip_b) + up(sc_b)))) goto fail;
+    c->clv_arena = reinterpret_cast<double *>(base);
+    if (tip_b) c->tipchars = reinterpret_cast<unsigned char *>(base + up(clv_b));
+    c->scaler_arena = reinterpret_cast<unsigned int *>(base + up(clv_b) + up(tip_b));
+    c->clv_arena_alloc_bytes = clv_b;
+  }
   c->clv_arena_bytes = n_clv * c->clv_elems * sizeof(double);
-  c->clv_arena_alloc_bytes = n_clv * c->clv_stride * sizeof(double);
   c->clv.assign(nodes, nullptr);
   for (unsigned int i = first; i < nodes; ++i)
     c->clv[i] = c->clv_arena + (size_t)(i - first) * c->clv_stride;
-  if (shape->pattern_tip)
-    if ((rc = dev_alloc(&c->tipchars, shape->tips * c->tip_stride + PLLHIP_TAIL_SITES, true, c->stream)))
-      goto fail;
-  if ((rc = dev_alloc(&c->scaler_arena,
-                      (size_t)shape->scale_buffers * c->scaler_stride + PLLHIP_TAIL_SITES * R, true,
-                      c->stream))) goto fail;
   if ((rc = dev_alloc(&c->pmatrix, (size_t)shape->prob_matrices * c->pmat_elems, true,
                       c->stream))) goto fail;
   if ((rc = dev_alloc(&c->eigenvals, (size_t)shape->rate_matrices * S, true, c->stream))) goto fail;
@@ -552,7 +556,8 @@ extern "C" void pllhip_ctx_destroy(pllhip_ctx_t * c)
   (void)hipSetDevice(c->sh.device);
   if (c->stream) pllhip_stream_quiesce(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
-  void * bufs[] = {c->clv_arena, c->tipchars, c->scaler_arena, c->pmatrix, c->eigenvals,
+  // (c->tipchars and c->scaler_arena lie in c->clv_arena's allocation)
+  void * bufs[] = {c->clv_arena, c->pmatrix, c->eigenvals,
                    c->eigenvecs, c->inv_eigenvecs, c->freqs, c->prop_invar, c->rates,
                    c->rate_weights, c->pattern_weights, c->invariant, c->tipmap,
                    c->block_partials, c->d_result, c->d_counter, c->d_zero, c->d_tiptab, c->d_persite, c->d_stage, c->d_asc,
