@@ -348,6 +348,7 @@ def main():
     section("cpu baseline")
     part = W.setup_partition(amd, plan, seqs, S, R,
                              attrs | (ATTRIB_SITE_REPEATS if args.site_repeats else 0))
+    placement = part.placement()   # (where its CLVs lie: places tried at creation, the one kept)
     if use_comm:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -1026,7 +1027,7 @@ def main():
             "first_evaluation_ms": round(first_ms, 2),
             # where the partition's CLVs lie: places in device memory tried at creation, the write rate of a zeroing pass
             # over each, the one kept (pll_amd_placement_info; PLLHIP_PLACEMENT_TRIES=1: the first the allocator gives)
-            "placement": part.placement() if part is not None else None,
+            "placement": placement,
             # wall-clock seconds since this process (rank 0) started, at the end of each section: a first multi-GPU run
             # that times out says where it was
             "sections_s": sections,

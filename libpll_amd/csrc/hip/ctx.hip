@@ -1,7 +1,8 @@
 // ctx.hip -- device context of one partition: HBM allocation, host<->device
 // transfers, the HIP-event stopwatch and the RCCL communicator.
 //
-// HBM layout (one allocation per kind, sized for 288 GB parts):
+// HBM layout (sized for 288 GB parts; clv_arena, tipchars and scaler_arena are ONE allocation, placed where the
+// device writes fast -- "Where an arena lies" below):
 //   clv_arena     [n_clv][sites][rate_cats][states] f64   site-major, state fastest --
 //                 the reference layout (pll.c:527-541), which is also the coalesced
 //                 one for "one lane per (site,rate)" kernels: a wave touches
