@@ -39,14 +39,22 @@ def measure(p, label):
             p.update_partials(plan.ops)
         us.append(p.timer_stop_ms() * 1e3 / 10)
     us.sort()
+    # a pure read stream over the same memory: the edge log-likelihood (two CLVs of 128 MB), HIP events
+    for _ in range(5):
+        p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    p.wait()
+    p.timer_start()
+    for _ in range(20):
+        p.compute_edge_loglikelihood(*plan.root_edge, [0] * R)
+    lnl_us = p.timer_stop_ms() * 1e3 / 20
     ms, nbytes = p.write_ceiling(plan.ops, 20)
     fill = sorted(p.arena_fill_bandwidth() for _ in range(5))
     p.update_partials(plan.ops)
     p.wait()
     free, total = torch.cuda.mem_get_info()
     label = "%s %s" % (label, p.placement())
-    print("%-44s t = %5.1f s  list %8.1f us   bare stores %8.1f us = %6.1f GB/s   contiguous fill %6.1f GB/s (%6.1f - %6.1f)   device memory in use %5.1f GB"
-          % (label, time.perf_counter() - t_start, us[len(us) // 2], ms * 1e3, nbytes / ms / 1e6, fill[2], fill[0], fill[4], (total - free) / 1e9), flush=True)
+    print("%-44s t = %5.1f s  list %8.1f us   lnL call %5.1f us   bare stores %8.1f us = %6.1f GB/s   contiguous fill %6.1f GB/s (%6.1f - %6.1f)   device memory in use %5.1f GB"
+          % (label, time.perf_counter() - t_start, us[len(us) // 2], lnl_us, ms * 1e3, nbytes / ms / 1e6, fill[2], fill[0], fill[4], (total - free) / 1e9), flush=True)
 
 
 parts = []
