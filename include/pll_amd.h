@@ -729,7 +729,7 @@ PLL_EXPORT int pll_amd_scaling_certificate(pll_partition_t * partition, unsigned
 PLL_EXPORT int pll_amd_write_ceiling(pll_partition_t * partition, const pll_operation_t * operations, unsigned int count,
                                      unsigned int reps, float * ms_per_pass, double * bytes_per_pass);
 PLL_EXPORT int pll_amd_list_kinds(pll_partition_t * partition, unsigned int * kinds8);
-/* Where the partition's CLVs lie (pllhip.h: pllhip_placement_info): a partition of 1 GB or more tries up to
+/* Where the partition's CLVs lie (pllhip.h: pllhip_placement_info): a partition of 384 MB or more tries up to
  * PLLHIP_PLACEMENT_TRIES (environment, default 8) places in device memory when it is created and keeps the one it can
  * write fastest.  Returns the number of places tried (0: none -- a small partition, or PLLHIP_PLACEMENT_TRIES=1),
  * their write rates in GB/s and which one was kept. */

@@ -168,10 +168,10 @@ extern "C" int pllhip_arena_fill_bandwidth(pllhip_ctx_t * c, double * gbs)
 // The partition's per-site memory -- CLVs, tip characters, scale buffers: ONE allocation --, placed: up to `tries` allocations, each zeroed (as the arena is anyway) and zeroed twice more with
 // the clock running; the fastest is kept, the others are held until the choice is made -- a freed allocation is what
 // the next one gets -- and then freed.  An arena that reaches PLLHIP_PLACEMENT_GOOD of the HBM peak ends the search.
-// Never with less than another arena's worth (+ 4 GB) of device memory left free, never for arenas below 1 GB (the
-// write stream of a small partition is not what bounds it) -- config 4 whole (133 GB) takes what it gets, and is an
+// Never with less than another arena's worth (+ 4 GB) of device memory left free, never for arenas below 384 MB (4
+// states x 62,500 sites x 64 taxa = 0.5 GB: +7 %; 31,250 sites: nothing -- the write stream does not bound it) -- config 4 whole (133 GB) takes what it gets, and is an
 // average over the device anyway.  Costs 3-4 ms and 8 GB of transient memory per try at config 2's size.
-#define PLLHIP_PLACEMENT_MIN_BYTES ((size_t)1 << 30)
+#define PLLHIP_PLACEMENT_MIN_BYTES ((size_t)384 << 20)
 #define PLLHIP_PLACEMENT_GOOD_GBS 5150.0  // (k_fill_zero: 5.2-5.7 TB/s on the fast places, 4.6-4.9 on the slow ones)
 static int alloc_arena_placed(pllhip_ctx * c, char ** out, size_t bytes)
 {
@@ -180,7 +180,9 @@ static int alloc_arena_placed(pllhip_ctx * c, char ** out, size_t bytes)
   c->placement_gbs.clear();
   int tries = 8;
   if (const char * e = pllhip_env("PLLHIP_PLACEMENT_TRIES")) tries = atoi(e);
-  if (bytes < PLLHIP_PLACEMENT_MIN_BYTES || tries <= 1) return dev_alloc(out, bytes, true, c->stream);
+  size_t min_bytes = PLLHIP_PLACEMENT_MIN_BYTES;
+  if (const char * e = pllhip_env("PLLHIP_PLACEMENT_MIN_MB")) min_bytes = (size_t)atoi(e) << 20; // (tool switch)
+  if (bytes < min_bytes || tries <= 1) return dev_alloc(out, bytes, true, c->stream);
   std::vector<void *> held;
   size_t best = 0;
   for (int t = 0; t < tries; ++t)

@@ -563,7 +563,7 @@ def test_two_threads_two_partitions(gpu, orc):
 
 
 def test_clv_arena_is_placed_and_zeroed(gpu, monkeypatch):
-    """Round 6: a partition of 1 GB or more tries several places in device memory for its CLV arena and keeps the one it
+    """Round 6: a partition of 384 MB or more tries several places in device memory for its CLV arena and keeps the one it
     can write fastest (ctx.hip "Where an arena lies"); whatever it keeps is zeroed like the reference's CLVs
     (pll.c:525-542), results are what they are without the search, and PLLHIP_PLACEMENT_TRIES=1 switches it off."""
     case = make_case(4, "balanced", 64, 160_000, seed=5)     # 62 inner CLVs of 20 MB: 1.3 GB
