@@ -795,7 +795,10 @@ extern "C" int pllhip_update_partials(pllhip_ctx_t * c, const pllhip_op_t * ops,
     // written together with their CLV -- runs per level.
     const FusedGeom geom = {c->clv.size(), c->sh.scale_buffers, c->sh.tips, c->sh.pattern_tip != 0};
     // (PLLHIP_FUSED_WGS=2: the 8-wave, 7-slot configuration at once -- tests run both)
-    const unsigned int first_wgs = pllhip_env("PLLHIP_FUSED_WGS") && atoi(pllhip_env("PLLHIP_FUSED_WGS")) == 2 ? 2u : 3u;
+    unsigned int first_wgs = pllhip_env("PLLHIP_FUSED_WGS") && atoi(pllhip_env("PLLHIP_FUSED_WGS")) == 2 ? 2u : 3u;
+#ifdef PLLHIP_FUSED_WPS4
+    if (pllhip_env("PLLHIP_FUSED_WGS") && atoi(pllhip_env("PLLHIP_FUSED_WGS")) == 4) first_wgs = 4u; // (tool build)
+#endif
     // Round 5: independent sub-lists (the two sides of the root edge of a full traversal) as SEGMENTS of one launch
     // -- (tile, segment) work items -- while the tiles alone do not fill the chip's wave slots eight times over:
     // below that a launch's time is quantised by rounds of the list's length (partials_fused.hpp).

@@ -713,7 +713,7 @@ unsigned int pllhip_fused_slots(const pllhip_ctx * c, unsigned int wgs)
   // (four workgroups -- 16 waves of 128 registers, four slots -- were measured for short lists in round 3 and are
   // slower than three at every list length: 2 / 3 / 5 / 7 / 15 ops 257 / 286 / 335 / 282 / 421 us against 226 / 260 /
   // 310 / 246 / 411; the variant spills seven registers)
-  const size_t budget = PLLHIP_FUSED_J == 1 ? 9472 : (wgs >= 3 ? 13312 : 16384); // J = 1: four workgroups per CU
+  const size_t budget = PLLHIP_FUSED_J == 1 ? 9472 : (wgs >= 4 ? 9984 : wgs >= 3 ? 13312 : 16384); // J = 1: four workgroups per CU
   return (unsigned int)((budget - pmat) / per_slot);
 }
 
@@ -1118,7 +1118,13 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
   // walks its share of the tiles
   const size_t nsegs = bases.nsegs; // (work items: (tile, segment) pairs)
   size_t grid = (tiles * nsegs + 3) / 4;
-  const size_t cap = (size_t)c->num_cus * (J == 1 ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
+#ifdef PLLHIP_FUSED_WPS4
+  // (tool build, tools/fused_wps4.sh: four workgroups per CU -- sixteen waves of 128 registers, four slots each)
+  const bool four = J != 1 && nslots <= pllhip_fused_slots(c, 4);
+#else
+  const bool four = false;
+#endif
+  const size_t cap = (size_t)c->num_cus * (J == 1 || four ? 4 : (nslots <= pllhip_fused_slots(c, 3) ? 3 : 2));
   if (grid > cap) grid = cap;
   const bool nt = pllhip_use_nt(c);
   const bool static_tiles = pllhip_env("PLLHIP_FUSED_STATIC_TILES") != nullptr;
@@ -1170,7 +1176,15 @@ static int launch_fused_rc(pllhip_ctx * c, const FusedRec * d_plan, const FusedB
 #define LAUNCH_FUSED_ARGS (unsigned int)bgrid, 256, lds, c->stream>>>( \
       d_plan, bases, count, bsites, nslots, (double2 *)c->d_sink, tile_counter, dynamic_rounds, (unsigned int)base, tile_groups, \
       reset_tiles)
+#ifdef PLLHIP_FUSED_WPS4
+#define LAUNCH_FUSED(MODEV, NTV)                                                      \
+  do {                                                                                \
+    if (four) k_dna_fused<RC, J, MODEV, NTV, 4><<<LAUNCH_FUSED_ARGS;                  \
+    else k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<LAUNCH_FUSED_ARGS;        \
+  } while (0)
+#else
 #define LAUNCH_FUSED(MODEV, NTV) k_dna_fused<RC, J, MODEV, NTV, (J == 1 ? 4 : 3)><<<LAUNCH_FUSED_ARGS
+#endif
 #define LAUNCH_FUSED_MODE(NTV)                         \
   do {                                                  \
     if (mode == SCALE_NONE) LAUNCH_FUSED(0, NTV);       \
