@@ -783,7 +783,10 @@ static_assert(AF_J == 2 && AF_NSLOT == 5, "the slot macros spell out two sub-til
 // segment 0 first.  A workgroup that moves on to another segment starts cold -- everybody done with the blocks in
 // LDS, the new segment's first blocks requested -- which the segment-major order makes a once-per-launch event.
 // segtab: [segment] = {first record, ops}.
-template <int MODE, bool NT>
+// NT: 0 plain stores, 1 the tiles non-temporal, 2 non-temporal except the values a later op of the list copies back
+// (AF_KEEP).  An instance of its own: the branch around every store cost a list WITHOUT such values 3.5 % when all
+// non-temporal lists ran through it (config 3: 1,710 -> 1,767 us per call, profiles/r6_aa_keep_instance_ab.txt).
+template <int MODE, int NT>
 __global__ __launch_bounds__(256, 2) void k_aa_fused(const AaRec * __restrict__ plan0, const unsigned int * __restrict__ segtab,
                                                      unsigned int nsegs, unsigned int sites,
                                                      const char * aorder, unsigned int ms, double2 * sink,
@@ -1115,6 +1118,7 @@ struct pllhip_aa_fused_cache
   // tip-tip in the list, lookups, inner-inner on the matrix cores, tip-inner on the matrix cores, tip-inner on the
   // vector unit, operands reloaded
   unsigned int kinds_of_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool any_keep = false; // some op's value is copied back by a later op of the list (AF_KEEP): the kernel instance that looks
 };
 
 void pllhip_aa_fused_free(pllhip_ctx * c)
@@ -1192,9 +1196,16 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
         (const AaRec *)k.d_plan, (const unsigned int *)(plan + k.off_seg), k.nsegs, c->sh.sites, k.d_aorder,           \
         c->maxstates, (double2 *)c->d_sink, counter, static_rounds);                                                   \
   } while (0)
-  if (k.mode == SCALE_NONE) { if (nt) AF_LAUNCH(SCALE_NONE, true); else AF_LAUNCH(SCALE_NONE, false); }
-  else if (k.mode == SCALE_RATE) { if (nt) AF_LAUNCH(SCALE_RATE, true); else AF_LAUNCH(SCALE_RATE, false); }
-  else { if (nt) AF_LAUNCH(SCALE_SITE, true); else AF_LAUNCH(SCALE_SITE, false); }
+#define AF_LAUNCH_MODE(MODEV)                                                                                          \
+  do {                                                                                                                 \
+    if (!nt) AF_LAUNCH(MODEV, 0);                                                                                      \
+    else if (!k.any_keep) AF_LAUNCH(MODEV, 1);                                                                         \
+    else AF_LAUNCH(MODEV, 2);                                                                                          \
+  } while (0)
+  if (k.mode == SCALE_NONE) AF_LAUNCH_MODE(SCALE_NONE);
+  else if (k.mode == SCALE_RATE) AF_LAUNCH_MODE(SCALE_RATE);
+  else AF_LAUNCH_MODE(SCALE_SITE);
+#undef AF_LAUNCH_MODE
 #undef AF_LAUNCH
   HIP_TRY(hipGetLastError());
   // the scaling certificate: what the list leaves marked, and whether its flag has to be looked at
@@ -1404,6 +1415,7 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
   std::vector<PartialsArgs> rargs;
   std::vector<int> rkinds, orig;
   k.tt_ops.clear();
+  k.any_keep = false;
   k.tt_modes.clear();
   for (int pass = 0; pass < 2; ++pass) // (tip-tip ops grouped by mode: without a scale buffer first)
     for (unsigned int i = 0; i < count; ++i)
@@ -1641,7 +1653,11 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
       const FusedOp & f = fplan[first + pos];
       for (const double * src : {(f.dma_flags & 1) ? f.left_hbm : nullptr, (f.dma_flags & 2) ? f.right_hbm : nullptr})
         for (unsigned int w = 0; src && w < pos; ++w)
-          if (fplan[first + w].parent == src) R[w + 1].flags |= AF_KEEP;
+          if (fplan[first + w].parent == src)
+          {
+            R[w + 1].flags |= AF_KEEP;
+            k.any_keep = true;
+          }
     }
   // The left block of op i is staged by the four waves, a part each, while they run op i - 2, and the barrier that
   // tells a wave that everybody's part has landed is barrier A of op i - 1 -- which a lookup does not have.  Until

@@ -166,6 +166,7 @@ class PllLibrary:
             lib.pll_amd_profile_read.argtypes = [_PP, _up, _dp]
             if hasattr(lib, "pll_amd_scaling_certificate"):
                 lib.pll_amd_scaling_certificate.argtypes = [_PP, C.POINTER(C.c_ulonglong)]
+            if hasattr(lib, "pll_amd_write_ceiling"):   # (older builds under PLL_AMD_LIB: tools/list_time.py)
                 lib.pll_amd_write_ceiling.argtypes = [_PP, C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_float),
                                                       C.POINTER(C.c_double)]
                 lib.pll_amd_list_kinds.argtypes = [_PP, _up]

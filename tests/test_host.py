@@ -488,7 +488,7 @@ def test_whole_list_kernel_keeps_out_of_the_slot_registers():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_agprs.py")], capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "6 kernels checked, 0 instructions" in out.stdout  # (three scaling modes x two cache policies)
+    assert "9 kernels checked, 0 instructions" in out.stdout  # (three scaling modes x three cache policies)
 
 
 def test_device_selection_per_thread_with_a_process_wide_default(amd):
