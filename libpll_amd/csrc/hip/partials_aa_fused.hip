@@ -1196,10 +1196,12 @@ static int aa_fused_launch(pllhip_ctx * c, bool tables_built)
         (const AaRec *)k.d_plan, (const unsigned int *)(plan + k.off_seg), k.nsegs, c->sh.sites, k.d_aorder,           \
         c->maxstates, (double2 *)c->d_sink, counter, static_rounds);                                                   \
   } while (0)
+  // (tool switch: every non-temporal list through the instance that looks for AF_KEEP, profiles/r6_aa_keep_instance_ab.txt)
+  const bool force_keep_instance = pllhip_env("PLLHIP_AA_KEEP_INSTANCE") && atoi(pllhip_env("PLLHIP_AA_KEEP_INSTANCE")) != 0;
 #define AF_LAUNCH_MODE(MODEV)                                                                                          \
   do {                                                                                                                 \
     if (!nt) AF_LAUNCH(MODEV, 0);                                                                                      \
-    else if (!k.any_keep) AF_LAUNCH(MODEV, 1);                                                                         \
+    else if (!k.any_keep && !force_keep_instance) AF_LAUNCH(MODEV, 1);                                                 \
     else AF_LAUNCH(MODEV, 2);                                                                                          \
   } while (0)
   if (k.mode == SCALE_NONE) AF_LAUNCH_MODE(SCALE_NONE);
