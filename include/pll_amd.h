@@ -732,7 +732,7 @@ PLL_EXPORT int pll_amd_list_kinds(pll_partition_t * partition, unsigned int * ki
 /* Where the partition's CLVs lie (pllhip.h: pllhip_placement_info): a partition of 384 MB or more tries up to
  * PLLHIP_PLACEMENT_TRIES (environment, default 8) places in device memory when it is created and keeps the one it can
  * write fastest.  Returns the number of places tried (0: none -- a small partition, or PLLHIP_PLACEMENT_TRIES=1),
- * their write rates in GB/s and which one was kept. */
+ * the rate in GB/s at which each took the list kernels' store pattern, and which one was kept. */
 PLL_EXPORT int pll_amd_placement_info(pll_partition_t * partition, double * gbs, unsigned int cap, int * kept);
 /* Measurement only (pllhip.h: pllhip_arena_fill_bandwidth): GB/s of one timed zeroing pass over the partition's CLV
  * arena -- OVERWRITES every CLV (tip CLVs included: upload them again). */

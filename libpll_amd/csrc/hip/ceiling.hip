@@ -66,6 +66,55 @@ __global__ __launch_bounds__(256) void k_write_ceiling(const CeilStream * __rest
 }
 } // namespace
 
+// The same stores over a candidate place for a partition's CLVs (ctx.hip "Where an arena lies"): n streams of
+// `stride_b` bytes from `base` on, every CLV a stream, no scale buffers; GB/s of the better of two passes behind an
+// untimed one.  Returns 1 if this shape has no tile (the caller then times a plain zeroing pass instead).
+int pllhip_probe_clv_streams(pllhip_ctx * c, char * base, size_t n, size_t stride_b, double * gbs)
+{
+  const size_t site_b = c->span * sizeof(double);
+  size_t tile_sites = c->sh.states == 20 ? 8 : (c->sh.states == 4 && c->sh.rate_cats == 4) ? 16 : std::max<size_t>(1, 4096 / site_b);
+  while ((tile_sites * site_b) % 1024 && tile_sites <= PLLHIP_TAIL_SITES) ++tile_sites;
+  if (tile_sites > PLLHIP_TAIL_SITES || !n) return 1;
+  std::vector<CeilStream> h(n);
+  for (size_t i = 0; i < n; ++i)
+  {
+    h[i].clv = (unsigned long long)(uintptr_t)(base + i * stride_b);
+    h[i].counts = 0ull;
+  }
+  CeilStream * d = nullptr;
+  unsigned int * counters = nullptr;
+  const size_t set_words = 8 * 32;
+  HIP_TRY(hipMalloc((void **)&d, n * sizeof(CeilStream)));
+  hipError_t e = hipMemcpyAsync(d, h.data(), n * sizeof(CeilStream), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMalloc((void **)&counters, 3 * set_words * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 3 * set_words * sizeof(unsigned int), c->stream);
+  const size_t tiles = ((size_t)c->sh.sites + tile_sites - 1) / tile_sites;
+  const unsigned int grid = (unsigned int)std::min<size_t>((tiles + 3) / 4, (size_t)c->num_cus * (c->sh.states == 20 ? 2 : 3));
+  const size_t rounds = tiles / ((size_t)grid * 4);
+  const unsigned int dynamic_rounds = (unsigned int)std::max<size_t>(2, rounds / 3);
+  const unsigned int static_rounds = rounds > dynamic_rounds ? (unsigned int)(rounds - dynamic_rounds) : 0u;
+  double best = 0.0;
+  for (unsigned int pass = 0; pass < 3 && e == hipSuccess; ++pass)
+  {
+    if (pass) e = hipEventRecord(c->ev0, c->stream);
+    k_write_ceiling<true><<<grid, 256, 0, c->stream>>>(d, (unsigned int)n, tiles, (unsigned int)(tile_sites * site_b), 0u, static_rounds,
+                                                       counters + pass * set_words);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (!pass || e != hipSuccess) continue;
+    e = hipEventRecord(c->ev1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (e == hipSuccess && ms > 0.f) best = std::max(best, (double)n * c->sh.sites * site_b / (ms * 1e6));
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (counters) (void)hipFree(counters);
+  if (e != hipSuccess) { pllhip_set_error("pllhip_probe_clv_streams: %s", hipGetErrorString(e)); return (int)e; }
+  *gbs = best;
+  return 0;
+}
+
 extern "C" int pllhip_write_ceiling(pllhip_ctx_t * c, const pllhip_op_t * ops, unsigned int count, unsigned int reps,
                                     float * ms_per_pass, double * bytes_per_pass)
 {

@@ -165,15 +165,19 @@ extern "C" int pllhip_arena_fill_bandwidth(pllhip_ctx_t * c, double * gbs)
   return fill_bandwidth(c->clv_arena, bytes, c->stream, c->ev0, c->ev1, c->num_cus, gbs);
 }
 
-// The partition's per-site memory -- CLVs, tip characters, scale buffers: ONE allocation --, placed: up to `tries` allocations, each zeroed (as the arena is anyway) and zeroed twice more with
-// the clock running; the fastest is kept, the others are held until the choice is made -- a freed allocation is what
-// the next one gets -- and then freed.  An arena that reaches PLLHIP_PLACEMENT_GOOD of the HBM peak ends the search.
-// Never with less than another arena's worth (+ 4 GB) of device memory left free, never for arenas below 384 MB (4
-// states x 62,500 sites x 64 taxa = 0.5 GB: +7 %; 31,250 sites: nothing -- the write stream does not bound it) -- config 4 whole (133 GB) takes what it gets, and is an
-// average over the device anyway.  Costs 3-4 ms and 8 GB of transient memory per try at config 2's size.
+// The partition's per-site memory -- CLVs, tip characters, scale buffers: ONE allocation --, placed: up to `tries`
+// allocations, each written with the list kernels' own store pattern (every CLV a stream, a wave's tile of each in
+// turn: pllhip_probe_clv_streams -- a plain zeroing pass tells slow places from fast ones for arenas of config 2's size
+// but not for twice that: profiles/r6_placement_probe.txt, last section) with the clock running; the first fast one or
+// else the fastest is kept, the others are held until the choice is made -- a freed allocation is what the next one
+// gets -- and then freed; the one kept is zeroed.  Never with less than another arena's worth (+ 4 GB) of device
+// memory left free, never for arenas below 384 MB (4 states x 62,500 sites x 64 taxa = 0.5 GB: +7 %; 31,250 sites:
+// nothing -- the write stream does not bound it) -- config 4 whole (133 GB) takes what it gets, and is an average over
+// the device anyway.  Costs 3-4 ms and 8 GB of transient memory per try at config 2's size.
 #define PLLHIP_PLACEMENT_MIN_BYTES ((size_t)384 << 20)
-#define PLLHIP_PLACEMENT_GOOD_GBS 5150.0  // (k_fill_zero: 5.2-5.7 TB/s on the fast places, 4.6-4.9 on the slow ones)
-static int alloc_arena_placed(pllhip_ctx * c, char ** out, size_t bytes)
+#define PLLHIP_PLACEMENT_GOOD_GBS 6500.0       // (the list pattern: 6.4-7.3 TB/s on the fast places, 5.5-5.9 on the slow ones)
+#define PLLHIP_PLACEMENT_GOOD_FILL_GBS 5150.0  // (shapes without a tile: k_fill_zero, 5.2-5.7 against 4.6-4.9 at 8 GB)
+static int alloc_arena_placed(pllhip_ctx * c, char ** out, size_t bytes, size_t first_clv, size_t n_clv, size_t clv_stride_b)
 {
   *out = nullptr;
   c->placement_tries = 0;
@@ -197,31 +201,47 @@ static int alloc_arena_placed(pllhip_ctx * c, char ** out, size_t bytes)
     const hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess)
     {
-      if (t == 0) { pllhip_set_error("hipMalloc of the CLV arena (%zu bytes): %s", bytes, hipGetErrorString(e)); return (int)e; }
+      if (t == 0) { pllhip_set_error("hipMalloc of the partition's per-site memory (%zu bytes): %s", bytes, hipGetErrorString(e)); return (int)e; }
       (void)hipGetLastError();
       break;
     }
     held.push_back(p);
-    double g[3] = {0.0, 0.0, 0.0};
-    int rc = 0;
-    for (int pass = 0; pass < 3 && !rc; ++pass) rc = fill_bandwidth(p, (bytes / 16) * 16, c->stream, c->ev0, c->ev1, c->num_cus, &g[pass]);
-    if (!rc && (bytes & 15)) rc = hipMemsetAsync((char *)p + (bytes / 16) * 16, 0, bytes & 15, c->stream) == hipSuccess ? 0 : 1;
+    double gbs = 0.0, good = PLLHIP_PLACEMENT_GOOD_GBS;
+    // (the CLVs the lists will write: the inner nodes' -- tip CLVs, if the partition has any, lie ahead of them)
+    int rc = pllhip_probe_clv_streams(c, static_cast<char *>(p) + first_clv * clv_stride_b, n_clv, clv_stride_b, &gbs);
+    if (rc == 1)
+    {
+      // (no tile for this shape: the better of two zeroing passes behind a first one)
+      double g[3] = {0.0, 0.0, 0.0};
+      rc = 0;
+      for (int pass = 0; pass < 3 && !rc; ++pass) rc = fill_bandwidth(p, (bytes / 16) * 16, c->stream, c->ev0, c->ev1, c->num_cus, &g[pass]);
+      gbs = std::max(g[1], g[2]);
+      good = PLLHIP_PLACEMENT_GOOD_FILL_GBS;
+    }
     if (rc)
     {
       for (void * h : held) (void)hipFree(h);
       return rc;
     }
-    // (the first pass also pays for whatever a first touch costs: the better of the two behind it)
-    c->placement_gbs.push_back(std::max(g[1], g[2]));
-    if (c->placement_gbs.back() > c->placement_gbs[best]) best = held.size() - 1;
-    if (c->placement_gbs.back() >= PLLHIP_PLACEMENT_GOOD_GBS) break;
+    c->placement_gbs.push_back(gbs);
+    if (gbs > c->placement_gbs[best]) best = held.size() - 1;
+    if (gbs >= good) break;
   }
   for (size_t i = 0; i < held.size(); ++i)
     if (i != best) (void)hipFree(held[i]);
   *out = static_cast<char *>(held[best]);
   c->placement_tries = (int)held.size();
   c->placement_best = (int)best;
-  return 0;
+  // (zeroed like the reference's, pll.c:525-542, 800-815: the probe wrote ones)
+  double unused = 0.0;
+  int rc = fill_bandwidth(*out, (bytes / 16) * 16, c->stream, c->ev0, c->ev1, c->num_cus, &unused);
+  if (!rc && (bytes & 15)) rc = hipMemsetAsync(*out + (bytes / 16) * 16, 0, bytes & 15, c->stream) == hipSuccess ? 0 : 1;
+  if (rc)
+  {
+    (void)hipFree(*out);
+    *out = nullptr;
+  }
+  return rc;
 }
 
 // what the search found: the write rate (GB/s of k_fill_zero) of every place tried, in order; which one was kept.
@@ -376,7 +396,8 @@ extern "C" int pllhip_ctx_create(const pllhip_shape_t * shape, pllhip_ctx_t ** o
     const size_t sc_b = ((size_t)shape->scale_buffers * c->scaler_stride + PLLHIP_TAIL_SITES * R) * sizeof(unsigned int);
     auto up = [](size_t b) { return (b + 4095) & ~(size_t)4095; };
     char * base = nullptr;
-    if ((rc = alloc_arena_placed(c, &base, up(clv_b) + up(tip_b) + up(sc_b)))) goto fail;
+    if ((rc = alloc_arena_placed(c, &base, up(clv_b) + up(tip_b) + up(sc_b), shape->pattern_tip ? 0 : shape->tips,
+                                 shape->clv_buffers, c->clv_stride * sizeof(double)))) goto fail;
     c->clv_arena = reinterpret_cast<double *>(base);
     if (tip_b) c->tipchars = reinterpret_cast<unsigned char *>(base + up(clv_b));
     c->scaler_arena = reinterpret_cast<unsigned int *>(base + up(clv_b) + up(tip_b));

@@ -454,6 +454,9 @@ int pllhip_aa_lookup_tables(pllhip_ctx * c, const PartialsArgs * ops, const Part
 // partials_aa_fused.hip: a 20-state op list in one site-blocked launch; returns 1 if the list (or
 // the partition) is not one it takes -- the caller then launches per level
 int pllhip_aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int count);
+// ceiling.hip: the list kernels' store pattern over a candidate place for the CLVs (n streams of stride_b bytes): GB/s;
+// 1: no tile for this shape
+int pllhip_probe_clv_streams(pllhip_ctx * c, char * base, size_t n, size_t stride_b, double * gbs);
 // The scaling certificate (see pllhip_ctx::clv_err).  What one op adds to the bound: either summation order
 // (core_partials_avx2.c:632-750 fused, core_partials_avx.c:1229-1284 not) rounds a sum of 20 non-negative products at
 // most 8 times per term, the product of the two factors once: both results lie within 17 units of roundoff (2^-53) of

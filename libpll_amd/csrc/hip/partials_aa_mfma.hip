@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
     // the matrix cores' rounding of a tip-inner op of the whole-list kernel; then a decision is the reference's for
     // certain only while no block's largest entry lies within rounding distance of the threshold.  Two integer
     // instructions on the high word per category (a window of 2^-20); the exact window only behind that.
+#ifndef PLLHIP_NO_II_CERT /* (tool build: what the test costs a launch that does not need it) */
     if (MODE != SCALE_NONE && SPLIT == 0 && a.cert)
     {
       bool wide = false, inside = false;
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_aa_ii_mfma(PartialsBatch batch)
       if (__ballot(wide))
         if (__ballot(inside && site0 + s < sites) && lane == 0u) *a.cert = 1u;
     }
+#endif
     if (MODE == SCALE_SITE && (SPLIT == 1 || SPLIT == 3))
     {
       // not the last chunk of the categories: no decision yet -- the verdict so far goes to the verdict buffer (the
