@@ -730,7 +730,7 @@ PLL_EXPORT int pll_amd_write_ceiling(pll_partition_t * partition, const pll_oper
                                      unsigned int reps, float * ms_per_pass, double * bytes_per_pass);
 PLL_EXPORT int pll_amd_list_kinds(pll_partition_t * partition, unsigned int * kinds8);
 /* Where the partition's CLVs lie (pllhip.h: pllhip_placement_info): a partition of 384 MB or more tries up to
- * PLLHIP_PLACEMENT_TRIES (environment, default 8) places in device memory when it is created and keeps the one it can
+ * PLLHIP_PLACEMENT_TRIES (environment, default 12) places in device memory when it is created and keeps the one it can
  * write fastest.  Returns the number of places tried (0: none -- a small partition, or PLLHIP_PLACEMENT_TRIES=1),
  * the rate in GB/s at which each took the list kernels' store pattern, and which one was kept. */
 PLL_EXPORT int pll_amd_placement_info(pll_partition_t * partition, double * gbs, unsigned int cap, int * kept);

@@ -345,7 +345,7 @@ PLLHIP_EXPORT int pllhip_write_ceiling(pllhip_ctx_t * ctx, const pllhip_op_t * h
                                        unsigned int reps, float * ms_per_pass, double * bytes_per_pass);
 /* Where the CLV arena lies (ctx.hip "Where an arena lies"): the speed of a partition's stores depends on where in
  * device memory it was placed (5.7-7.3 TB/s for the same list on one device), so an arena of 384 MB or more is
- * allocated up to PLLHIP_PLACEMENT_TRIES times (environment, default 8; 1: take the first), each place written with the
+ * allocated up to PLLHIP_PLACEMENT_TRIES times (environment, default 12; 1: take the first), each place written with the
  * list kernels' own store pattern with the clock running, the first fast one or else the fastest kept (and zeroed),
  * the others freed -- never with less than another arena's worth + 4 GB of
  * device memory left free.  Returns the number of places tried (0: no search), gbs[i] = GB/s of those stores

@@ -182,7 +182,7 @@ static int alloc_arena_placed(pllhip_ctx * c, char ** out, size_t bytes, size_t 
   *out = nullptr;
   c->placement_tries = 0;
   c->placement_gbs.clear();
-  int tries = 8;
+  int tries = 12; // (a fresh process has been handed six slow places in a row: profiles/r6_bench_driver_command.json)
   if (const char * e = pllhip_env("PLLHIP_PLACEMENT_TRIES")) tries = atoi(e);
   size_t min_bytes = PLLHIP_PLACEMENT_MIN_BYTES;
   if (const char * e = pllhip_env("PLLHIP_PLACEMENT_MIN_MB")) min_bytes = (size_t)atoi(e) << 20; // (tool switch)
