@@ -1648,7 +1648,10 @@ static int aa_fused_update(pllhip_ctx * c, const pllhip_op_t * ops, unsigned int
     }
     if (pos + 1 < m) reloads_of(r, fplan[first + pos + 1]);
   }
-  if (!(pllhip_env("PLLHIP_AA_KEEP") && atoi(pllhip_env("PLLHIP_AA_KEEP")) == 0))
+  // (opt-in since the end of round 6, PLLHIP_AA_KEEP=1: with the planner's walk fixed hardly a list copies a value of its
+  // own back any more -- one of 398 ops of a 400-taxon random tree -- and the kernel instance that looks for such values
+  // costs a list 1.9 %: 3,727-3,751 us with it against 3,686-3,692 without, profiles/r6_aa_keep_instance_ab.txt)
+  if (pllhip_env("PLLHIP_AA_KEEP") && atoi(pllhip_env("PLLHIP_AA_KEEP")) != 0)
     for (unsigned int pos = 0; pos < m; ++pos)
     {
       // (the writer of a value that op `pos` reloads, if it is an earlier op of this segment)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box (round 6): does storing a value that the list copies back later with the default cache policy
-# (PLLHIP_AA_KEEP=1, the default) instead of non-temporally (0) change where the copy comes from?  Root 1's list of
+# (PLLHIP_AA_KEEP=1; opt-in since the end of round 6) instead of non-temporally (0) change where the copy comes from?  Root 1's list of
 # tools/replay_pmc.py (three such copies).
 export TMPDIR=/tmp PLLHIP_DEVELOPER=1 REPLAY_ROOTS=1
 root=$(pwd); out=$root/gpurun_out/r6_keep; mkdir -p "$out"; cd /tmp
